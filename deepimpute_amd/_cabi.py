@@ -1,0 +1,120 @@
+"""ctypes view of the C ABI declared in include/dimn.h.
+
+`bind(lib, prefix)` attaches argtypes/restype for every entry point of the ABI to a loaded
+shared library.  The product binds `libdimn.so` with prefix ``dimn_`` (see `_lib.py`);
+the test-suite binds the CPU oracle, which exports the same signatures under ``dimo_``.
+Nothing in this module performs arithmetic.
+"""
+import ctypes as C
+
+import numpy as np
+
+ABI_VERSION = 1
+MAX_BATCH = 64
+COMM_ID_BYTES = 128
+
+
+class Config(C.Structure):
+    """struct dimn_config (include/dimn.h); mirrors MultiNet.build()'s arguments
+    (reference deepimpute/multinet.py:126-167)."""
+    _fields_ = [
+        ("n_subnets", C.c_int32),
+        ("subnet_offset", C.c_int32),
+        ("hidden", C.c_int32),
+        ("out_dim", C.c_int32),
+        ("batch_size", C.c_int32),
+        ("device_id", C.c_int32),
+        ("dropout_rate", C.c_float),
+        ("learning_rate", C.c_float),
+        ("beta1", C.c_float),
+        ("beta2", C.c_float),
+        ("eps", C.c_float),
+        ("loss_binary", C.c_int32),
+        ("seed", C.c_uint64),
+    ]
+
+
+_H = C.c_void_p
+_i32 = C.c_int32
+_i64 = C.c_int64
+_pf = C.POINTER(C.c_float)
+_pd = C.POINTER(C.c_double)
+_pi = C.POINTER(C.c_int32)
+_pu8 = C.POINTER(C.c_uint8)
+
+# name -> argtypes (restype int unless listed in _RESTYPE)
+SIGNATURES = {
+    "create": [C.POINTER(Config), _pi, C.POINTER(_H)],
+    "destroy": [_H],
+    "set_matrix": [_H, _pf, _i64, _i64],
+    "set_indices": [_H, _i32, _pi, _i32, _pi],
+    "gather": [_H, _i32],
+    "set_split": [_H, _pi, _i64, _pi, _i64],
+    "init_weights": [_H, C.c_uint64],
+    "set_weights": [_H, _i32, _pf, _pf, _pf, _pf],
+    "get_weights": [_H, _i32, _pf, _pf, _pf, _pf],
+    "get_adam_state": [_H, _i32, _i32, _pf, _pf, _pf, _pf],
+    "reset_optimizer": [_H],
+    "get_step_count": [_H, C.POINTER(_i64)],
+    "train_step": [_H, _pi, _i32, _pu8, _i32, _i32, _pf],
+    "train_epoch": [_H, _i32, _pi, _pd],
+    "val_loss": [_H, _pd],
+    "fit": [_H, _i32, _i32, _pd, _pd, _pi],
+    "predict": [_H, _pi, _i64, _pf],
+    "epoch_permutation": [C.c_uint64, _i32, _i64, _pi],
+}
+# entry points only the GPU library has
+GPU_ONLY = {
+    "abi_version": [],
+    "predict_device": [_H, _pi, _i64, C.POINTER(C.c_void_p)],
+    "synchronize": [_H],
+    "get_timers": [_H, _pd, _i32],
+    "set_profiling": [_H, _i32],
+    "comm_unique_id": [_pu8],
+    "comm_init": [_H, _pu8, _i32, _i32],
+    "comm_allreduce_sum": [_H, _pd, _i32],
+    "comm_gather_predictions": [_H, _i64, _pi, _i32, _pf],
+    "comm_destroy": [_H],
+}
+
+
+def bind(lib, prefix, gpu=False):
+    """Attach signatures; raises AttributeError naming the first missing symbol."""
+    table = dict(SIGNATURES)
+    if gpu:
+        table.update(GPU_ONLY)
+    fns = {}
+    for name, argtypes in table.items():
+        fn = getattr(lib, prefix + name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+        fns[name] = fn
+    le = getattr(lib, prefix + "last_error")
+    le.argtypes = []
+    le.restype = C.c_char_p
+    fns["last_error"] = le
+    return fns
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def p_f32(a):
+    return None if a is None else a.ctypes.data_as(_pf)
+
+
+def p_f64(a):
+    return None if a is None else a.ctypes.data_as(_pd)
+
+
+def p_i32(a):
+    return None if a is None else a.ctypes.data_as(_pi)
+
+
+def p_u8(a):
+    return None if a is None else a.ctypes.data_as(_pu8)

@@ -1,0 +1,36 @@
+"""Loader of the product library libdimn.so (HIP/gfx950).  Fails loudly: no fallback."""
+import ctypes as C
+import os
+
+from . import _cabi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdimn.so")
+_fns = None
+_lib = None
+
+
+def library():
+    """The loaded CDLL (for symbol checks)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "deepimpute_amd: %s is not built. Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (needs hipcc, --offload-arch=gfx950). There is no CPU fallback."
+                % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    return _lib
+
+
+def load():
+    """Bound function table of libdimn.so; raises ImportError if missing or ABI-mismatched."""
+    global _fns
+    if _fns is None:
+        fns = _cabi.bind(library(), "dimn_", gpu=True)
+        ver = fns["abi_version"]()
+        if ver != _cabi.ABI_VERSION:
+            raise ImportError("libdimn.so ABI version %d != expected %d; rebuild it"
+                              % (ver, _cabi.ABI_VERSION))
+        _fns = fns
+    return _fns

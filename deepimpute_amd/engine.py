@@ -1,0 +1,218 @@
+"""Host-side handle for one group of sub-networks living on one GPU.
+
+`Engine` is a thin, arithmetic-free Python face of the C ABI in include/dimn.h: it owns a
+`dimn_handle` and marshals numpy arrays.  It stands where the reference holds its Keras
+`Model` (deepimpute/multinet.py:226 `model = self.build(...)`, :238 `model.fit`, :253/:278
+`model.predict`).  `HipEngine` binds the product library libdimn.so and raises if it is
+missing -- there is no CPU fallback in the product.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _cabi
+from ._cabi import Config, f32, i32, p_f32, p_f64, p_i32, p_u8
+
+
+class DimnError(RuntimeError):
+    pass
+
+
+class Engine:
+    """Generic wrapper over a bound ABI function table (see `_cabi.bind`)."""
+
+    def __init__(self, fns, D, hidden, out_dim, batch_size=64, dropout_rate=0.2,
+                 learning_rate=1e-4, beta1=0.9, beta2=0.999, eps=1e-7, loss_binary=False,
+                 seed=1234, device_id=0, subnet_offset=0):
+        self._f = fns
+        self.D = [int(d) for d in D]
+        self.K = len(self.D)
+        self.H = int(hidden)
+        self.O = int(out_dim)
+        self.B = int(batch_size)
+        self.subnet_offset = int(subnet_offset)
+        self.cfg = Config(
+            n_subnets=self.K, subnet_offset=int(subnet_offset), hidden=self.H, out_dim=self.O,
+            batch_size=self.B, device_id=int(device_id), dropout_rate=float(dropout_rate),
+            learning_rate=float(learning_rate), beta1=float(beta1), beta2=float(beta2),
+            eps=float(eps), loss_binary=int(bool(loss_binary)), seed=int(seed))
+        self._h = C.c_void_p()
+        self.n_cells = 0
+        self.n_train = 0
+        self.n_val = 0
+        Darr = i32(self.D)
+        self._check(self._f["create"](C.byref(self.cfg), p_i32(Darr), C.byref(self._h)))
+
+    # -- plumbing ---------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._f["last_error"]()
+            raise DimnError("libdimn error %d: %s" % (rc, (msg or b"").decode("utf-8", "replace")))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._f["destroy"](self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data -------------------------------------------------------------
+    def set_matrix(self, norm):
+        norm = f32(norm)
+        if norm.ndim != 2:
+            raise ValueError("norm must be 2-D [cells, genes]")
+        self.n_cells, self.n_genes = norm.shape
+        self._check(self._f["set_matrix"](self._h, p_f32(norm), norm.shape[0], norm.shape[1]))
+
+    def set_indices(self, k, pred_idx, targ_idx):
+        pred_idx, targ_idx = i32(pred_idx), i32(targ_idx)
+        if targ_idx.size != self.O:
+            raise ValueError("targ_idx must have out_dim entries")
+        self._check(self._f["set_indices"](self._h, k, p_i32(pred_idx), pred_idx.size, p_i32(targ_idx)))
+
+    def gather(self, with_targets=True):
+        self._check(self._f["gather"](self._h, int(bool(with_targets))))
+
+    def set_split(self, train_rows, val_rows):
+        tr, va = i32(train_rows), i32(val_rows)
+        self.n_train, self.n_val = tr.size, va.size
+        self._check(self._f["set_split"](self._h, p_i32(tr), tr.size, p_i32(va), va.size))
+
+    # -- weights ----------------------------------------------------------
+    def init_weights(self, seed=None):
+        self._check(self._f["init_weights"](self._h, int(self.cfg.seed if seed is None else seed)))
+
+    def set_weights(self, k, W1, b1, W2, b2):
+        W1, b1, W2, b2 = f32(W1), f32(b1), f32(W2), f32(b2)
+        assert W1.shape == (self.D[k], self.H) and W2.shape == (self.H, self.O)
+        assert b1.shape == (self.H,) and b2.shape == (self.O,)
+        self._check(self._f["set_weights"](self._h, k, p_f32(W1), p_f32(b1), p_f32(W2), p_f32(b2)))
+
+    def _alloc_like_weights(self, k):
+        return (np.empty((self.D[k], self.H), np.float32), np.empty(self.H, np.float32),
+                np.empty((self.H, self.O), np.float32), np.empty(self.O, np.float32))
+
+    def get_weights(self, k):
+        W1, b1, W2, b2 = self._alloc_like_weights(k)
+        self._check(self._f["get_weights"](self._h, k, p_f32(W1), p_f32(b1), p_f32(W2), p_f32(b2)))
+        return W1, b1, W2, b2
+
+    def get_adam_state(self, k, which):
+        W1, b1, W2, b2 = self._alloc_like_weights(k)
+        self._check(self._f["get_adam_state"](self._h, k, int(which), p_f32(W1), p_f32(b1),
+                                              p_f32(W2), p_f32(b2)))
+        return W1, b1, W2, b2
+
+    def reset_optimizer(self):
+        self._check(self._f["reset_optimizer"](self._h))
+
+    def step_count(self):
+        t = C.c_int64()
+        self._check(self._f["get_step_count"](self._h, C.byref(t)))
+        return t.value
+
+    # -- training / inference --------------------------------------------
+    def train_step(self, rows, keep_mask=None, epoch_key=0, step_key=0, want_loss=True):
+        rows = i32(rows)
+        if keep_mask is not None:
+            keep_mask = np.ascontiguousarray(keep_mask, dtype=np.uint8)
+            assert keep_mask.shape == (self.K, rows.size, self.H)
+        loss = np.empty(self.K, np.float32) if want_loss else None
+        self._check(self._f["train_step"](self._h, p_i32(rows), rows.size, p_u8(keep_mask),
+                                          int(epoch_key), int(step_key), p_f32(loss)))
+        return loss
+
+    def train_epoch(self, epoch, perm=None):
+        perm = None if perm is None else i32(perm)
+        loss = np.empty(self.K, np.float64)
+        self._check(self._f["train_epoch"](self._h, int(epoch), p_i32(perm), p_f64(loss)))
+        return loss
+
+    def val_loss(self):
+        v = np.empty(self.K, np.float64)
+        self._check(self._f["val_loss"](self._h, p_f64(v)))
+        return v
+
+    def fit(self, max_epochs, patience):
+        lh = np.zeros(max_epochs, np.float64)
+        vh = np.zeros(max_epochs, np.float64)
+        n = C.c_int32()
+        self._check(self._f["fit"](self._h, int(max_epochs), int(patience), p_f64(lh), p_f64(vh),
+                                   C.byref(n)))
+        return n.value, lh[:n.value], vh[:n.value]
+
+    def predict(self, rows=None, n_rows=None):
+        if rows is not None:
+            rows = i32(rows)
+            n_rows = rows.size
+        elif n_rows is None:
+            n_rows = self.n_cells
+        out = np.empty((n_rows, self.K * self.O), np.float32)
+        self._check(self._f["predict"](self._h, p_i32(rows), n_rows, p_f32(out)))
+        return out
+
+    def epoch_permutation(self, epoch, n=None, seed=None):
+        n = self.n_train if n is None else n
+        perm = np.empty(n, np.int32)
+        self._check(self._f["epoch_permutation"](int(self.cfg.seed if seed is None else seed),
+                                                 int(epoch), n, p_i32(perm)))
+        return perm
+
+
+class HipEngine(Engine):
+    """Engine on libdimn.so (hand-written HIP kernels for gfx950).  Raises ImportError-like
+    `DimnError` when the library is not built: the product never falls back to a CPU path."""
+
+    def __init__(self, D, hidden, out_dim, **kw):
+        from ._lib import load
+        super().__init__(load(), D, hidden, out_dim, **kw)
+
+    def predict_device(self, rows=None, n_rows=None):
+        if rows is not None:
+            rows = i32(rows)
+            n_rows = rows.size
+        elif n_rows is None:
+            n_rows = self.n_cells
+        ptr = C.c_void_p()
+        self._check(self._f["predict_device"](self._h, p_i32(rows), n_rows, C.byref(ptr)))
+        return ptr.value
+
+    def synchronize(self):
+        self._check(self._f["synchronize"](self._h))
+
+    def set_profiling(self, on):
+        self._check(self._f["set_profiling"](self._h, int(bool(on))))
+
+    def get_timers(self, reset=True):
+        out = np.zeros(4, np.float64)
+        self._check(self._f["get_timers"](self._h, p_f64(out), int(bool(reset))))
+        return out
+
+    # RCCL -------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = np.zeros(_cabi.COMM_ID_BYTES, np.uint8)
+        self._check(self._f["comm_unique_id"](p_u8(buf)))
+        return buf
+
+    def comm_init(self, uid, n_ranks, rank):
+        uid = np.ascontiguousarray(uid, dtype=np.uint8)
+        self._check(self._f["comm_init"](self._h, p_u8(uid), int(n_ranks), int(rank)))
+
+    def comm_allreduce_sum(self, vec):
+        v = np.ascontiguousarray(vec, dtype=np.float64).copy()
+        self._check(self._f["comm_allreduce_sum"](self._h, p_f64(v), v.size))
+        return v
+
+    def comm_gather_predictions(self, n_rows, counts, root=0, is_root=False):
+        counts = i32(counts)
+        out = np.empty((n_rows, int(counts.sum()) * self.O), np.float32) if is_root else None
+        self._check(self._f["comm_gather_predictions"](self._h, n_rows, p_i32(counts), int(root),
+                                                       p_f32(out)))
+        return out
+
+    def comm_destroy(self):
+        self._check(self._f["comm_destroy"](self._h))

@@ -1,0 +1,173 @@
+/*
+ * dimn.h -- C ABI of libdimn, the MI355X-native replacement for the Keras/TensorFlow
+ * seam of DeepImpute's MultiNet (K independent Dense->Dropout->Dense sub-networks,
+ * wMSE loss, Keras-form Adam, global early stopping).
+ *
+ * The reference (lanagarmire/deepimpute) has NO FFI/plugin interface: its hot path is the
+ * eight Keras calls multinet.py makes.  Every entry point below names the reference
+ * call(s) it replaces (file:line into the reference tree).  Host code (Python, numpy
+ * only) binds these through ctypes; see INTEGRATION.md for the binding a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; the caller owns every host buffer; the library copies in /
+ *     writes into caller-allocated outputs and never keeps a host pointer past the call.
+ *   - every function returns 0 on success, <0 on error; dimn_last_error() gives the
+ *     message (thread-local).  No exceptions cross the ABI, nothing calls exit().
+ *   - a handle is bound to ONE GPU (cfg.device_id) and is not thread-safe.
+ *   - weights cross the ABI in Keras layout: kernel W[in][out] row-major fp32, bias[out].
+ *   - all arithmetic is fp32 (reference: multinet.py:217,273 cast to float32; Keras
+ *     default floatx) on the f32 MFMA path of gfx950.
+ */
+#ifndef DIMN_H
+#define DIMN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIMN_OK 0
+#define DIMN_ERR_ARG (-1)     /* bad argument / call order            */
+#define DIMN_ERR_HIP (-2)     /* HIP runtime error (message has code) */
+#define DIMN_ERR_STATE (-3)   /* object not ready (missing set_* call)*/
+#define DIMN_ERR_UNSUP (-4)   /* configuration not supported          */
+#define DIMN_ERR_COMM (-5)    /* RCCL error                           */
+
+#define DIMN_MAX_BATCH 64     /* rows per optimiser step handled by one MFMA row tile */
+
+typedef struct dimn_handle_s* dimn_handle;
+
+/*
+ * Hyper-parameters of one group of sub-networks.  Replaces the arguments of
+ * MultiNet.build() (multinet.py:126-167): Dense(hidden, relu) -> Dropout(rate, seed)
+ * -> Dense(out_dim, softplus), compiled with keras.optimizers.Adam(lr) and wMSE
+ * (multinet.py:36-41,164-165).  beta1/beta2/eps are Keras's Adam defaults
+ * (0.9, 0.999, 1e-7; eps OUTSIDE the bias correction).
+ */
+typedef struct dimn_config {
+    int32_t n_subnets;        /* K_local: sub-networks owned by this handle             */
+    int32_t subnet_offset;    /* global index of local sub-net 0 (RNG keys use the
+                                 global index, so results do not depend on sharding)    */
+    int32_t hidden;           /* H  (architecture[0].neurons, multinet.py:101)          */
+    int32_t out_dim;          /* O  (sub_outputdim, multinet.py:75)                     */
+    int32_t batch_size;       /* B  (multinet.py:69); 1..DIMN_MAX_BATCH                 */
+    int32_t device_id;        /* HIP device ordinal                                     */
+    float dropout_rate;       /* p  (architecture[1].rate, multinet.py:102); 0 = none   */
+    float learning_rate;      /* multinet.py:68                                         */
+    float beta1, beta2, eps;  /* Keras Adam                                             */
+    int32_t loss_binary;      /* wMSE(binary=True) weights 1[y>0] (multinet.py:37-38)   */
+    uint64_t seed;            /* multinet.py:77; keys the Philox streams                */
+} dimn_config;
+
+const char* dimn_last_error(void);
+/* ABI version; bumped on any signature change. */
+int dimn_abi_version(void);
+
+/* build(inputdims) (multinet.py:126-148,226): D[k] = predictor count of sub-net k. */
+int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle* out);
+int dimn_destroy(dimn_handle h);
+
+/*
+ * The shared log1p matrix (multinet.py:217 `norm_data`, :271 `norm_raw`), row-major
+ * [n_cells][n_genes] fp32.  Copied to HBM once; replaces the K pairs of pandas
+ * `.loc[cells, genes].values` host copies (multinet.py:231-235, 273-274).
+ */
+int dimn_set_matrix(dimn_handle h, const float* norm, int64_t n_cells, int64_t n_genes);
+/* Column lists of sub-net k: predictors (multinet.py:362) and targets (:338-342),
+ * as column indices into the matrix. */
+int dimn_set_indices(dimn_handle h, int32_t k, const int32_t* pred_idx, int32_t D_k,
+                     const int32_t* targ_idx /* [O] */);
+/* Device gather of X_k[n][D_k] and (with_targets) Y_k[n][O] for every sub-net from the
+ * shared matrix.  Must follow set_matrix + all set_indices. */
+int dimn_gather(dimn_handle h, int32_t with_targets);
+/* train_cells / test_cells (multinet.py:228-229) as row indices into the matrix. */
+int dimn_set_split(dimn_handle h, const int32_t* train_rows, int64_t n_train,
+                   const int32_t* val_rows, int64_t n_val);
+
+/* Glorot-uniform kernels, zero biases (Keras Dense defaults, multinet.py:137,145),
+ * Philox stream keyed by (seed, global sub-net, layer, element); zeroes Adam state. */
+int dimn_init_weights(dimn_handle h, uint64_t seed);
+/* Keras-layout weight I/O (replaces model.save_weights / load_weights,
+ * multinet.py:114,122).  set_weights leaves Adam state untouched. */
+int dimn_set_weights(dimn_handle h, int32_t k, const float* W1 /*[D_k][H]*/,
+                     const float* b1 /*[H]*/, const float* W2 /*[H][O]*/,
+                     const float* b2 /*[O]*/);
+int dimn_get_weights(dimn_handle h, int32_t k, float* W1, float* b1, float* W2, float* b2);
+/* Adam moments (which: 0 = m, 1 = v) in the same layout; test/checkpoint hook. */
+int dimn_get_adam_state(dimn_handle h, int32_t k, int32_t which, float* W1, float* b1,
+                        float* W2, float* b2);
+int dimn_reset_optimizer(dimn_handle h);
+/* Adam step counter t (shared by all variables, as in Keras). */
+int dimn_get_step_count(dimn_handle h, int64_t* t);
+
+/*
+ * One optimiser step on an injected batch (the body of model.fit's inner loop,
+ * multinet.py:238-244): forward, wMSE, backward, Adam for every local sub-net.
+ *   rows      [b_act] matrix row indices, b_act <= batch_size
+ *   keep_mask NULL -> Philox mask keyed (seed, epoch_key, step_key, sub-net, b, h);
+ *             else uint8 [K_local][b_act][H], 1 = keep (test hook)
+ *   loss_out  NULL or [K_local]: wMSE of this batch per sub-net
+ */
+int dimn_train_step(dimn_handle h, const int32_t* rows, int32_t b_act,
+                    const uint8_t* keep_mask, int32_t epoch_key, int32_t step_key,
+                    float* loss_out);
+/*
+ * One epoch of model.fit (multinet.py:238-244): one permutation of the train rows shared
+ * by all sub-nets, batches of batch_size including the last partial one.
+ *   perm        NULL -> dimn_epoch_permutation(seed, epoch); else [n_train] permutation
+ *   train_loss  NULL or [K_local]: sample-weighted mean of the batch losses
+ */
+int dimn_train_epoch(dimn_handle h, int32_t epoch, const int32_t* perm, double* train_loss);
+/* Validation pass (no dropout): val_loss[k] = mean over n_val*O elements of w*(y-yhat)^2. */
+int dimn_val_loss(dimn_handle h, double* val_loss /* [K_local] */);
+/*
+ * Whole model.fit(...) with EarlyStopping(monitor='val_loss', patience)
+ * (multinet.py:238-246) for a single-rank job: strict-< improvement on the SUM over
+ * sub-nets, stop after `patience` consecutive non-improving epochs, last-epoch weights.
+ *   loss_hist/val_hist  NULL or [max_epochs]
+ */
+int dimn_fit(dimn_handle h, int32_t max_epochs, int32_t patience, double* loss_hist,
+             double* val_hist, int32_t* epochs_run);
+
+/*
+ * model.predict(X_list) (multinet.py:253,278-280): forward only, dropout = identity.
+ *   rows  NULL -> all matrix rows 0..n_rows-1; else [n_rows] row indices
+ *   out   host [n_rows][K_local*O] row-major = np.hstack(predicted)
+ */
+int dimn_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out);
+/* Same, result left in HBM; *dev_out stays valid until the next predict/destroy. */
+int dimn_predict_device(dimn_handle h, const int32_t* rows, int64_t n_rows, void** dev_out);
+
+/* The epoch permutation the library uses when perm == NULL (host Fisher-Yates over a
+ * Philox stream); exported so callers/tests can reproduce the batch order. */
+int dimn_epoch_permutation(uint64_t seed, int32_t epoch, int64_t n, int32_t* perm_out);
+
+/* Wait for all queued GPU work of this handle. */
+int dimn_synchronize(dimn_handle h);
+/* Times (ms, HIP events on the handle's own stream) accumulated since the last call with
+ * reset != 0: [0] train-step kernels, [1] number of train steps, [2] w1-update kernel ms,
+ * [3] w1-update launches.  Used by bench.py for the live roofline figure. */
+int dimn_get_timers(dimn_handle h, double* out4, int32_t reset);
+int dimn_set_profiling(dimn_handle h, int32_t on);
+
+/* ---- multi-GPU: sub-nets sharded over ranks, RCCL over xGMI (no reference analogue:
+ * the reference is single-process, multinet.py:222-223 only sets TF CPU threads) ---- */
+#define DIMN_COMM_ID_BYTES 128
+int dimn_comm_unique_id(uint8_t* id /* [DIMN_COMM_ID_BYTES] */);
+int dimn_comm_init(dimn_handle h, const uint8_t* id, int32_t n_ranks, int32_t rank);
+/* In-place sum over ranks of a small host vector (per-epoch val-loss for the global
+ * early-stopping decision, multinet.py:242-243). */
+int dimn_comm_allreduce_sum(dimn_handle h, double* v, int32_t n);
+/* Gather the last dimn_predict_device result of every rank into root's host buffer
+ * out[n_rows][K_global*O] (column block of rank r at r's subnet_offset*O);
+ * counts[r] = K_local of rank r.  ncclSend/ncclRecv straight to root over xGMI. */
+int dimn_comm_gather_predictions(dimn_handle h, int64_t n_rows, const int32_t* counts,
+                                 int32_t root, float* out);
+int dimn_comm_destroy(dimn_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIMN_H */

@@ -1,0 +1,35 @@
+"""ctypes face of the CPU oracle (oracle/dimo.c).  TEST INFRASTRUCTURE ONLY: imported by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by deepimpute_amd."""
+import ctypes as C
+import os
+import subprocess
+
+from deepimpute_amd import _cabi
+from deepimpute_amd.engine import Engine
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_cache = {}
+
+
+def build(quiet=True):
+    subprocess.check_call(["make", "-C", _HERE] + (["-s"] if quiet else []))
+
+
+def _load(fp64=False, path=None):
+    name = path or os.path.join(_HERE, "libdimo64.so" if fp64 else "libdimo.so")
+    if name not in _cache:
+        if not os.path.exists(name):
+            build()
+        lib = C.CDLL(name)
+        fns = _cabi.bind(lib, "dimo_", gpu=False)
+        lib.dimo_real_bytes.restype = C.c_int
+        assert lib.dimo_real_bytes() == (8 if fp64 else 4)
+        _cache[name] = fns
+    return _cache[name]
+
+
+class OracleEngine(Engine):
+    """Same Python face as HipEngine, running the plain-loop C restatement on the CPU."""
+
+    def __init__(self, D, hidden, out_dim, fp64=False, lib_path=None, **kw):
+        super().__init__(_load(fp64, lib_path), D, hidden, out_dim, **kw)

@@ -1,0 +1,64 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_kat():
+    return np.load(os.path.join(GOLDEN, "kat_steps.npz"))
+
+
+def kat_engine(cls, kat, **kw):
+    """Build an engine of class `cls` loaded with the KAT problem (weights injected)."""
+    Ds = [int(d) for d in kat["Ds"]]
+    eng = cls(Ds, int(kat["H"]), int(kat["O"]), batch_size=int(kat["B"]),
+              dropout_rate=float(kat["p"]), learning_rate=float(kat["lr"]),
+              beta1=float(kat["beta1"]), beta2=float(kat["beta2"]), eps=float(kat["eps"]),
+              seed=7, **kw)
+    eng.set_matrix(kat["norm"])
+    for k in range(len(Ds)):
+        eng.set_indices(k, kat["pred%d" % k], kat["targ%d" % k])
+    eng.gather(True)
+    n = kat["norm"].shape[0]
+    val = kat["val_rows"]
+    train = np.setdiff1d(np.arange(n, dtype=np.int32), val).astype(np.int32)
+    eng.set_split(train, val)
+    eng.reset_optimizer()
+    for k in range(len(Ds)):
+        eng.set_weights(k, kat["W1_%d" % k], kat["b1_%d" % k], kat["W2_%d" % k], kat["b2_%d" % k])
+    return eng
+
+
+def run_kat_steps(eng, kat):
+    losses = []
+    for t in range(3):
+        losses.append(eng.train_step(kat["rows_%d" % t], keep_mask=kat["mask_%d" % t]))
+    return np.array(losses)  # [3][K]
+
+
+def check_kat(eng, kat, rtol, atol):
+    """Run the three KAT steps on `eng` and compare everything with the stored answers."""
+    K = len(kat["Ds"])
+    losses = run_kat_steps(eng, kat)
+    for k in range(K):
+        np.testing.assert_allclose(losses[:, k], kat["loss_%d" % k], rtol=rtol, atol=atol)
+    assert eng.step_count() == 3
+    vl = eng.val_loss()
+    pred = eng.predict()
+    for k in range(K):
+        W = eng.get_weights(k)
+        M = eng.get_adam_state(k, 0)
+        V = eng.get_adam_state(k, 1)
+        for i, name in enumerate(("W1", "b1", "W2", "b2")):
+            np.testing.assert_allclose(W[i], kat["out_%s_%d" % (name, k)], rtol=rtol, atol=atol,
+                                       err_msg="weights %s k=%d" % (name, k))
+            np.testing.assert_allclose(M[i], kat["m_%s_%d" % (name, k)], rtol=rtol, atol=atol * 1e-2,
+                                       err_msg="adam m %s k=%d" % (name, k))
+            np.testing.assert_allclose(V[i], kat["v_%s_%d" % (name, k)], rtol=rtol, atol=atol * 1e-4,
+                                       err_msg="adam v %s k=%d" % (name, k))
+        O = int(kat["O"])
+        np.testing.assert_allclose(pred[:, k * O:(k + 1) * O], kat["pred_all_%d" % k], rtol=rtol,
+                                   atol=atol, err_msg="predict k=%d" % k)
+        np.testing.assert_allclose(vl[k], kat["val_loss_%d" % k], rtol=rtol)
