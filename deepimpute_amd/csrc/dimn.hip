@@ -1,0 +1,816 @@
+// dimn.hip -- host side of libdimn: the C ABI of include/dimn.h on top of the gfx950 kernels
+// in dimn_kernels.h.  One handle = one GPU = one HIP stream; RCCL is bound lazily (dlopen).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/dimn.h"
+#include "dimn_kernels.h"
+
+#define DIMN_ABI_VERSION 1
+
+static thread_local char g_err[1024];
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(DIMN_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define CHK(expr)              \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_) return rc_;   \
+    } while (0)
+
+extern "C" const char* dimn_last_error(void) { return g_err; }
+extern "C" int dimn_abi_version(void) { return DIMN_ABI_VERSION; }
+
+// ---- RCCL, bound at first use so that the library loads on machines without it ----------
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+static Rccl g_rccl;
+static int rccl_bind() {
+    if (g_rccl.lib) return DIMN_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* n : names)
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!lib) return fail(DIMN_ERR_COMM, "cannot dlopen librccl: %s", dlerror());
+#define BIND(field, sym)                                                         \
+    *(void**)(&g_rccl.field) = dlsym(lib, sym);                                  \
+    if (!g_rccl.field) return fail(DIMN_ERR_COMM, "librccl lacks symbol %s", sym)
+    BIND(GetUniqueId, "ncclGetUniqueId");
+    BIND(CommInitRank, "ncclCommInitRank");
+    BIND(CommDestroy, "ncclCommDestroy");
+    BIND(AllReduce, "ncclAllReduce");
+    BIND(Send, "ncclSend");
+    BIND(Recv, "ncclRecv");
+    BIND(GroupStart, "ncclGroupStart");
+    BIND(GroupEnd, "ncclGroupEnd");
+    BIND(GetErrorString, "ncclGetErrorString");
+#undef BIND
+    g_rccl.lib = lib;
+    return DIMN_OK;
+}
+#define NCCLCHK(expr)                                                                          \
+    do {                                                                                       \
+        int r_ = (expr);                                                                       \
+        if (r_ != 0) return fail(DIMN_ERR_COMM, "%s failed: %s", #expr, g_rccl.GetErrorString(r_)); \
+    } while (0)
+enum { kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0 };
+
+// ---- handle --------------------------------------------------------------------------------
+struct dimn_handle_s {
+    dimn_config cfg;
+    Dims dm;
+    int K, H, O, B, NT, OTW, HS;   // NT hidden tiles per wave; OTW out tiles per wave; HS = ceil(HT/2)
+    int ncu = 256;
+    std::vector<SubnetDev> sn;
+    std::vector<Work> work;
+    std::vector<std::vector<int32_t>> pred, targ;
+    int nslots = 0;
+    int64_t w1_total = 0, x_total = 0;
+    int64_t n = 0, g = 0, n_tr = 0, n_val = 0;
+    bool gathered = false, gathered_targets = false, have_idx = false;
+    // device
+    SubnetDev* d_sn = nullptr; Work* d_work = nullptr;
+    float *d_norm = nullptr, *d_X = nullptr, *d_Y = nullptr;
+    int32_t *d_pred = nullptr, *d_targ = nullptr; int64_t* d_pred_off = nullptr;
+    float *d_W1 = nullptr, *d_M1 = nullptr, *d_V1 = nullptr;
+    float *d_W2 = nullptr, *d_M2 = nullptr, *d_V2 = nullptr;
+    float *d_b1 = nullptr, *d_b2 = nullptr;   // [3][K][Hp|Op]: w, m, v
+    float *d_P = nullptr, *d_Dd = nullptr, *d_dZ = nullptr, *d_dA = nullptr;
+    float* d_loss_step = nullptr; double* d_loss_acc = nullptr;
+    uint8_t* d_mask = nullptr;
+    int32_t *d_rows_step = nullptr, *d_epoch_rows = nullptr, *d_val_rows = nullptr, *d_pred_rows = nullptr;
+    int64_t pred_rows_cap = 0;
+    std::vector<int32_t> train_rows, val_rows;
+    float* d_out = nullptr; int64_t out_cap = 0; int64_t out_rows = 0;
+    float* d_loss_part = nullptr; int64_t loss_part_cap = 0;
+    hipStream_t stream = nullptr;
+    int64_t t = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;   // pairs around k_w1_update, plus step brackets
+    size_t ev_used = 0;
+    double tm_step_ms = 0, tm_w1_ms = 0; int64_t tm_steps = 0, tm_w1 = 0;
+    // comm
+    ncclComm_t comm = nullptr; int n_ranks = 1, rank = 0;
+};
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+static int use_device(dimn_handle h) {
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    return DIMN_OK;
+}
+
+template <typename T>
+static int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIPCHK(hipMalloc((void**)p, count * sizeof(T)));
+    return DIMN_OK;
+}
+#define DEV_FREE(p)            \
+    do {                       \
+        if (p) (void)hipFree(p); \
+        p = nullptr;           \
+    } while (0)
+
+static void build_work(dimn_handle h) {
+    // Split every sub-net's chunk range into slices so that the whole job is ~2 workgroups
+    // per CU of near-equal bytes (the kernels are HBM-bound; balance = bandwidth).
+    int64_t total_chunks = 0;
+    for (auto& s : h->sn) total_chunks += s.nchunk;
+    const int target_wgs = h->ncu * 2;
+    const int per = (int)std::max<int64_t>(1, (total_chunks + target_wgs - 1) / target_wgs);
+    h->work.clear();
+    int slot = 0;
+    for (int k = 0; k < h->K; ++k) {
+        SubnetDev& s = h->sn[k];
+        const int ns = std::max(1, ceil_div(s.nchunk, per));
+        s.slot0 = slot;
+        s.nslice = ns;
+        for (int i = 0; i < ns; ++i) {
+            Work w;
+            w.k = k;
+            w.c0 = (int)((int64_t)s.nchunk * i / ns);
+            w.c1 = (int)((int64_t)s.nchunk * (i + 1) / ns);
+            w.slot = slot++;
+            h->work.push_back(w);
+        }
+    }
+    h->nslots = slot;
+}
+
+extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle* out) {
+    if (!cfg || !D || !out) return fail(DIMN_ERR_ARG, "dimn_create: null argument");
+    if (cfg->n_subnets < 1 || cfg->hidden < 1 || cfg->out_dim < 1)
+        return fail(DIMN_ERR_ARG, "dimn_create: n_subnets/hidden/out_dim must be >= 1");
+    if (cfg->batch_size < 1 || cfg->batch_size > DIMN_MAX_BATCH)
+        return fail(DIMN_ERR_UNSUP, "dimn_create: batch_size %d not in 1..%d", cfg->batch_size, DIMN_MAX_BATCH);
+    if (!(cfg->dropout_rate >= 0.f && cfg->dropout_rate < 1.f))
+        return fail(DIMN_ERR_ARG, "dimn_create: dropout_rate must be in [0,1)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(DIMN_ERR_HIP, "dimn_create: no HIP device visible (libdimn has no CPU fallback)");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev)
+        return fail(DIMN_ERR_ARG, "dimn_create: device_id %d out of range (%d devices)", cfg->device_id, ndev);
+
+    dimn_handle h = new dimn_handle_s();
+    h->cfg = *cfg;
+    h->K = cfg->n_subnets; h->H = cfg->hidden; h->O = cfg->out_dim; h->B = cfg->batch_size;
+    Dims& dm = h->dm;
+    dm.K = h->K; dm.H = h->H; dm.O = h->O;
+    dm.Hp = ceil_div(h->H, 16) * 16; dm.HT = dm.Hp / 16;
+    dm.Op = ceil_div(h->O, 16) * 16; dm.OT = dm.Op / 16;
+    dm.ldd = dm.Hp + ((dm.Hp % 32 == 0) ? 2 : 18);   // LDS row stride = 2 (mod 32) words: conflict-free b32 column reads
+    dm.OS = ceil_div(dm.OT, 4);
+    h->NT = ceil_div(dm.HT, 4);
+    h->OTW = ceil_div(dm.OT, 4);
+    h->HS = ceil_div(dm.HT, 2);
+    if (h->NT > 6) {
+        delete h;
+        return fail(DIMN_ERR_UNSUP, "dimn_create: hidden=%d > 384 not supported by the gfx950 kernels yet", cfg->hidden);
+    }
+    if ((size_t)DIMN_TB * dm.ldd * sizeof(float) > 160 * 1024) {
+        delete h;
+        return fail(DIMN_ERR_UNSUP, "dimn_create: hidden too large for LDS staging");
+    }
+    hipDeviceProp_t prop;
+    if (hipSetDevice(cfg->device_id) != hipSuccess || hipGetDeviceProperties(&prop, cfg->device_id) != hipSuccess) {
+        delete h;
+        return fail(DIMN_ERR_HIP, "dimn_create: cannot select device %d", cfg->device_id);
+    }
+    h->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+    h->sn.resize(h->K);
+    h->pred.resize(h->K); h->targ.resize(h->K);
+    int64_t w1 = 0;
+    for (int k = 0; k < h->K; ++k) {
+        if (D[k] < 1) { delete h; return fail(DIMN_ERR_ARG, "dimn_create: D[%d] < 1", k); }
+        SubnetDev& s = h->sn[k];
+        s.D = D[k]; s.Dp = ceil_div(D[k], 16) * 16; s.nchunk = s.Dp / 16;
+        s.kg = cfg->subnet_offset + k;
+        s.xoff = 0;
+        s.w1off = w1;
+        s.lim1 = (float)sqrt(6.0 / ((double)s.D + h->H));
+        s.lim2 = (float)sqrt(6.0 / ((double)h->H + h->O));
+        w1 += (int64_t)s.Dp * dm.Hp;
+    }
+    h->w1_total = w1;
+    build_work(h);
+
+    const size_t w2n = (size_t)h->K * dm.Hp * dm.Op;
+#define TRY(expr) do { int rc_ = (expr); if (rc_) { dimn_destroy(h); return rc_; } } while (0)
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(DIMN_ERR_HIP, "dimn_create: hipStreamCreate failed");
+    }
+    TRY(dev_alloc(&h->d_sn, (size_t)h->K));
+    TRY(dev_alloc(&h->d_work, h->work.size()));
+    TRY(dev_alloc(&h->d_W1, (size_t)w1)); TRY(dev_alloc(&h->d_M1, (size_t)w1)); TRY(dev_alloc(&h->d_V1, (size_t)w1));
+    TRY(dev_alloc(&h->d_W2, w2n)); TRY(dev_alloc(&h->d_M2, w2n)); TRY(dev_alloc(&h->d_V2, w2n));
+    TRY(dev_alloc(&h->d_b1, (size_t)3 * h->K * dm.Hp)); TRY(dev_alloc(&h->d_b2, (size_t)3 * h->K * dm.Op));
+    TRY(dev_alloc(&h->d_P, (size_t)h->nslots * DIMN_TB * dm.Hp));
+    TRY(dev_alloc(&h->d_Dd, (size_t)h->K * DIMN_TB * dm.Hp));
+    TRY(dev_alloc(&h->d_dA, (size_t)h->K * DIMN_TB * dm.Hp));
+    TRY(dev_alloc(&h->d_dZ, (size_t)h->K * DIMN_TB * dm.Op));
+    TRY(dev_alloc(&h->d_loss_step, (size_t)h->K * dm.OS));
+    TRY(dev_alloc(&h->d_loss_acc, (size_t)h->K * dm.OS));
+    TRY(dev_alloc(&h->d_mask, (size_t)h->K * DIMN_TB * dm.Hp));
+    TRY(dev_alloc(&h->d_rows_step, (size_t)DIMN_TB));
+    auto zero = [&](void* p, size_t bytes) { return hipMemset(p, 0, bytes) == hipSuccess ? 0 : fail(DIMN_ERR_HIP, "hipMemset failed"); };
+    TRY(zero(h->d_W1, w1 * 4)); TRY(zero(h->d_M1, w1 * 4)); TRY(zero(h->d_V1, w1 * 4));
+    TRY(zero(h->d_W2, w2n * 4)); TRY(zero(h->d_M2, w2n * 4)); TRY(zero(h->d_V2, w2n * 4));
+    TRY(zero(h->d_b1, (size_t)3 * h->K * dm.Hp * 4)); TRY(zero(h->d_b2, (size_t)3 * h->K * dm.Op * 4));
+    TRY(zero(h->d_Dd, (size_t)h->K * DIMN_TB * dm.Hp * 4)); TRY(zero(h->d_dA, (size_t)h->K * DIMN_TB * dm.Hp * 4));
+    TRY(zero(h->d_dZ, (size_t)h->K * DIMN_TB * dm.Op * 4));
+    if (hipMemcpy(h->d_work, h->work.data(), h->work.size() * sizeof(Work), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_sn, h->sn.data(), h->sn.size() * sizeof(SubnetDev), hipMemcpyHostToDevice) != hipSuccess) {
+        dimn_destroy(h);
+        return fail(DIMN_ERR_HIP, "dimn_create: descriptor upload failed");
+    }
+#undef TRY
+    *out = h;
+    return DIMN_OK;
+}
+
+extern "C" int dimn_destroy(dimn_handle h) {
+    if (!h) return DIMN_OK;
+    (void)hipSetDevice(h->cfg.device_id);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    for (auto e : h->ev) (void)hipEventDestroy(e);
+    DEV_FREE(h->d_sn); DEV_FREE(h->d_work); DEV_FREE(h->d_norm); DEV_FREE(h->d_X); DEV_FREE(h->d_Y);
+    DEV_FREE(h->d_pred); DEV_FREE(h->d_targ); DEV_FREE(h->d_pred_off);
+    DEV_FREE(h->d_W1); DEV_FREE(h->d_M1); DEV_FREE(h->d_V1); DEV_FREE(h->d_W2); DEV_FREE(h->d_M2); DEV_FREE(h->d_V2);
+    DEV_FREE(h->d_b1); DEV_FREE(h->d_b2); DEV_FREE(h->d_P); DEV_FREE(h->d_Dd); DEV_FREE(h->d_dZ); DEV_FREE(h->d_dA);
+    DEV_FREE(h->d_loss_step); DEV_FREE(h->d_loss_acc); DEV_FREE(h->d_mask); DEV_FREE(h->d_rows_step);
+    DEV_FREE(h->d_epoch_rows); DEV_FREE(h->d_val_rows); DEV_FREE(h->d_pred_rows); DEV_FREE(h->d_out);
+    DEV_FREE(h->d_loss_part);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return DIMN_OK;
+}
+
+extern "C" int dimn_set_matrix(dimn_handle h, const float* norm, int64_t n, int64_t g) {
+    if (!h || !norm || n < 1 || g < 1) return fail(DIMN_ERR_ARG, "dimn_set_matrix: bad argument");
+    if (n > 0x7fffffffLL || g > 0x7fffffffLL) return fail(DIMN_ERR_UNSUP, "dimn_set_matrix: dimension exceeds int32");
+    CHK(use_device(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (n != h->n || g != h->g) {
+        DEV_FREE(h->d_norm);
+        CHK(dev_alloc(&h->d_norm, (size_t)n * g));
+        h->gathered = false;
+    }
+    HIPCHK(hipMemcpy(h->d_norm, norm, (size_t)n * g * sizeof(float), hipMemcpyHostToDevice));
+    h->n = n; h->g = g;
+    h->gathered = false;
+    return DIMN_OK;
+}
+
+extern "C" int dimn_set_indices(dimn_handle h, int32_t k, const int32_t* pred_idx, int32_t D_k, const int32_t* targ_idx) {
+    if (!h || k < 0 || k >= h->K || !pred_idx || !targ_idx) return fail(DIMN_ERR_ARG, "dimn_set_indices: bad argument");
+    if (D_k != h->sn[k].D) return fail(DIMN_ERR_ARG, "dimn_set_indices: D_k=%d differs from create() (%d)", D_k, h->sn[k].D);
+    h->pred[k].assign(pred_idx, pred_idx + D_k);
+    h->targ[k].assign(targ_idx, targ_idx + h->O);
+    h->gathered = false;
+    return DIMN_OK;
+}
+
+extern "C" int dimn_gather(dimn_handle h, int32_t with_targets) {
+    if (!h) return fail(DIMN_ERR_ARG, "dimn_gather: null handle");
+    if (!h->d_norm) return fail(DIMN_ERR_STATE, "dimn_gather: call dimn_set_matrix first");
+    for (int k = 0; k < h->K; ++k) {
+        if ((int)h->pred[k].size() != h->sn[k].D) return fail(DIMN_ERR_STATE, "dimn_gather: dimn_set_indices missing for sub-net %d", k);
+        for (int32_t c : h->pred[k]) if (c < 0 || c >= h->g) return fail(DIMN_ERR_ARG, "dimn_gather: predictor column %d out of range", c);
+        for (int32_t c : h->targ[k]) if (c < 0 || c >= h->g) return fail(DIMN_ERR_ARG, "dimn_gather: target column %d out of range", c);
+    }
+    CHK(use_device(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    // index lists
+    std::vector<int32_t> pflat, tflat;
+    std::vector<int64_t> poff(h->K);
+    for (int k = 0; k < h->K; ++k) {
+        poff[k] = (int64_t)pflat.size();
+        pflat.insert(pflat.end(), h->pred[k].begin(), h->pred[k].end());
+        tflat.insert(tflat.end(), h->targ[k].begin(), h->targ[k].end());
+    }
+    DEV_FREE(h->d_pred); DEV_FREE(h->d_targ); DEV_FREE(h->d_pred_off);
+    CHK(dev_alloc(&h->d_pred, pflat.size())); CHK(dev_alloc(&h->d_targ, tflat.size())); CHK(dev_alloc(&h->d_pred_off, (size_t)h->K));
+    HIPCHK(hipMemcpy(h->d_pred, pflat.data(), pflat.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_targ, tflat.data(), tflat.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_pred_off, poff.data(), poff.size() * 8, hipMemcpyHostToDevice));
+    // arenas
+    int64_t x = 0;
+    for (int k = 0; k < h->K; ++k) {
+        if ((int64_t)h->n * h->sn[k].Dp > 0xffffffffLL) return fail(DIMN_ERR_UNSUP, "dimn_gather: n*Dp exceeds 32-bit row offsets");
+        h->sn[k].xoff = x;
+        x += (int64_t)h->n * h->sn[k].Dp;
+    }
+    DEV_FREE(h->d_X);
+    CHK(dev_alloc(&h->d_X, (size_t)x));
+    h->x_total = x;
+    if (with_targets) {
+        DEV_FREE(h->d_Y);
+        CHK(dev_alloc(&h->d_Y, (size_t)h->K * h->n * h->dm.Op));
+    }
+    HIPCHK(hipMemcpy(h->d_sn, h->sn.data(), h->sn.size() * sizeof(SubnetDev), hipMemcpyHostToDevice));
+    dim3 grid((unsigned)h->K, (unsigned)std::min<int64_t>(h->n, 8192));
+    hipLaunchKernelGGL(k_gather, grid, dim3(256), 0, h->stream, h->d_sn, h->d_norm, h->n, h->g, h->d_pred, h->d_pred_off,
+                       h->d_targ, h->d_X, h->d_Y, h->dm, with_targets ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->gathered = true;
+    h->gathered_targets = with_targets != 0;
+    return DIMN_OK;
+}
+
+extern "C" int dimn_set_split(dimn_handle h, const int32_t* tr, int64_t n_tr, const int32_t* va, int64_t n_val) {
+    if (!h || n_tr < 0 || n_val < 0 || (n_tr > 0 && !tr) || (n_val > 0 && !va)) return fail(DIMN_ERR_ARG, "dimn_set_split: bad argument");
+    CHK(use_device(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->train_rows.assign(tr, tr + n_tr);
+    h->val_rows.assign(va, va + n_val);
+    DEV_FREE(h->d_epoch_rows); DEV_FREE(h->d_val_rows);
+    CHK(dev_alloc(&h->d_epoch_rows, (size_t)n_tr));
+    CHK(dev_alloc(&h->d_val_rows, (size_t)n_val));
+    if (n_val) HIPCHK(hipMemcpy(h->d_val_rows, va, (size_t)n_val * 4, hipMemcpyHostToDevice));
+    h->n_tr = n_tr; h->n_val = n_val;
+    return DIMN_OK;
+}
+
+static int zero_opt(dimn_handle h) {
+    const Dims& dm = h->dm;
+    const size_t w2n = (size_t)h->K * dm.Hp * dm.Op;
+    HIPCHK(hipMemsetAsync(h->d_M1, 0, (size_t)h->w1_total * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_V1, 0, (size_t)h->w1_total * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_M2, 0, w2n * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_V2, 0, w2n * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_b1 + (size_t)h->K * dm.Hp, 0, (size_t)2 * h->K * dm.Hp * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_b2 + (size_t)h->K * dm.Op, 0, (size_t)2 * h->K * dm.Op * 4, h->stream));
+    h->t = 0;
+    return DIMN_OK;
+}
+
+extern "C" int dimn_reset_optimizer(dimn_handle h) {
+    if (!h) return fail(DIMN_ERR_ARG, "null handle");
+    CHK(use_device(h));
+    CHK(zero_opt(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DIMN_OK;
+}
+
+extern "C" int dimn_init_weights(dimn_handle h, uint64_t seed) {
+    if (!h) return fail(DIMN_ERR_ARG, "null handle");
+    CHK(use_device(h));
+    const Dims& dm = h->dm;
+    HIPCHK(hipMemsetAsync(h->d_W1, 0, (size_t)h->w1_total * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_W2, 0, (size_t)h->K * dm.Hp * dm.Op * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_b1, 0, (size_t)h->K * dm.Hp * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_b2, 0, (size_t)h->K * dm.Op * 4, h->stream));
+    CHK(zero_opt(h));
+    hipLaunchKernelGGL(k_init_weights, dim3(256, (unsigned)h->K), dim3(256), 0, h->stream, h->d_sn, h->d_W1, h->d_W2, dm, seed);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DIMN_OK;
+}
+
+extern "C" int dimn_get_step_count(dimn_handle h, int64_t* t) {
+    if (!h || !t) return fail(DIMN_ERR_ARG, "null argument");
+    *t = h->t;
+    return DIMN_OK;
+}
+
+// ---- Keras-layout <-> blocked-layout weight I/O (host side; replaces save/load_weights) ----
+static int io_weights(dimn_handle h, int k, float* dW1, float* dB1, float* dW2, float* dB2, int bslot,
+                      float* W1, float* b1, float* W2, float* b2, bool to_device) {
+    const Dims& dm = h->dm;
+    const SubnetDev& s = h->sn[k];
+    const size_t n1 = (size_t)s.Dp * dm.Hp, n2 = (size_t)dm.Hp * dm.Op;
+    std::vector<float> t1(n1, 0.f), t2(n2, 0.f), tb1(dm.Hp, 0.f), tb2(dm.Op, 0.f);
+    float* p1 = dW1 + s.w1off;
+    float* p2 = dW2 + (size_t)k * n2;
+    float* pb1 = dB1 + ((size_t)bslot * h->K + k) * dm.Hp;
+    float* pb2 = dB2 + ((size_t)bslot * h->K + k) * dm.Op;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (!to_device) {
+        HIPCHK(hipMemcpy(t1.data(), p1, n1 * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(t2.data(), p2, n2 * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(tb1.data(), pb1, dm.Hp * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(tb2.data(), pb2, dm.Op * 4, hipMemcpyDeviceToHost));
+    }
+    for (int d = 0; d < s.D; ++d)
+        for (int j = 0; j < dm.H; ++j) {
+            float& blk = t1[((size_t)(d >> 4) * dm.Hp + j) * 16 + (d & 15)];
+            float& ker = W1[(size_t)d * dm.H + j];
+            if (to_device) blk = ker; else ker = blk;
+        }
+    for (int j = 0; j < dm.H; ++j)
+        for (int o = 0; o < dm.O; ++o) {
+            float& blk = t2[((size_t)(j >> 4) * dm.OT + (o >> 4)) * 256 + (j & 15) * 16 + (o & 15)];
+            float& ker = W2[(size_t)j * dm.O + o];
+            if (to_device) blk = ker; else ker = blk;
+        }
+    for (int j = 0; j < dm.H; ++j) { if (to_device) tb1[j] = b1[j]; else b1[j] = tb1[j]; }
+    for (int o = 0; o < dm.O; ++o) { if (to_device) tb2[o] = b2[o]; else b2[o] = tb2[o]; }
+    if (to_device) {
+        HIPCHK(hipMemcpy(p1, t1.data(), n1 * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(p2, t2.data(), n2 * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(pb1, tb1.data(), dm.Hp * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(pb2, tb2.data(), dm.Op * 4, hipMemcpyHostToDevice));
+    }
+    return DIMN_OK;
+}
+
+extern "C" int dimn_set_weights(dimn_handle h, int32_t k, const float* W1, const float* b1, const float* W2, const float* b2) {
+    if (!h || k < 0 || k >= h->K || !W1 || !b1 || !W2 || !b2) return fail(DIMN_ERR_ARG, "dimn_set_weights: bad argument");
+    CHK(use_device(h));
+    return io_weights(h, k, h->d_W1, h->d_b1, h->d_W2, h->d_b2, 0, (float*)W1, (float*)b1, (float*)W2, (float*)b2, true);
+}
+extern "C" int dimn_get_weights(dimn_handle h, int32_t k, float* W1, float* b1, float* W2, float* b2) {
+    if (!h || k < 0 || k >= h->K || !W1 || !b1 || !W2 || !b2) return fail(DIMN_ERR_ARG, "dimn_get_weights: bad argument");
+    CHK(use_device(h));
+    return io_weights(h, k, h->d_W1, h->d_b1, h->d_W2, h->d_b2, 0, W1, b1, W2, b2, false);
+}
+extern "C" int dimn_get_adam_state(dimn_handle h, int32_t k, int32_t which, float* W1, float* b1, float* W2, float* b2) {
+    if (!h || k < 0 || k >= h->K || which < 0 || which > 1 || !W1 || !b1 || !W2 || !b2)
+        return fail(DIMN_ERR_ARG, "dimn_get_adam_state: bad argument");
+    CHK(use_device(h));
+    return io_weights(h, k, which ? h->d_V1 : h->d_M1, h->d_b1, which ? h->d_V2 : h->d_M2, h->d_b2, 1 + which, W1, b1, W2, b2, false);
+}
+
+// ---- one optimiser step: F1 -> MF -> MB -> B1 on the handle's stream ----------------------
+static hipEvent_t next_event(dimn_handle h) {
+    if (h->ev_used == h->ev.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        h->ev.push_back(e);
+    }
+    return h->ev[h->ev_used++];
+}
+
+template <int NT>
+static void launch_fwd1(dimn_handle h, const int32_t* rows, int b_act) {
+    hipLaunchKernelGGL(k_fwd1<NT>, dim3((unsigned)h->work.size()), dim3(256), 0, h->stream, h->d_work, h->d_sn, h->d_X, h->d_W1,
+                       rows, b_act, h->d_P, h->dm);
+}
+template <int NT>
+static void launch_w1(dimn_handle h, const int32_t* rows, int b_act, AdamP ap) {
+    hipLaunchKernelGGL(k_w1_update<NT>, dim3((unsigned)h->work.size()), dim3(256), 0, h->stream, h->d_work, h->d_sn, h->d_X,
+                       h->d_W1, h->d_M1, h->d_V1, rows, b_act, h->d_dA, h->dm, ap);
+}
+template <int NT>
+static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out, float* loss_part) {
+    const unsigned tiles = (unsigned)((n_rows + DIMN_TB - 1) / DIMN_TB);
+    const size_t lds = (size_t)DIMN_TB * h->dm.ldd * sizeof(float);
+    hipLaunchKernelGGL(k_predict<NT>, dim3(tiles, (unsigned)h->K), dim3(256), lds, h->stream, h->d_sn, h->d_X, h->d_W1, h->d_b1,
+                       h->d_W2, h->d_b2, rows, n_rows, out, h->d_Y, h->n, loss_part, h->dm, h->cfg.loss_binary);
+}
+#define DISPATCH_NT(fn, ...)                          \
+    switch (h->NT) {                                  \
+        case 1: fn<1>(__VA_ARGS__); break;            \
+        case 2: fn<2>(__VA_ARGS__); break;            \
+        case 3: fn<3>(__VA_ARGS__); break;            \
+        case 4: fn<4>(__VA_ARGS__); break;            \
+        case 5: fn<5>(__VA_ARGS__); break;            \
+        default: fn<6>(__VA_ARGS__); break;           \
+    }
+
+static int step_launch(dimn_handle h, const int32_t* d_rows, int b_act, const uint8_t* d_mask, uint32_t epoch_key,
+                       uint32_t step_key, double* d_loss_acc) {
+    const Dims& dm = h->dm;
+    const int64_t t = h->t + 1;
+    AdamP ap;
+    const double b1 = h->cfg.beta1, b2 = h->cfg.beta2;
+    ap.alpha = (float)((double)h->cfg.learning_rate * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t)));
+    ap.omb1 = 1.0f - h->cfg.beta1;
+    ap.omb2 = 1.0f - h->cfg.beta2;
+    ap.eps = h->cfg.eps;
+    const float rate = h->cfg.dropout_rate;
+    const float scale = 1.0f / (1.0f - rate);
+    const float inv_n = (float)(1.0 / ((double)b_act * h->O));
+    const size_t kh = (size_t)h->K * dm.Hp, ko = (size_t)h->K * dm.Op;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (h->profiling) { e0 = next_event(h); e1 = next_event(h); e2 = next_event(h); (void)hipEventRecord(e0, h->stream); }
+
+    DISPATCH_NT(launch_fwd1, h, d_rows, b_act);
+    hipLaunchKernelGGL(k_mid_fwd, dim3((unsigned)dm.OS, (unsigned)h->K), dim3(256), (size_t)DIMN_TB * dm.ldd * sizeof(float), h->stream,
+                       h->d_sn, h->d_P, h->d_b1, h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, d_mask,
+                       h->d_Dd, h->d_dZ, h->d_loss_step, d_loss_acc, dm, ap, rate, scale, inv_n, h->cfg.loss_binary, h->cfg.seed,
+                       epoch_key, step_key);
+    hipLaunchKernelGGL(k_mid_bwd, dim3((unsigned)h->HS, (unsigned)h->K), dim3(256), 0, h->stream, h->d_Dd, h->d_dZ, h->d_W2, h->d_M2,
+                       h->d_V2, h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW);
+    if (h->profiling) (void)hipEventRecord(e1, h->stream);
+    DISPATCH_NT(launch_w1, h, d_rows, b_act, ap);
+    if (h->profiling) (void)hipEventRecord(e2, h->stream);
+    HIPCHK(hipGetLastError());
+    h->t = t;
+    return DIMN_OK;
+}
+
+static int collect_timers(dimn_handle h) {
+    // events are recorded as triples (step begin, before w1 update, step end)
+    for (size_t i = 0; i + 3 <= h->ev_used; i += 3) {
+        float a = 0, b = 0;
+        if (hipEventElapsedTime(&a, h->ev[i], h->ev[i + 2]) == hipSuccess &&
+            hipEventElapsedTime(&b, h->ev[i + 1], h->ev[i + 2]) == hipSuccess) {
+            h->tm_step_ms += a; h->tm_w1_ms += b; h->tm_steps++; h->tm_w1++;
+        }
+    }
+    h->ev_used = 0;
+    return DIMN_OK;
+}
+
+static int ready_for_training(dimn_handle h, const char* who) {
+    if (!h->gathered || !h->gathered_targets) return fail(DIMN_ERR_STATE, "%s: call dimn_set_matrix, dimn_set_indices and dimn_gather(with_targets=1) first", who);
+    return DIMN_OK;
+}
+
+extern "C" int dimn_train_step(dimn_handle h, const int32_t* rows, int32_t b_act, const uint8_t* keep_mask, int32_t epoch_key,
+                               int32_t step_key, float* loss_out) {
+    if (!h || !rows || b_act < 1 || b_act > h->B) return fail(DIMN_ERR_ARG, "dimn_train_step: bad batch (b_act must be 1..batch_size)");
+    CHK(ready_for_training(h, "dimn_train_step"));
+    for (int b = 0; b < b_act; ++b) if (rows[b] < 0 || rows[b] >= h->n) return fail(DIMN_ERR_ARG, "dimn_train_step: row %d out of range", rows[b]);
+    CHK(use_device(h));
+    const Dims& dm = h->dm;
+    HIPCHK(hipMemcpyAsync(h->d_rows_step, rows, (size_t)b_act * 4, hipMemcpyHostToDevice, h->stream));
+    const uint8_t* dmask = nullptr;
+    std::vector<uint8_t> padded;
+    if (keep_mask) {
+        padded.assign((size_t)h->K * DIMN_TB * dm.Hp, 0);
+        for (int k = 0; k < h->K; ++k)
+            for (int b = 0; b < b_act; ++b)
+                memcpy(&padded[((size_t)k * DIMN_TB + b) * dm.Hp], &keep_mask[((size_t)k * b_act + b) * h->H], (size_t)h->H);
+        HIPCHK(hipMemcpyAsync(h->d_mask, padded.data(), padded.size(), hipMemcpyHostToDevice, h->stream));
+        dmask = h->d_mask;
+    }
+    CHK(step_launch(h, h->d_rows_step, b_act, dmask, (uint32_t)epoch_key, (uint32_t)step_key, nullptr));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->profiling) collect_timers(h);
+    if (loss_out) {
+        std::vector<float> ls((size_t)h->K * dm.OS);
+        HIPCHK(hipMemcpy(ls.data(), h->d_loss_step, ls.size() * 4, hipMemcpyDeviceToHost));
+        for (int k = 0; k < h->K; ++k) {
+            double s = 0;
+            for (int j = 0; j < dm.OS; ++j) s += ls[(size_t)k * dm.OS + j];
+            loss_out[k] = (float)(s / ((double)b_act * h->O));
+        }
+    }
+    return DIMN_OK;
+}
+
+extern "C" int dimn_epoch_permutation(uint64_t seed, int32_t epoch, int64_t n, int32_t* perm_out) {
+    if (n < 0 || (n > 0 && !perm_out)) return fail(DIMN_ERR_ARG, "dimn_epoch_permutation: bad argument");
+    dimn_fill_permutation(seed, (uint32_t)epoch, n, perm_out);
+    return DIMN_OK;
+}
+
+extern "C" int dimn_train_epoch(dimn_handle h, int32_t epoch, const int32_t* perm, double* train_loss) {
+    if (!h) return fail(DIMN_ERR_ARG, "null handle");
+    CHK(ready_for_training(h, "dimn_train_epoch"));
+    if (h->n_tr < 1) return fail(DIMN_ERR_STATE, "dimn_train_epoch: call dimn_set_split first");
+    CHK(use_device(h));
+    const Dims& dm = h->dm;
+    std::vector<int32_t> p;
+    if (!perm) {
+        p.resize((size_t)h->n_tr);
+        dimn_fill_permutation(h->cfg.seed, (uint32_t)epoch, h->n_tr, p.data());
+        perm = p.data();
+    }
+    std::vector<int32_t> rows((size_t)h->n_tr);
+    for (int64_t i = 0; i < h->n_tr; ++i) {
+        if (perm[i] < 0 || perm[i] >= h->n_tr) return fail(DIMN_ERR_ARG, "dimn_train_epoch: perm[%lld] out of range", (long long)i);
+        rows[(size_t)i] = h->train_rows[(size_t)perm[i]];
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_epoch_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_loss_acc, 0, (size_t)h->K * dm.OS * sizeof(double), h->stream));
+    // d_loss_acc accumulates sum(w e^2) per step; the per-step means are weighted by b_act,
+    // i.e. sum_steps (sum/(b_act*O))*b_act / n_tr = total / (O*n_tr)
+    int step = 0;
+    for (int64_t i0 = 0; i0 < h->n_tr; i0 += h->B, ++step) {
+        const int b_act = (int)std::min<int64_t>(h->B, h->n_tr - i0);
+        CHK(step_launch(h, h->d_epoch_rows + i0, b_act, nullptr, (uint32_t)epoch, (uint32_t)step, h->d_loss_acc));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));   // also keeps `rows` alive until the H2D copy is done
+    if (h->profiling) collect_timers(h);
+    if (train_loss) {
+        std::vector<double> acc((size_t)h->K * dm.OS);
+        HIPCHK(hipMemcpy(acc.data(), h->d_loss_acc, acc.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int k = 0; k < h->K; ++k) {
+            double s = 0;
+            for (int j = 0; j < dm.OS; ++j) s += acc[(size_t)k * dm.OS + j];
+            train_loss[k] = s / ((double)h->O * (double)h->n_tr);
+        }
+    }
+    return DIMN_OK;
+}
+
+extern "C" int dimn_val_loss(dimn_handle h, double* val_loss) {
+    if (!h || !val_loss) return fail(DIMN_ERR_ARG, "dimn_val_loss: null argument");
+    CHK(ready_for_training(h, "dimn_val_loss"));
+    if (h->n_val < 1) return fail(DIMN_ERR_STATE, "dimn_val_loss: no validation rows (dimn_set_split)");
+    CHK(use_device(h));
+    const int64_t tiles = (h->n_val + DIMN_TB - 1) / DIMN_TB;
+    if (h->loss_part_cap < tiles * h->K) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        DEV_FREE(h->d_loss_part);
+        CHK(dev_alloc(&h->d_loss_part, (size_t)(tiles * h->K)));
+        h->loss_part_cap = tiles * h->K;
+    }
+    DISPATCH_NT(launch_predict, h, h->d_val_rows, h->n_val, (float*)nullptr, h->d_loss_part);
+    HIPCHK(hipGetLastError());
+    std::vector<float> part((size_t)(tiles * h->K));
+    HIPCHK(hipMemcpyAsync(part.data(), h->d_loss_part, part.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < h->K; ++k) {
+        double s = 0;
+        for (int64_t i = 0; i < tiles; ++i) s += part[(size_t)(k * tiles + i)];
+        val_loss[k] = s / ((double)h->n_val * h->O);
+    }
+    return DIMN_OK;
+}
+
+extern "C" int dimn_fit(dimn_handle h, int32_t max_epochs, int32_t patience, double* loss_hist, double* val_hist, int32_t* epochs_run) {
+    if (!h || max_epochs < 0) return fail(DIMN_ERR_ARG, "dimn_fit: bad argument");
+    std::vector<double> tl((size_t)h->K), vl((size_t)h->K);
+    double best = INFINITY;
+    int wait = 0, e = 0;
+    for (e = 0; e < max_epochs; ++e) {
+        CHK(dimn_train_epoch(h, e, nullptr, tl.data()));
+        CHK(dimn_val_loss(h, vl.data()));
+        double st = 0, sv = 0;
+        for (int k = 0; k < h->K; ++k) { st += tl[k]; sv += vl[k]; }
+        if (loss_hist) loss_hist[e] = st;
+        if (val_hist) val_hist[e] = sv;
+        // EarlyStopping(monitor='val_loss', patience): strict <, min_delta 0 (multinet.py:242-243)
+        if (sv < best) { best = sv; wait = 0; }
+        else if (++wait >= patience) { ++e; break; }
+    }
+    if (epochs_run) *epochs_run = e;
+    return DIMN_OK;
+}
+
+extern "C" int dimn_predict_device(dimn_handle h, const int32_t* rows, int64_t n_rows, void** dev_out) {
+    if (!h || n_rows < 0) return fail(DIMN_ERR_ARG, "dimn_predict: bad argument");
+    if (!h->gathered) return fail(DIMN_ERR_STATE, "dimn_predict: call dimn_set_matrix, dimn_set_indices and dimn_gather first");
+    if (!rows && n_rows > h->n) return fail(DIMN_ERR_ARG, "dimn_predict: n_rows exceeds the matrix");
+    CHK(use_device(h));
+    const int64_t need = n_rows * h->K * h->O;
+    if (h->out_cap < need) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        DEV_FREE(h->d_out);
+        CHK(dev_alloc(&h->d_out, (size_t)need));
+        h->out_cap = need;
+    }
+    const int32_t* drows = nullptr;
+    if (rows) {
+        for (int64_t i = 0; i < n_rows; ++i) if (rows[i] < 0 || rows[i] >= h->n) return fail(DIMN_ERR_ARG, "dimn_predict: row out of range");
+        if (h->pred_rows_cap < n_rows) {
+            HIPCHK(hipStreamSynchronize(h->stream));
+            DEV_FREE(h->d_pred_rows);
+            CHK(dev_alloc(&h->d_pred_rows, (size_t)n_rows));
+            h->pred_rows_cap = n_rows;
+        }
+        HIPCHK(hipMemcpyAsync(h->d_pred_rows, rows, (size_t)n_rows * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        drows = h->d_pred_rows;
+    }
+    if (n_rows > 0) {
+        DISPATCH_NT(launch_predict, h, drows, n_rows, h->d_out, (float*)nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    h->out_rows = n_rows;
+    if (dev_out) *dev_out = h->d_out;
+    return DIMN_OK;
+}
+
+extern "C" int dimn_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out) {
+    if (!out && n_rows > 0) return fail(DIMN_ERR_ARG, "dimn_predict: null output");
+    CHK(dimn_predict_device(h, rows, n_rows, nullptr));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (n_rows > 0) HIPCHK(hipMemcpy(out, h->d_out, (size_t)n_rows * h->K * h->O * 4, hipMemcpyDeviceToHost));
+    return DIMN_OK;
+}
+
+extern "C" int dimn_synchronize(dimn_handle h) {
+    if (!h) return fail(DIMN_ERR_ARG, "null handle");
+    CHK(use_device(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DIMN_OK;
+}
+
+extern "C" int dimn_set_profiling(dimn_handle h, int32_t on) {
+    if (!h) return fail(DIMN_ERR_ARG, "null handle");
+    h->profiling = on != 0;
+    return DIMN_OK;
+}
+extern "C" int dimn_get_timers(dimn_handle h, double* out4, int32_t reset) {
+    if (!h || !out4) return fail(DIMN_ERR_ARG, "null argument");
+    out4[0] = h->tm_step_ms; out4[1] = (double)h->tm_steps; out4[2] = h->tm_w1_ms; out4[3] = (double)h->tm_w1;
+    if (reset) { h->tm_step_ms = h->tm_w1_ms = 0; h->tm_steps = h->tm_w1 = 0; }
+    return DIMN_OK;
+}
+
+// ---- RCCL over xGMI ------------------------------------------------------------------------
+extern "C" int dimn_comm_unique_id(uint8_t* id) {
+    if (!id) return fail(DIMN_ERR_ARG, "null id");
+    CHK(rccl_bind());
+    ncclUniqueId u;
+    NCCLCHK(g_rccl.GetUniqueId(&u));
+    static_assert(sizeof(u) == DIMN_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id, &u, sizeof u);
+    return DIMN_OK;
+}
+extern "C" int dimn_comm_init(dimn_handle h, const uint8_t* id, int32_t n_ranks, int32_t rank) {
+    if (!h || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(DIMN_ERR_ARG, "dimn_comm_init: bad argument");
+    CHK(rccl_bind());
+    CHK(use_device(h));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    NCCLCHK(g_rccl.CommInitRank(&h->comm, n_ranks, u, rank));
+    h->n_ranks = n_ranks; h->rank = rank;
+    return DIMN_OK;
+}
+extern "C" int dimn_comm_allreduce_sum(dimn_handle h, double* v, int32_t n) {
+    if (!h || !v || n < 1) return fail(DIMN_ERR_ARG, "dimn_comm_allreduce_sum: bad argument");
+    if (!h->comm) return fail(DIMN_ERR_STATE, "dimn_comm_allreduce_sum: dimn_comm_init first");
+    CHK(use_device(h));
+    double* d = nullptr;
+    CHK(dev_alloc(&d, (size_t)n));
+    HIPCHK(hipMemcpyAsync(d, v, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    NCCLCHK(g_rccl.AllReduce(d, d, (size_t)n, kNcclFloat64, kNcclSum, h->comm, h->stream));
+    HIPCHK(hipMemcpyAsync(v, d, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    (void)hipFree(d);
+    return DIMN_OK;
+}
+extern "C" int dimn_comm_gather_predictions(dimn_handle h, int64_t n_rows, const int32_t* counts, int32_t root, float* out) {
+    if (!h || !counts || n_rows < 0) return fail(DIMN_ERR_ARG, "dimn_comm_gather_predictions: bad argument");
+    if (!h->comm) return fail(DIMN_ERR_STATE, "dimn_comm_gather_predictions: dimn_comm_init first");
+    if (h->out_rows != n_rows) return fail(DIMN_ERR_STATE, "dimn_comm_gather_predictions: last dimn_predict_device had %lld rows", (long long)h->out_rows);
+    if (counts[h->rank] != h->K) return fail(DIMN_ERR_ARG, "dimn_comm_gather_predictions: counts[rank] != n_subnets");
+    CHK(use_device(h));
+    const int O = h->O;
+    if (h->rank != root) {
+        NCCLCHK(g_rccl.GroupStart());
+        NCCLCHK(g_rccl.Send(h->d_out, (size_t)n_rows * h->K * O, kNcclFloat32, root, h->comm, h->stream));
+        NCCLCHK(g_rccl.GroupEnd());
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return DIMN_OK;
+    }
+    if (!out) return fail(DIMN_ERR_ARG, "dimn_comm_gather_predictions: root needs an output buffer");
+    // root: every peer sends over its own xGMI link; blocks land contiguously, then each
+    // [n_rows][K_r*O] block is copied into its column range of out (strided host copy).
+    int64_t ktot = 0;
+    std::vector<int64_t> koff((size_t)h->n_ranks);
+    for (int r = 0; r < h->n_ranks; ++r) { koff[(size_t)r] = ktot; ktot += counts[r]; }
+    float* stage = nullptr;
+    CHK(dev_alloc(&stage, (size_t)n_rows * ktot * O));
+    NCCLCHK(g_rccl.GroupStart());
+    for (int r = 0; r < h->n_ranks; ++r) {
+        if (r == root) continue;
+        NCCLCHK(g_rccl.Recv(stage + (size_t)n_rows * koff[(size_t)r] * O, (size_t)n_rows * counts[r] * O, kNcclFloat32, r, h->comm, h->stream));
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    HIPCHK(hipMemcpyAsync(stage + (size_t)n_rows * koff[(size_t)root] * O, h->d_out, (size_t)n_rows * h->K * O * 4, hipMemcpyDeviceToDevice, h->stream));
+    for (int r = 0; r < h->n_ranks; ++r)
+        HIPCHK(hipMemcpy2DAsync(out + koff[(size_t)r] * O, (size_t)ktot * O * 4, stage + (size_t)n_rows * koff[(size_t)r] * O,
+                                (size_t)counts[r] * O * 4, (size_t)counts[r] * O * 4, (size_t)n_rows, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    (void)hipFree(stage);
+    return DIMN_OK;
+}
+extern "C" int dimn_comm_destroy(dimn_handle h) {
+    if (!h) return fail(DIMN_ERR_ARG, "null handle");
+    if (h->comm) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+    return DIMN_OK;
+}

@@ -1,0 +1,573 @@
+// dimn_kernels.h -- hand-written CDNA4 (gfx950) kernels of libdimn.
+//
+// The hot path of DeepImpute's MultiNet (reference deepimpute/multinet.py:126-167 build,
+// :238-244 model.fit, :253/:278 model.predict) as a batched pipeline over K independent
+// sub-networks  Dense(H,relu) -> Dropout(p) -> Dense(O,softplus)  with wMSE and Keras-form
+// Adam.  All matmuls run on the exact-f32 matrix cores (v_mfma_f32_16x16x4_f32, 64-lane
+// wavefronts); nothing here is a translation of the reference, which has no kernels.
+//
+// MFMA 16x16x4 f32 fragment maps (lane l, li = l&15, lj = l>>4):
+//   A[i=li][k=lj]   B[k=lj][j=li]   C/D: col = li, row = 4*lj + reg
+// "k-slot trick": the hardware sums over the 4 k-slots in any order we like, so for a
+// 16-deep K chunk we let MFMA r (r=0..3) use k = 4*lj + r.  A lane then needs 4
+// CONSECUTIVE k's of one row: one 16-byte load feeds 4 MFMAs, and a C/D register block
+// (row = 4*lj + r) can be re-used directly as a B operand.
+//
+// HBM layouts (all fp32):
+//   X_k  [n][Dp_k]            gathered predictors of sub-net k, Dp = ceil16(D), zero padded
+//   Y_k  [n][Op]              gathered targets, Op = ceil16(O)
+//   W1_k [Dp/16][Hp][16]      "chunk-blocked": chunk c, hidden unit h, 16 consecutive d
+//                             -> a 16x16 MFMA tile is one contiguous 1 KiB; same for m, v
+//   W2_k [Hp/16][Op/16][16h][16o]  tile-blocked, 1 KiB per tile; same for m, v
+//   b1 [Hp], b2 [Op]; workspaces P (split-K partials), Dd, dZ, dA: [64][Hp|Op] per sub-net
+// Padded rows/columns are zero and provably stay zero under Adam (g=0, m=v=0 -> dw=0).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dimn_rng.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+#define DIMN_TB 64  // batch rows per optimiser step tile (4 MFMA M-tiles)
+
+struct SubnetDev {
+    int32_t D, Dp, nchunk;   // predictors, padded, Dp/16
+    int32_t slot0, nslice;   // split-K partial slots of this sub-net
+    int32_t kg;              // global sub-net index (RNG key)
+    int64_t xoff;            // float offset of X_k in the X arena (row stride Dp)
+    int64_t w1off;           // float offset of W1_k in the W1/M1/V1 arenas
+    float lim1, lim2;        // Glorot limits
+};
+
+struct Work {               // one workgroup of the split-K / weight-update kernels
+    int32_t k, c0, c1, slot;
+};
+
+struct Dims {
+    int32_t K, H, O, Hp, Op, HT, OT, ldd, OS;
+    // Hp = ceil16(H), HT = Hp/16, Op = ceil16(O), OT = Op/16, ldd = LDS row stride of Dd,
+    // OS = ceil(OT/4) output slices of 64 columns
+};
+
+struct AdamP {
+    float alpha, omb1, omb2, eps;   // alpha = lr*sqrt(1-b2^t)/(1-b1^t); 1-beta1; 1-beta2
+};
+
+__device__ __forceinline__ void adam4(f32x4& w, f32x4& m, f32x4& v, const f32x4 g, const AdamP a) {
+    // TF ResourceApplyAdam (Keras Adam, multinet.py:164): eps outside the bias correction
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        m[r] += (g[r] - m[r]) * a.omb1;
+        v[r] += (g[r] * g[r] - v[r]) * a.omb2;
+        w[r] -= (m[r] * a.alpha) / (sqrtf(v[r]) + a.eps);
+    }
+}
+__device__ __forceinline__ void adam1(float& w, float& m, float& v, const float g, const AdamP a) {
+    m += (g - m) * a.omb1;
+    v += (g * g - v) * a.omb2;
+    w -= (m * a.alpha) / (sqrtf(v) + a.eps);
+}
+
+__device__ __forceinline__ float softplus_f(float x) {
+    // TensorFlow's fp32 softplus thresholds (log(eps)+2 ~ -13.94), S4
+    const float thr = 13.942385f;
+    if (x > thr) return x;
+    if (x < -thr) return expf(x);
+    return log1pf(expf(x));
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------
+// gather: X_k[i][d] = norm[i][pred_k[d]], Y_k[i][o] = norm[i][targ_k[o]]
+// (replaces the K pandas .loc gathers, multinet.py:231-235 / 273-274).  grid (K, rows)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather(const SubnetDev* __restrict__ sn, const float* __restrict__ norm,
+                                                int64_t n, int64_t g, const int32_t* __restrict__ pred,
+                                                const int64_t* __restrict__ pred_off, const int32_t* __restrict__ targ,
+                                                float* __restrict__ X, float* __restrict__ Y, Dims dm, int with_targets) {
+    const int k = blockIdx.x;
+    const SubnetDev s = sn[k];
+    const int32_t* pk = pred + pred_off[k];
+    for (int64_t i = blockIdx.y; i < n; i += gridDim.y) {
+        const float* row = norm + i * g;
+        float* xr = X + s.xoff + i * s.Dp;
+        for (int d = threadIdx.x; d < s.Dp; d += 256) xr[d] = d < s.D ? row[pk[d]] : 0.f;
+        if (with_targets) {
+            float* yr = Y + ((int64_t)k * n + i) * dm.Op;
+            const int32_t* tk = targ + (int64_t)k * dm.O;
+            for (int o = threadIdx.x; o < dm.Op; o += 256) yr[o] = o < dm.O ? row[tk[o]] : 0.f;
+        }
+    }
+}
+
+// Glorot-uniform init straight into the blocked layouts; element index = Keras row-major.
+__global__ __launch_bounds__(256) void k_init_weights(const SubnetDev* __restrict__ sn, float* __restrict__ W1,
+                                                      float* __restrict__ W2, Dims dm, uint64_t seed) {
+    const int k = blockIdx.y;
+    const SubnetDev s = sn[k];
+    const int64_t n1 = (int64_t)s.D * dm.H, n2 = (int64_t)dm.H * dm.O;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n1 + n2; e += (int64_t)gridDim.x * 256) {
+        if (e < n1) {
+            const int d = (int)(e / dm.H), h = (int)(e % dm.H);
+            W1[s.w1off + ((int64_t)(d >> 4) * dm.Hp + h) * 16 + (d & 15)] =
+                dimn_init_value(seed, (uint32_t)s.kg, 0u, (uint32_t)e, s.lim1);
+        } else {
+            const int64_t e2 = e - n1;
+            const int h = (int)(e2 / dm.O), o = (int)(e2 % dm.O);
+            W2[(int64_t)k * dm.Hp * dm.Op + ((int64_t)(h >> 4) * dm.OT + (o >> 4)) * 256 + (h & 15) * 16 + (o & 15)] =
+                dimn_init_value(seed, (uint32_t)s.kg, 1u, (uint32_t)e2, s.lim2);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// F1: split-K first layer.  Workgroup = (sub-net k, chunk range [c0,c1)); 4 waves, wave w
+// owns hidden tiles [w*NT, w*NT+NT).  P[slot][b][h] = sum_{d in chunks} X[rows[b]][d] W1[d][h]
+// ---------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_fwd1(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
+                                              const float* __restrict__ X, const float* __restrict__ W1,
+                                              const int32_t* __restrict__ rows, int b_act,
+                                              float* __restrict__ P, Dims dm) {
+    const Work wk = work[blockIdx.x];
+    const SubnetDev s = sn[wk.k];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    const int nt0 = wave * NT;
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* xk = X + s.xoff;
+    uint32_t xo[4];
+    bool valid[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int b = 16 * mt + li;
+        valid[mt] = b < b_act;
+        xo[mt] = valid[mt] ? (uint32_t)rows[b] * (uint32_t)s.Dp + 4u * lj : 0u;
+    }
+    const float* wb = W1 + s.w1off + (int64_t)(16 * nt0 + li) * 16 + 4 * lj;
+    const int64_t cstride = (int64_t)dm.Hp * 16;
+
+    for (int c = wk.c0; c < wk.c1; ++c) {
+        f32x4 a[4], b[NT];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            a[mt] = valid[mt] ? *(const f32x4*)(xk + xo[mt] + 16 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            b[nt] = (nt0 + nt < dm.HT) ? *(const f32x4*)(wb + c * cstride + nt * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA16(a[mt][r], b[nt][r], acc[mt][nt]);
+    }
+    float* p = P + (int64_t)wk.slot * DIMN_TB * dm.Hp;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            if (nt0 + nt < dm.HT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[(16 * mt + 4 * lj + r) * dm.Hp + 16 * (nt0 + nt) + li] = acc[mt][nt][r];
+            }
+}
+
+// ---------------------------------------------------------------------------------------
+// MF: middle forward.  Workgroup = (sub-net k, output slice os of 64 columns).
+//  a) A = b1 + sum_slices P ; relu ; dropout -> Dd[64][Hp] into LDS (slice 0 also -> HBM)
+//  b) Z[:,slice] = Dd W2[:,slice] + b2 ; yhat = softplus ; wMSE ; dZ ; gb2 -> Adam(b2)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mid_fwd(const SubnetDev* __restrict__ sn, const float* __restrict__ P,
+                                                 const float* __restrict__ b1, const float* __restrict__ W2,
+                                                 float* __restrict__ b2w, float* __restrict__ b2m, float* __restrict__ b2v,
+                                                 const float* __restrict__ Y, int64_t n_cells,
+                                                 const int32_t* __restrict__ rows, int b_act,
+                                                 const uint8_t* __restrict__ mask, float* __restrict__ Dd,
+                                                 float* __restrict__ dZ, float* __restrict__ loss_step,
+                                                 double* __restrict__ loss_acc, Dims dm, AdamP ap, float rate, float scale,
+                                                 float inv_n, int loss_binary, uint64_t seed, uint32_t epoch_key,
+                                                 uint32_t step_key) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int os = blockIdx.x, k = blockIdx.y;
+    const SubnetDev s = sn[k];
+    const int Hp = dm.Hp, ldd = dm.ldd;
+
+    // ---- a) reduce split-K partials, bias, relu, dropout ----
+    const float* pk = P + (int64_t)s.slot0 * DIMN_TB * Hp;
+    const int64_t pstride = (int64_t)DIMN_TB * Hp;
+    for (int e = threadIdx.x * 4; e < DIMN_TB * Hp; e += 1024) {
+        const int b = e / Hp, h = e - b * Hp;
+        f32x4 a = *(const f32x4*)(b1 + (int64_t)k * Hp + h);
+        for (int sl = 0; sl < s.nslice; ++sl) a += *(const f32x4*)(pk + sl * pstride + e);
+        f32x4 dd;
+        bool keep[4];
+        if (mask) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) keep[r] = mask[((int64_t)k * DIMN_TB + b) * Hp + h + r] != 0;
+        } else if (rate > 0.f) {
+            if ((dm.H & 3) == 0) {
+                const dimn_u32x4 rnd = dimn_dropout_block(seed, (uint32_t)s.kg, epoch_key, step_key, (uint32_t)(b * dm.H + h) >> 2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) keep[r] = dimn_u01(rnd.v[r]) >= rate;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    keep[r] = (h + r < dm.H) && dimn_dropout_keep(seed, (uint32_t)s.kg, epoch_key, step_key, (uint32_t)(b * dm.H + h + r), rate);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) keep[r] = true;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float relu = a[r] > 0.f ? a[r] : 0.f;
+            dd[r] = (keep[r] && b < b_act) ? relu * scale : 0.f;
+            lds[b * ldd + h + r] = dd[r];
+        }
+        if (os == 0) *(f32x4*)(Dd + (int64_t)k * DIMN_TB * Hp + e) = dd;
+    }
+    __syncthreads();
+
+    // ---- b) second layer on this 64-column slice: wave w owns output tile ot ----
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    const int ot = os * 4 + wave;
+    float lsum = 0.f;
+    if (ot < dm.OT) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* w2 = W2 + (int64_t)k * Hp * dm.Op + (int64_t)ot * 256 + lj * 16 + li;
+        for (int ht = 0; ht < dm.HT; ++ht) {
+            const float* wt = w2 + (int64_t)ht * dm.OT * 256;
+            float bv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = wt[q * 64];          // W2[h=16ht+4q+lj][o=16ot+li]
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt] = MFMA16(lds[(16 * mt + li) * ldd + 16 * ht + 4 * q + lj], bv[q], acc[mt]);
+        }
+        const int o = 16 * ot + li;
+        const float bias = b2w[(int64_t)k * dm.Op + o];
+        float gb = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = 16 * mt + 4 * lj + r;
+                float dz = 0.f;
+                if (b < b_act && o < dm.O) {
+                    const float z = acc[mt][r] + bias;
+                    const float y = Y[((int64_t)k * n_cells + rows[b]) * dm.Op + o];
+                    const float w = loss_binary ? (y > 0.f ? 1.f : 0.f) : y;   // multinet.py:37-40
+                    const float e = y - softplus_f(z);
+                    lsum += w * e * e;
+                    dz = -2.f * w * e * inv_n * sigmoid_f(z);
+                }
+                dZ[((int64_t)k * DIMN_TB + b) * dm.Op + o] = dz;
+                gb += dz;
+            }
+        gb += __shfl_xor(gb, 16);
+        gb += __shfl_xor(gb, 32);
+        if (lj == 0) {
+            const int64_t i = (int64_t)k * dm.Op + o;
+            float w = b2w[i], m = b2m[i], v = b2v[i];
+            adam1(w, m, v, gb, ap);
+            b2w[i] = w; b2m[i] = m; b2v[i] = v;
+        }
+    }
+    // block loss reduction -> one float per (k, slice)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
+    __syncthreads();
+    if (lane == 0) lds[wave] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = lds[0] + lds[1] + lds[2] + lds[3];
+        loss_step[k * dm.OS + os] = tot;
+        if (loss_acc) loss_acc[k * dm.OS + os] += (double)tot;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// MB: middle backward.  Workgroup = (sub-net k, two hidden tiles = 32 rows of W2).
+//  gW2^T tile = dZ^T Dd  (K = batch)  -> Adam on W2/m/v (tile-blocked, 1 KiB/tile)
+//  dD[:,32] = dZ W2^T (OLD W2, K = O split over the 4 waves, reduced through LDS)
+//  dA = dD * scale * [Dd>0] ; gb1 -> Adam(b1)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mid_bwd(const float* __restrict__ Dd, const float* __restrict__ dZ,
+                                                 float* __restrict__ W2, float* __restrict__ M2, float* __restrict__ V2,
+                                                 float* __restrict__ b1w, float* __restrict__ b1m, float* __restrict__ b1v,
+                                                 float* __restrict__ dA, Dims dm, AdamP ap, float scale, int otw) {
+    __shared__ __attribute__((aligned(16))) float red[4 * DIMN_TB * 33];
+    const int hs = blockIdx.x, k = blockIdx.y;
+    const int Hp = dm.Hp, Op = dm.Op;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    const int ht0 = 2 * hs;
+    const int nht = (dm.HT - ht0) < 2 ? (dm.HT - ht0) : 2;
+    const float* ddk = Dd + (int64_t)k * DIMN_TB * Hp;
+    const float* dzk = dZ + (int64_t)k * DIMN_TB * Op;
+
+    float ddf[16][2];    // B operand of gW2: Dd[b=4kb+lj][h=16(ht0+ht)+li]
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) ddf[kb][ht] = ht < nht ? ddk[(4 * kb + lj) * Hp + 16 * (ht0 + ht) + li] : 0.f;
+
+    f32x4 dacc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) dacc[mt][ht] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ot_end = (wave + 1) * otw < dm.OT ? (wave + 1) * otw : dm.OT;
+    for (int ot = wave * otw; ot < ot_end; ++ot) {
+        f32x4 g[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            const float az = dzk[(4 * kb + lj) * Op + 16 * ot + li];   // dZ^T[o=li][b=4kb+lj]
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht) g[ht] = MFMA16(az, ddf[kb][ht], g[ht]);
+        }
+        f32x4 zf[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) zf[mt] = *(const f32x4*)(dzk + (16 * mt + li) * Op + 16 * ot + 4 * lj);
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+            if (ht < nht) {
+                const int64_t idx = (int64_t)k * Hp * Op + ((int64_t)(ht0 + ht) * dm.OT + ot) * 256 + li * 16 + 4 * lj;
+                f32x4 w = *(const f32x4*)(W2 + idx), m = *(const f32x4*)(M2 + idx), v = *(const f32x4*)(V2 + idx);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) dacc[mt][ht] = MFMA16(zf[mt][r], w[r], dacc[mt][ht]);   // OLD W2
+                adam4(w, m, v, g[ht], ap);
+                *(f32x4*)(W2 + idx) = w; *(f32x4*)(M2 + idx) = m; *(f32x4*)(V2 + idx) = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * DIMN_TB + 16 * mt + 4 * lj + r) * 33 + 16 * ht + li] = dacc[mt][ht][r];
+    __syncthreads();
+    // 64 x 32 outputs, 8 per thread: thread -> column hh = tid & 31, rows b = (tid>>5) + 8*i
+    const int hh = threadIdx.x & 31, b0 = threadIdx.x >> 5;
+    const int h = 32 * hs + hh;
+    float gsum = 0.f;
+    if (h < Hp) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int b = b0 + 8 * i;
+            const float d = red[(0 * DIMN_TB + b) * 33 + hh] + red[(1 * DIMN_TB + b) * 33 + hh] +
+                            red[(2 * DIMN_TB + b) * 33 + hh] + red[(3 * DIMN_TB + b) * 33 + hh];
+            const float da = ddk[b * Hp + h] > 0.f ? d * scale : 0.f;
+            dA[((int64_t)k * DIMN_TB + b) * Hp + h] = da;
+            gsum += da;
+        }
+    }
+    __syncthreads();
+    red[b0 * 33 + hh] = gsum;
+    __syncthreads();
+    if (threadIdx.x < 32 && h < Hp) {
+        float gb = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gb += red[i * 33 + hh];
+        const int64_t idx = (int64_t)k * Hp + h;
+        float w = b1w[idx], m = b1m[idx], v = b1v[idx];
+        adam1(w, m, v, gb, ap);
+        b1w[idx] = w; b1m[idx] = m; b1v[idx] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// B1: first-layer weight gradient + fused Keras-Adam.  Same work table as F1.
+//  gW1 tile[16 d][16 h] = X^T[d][b] dA[b][h]  (K = batch, dA fragments live in registers),
+//  accumulator (row = 4*lj + r = d, col = li = h) == the float4 the lane owns in the
+//  chunk-blocked W1/m/v -> read, update, write 1 KiB per wave instruction; dW never exists.
+// ---------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_w1_update(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
+                                                   const float* __restrict__ X, float* __restrict__ W1,
+                                                   float* __restrict__ M1, float* __restrict__ V1,
+                                                   const int32_t* __restrict__ rows, int b_act,
+                                                   const float* __restrict__ dA, Dims dm, AdamP ap) {
+    const Work wk = work[blockIdx.x];
+    const SubnetDev s = sn[wk.k];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    const int nt0 = wave * NT;
+    const int Hp = dm.Hp;
+
+    float bfr[16][NT];   // dA[b=4kb+lj][h=16(nt0+nt)+li]; rows >= b_act are zero
+    const float* dak = dA + (int64_t)wk.k * DIMN_TB * Hp;
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bfr[kb][nt] = (nt0 + nt < dm.HT) ? dak[(4 * kb + lj) * Hp + 16 * (nt0 + nt) + li] : 0.f;
+
+    const float* xk = X + s.xoff;
+    uint32_t xo[16];
+    bool valid[16];
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+        const int b = 4 * kb + lj;
+        valid[kb] = b < b_act;
+        xo[kb] = valid[kb] ? (uint32_t)rows[b] * (uint32_t)s.Dp + (uint32_t)li : 0u;
+    }
+    const int64_t cstride = (int64_t)Hp * 16;
+    const int64_t wb = s.w1off + (int64_t)(16 * nt0 + li) * 16 + 4 * lj;
+
+    for (int c = wk.c0; c < wk.c1; ++c) {
+        float a[16];
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) a[kb] = valid[kb] ? xk[xo[kb] + 16 * c] : 0.f;   // X^T[d=16c+li][b]
+        f32x4 g[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) g[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) g[nt] = MFMA16(a[kb], bfr[kb][nt], g[nt]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            if (nt0 + nt < dm.HT) {
+                const int64_t idx = wb + c * cstride + nt * 256;
+                f32x4 w = *(const f32x4*)(W1 + idx), m = *(const f32x4*)(M1 + idx), v = *(const f32x4*)(V1 + idx);
+                adam4(w, m, v, g[nt], ap);
+                *(f32x4*)(W1 + idx) = w; *(f32x4*)(M1 + idx) = m; *(f32x4*)(V1 + idx) = v;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused forward for 64 rows: model.predict (multinet.py:253,278) and the validation pass.
+// grid (row tiles, K).  out != NULL: out[i][k*O + o] = softplus(z).  loss_part != NULL:
+// loss_part[k*gridDim.x + tile] = sum w*(y-yhat)^2 over the tile (S9).
+// ---------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ sn, const float* __restrict__ X,
+                                                 const float* __restrict__ W1, const float* __restrict__ b1,
+                                                 const float* __restrict__ W2, const float* __restrict__ b2,
+                                                 const int32_t* __restrict__ rows, int64_t n_rows,
+                                                 float* __restrict__ out, const float* __restrict__ Y, int64_t n_cells,
+                                                 float* __restrict__ loss_part, Dims dm, int loss_binary) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int k = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * DIMN_TB;
+    const SubnetDev s = sn[k];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    const int nt0 = wave * NT;
+    const int Hp = dm.Hp, ldd = dm.ldd;
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* xk = X + s.xoff;
+    int64_t xo[4];
+    bool valid[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int64_t i = r0 + 16 * mt + li;
+        valid[mt] = i < n_rows;
+        const int64_t row = valid[mt] ? (rows ? (int64_t)rows[i] : i) : 0;
+        xo[mt] = row * s.Dp + 4 * lj;
+    }
+    const float* wb = W1 + s.w1off + (int64_t)(16 * nt0 + li) * 16 + 4 * lj;
+    const int64_t cstride = (int64_t)Hp * 16;
+    for (int c = 0; c < s.nchunk; ++c) {
+        f32x4 a[4], b[NT];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            a[mt] = valid[mt] ? *(const f32x4*)(xk + xo[mt] + 16 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            b[nt] = (nt0 + nt < dm.HT) ? *(const f32x4*)(wb + c * cstride + nt * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA16(a[mt][r], b[nt][r], acc[mt][nt]);
+    }
+    // bias + relu -> LDS (dropout is identity at inference, S3/S12)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+        if (nt0 + nt < dm.HT) {
+            const int h = 16 * (nt0 + nt) + li;
+            const float bias = b1[(int64_t)k * Hp + h];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[mt][nt][r] + bias;
+                    lds[(16 * mt + 4 * lj + r) * ldd + h] = v > 0.f ? v : 0.f;
+                }
+        }
+    __syncthreads();
+
+    float lsum = 0.f;
+    for (int ot = wave; ot < dm.OT; ot += 4) {
+        f32x4 z[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) z[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* w2 = W2 + (int64_t)k * Hp * dm.Op + (int64_t)ot * 256 + lj * 16 + li;
+        for (int ht = 0; ht < dm.HT; ++ht) {
+            const float* wt = w2 + (int64_t)ht * dm.OT * 256;
+            float bv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = wt[q * 64];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    z[mt] = MFMA16(lds[(16 * mt + li) * ldd + 16 * ht + 4 * q + lj], bv[q], z[mt]);
+        }
+        const int o = 16 * ot + li;
+        if (o < dm.O) {
+            const float bias = b2[(int64_t)k * dm.Op + o];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t i = r0 + 16 * mt + 4 * lj + r;
+                    if (i < n_rows) {
+                        const float yh = softplus_f(z[mt][r] + bias);
+                        if (out) out[(i * dm.K + k) * dm.O + o] = yh;
+                        if (loss_part) {
+                            const int64_t row = rows ? (int64_t)rows[i] : i;
+                            const float y = Y[((int64_t)k * n_cells + row) * dm.Op + o];
+                            const float w = loss_binary ? (y > 0.f ? 1.f : 0.f) : y;
+                            const float e = y - yh;
+                            lsum += w * e * e;
+                        }
+                    }
+                }
+        }
+    }
+    if (loss_part) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
+        __syncthreads();
+        if (lane == 0) lds[wave] = lsum;
+        __syncthreads();
+        if (threadIdx.x == 0) loss_part[(int64_t)k * gridDim.x + blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+    }
+}

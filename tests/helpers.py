@@ -62,3 +62,25 @@ def check_kat(eng, kat, rtol, atol):
         np.testing.assert_allclose(pred[:, k * O:(k + 1) * O], kat["pred_all_%d" % k], rtol=rtol,
                                    atol=atol, err_msg="predict k=%d" % k)
         np.testing.assert_allclose(vl[k], kat["val_loss_%d" % k], rtol=rtol)
+
+
+def make_problem(n, g, Ds, H, O, seed=0, val_frac=0.1):
+    """Seeded synthetic log1p(count) matrix + random predictor/target column lists."""
+    rng = np.random.default_rng(seed)
+    lam = rng.lognormal(0.5, 1.2, size=g)
+    norm = np.log1p(rng.poisson(rng.gamma(2.0, lam / 2.0, size=(n, g)))).astype(np.float32)
+    pred = [rng.choice(g, D, replace=False).astype(np.int32) for D in Ds]
+    targ = [rng.choice(g, O, replace=O > g).astype(np.int32) for _ in Ds]
+    val = np.sort(rng.choice(n, max(1, int(val_frac * n)), replace=False)).astype(np.int32)
+    train = np.setdiff1d(np.arange(n, dtype=np.int32), val).astype(np.int32)
+    return dict(norm=norm, pred=pred, targ=targ, Ds=list(Ds), H=H, O=O, train=train, val=val)
+
+
+def load_problem(cls, prob, **kw):
+    eng = cls(prob["Ds"], prob["H"], prob["O"], **kw)
+    eng.set_matrix(prob["norm"])
+    for k in range(len(prob["Ds"])):
+        eng.set_indices(k, prob["pred"][k], prob["targ"][k])
+    eng.gather(True)
+    eng.set_split(prob["train"], prob["val"])
+    return eng

@@ -1,0 +1,66 @@
+"""CPU-side checks of the drop-in boundary: libdimn.so loads without a GPU and exports every
+symbol include/dimn.h declares; the ctypes struct matches the C struct; no compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from deepimpute_amd import _cabi, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "dimn.h")).read()
+    return sorted(set(re.findall(r"\b(dimn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared()
+    assert len(names) >= 28
+    lib = _lib.library()
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_bound_table_covers_header():
+    fns = _lib.load()
+    bound = {"dimn_" + k for k in fns}
+    assert set(_declared()) <= bound, set(_declared()) - bound
+
+
+def test_abi_version_and_struct_layout():
+    lib = _lib.library()
+    lib.dimn_abi_version.restype = C.c_int
+    assert lib.dimn_abi_version() == _cabi.ABI_VERSION
+    # 6 int32, 5 float, 1 int32, (pad), uint64  -> 56 bytes, seed at offset 48
+    assert C.sizeof(_cabi.Config) == 56
+    assert _cabi.Config.seed.offset == 48
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """Without a visible GPU dimn_create must fail with a message (no CPU fallback)."""
+    import subprocess, sys
+    code = ("import numpy as np\n"
+            "from deepimpute_amd.engine import HipEngine, DimnError\n"
+            "try:\n"
+            "    HipEngine([8], 16, 16)\n"
+            "    print('CREATED')\n"
+            "except DimnError as e:\n"
+            "    print('LOUD', e)\n")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout
+    assert "LOUD" in out and "no HIP device" in out, out
+
+
+def test_permutation_export_matches_oracle_without_gpu():
+    """dimn_epoch_permutation is host-only: same stream as the oracle's."""
+    from oracle.dimo import OracleEngine
+    fns = _lib.load()
+    p = np.empty(997, np.int32)
+    assert fns["epoch_permutation"](1234, 7, 997, _cabi.p_i32(p)) == 0
+    q = OracleEngine([4], 8, 8, seed=1234).epoch_permutation(7, n=997)
+    assert np.array_equal(p, q)
+    assert sorted(p.tolist()) == list(range(997))

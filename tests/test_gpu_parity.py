@@ -1,0 +1,121 @@
+"""GPU parity tests: the HIP path (libdimn.so through the C ABI) against the CPU oracle and
+the committed torch-fp64 known answers.  Run on the MI355X box: pytest -m gpu."""
+import numpy as np
+import pytest
+
+from helpers import check_kat, kat_engine, load_kat, make_problem, load_problem
+
+pytestmark = pytest.mark.gpu
+
+# fp32 tolerance of the path: MFMA accumulates in a different order than the oracle's plain
+# loops; 2e-4 relative after three Adam steps is ~100x the single-product rounding.
+RTOL, ATOL = 2e-4, 2e-6
+
+
+def _hip():
+    from deepimpute_amd.engine import HipEngine
+    return HipEngine
+
+
+def _oracle():
+    from oracle.dimo import OracleEngine
+    return OracleEngine
+
+
+def test_kat_steps_match_autograd_golden():
+    kat = load_kat()
+    eng = kat_engine(_hip(), kat)
+    check_kat(eng, kat, rtol=RTOL, atol=ATOL)
+
+
+def test_init_weights_bit_exact_vs_oracle():
+    prob = make_problem(n=150, g=400, Ds=[70, 33, 128], H=48, O=32, seed=5)
+    a = load_problem(_hip(), prob, seed=99)
+    b = load_problem(_oracle(), prob, seed=99)
+    a.init_weights(); b.init_weights()
+    for k in range(a.K):
+        for x, y in zip(a.get_weights(k), b.get_weights(k)):
+            assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("H,O,B,Ds,p", [
+    (64, 64, 64, [200, 96], 0.2),       # aligned
+    (150, 100, 37, [97, 64, 33], 0.2),  # ragged everything (reference test uses hidden=150)
+    (300, 512, 64, [260], 0.35),        # CLI default hidden=300
+    (32, 48, 16, [40, 41, 42, 43, 44], 0.0),  # no dropout
+])
+def test_two_epochs_match_oracle(H, O, B, Ds, p):
+    prob = make_problem(n=330, g=700, Ds=Ds, H=H, O=O, seed=11)
+    kw = dict(batch_size=B, dropout_rate=p, learning_rate=1e-3, seed=4242)
+    a = load_problem(_hip(), prob, **kw)
+    b = load_problem(_oracle(), prob, **kw)
+    a.init_weights(); b.init_weights()
+    for epoch in range(2):
+        la = a.train_epoch(epoch)
+        lb = b.train_epoch(epoch)
+        np.testing.assert_allclose(la, lb, rtol=1e-4)
+        np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
+    assert a.step_count() == b.step_count()
+    for k in range(a.K):
+        for x, y, name in zip(a.get_weights(k), b.get_weights(k), ("W1", "b1", "W2", "b2")):
+            np.testing.assert_allclose(x, y, rtol=1e-3, atol=2e-5, err_msg="%s k=%d" % (name, k))
+    pa, pb = a.predict(), b.predict()
+    # north_star: imputed values within 1e-4 relative
+    np.testing.assert_allclose(pa, pb, rtol=1e-4, atol=1e-6)
+
+
+def test_single_forward_tight():
+    prob = make_problem(n=200, g=500, Ds=[300, 150], H=256, O=512, seed=3)
+    a = load_problem(_hip(), prob, seed=1)
+    b = load_problem(_oracle(), prob, seed=1)
+    a.init_weights(); b.init_weights()
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=1e-5, atol=1e-6)
+    rows = np.array([5, 199, 0, 0, 77], np.int32)          # arbitrary, repeated rows
+    np.testing.assert_allclose(a.predict(rows), b.predict(rows), rtol=1e-5, atol=1e-6)
+    assert a.predict(np.zeros(0, np.int32)).shape == (0, 2 * 512)   # empty input
+
+
+def test_injected_permutation_and_partial_batch():
+    prob = make_problem(n=131, g=300, Ds=[50, 60], H=64, O=64, seed=8)
+    kw = dict(batch_size=64, dropout_rate=0.2, learning_rate=5e-4, seed=77)
+    a = load_problem(_hip(), prob, **kw)
+    b = load_problem(_oracle(), prob, **kw)
+    a.init_weights(); b.init_weights()
+    perm = np.random.default_rng(0).permutation(a.n_train).astype(np.int32)
+    np.testing.assert_allclose(a.train_epoch(3, perm), b.train_epoch(3, perm), rtol=1e-4)
+    # the library's own permutation is exported and identical on both sides
+    assert np.array_equal(a.epoch_permutation(1), b.epoch_permutation(1))
+    for k in range(a.K):
+        np.testing.assert_allclose(a.get_adam_state(k, 1)[0], b.get_adam_state(k, 1)[0], rtol=1e-3, atol=1e-12)
+
+
+def test_fit_early_stopping_matches_oracle():
+    prob = make_problem(n=260, g=420, Ds=[64, 80], H=32, O=48, seed=21)
+    kw = dict(batch_size=64, dropout_rate=0.2, learning_rate=2e-3, seed=9)
+    a = load_problem(_hip(), prob, **kw)
+    b = load_problem(_oracle(), prob, **kw)
+    a.init_weights(); b.init_weights()
+    na, la, va = a.fit(12, 2)
+    nb, lb, vb = b.fit(12, 2)
+    assert na == nb
+    np.testing.assert_allclose(va, vb, rtol=2e-4)
+    np.testing.assert_allclose(la, lb, rtol=2e-4)
+
+
+def test_error_paths_are_loud():
+    from deepimpute_amd.engine import DimnError
+    Hip = _hip()
+    with pytest.raises(DimnError):
+        Hip([10], 32, 32, batch_size=65)          # > DIMN_MAX_BATCH
+    e = Hip([10], 32, 32)
+    with pytest.raises(DimnError):
+        e.predict(n_rows=4)                       # no matrix yet
+    e.set_matrix(np.ones((8, 20), np.float32))
+    with pytest.raises(DimnError):
+        e.gather(True)                            # indices missing
+    e.set_indices(0, np.arange(10), np.arange(32) % 20)
+    e.gather(True)
+    with pytest.raises(DimnError):
+        e.train_epoch(0)                          # no split
+    with pytest.raises(DimnError):
+        e.train_step(np.array([99], np.int32))    # row out of range
