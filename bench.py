@@ -1,0 +1,316 @@
+#!/usr/bin/env python
+"""bench.py -- cells/sec of the MultiNet hot path (fit + predict) on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1: launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per
+GPU; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* are read from the environment).
+
+A *step* is one end-to-end impute of the synthetic matrix through the hot path with the inputs
+(log1p matrix + predictor/target index lists) already resident: device gather of the K
+(cells x predictors)/(cells x targets) blocks, weight init, E epochs of training (each followed
+by the validation pass, as model.fit does) and the forward pass over all cells, results left in
+HBM (N>1: gathered into root's HBM over RCCL).  value = n_cells / seconds per step.
+
+Workload = BASELINE.json configs[2] (the config the metric is quoted on; it fits one GPU):
+50k cells x 20k genes, K=40 sub-nets, H=256, O=512, batch 64, dropout 0.2, Adam lr 1e-4.
+Early stopping makes the epoch count data dependent, so the bench fixes E (--epochs) on every
+leg; DESIGN.md records what the early-stopped run takes on this generator.
+
+No torch in this process: the GPU work goes through libdimn.so (ctypes); multi-rank control
+uses a file rendezvous under /tmp and RCCL itself (libdimn's dimn_comm_*).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (cells, genes, hidden, out, batch)
+    "cfg3": dict(n=50000, g=20000, H=256, O=512, B=64, label="50k cells x 20k genes, K=40 sub-nets, H=256, O=512, batch 64"),
+    "cfg2": dict(n=5000, g=5000, H=256, O=512, B=64, label="5k cells x 5k genes, K=10 sub-nets, H=256, O=512, batch 64"),
+    "tiny": dict(n=2000, g=1500, H=256, O=512, B=64, label="2k cells x 1.5k genes (plumbing check)"),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def synth_counts(n, g, seed=0, threads=None):
+    """BASELINE.md generator: mu_j ~ LogNormal(0.5,1.2); lambda_ij ~ Gamma(2, mu_j/2);
+    X_ij ~ Poisson(lambda_ij).  Row blocks are drawn by independent child streams in threads
+    (numpy releases the GIL), so the matrix is a pure function of (n, g, seed)."""
+    threads = threads or min(32, os.cpu_count() or 1)
+    root = np.random.default_rng(seed)
+    mu = root.lognormal(0.5, 1.2, size=g)
+    out = np.empty((n, g), np.float32)
+    blk = 512
+    starts = list(range(0, n, blk))
+    seeds = np.random.SeedSequence(seed).spawn(len(starts))
+
+    def fill(i):
+        r = np.random.default_rng(seeds[i])
+        a, b = starts[i], min(n, starts[i] + blk)
+        lam = r.gamma(2.0, mu / 2.0, size=(b - a, g))
+        out[a:b] = np.log1p(r.poisson(lam)).astype(np.float32)    # log1p matrix (multinet.py:217)
+
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(fill, range(len(starts))))
+    return out
+
+
+def synth_indices(g, O, seed=0, ntop=5):
+    """Target partition as filter_genes/setTargets produce with NN_lim=g (K = ceil(g/O), the
+    last slots filled with random genes, multinet.py:312-342) and predictor lists of the size
+    setPredictors yields (union of ntop picks per target over non-target genes: D_k ~
+    (g-O)(1-exp(-ntop*O/(g-O))), BASELINE.md section 2 probe: 2373..2418 at g=20k)."""
+    rng = np.random.default_rng(seed + 1)
+    K = -(-g // O)
+    genes = rng.permutation(g)
+    fill = rng.integers(0, g, size=K * O - g)
+    targets = np.concatenate([genes, fill]).reshape(K, O).astype(np.int32)
+    preds = []
+    for k in range(K):
+        non = np.setdiff1d(np.arange(g, dtype=np.int32), targets[k])
+        picks = rng.integers(0, non.size, size=ntop * O)
+        _, first = np.unique(picks, return_index=True)
+        preds.append(non[picks[np.sort(first)]].astype(np.int32))
+    return targets, preds
+
+
+def split_rows(n, seed=0):
+    rng = np.random.default_rng(seed + 2)
+    val = rng.choice(n, int(0.05 * n), replace=False).astype(np.int32)     # multinet.py:228
+    train = np.setdiff1d(np.arange(n, dtype=np.int32), val).astype(np.int32)
+    return train, val
+
+
+def shard(K, world):
+    """Contiguous, balanced split of sub-nets over ranks: counts[r], offsets[r]."""
+    counts = [K // world + (1 if r < K % world else 0) for r in range(world)]
+    offs = [sum(counts[:r]) for r in range(world)]
+    return counts, offs
+
+
+class FileRendezvous:
+    """Single-node rendezvous for the RCCL unique id (all ranks are children of one torchrun
+    agent -> the parent pid + MASTER_PORT name a directory nobody else uses)."""
+
+    def __init__(self, rank, world):
+        tag = "%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+        self.dir = os.path.join("/tmp", "dimn_rdzv_" + tag)
+        self.rank, self.world = rank, world
+        os.makedirs(self.dir, exist_ok=True)
+
+    def broadcast_bytes(self, name, payload=None, timeout=300.0):
+        path = os.path.join(self.dir, name)
+        if self.rank == 0:
+            tmp = path + ".tmp"
+            with open(tmp, "wb") as f:
+                f.write(payload)
+            os.replace(tmp, path)
+            return payload
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > timeout:
+                raise TimeoutError("rendezvous: %s never appeared" % path)
+            time.sleep(0.01)
+        with open(path, "rb") as f:
+            return f.read()
+
+    def cleanup(self):
+        if self.rank == 0:
+            import shutil
+            shutil.rmtree(self.dir, ignore_errors=True)
+
+
+def make_engine(cls, cfg, targets, preds, norm, train, val, counts, offs, rank, device_id, lr, **kw):
+    ks = range(offs[rank], offs[rank] + counts[rank])
+    eng = cls([len(preds[k]) for k in ks], cfg["H"], cfg["O"], batch_size=cfg["B"], dropout_rate=0.2,
+              learning_rate=lr, seed=1234, device_id=device_id, subnet_offset=offs[rank], **kw)
+    eng.set_matrix(norm)
+    for i, k in enumerate(ks):
+        eng.set_indices(i, preds[k], targets[k])
+    eng.set_split(train, val)
+    return eng
+
+
+def impute_once(eng, epochs, comm=None, counts=None, n=None):
+    """The timed unit: gather -> init -> E x (train epoch + validation) -> predict (-> gather)."""
+    eng.gather(True)
+    eng.init_weights()
+    vsum = 0.0
+    for e in range(epochs):
+        eng.train_epoch(e)
+        v = eng.val_loss()
+        if comm is not None:                       # global early-stopping quantity (multinet.py:242-243)
+            v = eng.comm_allreduce_sum(np.array([v.sum()]))
+        vsum = float(np.sum(v))
+    eng.predict_device()
+    if comm is not None:
+        eng.comm_gather_predictions(n, counts, root=0, is_root=False)   # result stays in root's HBM
+    eng.synchronize()
+    return vsum
+
+
+def w1_update_bytes(eng):
+    """ALGORITHMIC HBM bytes of one k_w1_update launch: read+write of W1, m, v
+    (24 B per first-layer parameter) + the batch's X rows (4*B*sum(D_k)) + dA (4*B*H*K)."""
+    P1 = sum(d * eng.H for d in eng.D)
+    return 24.0 * P1 + 4.0 * eng.B * sum(eng.D) + 4.0 * eng.B * eng.H * eng.K
+
+
+def cpu_baseline(cfg, targets, preds, norm, train, val, epochs, lr, budget_s=20.0):
+    """Oracle ("port" of the Keras path) timed on this box's host cores on a
+    bounded sample of the SAME workload, extrapolated linearly to the full step."""
+    import subprocess
+    from oracle.dimo import OracleEngine
+    lib = None
+    try:   # rebuild for this host's ISA so the baseline is not handicapped by the portable build
+        lib = "/tmp/libdimo_native_%d.so" % os.getpid()
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=gnu11",
+                               "-ffp-contract=off", "-o", lib, os.path.join(ROOT, "oracle", "dimo.c"), "-lm"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        lib = None
+    K = targets.shape[0]
+    eng = make_engine(OracleEngine, cfg, targets, preds, norm, train, val, [K], [0], 0, 0, lr, lib_path=lib)
+    eng.init_weights()
+    rows = train[:cfg["B"]]
+    eng.train_step(rows, epoch_key=0, step_key=0)            # warm-up (page in the weights)
+    t0 = time.time(); steps = 0
+    while steps < 3 or (time.time() - t0 < budget_s * 0.6 and steps < 64):
+        eng.train_step(train[(steps * cfg["B"]) % (train.size - cfg["B"]):][:cfg["B"]], epoch_key=0, step_key=steps + 1)
+        steps += 1
+    t_step = (time.time() - t0) / steps
+    n_fwd = 512
+    t0 = time.time()
+    eng.predict(np.arange(n_fwd, dtype=np.int32))
+    t_row = (time.time() - t0) / n_fwd
+    n = norm.shape[0]
+    steps_per_epoch = -(-train.size // cfg["B"])
+    t_full = epochs * (steps_per_epoch * t_step + val.size * t_row) + n * t_row
+    cores = os.cpu_count() or 1
+    eng.close()
+    if lib and os.path.exists(lib):
+        os.remove(lib)
+    return {"value": n / t_full, "unit": "cells/s", "cores": cores, "kind": "port",
+            "sample": "%d train steps (%.3f s/step) + forward of %d rows (%.2e s/row), all %d host threads (OpenMP), "
+                      "extrapolated to %d epochs x %d steps + validation + predict of %d cells"
+                      % (steps, t_step, n_fwd, t_row, cores, epochs, steps_per_epoch, n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--epochs", type=int, default=20, help="fixed epoch count E of every fit (see DESIGN.md)")
+    ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--early-stop-probe", action="store_true", help="also run the early-stopped fit once and report its epoch count")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    from deepimpute_amd.engine import HipEngine
+    cfg = CONFIGS[args.config]
+    n, g = cfg["n"], cfg["g"]
+    t_gen = time.time()
+    norm = synth_counts(n, g, seed=0)
+    targets, preds = synth_indices(g, cfg["O"], seed=0)
+    train, val = split_rows(n, seed=0)
+    K = targets.shape[0]
+    counts, offs = shard(K, world)
+    t_gen = time.time() - t_gen
+
+    eng = make_engine(HipEngine, cfg, targets, preds, norm, train, val, counts, offs, rank, local_rank, args.lr)
+    comm = None
+    if world > 1:
+        rdzv = FileRendezvous(rank, world)
+        uid = eng.comm_unique_id().tobytes() if rank == 0 else None
+        uid = rdzv.broadcast_bytes("uid", uid)
+        eng.comm_init(np.frombuffer(uid, np.uint8), world, rank)
+        comm = True
+
+    def barrier():
+        eng.synchronize()
+        if comm:
+            eng.comm_allreduce_sum(np.zeros(1))
+
+    for _ in range(args.warmup):
+        impute_once(eng, args.epochs, comm, counts, n)
+    eng.set_profiling(True)
+    eng.get_timers(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        vsum = impute_once(eng, args.epochs, comm, counts, n)
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.set_profiling(False)
+    if comm:
+        times = np.zeros(world); times[rank] = dt
+        dt = float(eng.comm_allreduce_sum(times).max())
+    timers = eng.get_timers(reset=True)
+
+    result = None
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        value = n / (dt / args.steps)
+        w1_ms = timers[2] / max(1.0, timers[3])
+        abytes = w1_update_bytes(eng)
+        achieved = abytes / (w1_ms * 1e-3) / 1e9 if w1_ms > 0 else 0.0
+        steps_per_epoch = -(-train.size // cfg["B"])
+        result = {
+            "metric": "cells/sec end-to-end impute (fit+predict)", "value": value, "unit": "cells/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded Poisson-Gamma counts, BASELINE.md generator; random-init Glorot weights)",
+            "config": {"workload": cfg["label"], "cells": n, "genes": g, "subnets": K, "epochs_per_fit": args.epochs,
+                       "train_steps_per_epoch": steps_per_epoch, "parallelism": "subnets sharded x%d" % world,
+                       "final_val_loss": vsum, "train_step_ms": timers[0] / max(1.0, timers[1])},
+            "roofline": {"bound": "hbm", "kernel": "k_w1_update", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": w1_ms},
+        }
+        if args.early_stop_probe:
+            eng.gather(True); eng.init_weights()
+            t1 = time.perf_counter()
+            ne, lh, vh = eng.fit(500, 5)
+            eng.predict_device(); eng.synchronize()
+            result["config"]["early_stopped"] = {"epochs": int(ne), "seconds": time.perf_counter() - t1,
+                                                 "val_loss": [float(x) for x in vh[-6:]]}
+    if comm:
+        eng.comm_destroy()
+        rdzv.cleanup()
+    eng.close()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(cfg, targets, preds, norm, train, val, args.epochs, args.lr, args.cpu_budget)
+            except Exception as e:   # the baseline is a reported figure, never the product path
+                result["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        else:
+            result["cpu_baseline"] = None
+        result["config"]["synth_seconds"] = t_gen
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -112,6 +112,7 @@ struct dimn_handle_s {
     std::vector<int32_t> train_rows, val_rows;
     float* d_out = nullptr; int64_t out_cap = 0; int64_t out_rows = 0;
     float* d_loss_part = nullptr; int64_t loss_part_cap = 0;
+    float *d_full = nullptr, *d_stage = nullptr; int64_t full_cap = 0;   // root's gathered predictions
     hipStream_t stream = nullptr;
     int64_t t = 0;
     // profiling
@@ -274,7 +275,7 @@ extern "C" int dimn_destroy(dimn_handle h) {
     DEV_FREE(h->d_b1); DEV_FREE(h->d_b2); DEV_FREE(h->d_P); DEV_FREE(h->d_Dd); DEV_FREE(h->d_dZ); DEV_FREE(h->d_dA);
     DEV_FREE(h->d_loss_step); DEV_FREE(h->d_loss_acc); DEV_FREE(h->d_mask); DEV_FREE(h->d_rows_step);
     DEV_FREE(h->d_epoch_rows); DEV_FREE(h->d_val_rows); DEV_FREE(h->d_pred_rows); DEV_FREE(h->d_out);
-    DEV_FREE(h->d_loss_part);
+    DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return DIMN_OK;
@@ -642,7 +643,7 @@ extern "C" int dimn_val_loss(dimn_handle h, double* val_loss) {
     const int64_t tiles = (h->n_val + DIMN_TB - 1) / DIMN_TB;
     if (h->loss_part_cap < tiles * h->K) {
         HIPCHK(hipStreamSynchronize(h->stream));
-        DEV_FREE(h->d_loss_part);
+        DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage);
         CHK(dev_alloc(&h->d_loss_part, (size_t)(tiles * h->K)));
         h->loss_part_cap = tiles * h->K;
     }
@@ -787,26 +788,35 @@ extern "C" int dimn_comm_gather_predictions(dimn_handle h, int64_t n_rows, const
         HIPCHK(hipStreamSynchronize(h->stream));
         return DIMN_OK;
     }
-    if (!out) return fail(DIMN_ERR_ARG, "dimn_comm_gather_predictions: root needs an output buffer");
-    // root: every peer sends over its own xGMI link; blocks land contiguously, then each
-    // [n_rows][K_r*O] block is copied into its column range of out (strided host copy).
+    // root: every peer sends over its own xGMI link; blocks land contiguously in a staging
+    // arena, then each [n_rows][K_r*O] block is placed into its column range of the full
+    // [n_rows][K_global*O] matrix in HBM (strided D2D copy); host copy only if out != NULL.
     int64_t ktot = 0;
     std::vector<int64_t> koff((size_t)h->n_ranks);
     for (int r = 0; r < h->n_ranks; ++r) { koff[(size_t)r] = ktot; ktot += counts[r]; }
-    float* stage = nullptr;
-    CHK(dev_alloc(&stage, (size_t)n_rows * ktot * O));
+    const int64_t need = n_rows * ktot * O;
+    if (h->full_cap < need) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        DEV_FREE(h->d_full); DEV_FREE(h->d_stage);
+        CHK(dev_alloc(&h->d_full, (size_t)need));
+        CHK(dev_alloc(&h->d_stage, (size_t)need));
+        h->full_cap = need;
+    }
+    float* stage = h->d_stage;
     NCCLCHK(g_rccl.GroupStart());
     for (int r = 0; r < h->n_ranks; ++r) {
         if (r == root) continue;
         NCCLCHK(g_rccl.Recv(stage + (size_t)n_rows * koff[(size_t)r] * O, (size_t)n_rows * counts[r] * O, kNcclFloat32, r, h->comm, h->stream));
     }
     NCCLCHK(g_rccl.GroupEnd());
-    HIPCHK(hipMemcpyAsync(stage + (size_t)n_rows * koff[(size_t)root] * O, h->d_out, (size_t)n_rows * h->K * O * 4, hipMemcpyDeviceToDevice, h->stream));
-    for (int r = 0; r < h->n_ranks; ++r)
-        HIPCHK(hipMemcpy2DAsync(out + koff[(size_t)r] * O, (size_t)ktot * O * 4, stage + (size_t)n_rows * koff[(size_t)r] * O,
-                                (size_t)counts[r] * O * 4, (size_t)counts[r] * O * 4, (size_t)n_rows, hipMemcpyDeviceToHost, h->stream));
+    for (int r = 0; r < h->n_ranks; ++r) {
+        const float* src = (r == root) ? h->d_out : stage + (size_t)n_rows * koff[(size_t)r] * O;
+        if (n_rows > 0)
+            HIPCHK(hipMemcpy2DAsync(h->d_full + koff[(size_t)r] * O, (size_t)ktot * O * 4, src, (size_t)counts[r] * O * 4,
+                                    (size_t)counts[r] * O * 4, (size_t)n_rows, hipMemcpyDeviceToDevice, h->stream));
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
-    (void)hipFree(stage);
+    if (out && need > 0) HIPCHK(hipMemcpy(out, h->d_full, (size_t)need * 4, hipMemcpyDeviceToHost));
     return DIMN_OK;
 }
 extern "C" int dimn_comm_destroy(dimn_handle h) {

@@ -1,0 +1,35 @@
+"""`deepImpute` entry point (function + console script), same call shape as the reference's
+deepimpute/deepImpute.py:6-40: parse flags, let keyword arguments override them, read the CSV,
+fit a MultiNet on the GPU, impute, write or return the result."""
+import pandas as pd
+
+from .multinet import MultiNet
+from .parser import parse_args
+
+
+def deepImpute(**kwargs):
+    args = parse_args()                 # always parses sys.argv, as the reference does
+    for name, value in kwargs.items():
+        setattr(args, name, value)
+
+    counts = pd.read_csv(args.inputFile, index_col=0)
+    if args.cell_axis == "columns":
+        counts = counts.T
+
+    net = MultiNet(learning_rate=args.learning_rate,
+                   batch_size=args.batch_size,
+                   max_epochs=args.max_epochs,
+                   ncores=args.cores,
+                   sub_outputdim=args.output_neurons,
+                   architecture=[{"type": "dense", "activation": "relu", "neurons": args.hidden_neurons},
+                                 {"type": "dropout", "activation": "dropout", "rate": args.dropout_rate}])
+    net.fit(counts, NN_lim=args.limit, cell_subset=args.subset, minVMR=args.minVMR, n_pred=args.n_pred)
+    imputed = net.predict(counts, imputed_only=False, policy=args.policy)
+
+    if args.output is None:
+        return imputed
+    imputed.to_csv(args.output)
+
+
+if __name__ == "__main__":
+    deepImpute()

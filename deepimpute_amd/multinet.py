@@ -1,16 +1,23 @@
 """Drop-in `MultiNet` estimator on the MI355X-native engine.
 
-Same public surface as the reference's `deepimpute.multinet` (class MultiNet with
-fit/predict/score, module functions get_distance_matrix / wMSE / inspect_data; reference
-deepimpute/multinet.py:20-63, 65-374).  Everything the reference hands to Keras/TensorFlow
-(build -> compile -> model.fit -> model.predict, multinet.py:126-167, 238-253, 276-280) goes
-to `deepimpute_amd.engine.HipEngine` instead, i.e. to hand-written gfx950 kernels behind the C
-ABI of include/dimn.h.  The host-side gene selection / predictor selection / post-processing
-around that seam is restated here with numpy/pandas so that the global-numpy-RNG call order,
-the printed messages and the returned frames match the reference (pinned by
-tests/golden/shell_*.npz, captured from the imported reference).
+Public surface = the reference's `deepimpute.multinet`: class `MultiNet` (fit / predict /
+score, attributes NN_parameters, predictors, targets, trained_epochs, test_metrics ...) and the
+module functions `get_distance_matrix`, `wMSE`, `inspect_data` (reference
+deepimpute/multinet.py:20-63, 65-374).
 
-There is no CPU fallback: without libdimn.so + a GPU, fit()/predict() raise.
+What differs is what sits behind it.  The reference builds one Keras model with K inputs and
+K outputs and calls model.fit / model.predict (multinet.py:126-167, 238-253, 276-280); here
+those calls go to `deepimpute_amd.engine.HipEngine`, i.e. hand-written gfx950 kernels behind the
+C ABI of include/dimn.h.  The shared log1p matrix is uploaded once and the per-sub-net
+(cells x predictors)/(cells x targets) blocks are gathered on the GPU from column index lists,
+instead of 4K pandas `.loc` copies on the host.
+
+The host-side planning around the seam (which genes, which targets per sub-net, which
+predictors, the 5 % validation split, the post-processing of predictions) follows the
+reference's behaviour including its use of the global numpy RNG, so that a given seed yields the
+same plan; tests/golden/shell_*.npz (captured from the imported reference) pin that.
+
+There is no CPU fallback: without libdimn.so and a GPU, fit()/predict() raise.
 """
 import json
 import os
@@ -21,384 +28,326 @@ import numpy as np
 import pandas as pd
 from scipy.stats import pearsonr
 
-_DEFAULT_OUTPUT_PREFIX = tempfile.mkdtemp()   # one temp dir per import, as in the reference (:74)
+# one scratch directory per process, shared by every instance that does not pass its own
+# (the reference evaluates tempfile.mkdtemp() once, as a default argument: multinet.py:74)
+_SCRATCH = tempfile.mkdtemp()
+_VALIDATION_FRACTION = 0.05     # multinet.py:228
 
 
+# --------------------------------------------------------------------------- module functions
 def get_distance_matrix(raw, n_pred=None):
-    """|Pearson| between genes with non-zero variance/mean ratio (reference multinet.py:20-34)."""
-    vmr = raw.std() / raw.mean()
-    vmr[np.isinf(vmr)] = 0
+    """Absolute Pearson correlation between candidate predictor genes (multinet.py:20-34).
+    Candidates: genes with std/mean > 0, or the `n_pred` genes with the largest ratio."""
+    ratio = raw.std() / raw.mean()
+    ratio[np.isinf(ratio)] = 0
     if n_pred is None:
-        candidates = raw.columns[vmr > 0]
+        keep = raw.columns[ratio > 0]
     else:
         print("Using {} predictors".format(n_pred))
-        candidates = vmr.sort_values(ascending=False).index[:n_pred]
-    corr = np.abs(np.corrcoef(raw.T.loc[candidates]))
-    return pd.DataFrame(corr, index=candidates, columns=candidates).fillna(0)
+        keep = ratio.sort_values(ascending=False).index[:n_pred]
+    table = pd.DataFrame(np.abs(np.corrcoef(raw.T.loc[keep])), index=keep, columns=keep)
+    return table.fillna(0)
 
 
 def wMSE(y_true, y_pred, binary=False):
-    """Weighted MSE of the reference (multinet.py:36-41) as a numpy function: mean over all
-    elements of w*(y-yhat)^2 with w = y_true (or 1[y_true>0]).  The training kernels implement
-    exactly this; the function is kept for API compatibility and for checks."""
-    y_true = np.asarray(y_true)
-    y_pred = np.asarray(y_pred)
-    weights = (y_true > 0).astype(np.float32) if binary else y_true
-    return np.mean(weights * np.square(y_true - y_pred))
+    """The reference's loss (multinet.py:36-41) on numpy arrays: mean over every element of
+    w * (y - yhat)^2 with w = y_true, or 1[y_true > 0] when `binary`.  Training evaluates it
+    inside the kernels; this function exists for API compatibility and for checks."""
+    y_true, y_pred = np.asarray(y_true), np.asarray(y_pred)
+    w = (y_true > 0).astype(np.float32) if binary else y_true
+    return np.mean(w * np.square(y_true - y_pred))
 
 
 def inspect_data(data):
-    """Input guards of the reference (multinet.py:43-63): unique labels, raw counts."""
-    if sum(data.index.duplicated()):
-        print("ERROR: duplicated cell labels. Please provide unique cell labels.")
-        exit(1)
-    if sum(data.columns.duplicated()):
-        print("ERROR: duplicated gene labels. Please provide unique gene labels.")
-        exit(1)
-    max_value = np.max(data.values)
-    if max_value < 10:
-        print("ERROR: max value = {}. Is your data log-transformed? Please provide raw counts"
-              .format(max_value))
+    """Guards of multinet.py:43-63: unique cell / gene labels, and raw (not log) counts."""
+    problems = (("cell", data.index), ("gene", data.columns))
+    for what, labels in problems:
+        if sum(labels.duplicated()):
+            print("ERROR: duplicated {0} labels. Please provide unique {0} labels.".format(what))
+            exit(1)
+    top = np.max(data.values)
+    if top < 10:
+        print("ERROR: max value = {}. Is your data log-transformed? Please provide raw counts".format(top))
         exit(1)
     print("Input dataset is {} cells (rows) and {} genes (columns)".format(*data.shape))
     print("First 3 rows and columns:")
     print(data.iloc[:3, :3])
 
 
-_LOSSES = {"wMSE": 0, "wmse": 0}
-
-
-def _parse_architecture(architecture):
-    """The kernels implement Dense(H, relu) [-> Dropout(p)] -> Dense(O, softplus), the only form
-    any caller of the reference uses (multinet.py:99-103, deepImpute.py:24-26).  Returns (H, p)."""
-    hidden, rate, seen_dropout = None, 0.0, False
-    for layer in architecture:
-        kind = str(layer.get("type", "")).lower()
-        if kind == "dense":
-            if hidden is not None or seen_dropout:
-                raise NotImplementedError(
-                    "deepimpute_amd supports one hidden dense layer followed by an optional dropout; "
-                    "got architecture %r" % (architecture,))
-            if str(layer.get("activation", "relu")).lower() != "relu":
-                raise NotImplementedError("hidden activation %r is not implemented (relu only)"
-                                          % (layer.get("activation"),))
-            hidden = int(layer["neurons"])
-        elif kind == "dropout":
-            if hidden is None or seen_dropout:
-                raise NotImplementedError("dropout must follow the hidden dense layer, once")
-            rate = float(layer["rate"])
-            seen_dropout = True
+def _hidden_and_dropout(architecture):
+    """(H, p) of an architecture list.  The kernels implement Dense(H, relu) [-> Dropout(p)]
+    -> Dense(O, softplus): the form of loadDefaultArchitecture (multinet.py:99-103) and of every
+    caller in the reference tree (deepImpute.py:24-26, tests/multinet_test.py:17-20)."""
+    hidden, rate, dropped = None, 0.0, False
+    for spec in architecture:
+        kind = str(spec.get("type", "")).lower()
+        if kind == "dense" and hidden is None and not dropped:
+            act = str(spec.get("activation", "relu")).lower()
+            if act != "relu":
+                raise NotImplementedError("hidden activation %r: only 'relu' has a gfx950 kernel" % act)
+            hidden = int(spec["neurons"])
+        elif kind == "dropout" and hidden is not None and not dropped:
+            rate, dropped = float(spec["rate"]), True
+        elif kind in ("dense", "dropout"):
+            raise NotImplementedError("only [dense(relu), dropout] architectures are implemented, got %r" % (architecture,))
         else:
-            print("Unknown layer type.")   # reference multinet.py:142-143 ignores it
+            print("Unknown layer type.")       # the reference skips such entries (multinet.py:142-143)
     if hidden is None:
-        raise NotImplementedError("architecture needs one hidden dense layer")
+        raise NotImplementedError("architecture needs a hidden dense layer")
     return hidden, rate
 
 
+# ------------------------------------------------------------------------------- the estimator
 class MultiNet:
-    def __init__(self,
-                 learning_rate=1e-4,
-                 batch_size=64,
-                 max_epochs=500,
-                 patience=5,
-                 ncores=-1,
-                 loss="wMSE",
-                 output_prefix=_DEFAULT_OUTPUT_PREFIX,
-                 sub_outputdim=512,
-                 verbose=1,
-                 seed=1234,
-                 architecture=None,
-                 device_id=0,
-                 engine_factory=None):
-        # same hyper-parameter dict as the reference (multinet.py:80-85)
-        self.NN_parameters = {"learning_rate": learning_rate,
-                              "batch_size": batch_size,
-                              "loss": loss,
-                              "architecture": architecture,
-                              "max_epochs": max_epochs,
-                              "patience": patience}
+    def __init__(self, learning_rate=1e-4, batch_size=64, max_epochs=500, patience=5, ncores=-1,
+                 loss="wMSE", output_prefix=_SCRATCH, sub_outputdim=512, verbose=1, seed=1234,
+                 architecture=None, device_id=0, engine_factory=None):
+        self.NN_parameters = dict(learning_rate=learning_rate, batch_size=batch_size, loss=loss,
+                                  architecture=architecture, max_epochs=max_epochs, patience=patience)
         self.sub_outputdim = sub_outputdim
         self.outputdir = output_prefix
         self.verbose = verbose
         self.seed = seed
-        self.device_id = device_id
-        self._engine_factory = engine_factory   # test hook; None -> HipEngine (GPU, no fallback)
+        self.device_id = device_id                 # extension: which GPU
+        self._engine_factory = engine_factory      # extension (tests): None -> HipEngine, no fallback
         self._engine = None
         self.setCores(ncores)
 
-    # ncores only sets TF's CPU thread pools in the reference (multinet.py:222-223); the GPU
-    # path has no use for it but the attribute and the message are kept.
     def setCores(self, ncores):
-        if ncores > 0:
-            self.ncores = ncores
-        else:
-            self.ncores = os.cpu_count()
+        # the reference only sizes TensorFlow's CPU thread pools with this (multinet.py:222-223);
+        # kept as an attribute (and message) for compatibility, unused by the GPU path
+        self.ncores = ncores if ncores > 0 else os.cpu_count()
+        if ncores <= 0:
             print("Using all the cores ({})".format(self.ncores))
 
     def loadDefaultArchitecture(self):
         self.NN_parameters['architecture'] = [
             {"type": "dense", "neurons": self.sub_outputdim // 2, "activation": "relu"},
-            {"type": "dropout", "rate": 0.2},
-        ]
+            {"type": "dropout", "rate": 0.2}]
 
-    # ---- engine construction: stands where build() creates the Keras model (:126-167) ----
+    # -- the seam: where the reference builds/compiles the Keras model (multinet.py:126-167) --
     def build(self, inputdims, subnet_offset=0):
         if self.NN_parameters['architecture'] is None:
             self.loadDefaultArchitecture()
         print(self.NN_parameters['architecture'])
-        hidden, rate = _parse_architecture(self.NN_parameters['architecture'])
+        hidden, rate = _hidden_and_dropout(self.NN_parameters['architecture'])
         loss = self.NN_parameters['loss']
-        if callable(loss):
-            loss = getattr(loss, "__name__", "")
-        if loss not in _LOSSES:
+        loss = getattr(loss, "__name__", loss)
+        if str(loss).lower() != "wmse":
             print('Unknown loss: {}. Aborting.'.format(loss))
             exit(1)
-        factory = self._engine_factory
-        if factory is None:
-            from .engine import HipEngine
-            factory = HipEngine
-        return factory(list(inputdims), hidden, self.sub_outputdim,
-                       batch_size=self.NN_parameters["batch_size"], dropout_rate=rate,
-                       learning_rate=self.NN_parameters["learning_rate"],
-                       seed=self.seed if self.seed is not None else 0,
-                       device_id=self.device_id, subnet_offset=subnet_offset)
+        make = self._engine_factory
+        if make is None:
+            from .engine import HipEngine as make
+        return make(list(inputdims), hidden, self.sub_outputdim,
+                    batch_size=self.NN_parameters["batch_size"], dropout_rate=rate,
+                    learning_rate=self.NN_parameters["learning_rate"],
+                    seed=0 if self.seed is None else self.seed,
+                    device_id=self.device_id, subnet_offset=subnet_offset)
 
-    # ---- persistence: model.json + weights (reference writes model.json + model.h5) ----
+    # -- persistence (reference: model.json + model.h5, multinet.py:105-124) --
     def save(self, model):
         os.makedirs(self.outputdir, exist_ok=True)
-        hidden, rate = _parse_architecture(self.NN_parameters['architecture'])
-        meta = {"format": "deepimpute_amd-1", "inputdims": list(model.D), "hidden": hidden,
-                "dropout_rate": rate, "sub_outputdim": self.sub_outputdim,
-                "architecture": self.NN_parameters['architecture']}
-        with open("{}/model.json".format(self.outputdir), "w") as json_file:
-            json.dump(meta, json_file)
-        arrays = {}
+        hidden, rate = _hidden_and_dropout(self.NN_parameters['architecture'])
+        with open(os.path.join(self.outputdir, "model.json"), "w") as fh:
+            json.dump({"format": "deepimpute_amd-1", "inputdims": list(model.D), "hidden": hidden,
+                       "dropout_rate": rate, "sub_outputdim": self.sub_outputdim,
+                       "architecture": self.NN_parameters['architecture']}, fh)
+        blobs = {}
         for k in range(model.K):
-            W1, b1, W2, b2 = model.get_weights(k)
-            arrays["W1_%d" % k], arrays["b1_%d" % k] = W1, b1
-            arrays["W2_%d" % k], arrays["b2_%d" % k] = W2, b2
-        np.savez("{}/model.npz".format(self.outputdir), **arrays)
+            for name, arr in zip(("W1", "b1", "W2", "b2"), model.get_weights(k)):
+                blobs["%s_%d" % (name, k)] = arr
+        np.savez(os.path.join(self.outputdir, "model.npz"), **blobs)
         print("Saved model to disk in {}".format(self.outputdir))
 
     def load(self):
-        """Engine with the weights saved by fit() (reference load(): model_from_json + load_weights,
-        multinet.py:117-124).  Re-uses the live engine when this object trained it."""
-        if self._engine is not None:
-            return self._engine
-        with open('{}/model.json'.format(self.outputdir), 'r') as json_file:
-            meta = json.load(json_file)
-        self.NN_parameters['architecture'] = meta["architecture"]
-        self.sub_outputdim = meta["sub_outputdim"]
-        model = self.build(meta["inputdims"])
-        with np.load('{}/model.npz'.format(self.outputdir)) as z:
-            for k in range(model.K):
-                model.set_weights(k, z["W1_%d" % k], z["b1_%d" % k], z["W2_%d" % k], z["b2_%d" % k])
-        self._engine = model
-        return model
+        """The engine holding the fitted weights: the live one if this object trained it, else
+        rebuilt from outputdir (weights only, like Keras load_weights: no optimizer state)."""
+        if self._engine is None:
+            with open(os.path.join(self.outputdir, "model.json")) as fh:
+                meta = json.load(fh)
+            self.NN_parameters['architecture'] = meta["architecture"]
+            self.sub_outputdim = meta["sub_outputdim"]
+            engine = self.build(meta["inputdims"])
+            with np.load(os.path.join(self.outputdir, "model.npz")) as z:
+                for k in range(engine.K):
+                    engine.set_weights(k, *(z["%s_%d" % (nm, k)] for nm in ("W1", "b1", "W2", "b2")))
+            self._engine = engine
+        return self._engine
 
-    def _set_columns(self, model, columns):
-        col_index = pd.Index(columns)
-        for k in range(model.K):
-            p = col_index.get_indexer(self.predictors[k])
-            t = col_index.get_indexer(self.targets[k])
-            if (p < 0).any() or (t < 0).any():
+    def _bind_columns(self, engine, columns):
+        """Translate gene labels of predictors/targets into column positions of the matrix."""
+        where = pd.Index(columns)
+        for k in range(engine.K):
+            cols_in, cols_out = where.get_indexer(self.predictors[k]), where.get_indexer(self.targets[k])
+            if (cols_in < 0).any() or (cols_out < 0).any():
                 raise KeyError("predictor/target genes missing from the data columns")
-            model.set_indices(k, p, t)
+            engine.set_indices(k, cols_in, cols_out)
 
-    def fit(self,
-            raw,
-            cell_subset=1,
-            NN_lim=None,
-            genes_to_impute=None,
-            n_pred=None,
-            ntop=5,
-            minVMR=0.5,
-            mode='random'):
+    # -- fit: planning on the host, training on the GPU --
+    def fit(self, raw, cell_subset=1, NN_lim=None, genes_to_impute=None, n_pred=None, ntop=5,
+            minVMR=0.5, mode='random'):
         inspect_data(raw)
-
         if self.seed is not None:
             np.random.seed(self.seed)
-
         if cell_subset != 1:
-            if cell_subset < 1:
-                raw = raw.sample(frac=cell_subset)
-            else:
-                raw = raw.sample(int(cell_subset))   # the CLI passes a float (parser.py:38)
+            # fraction below 1, absolute cell count otherwise (the CLI passes a float)
+            raw = raw.sample(frac=cell_subset) if cell_subset < 1 else raw.sample(int(cell_subset))
 
+        # variance over (1 + mean), most variable first, strictly positive (multinet.py:191-192)
         gene_metric = (raw.var() / (1 + raw.mean())).sort_values(ascending=False)
         gene_metric = gene_metric[gene_metric > 0]
-
         if genes_to_impute is None:
             genes_to_impute = self.filter_genes(gene_metric, minVMR, NN_lim=NN_lim)
         else:
-            n_genes = len(genes_to_impute)
-            if n_genes % self.sub_outputdim != 0:
-                print("The number of input genes is not a multiple of {}. Filling with other genes.".format(n_genes))
-                fill_genes = gene_metric.index[:self.sub_outputdim - n_genes]
-                if len(fill_genes) < self.sub_outputdim - n_genes:
-                    rest = self.sub_outputdim - n_genes - len(fill_genes)
-                    fill_genes = np.concatenate([fill_genes,
-                                                 np.random.choice(gene_metric.index, rest, replace=True)])
-                genes_to_impute = np.concatenate([genes_to_impute, fill_genes])
+            genes_to_impute = self._pad_gene_list(genes_to_impute, gene_metric)
 
-        covariance_matrix = get_distance_matrix(raw, n_pred=n_pred)
-
+        correlations = get_distance_matrix(raw, n_pred=n_pred)
         self.setTargets(raw.reindex(columns=genes_to_impute), mode=mode)
-        self.setPredictors(covariance_matrix, ntop=ntop)
+        self.setPredictors(correlations, ntop=ntop)
 
         print("Normalization")
         norm_data = np.log1p(raw).astype(np.float32)
-
-        np.random.seed(self.seed)
+        np.random.seed(self.seed)                      # second seeding, multinet.py:219
 
         print("Building network")
         if self._engine is not None:
             self._engine.close()
             self._engine = None
-        model = self.build([len(genes) for genes in self.predictors])
+        engine = self.build([len(p) for p in self.predictors])
 
-        test_cells = np.random.choice(norm_data.index, int(0.05 * norm_data.shape[0]), replace=False)
-        train_cells = np.setdiff1d(norm_data.index, test_cells)
+        held_out = np.random.choice(norm_data.index, int(_VALIDATION_FRACTION * norm_data.shape[0]), replace=False)
+        kept = np.setdiff1d(norm_data.index, held_out)          # label-sorted, multinet.py:229
+        rows_val, rows_train = norm_data.index.get_indexer(held_out), norm_data.index.get_indexer(kept)
 
-        # the reference materialises 4K host arrays here (multinet.py:231-235); the engine
-        # takes the shared matrix once plus index lists and gathers on the device
-        model.set_matrix(norm_data.values)
-        self._set_columns(model, norm_data.columns)
-        model.gather(True)
-        train_rows = norm_data.index.get_indexer(train_cells)
-        test_rows = norm_data.index.get_indexer(test_cells)
-        model.set_split(train_rows, test_rows)
-        model.init_weights(self.seed if self.seed is not None else 0)
+        engine.set_matrix(norm_data.values)
+        self._bind_columns(engine, norm_data.columns)
+        engine.gather(True)
+        engine.set_split(rows_train, rows_val)
+        engine.init_weights(0 if self.seed is None else self.seed)
 
         print("Fitting with {} cells".format(norm_data.shape[0]))
-        epochs_run, loss_hist, val_hist = model.fit(self.NN_parameters["max_epochs"],
-                                                    self.NN_parameters["patience"])
-        self.history = {"loss": list(loss_hist), "val_loss": list(val_hist)}
+        epochs, loss_curve, val_curve = engine.fit(self.NN_parameters["max_epochs"], self.NN_parameters["patience"])
+        self.history = {"loss": [float(x) for x in loss_curve], "val_loss": [float(x) for x in val_curve]}
         if self.verbose:
-            for e, (l, v) in enumerate(zip(loss_hist, val_hist)):
-                print("Epoch {}/{} - loss: {:.4f} - val_loss: {:.4f}".format(
-                    e + 1, self.NN_parameters["max_epochs"], l, v))
-
-        self.trained_epochs = epochs_run
+            for i, (a, b) in enumerate(zip(loss_curve, val_curve), start=1):
+                print("Epoch {}/{} - loss: {:.4f} - val_loss: {:.4f}".format(i, self.NN_parameters["max_epochs"], a, b))
+        self.trained_epochs = int(epochs)
         print("Stopped fitting after {} epochs".format(self.trained_epochs))
 
-        self._engine = model
-        self.save(model)
-
-        # held-out metrics on the validation cells (reference multinet.py:251-262)
-        Y_test_raw = np.hstack([norm_data.loc[test_cells, t].values for t in self.targets]).flatten()
-        Y_test_imputed = model.predict(test_rows).flatten()
-        Y_test_imputed = Y_test_imputed[Y_test_raw > 0]
-        Y_test_raw = Y_test_raw[Y_test_raw > 0]
-        self.test_metrics = {
-            'correlation': pearsonr(Y_test_raw, Y_test_imputed)[0],
-            'MSE': np.sum((Y_test_raw - Y_test_imputed) ** 2) / len(Y_test_raw)
-        }
+        self._engine = engine
+        self.save(engine)
+        self.test_metrics = self._held_out_metrics(engine, norm_data, held_out, rows_val)
         return self
 
-    def predict(self,
-                raw,
-                imputed_only=False,
-                policy="restore"):
+    def _pad_gene_list(self, genes, gene_metric):
+        """User-supplied gene list made a multiple of sub_outputdim (multinet.py:196-209)."""
+        count = len(genes)
+        if count % self.sub_outputdim == 0:
+            return genes
+        print("The number of input genes is not a multiple of {}. Filling with other genes.".format(count))
+        wanted = self.sub_outputdim - count
+        extra = gene_metric.index[:wanted]
+        if len(extra) < wanted:
+            extra = np.concatenate([extra, np.random.choice(gene_metric.index, wanted - len(extra), replace=True)])
+        return np.concatenate([genes, extra])
+
+    def _held_out_metrics(self, engine, norm_data, held_out, rows_val):
+        """Pearson r and MSE on the positive entries of the validation targets (multinet.py:251-262)."""
+        truth = np.hstack([norm_data.loc[held_out, genes].values for genes in self.targets]).flatten()
+        guess = engine.predict(rows_val).flatten()
+        positive = truth > 0
+        truth, guess = truth[positive], guess[positive]
+        return {'correlation': pearsonr(truth, guess)[0],
+                'MSE': np.sum((truth - guess) ** 2) / len(truth)}
+
+    # -- predict: forward on the GPU, post-processing as multinet.py:282-310 --
+    def predict(self, raw, imputed_only=False, policy="restore"):
         norm_raw = np.log1p(raw)
+        engine = self.load()
+        engine.set_matrix(norm_raw.values.astype(np.float32))
+        self._bind_columns(engine, norm_raw.columns)
+        engine.gather(False)
+        block = engine.predict()                         # [cells, K*O], np.hstack of the K outputs
 
-        model = self.load()
-        model.set_matrix(norm_raw.values.astype(np.float32))
-        self._set_columns(model, norm_raw.columns)
-        model.gather(False)
-        predicted = model.predict()             # [cells, K*O] == np.hstack(model.predict(inputs))
+        # a gene may occupy several target slots: average them; columns come out label-sorted,
+        # like the reference's groupby(columns).mean() (multinet.py:282-284)
+        slots = self.targets.flatten()
+        genes, slot_gene = np.unique(slots, return_inverse=True)
+        acc = np.zeros((len(genes), block.shape[0]), dtype=np.float32)
+        np.add.at(acc, slot_gene, block.T)
+        acc /= np.bincount(slot_gene, minlength=len(genes)).astype(np.float32)[:, None]
+        predicted = pd.DataFrame(acc.T, index=raw.index, columns=genes)
 
-        # duplicated target genes are averaged; columns come back label-sorted (the
-        # reference's groupby(by=columns, axis=1).mean(), multinet.py:282-284)
-        flat_targets = self.targets.flatten()
-        uniq, inverse = np.unique(flat_targets, return_inverse=True)
-        counts = np.bincount(inverse, minlength=len(uniq)).astype(np.float32)
-        summed = np.zeros((predicted.shape[0], len(uniq)), dtype=np.float32)
-        np.add.at(summed.T, inverse, predicted.T)
-        predicted = pd.DataFrame(summed / counts, index=raw.index, columns=uniq)
-        not_predicted = norm_raw.drop(uniq, axis=1)
+        untouched = norm_raw.drop(genes, axis=1)
+        values = pd.concat([predicted, untouched], axis=1).loc[raw.index, raw.columns].values
+        ceiling = 2 * norm_raw.values.max()              # overflow guard, multinet.py:292
+        values[(values > ceiling) | np.isnan(values)] = 0
+        values = np.expm1(values)                        # back to counts
 
-        imputed = (pd.concat([predicted, not_predicted], axis=1)
-                   .loc[raw.index, raw.columns]
-                   .values)
-
-        # To prevent overflow (multinet.py:292), then back to counts
-        imputed[(imputed > 2 * norm_raw.values.max()) | (np.isnan(imputed))] = 0
-        imputed = np.expm1(imputed)
-
+        observed = raw.values
         if policy == "restore":
             print("Filling zeros")
-            mask = (raw.values > 0)
-            imputed[mask] = raw.values[mask]
+            keep_raw = observed > 0
+            values[keep_raw] = observed[keep_raw]
         elif policy == "max":
             print("Imputing data with 'max' policy")
-            mask = (raw.values > imputed)
-            imputed[mask] = raw.values[mask]
+            keep_raw = observed > values
+            values[keep_raw] = observed[keep_raw]
 
-        imputed = pd.DataFrame(imputed, index=raw.index, columns=raw.columns)
+        imputed = pd.DataFrame(values, index=raw.index, columns=raw.columns)
+        return imputed.loc[:, predicted.columns] if imputed_only else imputed
 
-        if imputed_only:
-            return imputed.loc[:, predicted.columns]
-        else:
-            return imputed
-
-    def filter_genes(self,
-                     gene_metric,   # assumes gene_metric is sorted
-                     threshold,
-                     NN_lim=None):
-        if not str(NN_lim).isdigit():
-            NN_lim = (gene_metric > threshold).sum()
-        NN_lim = int(NN_lim)           # the CLI hands a digit string (parser.py:26)
-
-        n_subsets = int(np.ceil(NN_lim / self.sub_outputdim))
-        genes_to_impute = gene_metric.index[:n_subsets * self.sub_outputdim]
-
-        rest = self.sub_outputdim - (len(genes_to_impute) % self.sub_outputdim)
-        if rest > 0:
-            fill_genes = np.random.choice(gene_metric.index, rest)
-            genes_to_impute = np.concatenate([genes_to_impute, fill_genes])
-
-        print("{} genes selected for imputation".format(len(genes_to_impute)))
-        return genes_to_impute
+    # -- planning helpers (public in the reference, so public here) --
+    def filter_genes(self, gene_metric, threshold, NN_lim=None):
+        """Genes to impute: the NN_lim most variable ones (default: all above `threshold`),
+        rounded up to whole sub-networks and topped up with random genes (multinet.py:312-331;
+        note the top-up is a full extra sub-network when the count is already a multiple)."""
+        limit = int(NN_lim) if str(NN_lim).isdigit() else int((gene_metric > threshold).sum())
+        width = self.sub_outputdim
+        chosen = gene_metric.index[:int(np.ceil(limit / width)) * width]
+        missing = width - (len(chosen) % width)
+        if missing > 0:
+            chosen = np.concatenate([chosen, np.random.choice(gene_metric.index, missing)])
+        print("{} genes selected for imputation".format(len(chosen)))
+        return chosen
 
     def setTargets(self, data, mode='random'):
-        n_subsets = int(data.shape[1] / self.sub_outputdim)
+        """Partition the genes to impute into K rows of sub_outputdim targets (multinet.py:333-342)."""
+        shape = [int(data.shape[1] / self.sub_outputdim), self.sub_outputdim]
         if mode == 'progressive':
-            self.targets = data.columns.values.reshape([n_subsets, self.sub_outputdim])
+            self.targets = data.columns.values.reshape(shape)
         else:
-            self.targets = np.random.choice(data.columns,
-                                            [n_subsets, self.sub_outputdim],
-                                            replace=False)
+            self.targets = np.random.choice(data.columns, shape, replace=False)
 
     def setPredictors(self, covariance_matrix, ntop=5):
-        """Top-`ntop` most correlated non-target genes per target, first-occurrence order
-        (reference multinet.py:344-365).  The reference argsorts every full row; a partial
-        selection gives the same genes in the same order whenever correlations are distinct."""
+        """Per sub-network: for each target the `ntop` most correlated genes outside the target
+        set, in first-occurrence order (multinet.py:344-365).  The reference argsorts every full
+        row; picking the top-ntop by partial selection yields the same genes in the same order
+        whenever the correlations involved are distinct."""
+        pool = covariance_matrix.columns
         self.predictors = []
-        all_cols = covariance_matrix.columns
-        for i, targets in enumerate(self.targets):
-            genes_not_in_target = np.setdiff1d(all_cols, targets)
-            if genes_not_in_target.size == 0:
+        for net, targets in enumerate(self.targets):
+            outside = np.setdiff1d(pool, targets)
+            if outside.size == 0:
                 warnings.warn('Warning: number of target genes lower than output dim. '
                               'Consider lowering down the sub_outputdim parameter', UserWarning)
-                genes_not_in_target = all_cols
-            sub = covariance_matrix.loc[targets, genes_not_in_target].values
-            take = min(ntop, sub.shape[1])
-            if take < sub.shape[1]:
-                part = np.argpartition(-sub, take - 1, axis=1)[:, :take]
+                outside = pool
+            scores = covariance_matrix.loc[targets, outside].values
+            width = min(ntop, scores.shape[1])
+            if width < scores.shape[1]:
+                cand = np.argpartition(-scores, width - 1, axis=1)[:, :width]
             else:
-                part = np.tile(np.arange(sub.shape[1]), (sub.shape[0], 1))
-            vals = np.take_along_axis(sub, part, axis=1)
-            order = np.argsort(-vals, axis=1, kind="stable")
-            top = np.take_along_axis(part, order, axis=1)
-            predictors = pd.Index(genes_not_in_target)[top.flatten()]
-            self.predictors.append(predictors.unique())
-            print("Net {}: {} predictors, {} targets".format(i, len(np.unique(predictors)), len(targets)))
+                cand = np.broadcast_to(np.arange(scores.shape[1]), scores.shape).copy()
+            rank = np.argsort(-np.take_along_axis(scores, cand, axis=1), axis=1, kind="stable")
+            best = np.take_along_axis(cand, rank, axis=1)
+            picked = pd.Index(outside)[best.flatten()]
+            self.predictors.append(picked.unique())
+            print("Net {}: {} predictors, {} targets".format(net, len(np.unique(picked)), len(targets)))
 
     def score(self, data, policy=None):
-        warnings.warn(
-            "This method is deprecated. Please use model.test_metrics to measure model accuracy instead",
-            DeprecationWarning)
-        Y_hat = self.predict(data, policy=policy)
-        Y = data.loc[Y_hat.index, Y_hat.columns]
-        return pearsonr(Y_hat.values.reshape(-1), Y.values.reshape(-1))
+        warnings.warn("This method is deprecated. Please use model.test_metrics to measure model accuracy instead",
+                      DeprecationWarning)
+        estimate = self.predict(data, policy=policy)
+        truth = data.loc[estimate.index, estimate.columns]
+        return pearsonr(estimate.values.reshape(-1), truth.values.reshape(-1))

@@ -160,9 +160,10 @@ int dimn_comm_init(dimn_handle h, const uint8_t* id, int32_t n_ranks, int32_t ra
 /* In-place sum over ranks of a small host vector (per-epoch val-loss for the global
  * early-stopping decision, multinet.py:242-243). */
 int dimn_comm_allreduce_sum(dimn_handle h, double* v, int32_t n);
-/* Gather the last dimn_predict_device result of every rank into root's host buffer
- * out[n_rows][K_global*O] (column block of rank r at r's subnet_offset*O);
- * counts[r] = K_local of rank r.  ncclSend/ncclRecv straight to root over xGMI. */
+/* Gather the last dimn_predict_device result of every rank into the full matrix
+ * [n_rows][K_global*O] in ROOT's HBM (column block of rank r at r's subnet_offset*O;
+ * counts[r] = K_local of rank r): ncclSend/ncclRecv straight to root, one xGMI link per
+ * peer.  If out != NULL on root it is also copied to that host buffer. */
 int dimn_comm_gather_predictions(dimn_handle h, int64_t n_rows, const int32_t* counts,
                                  int32_t root, float* out);
 int dimn_comm_destroy(dimn_handle h);
