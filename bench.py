@@ -167,43 +167,80 @@ def w1_update_bytes(eng):
 
 
 def cpu_baseline(cfg, targets, preds, norm, train, val, epochs, lr, budget_s=20.0):
-    """Oracle ("port" of the Keras path) timed on this box's host cores on a
-    bounded sample of the SAME workload, extrapolated linearly to the full step."""
+    """The reference's CPU path restated ("port"), timed on this box's host cores on
+    a bounded sample of the SAME workload and extrapolated linearly to the full step.  Two ports
+    are timed and the FASTER one is reported: oracle/np_port.py (OpenBLAS sgemm per contraction,
+    sub-nets on a thread pool -- the shape of Keras/TF-on-CPU) and oracle/dimo.c (plain loops,
+    OpenMP)."""
     import subprocess
     from oracle.dimo import OracleEngine
-    lib = None
-    try:   # rebuild for this host's ISA so the baseline is not handicapped by the portable build
-        lib = "/tmp/libdimo_native_%d.so" % os.getpid()
+    from oracle.np_port import NumpyPort
+    cores = os.cpu_count() or 1
+    K, B, n = targets.shape[0], cfg["B"], norm.shape[0]
+    steps_per_epoch = -(-train.size // B)
+    n_sample = min(n, 4096)
+    sub = np.ascontiguousarray(norm[:n_sample])         # the sampled cells; all genes
+    notes = []
+
+    def timed_steps(step_fn, budget):
+        step_fn(0)                                       # warm-up
+        t0 = time.time(); i = 0
+        while i < 2 or (time.time() - t0 < budget and i < 64):
+            i += 1; step_fn(i)
+        return (time.time() - t0) / i, i
+
+    rows_of = lambda i: (np.arange(B, dtype=np.int32) + (i * B) % (n_sample - B)).astype(np.int32)
+    best = None
+    # --- BLAS port, small search over (concurrent sub-nets) x (BLAS threads) ---
+    try:
+        from threadpoolctl import threadpool_limits
+        port = NumpyPort([len(p) for p in preds], cfg["H"], cfg["O"], batch_size=B, dropout_rate=0.2, learning_rate=lr,
+                         threads=min(K, cores))
+        port.set_matrix(sub)
+        for k in range(K):
+            port.set_indices(k, preds[k], targets[k])
+        port.gather(True)
+        port.init_weights()
+        for blas in sorted({1, max(1, cores // (2 * K)), max(1, cores // K)}):
+            with threadpool_limits(limits=blas, user_api="blas"):
+                t_step, cnt = timed_steps(lambda i: port.train_step(rows_of(i)), budget_s * 0.15)
+                t0 = time.time(); port.predict(np.arange(512)); t_row = (time.time() - t0) / 512
+            notes.append("np_port[blas=%d x pool=%d]: %.4f s/step, %.2e s/row" % (blas, min(K, cores), t_step, t_row))
+            if best is None or t_step < best[0]:
+                best = (t_step, t_row, "oracle/np_port.py (OpenBLAS, %d BLAS threads x %d concurrent sub-nets)" % (blas, min(K, cores)), cnt)
+        port.close()
+    except Exception as e:
+        notes.append("np_port failed: %r" % (e,))
+    # --- plain-loop C oracle, rebuilt for this host's ISA ---
+    lib = "/tmp/libdimo_native_%d.so" % os.getpid()
+    try:
         subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=gnu11",
                                "-ffp-contract=off", "-o", lib, os.path.join(ROOT, "oracle", "dimo.c"), "-lm"],
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     except Exception:
         lib = None
-    K = targets.shape[0]
-    eng = make_engine(OracleEngine, cfg, targets, preds, norm, train, val, [K], [0], 0, 0, lr, lib_path=lib)
-    eng.init_weights()
-    rows = train[:cfg["B"]]
-    eng.train_step(rows, epoch_key=0, step_key=0)            # warm-up (page in the weights)
-    t0 = time.time(); steps = 0
-    while steps < 3 or (time.time() - t0 < budget_s * 0.6 and steps < 64):
-        eng.train_step(train[(steps * cfg["B"]) % (train.size - cfg["B"]):][:cfg["B"]], epoch_key=0, step_key=steps + 1)
-        steps += 1
-    t_step = (time.time() - t0) / steps
-    n_fwd = 512
-    t0 = time.time()
-    eng.predict(np.arange(n_fwd, dtype=np.int32))
-    t_row = (time.time() - t0) / n_fwd
-    n = norm.shape[0]
-    steps_per_epoch = -(-train.size // cfg["B"])
-    t_full = epochs * (steps_per_epoch * t_step + val.size * t_row) + n * t_row
-    cores = os.cpu_count() or 1
-    eng.close()
+    try:
+        eng = make_engine(OracleEngine, cfg, targets, preds, sub, np.arange(n_sample - 64, dtype=np.int32),
+                          np.arange(n_sample - 64, n_sample, dtype=np.int32), [K], [0], 0, 0, lr, lib_path=lib)
+        eng.init_weights()
+        t_step, cnt = timed_steps(lambda i: eng.train_step(rows_of(i), epoch_key=0, step_key=i), budget_s * 0.3)
+        t0 = time.time(); eng.predict(np.arange(256, dtype=np.int32)); t_row = (time.time() - t0) / 256
+        notes.append("dimo.c[OpenMP %d threads]: %.4f s/step, %.2e s/row" % (cores, t_step, t_row))
+        if best is None or t_step < best[0]:
+            best = (t_step, t_row, "oracle/dimo.c (OpenMP, %d threads)" % cores, cnt)
+        eng.close()
+    except Exception as e:
+        notes.append("dimo.c failed: %r" % (e,))
     if lib and os.path.exists(lib):
         os.remove(lib)
+    if best is None:
+        raise RuntimeError("; ".join(notes))
+    t_step, t_row, which, cnt = best
+    t_full = epochs * (steps_per_epoch * t_step + val.size * t_row) + n * t_row
     return {"value": n / t_full, "unit": "cells/s", "cores": cores, "kind": "port",
-            "sample": "%d train steps (%.3f s/step) + forward of %d rows (%.2e s/row), all %d host threads (OpenMP), "
-                      "extrapolated to %d epochs x %d steps + validation + predict of %d cells"
-                      % (steps, t_step, n_fwd, t_row, cores, epochs, steps_per_epoch, n)}
+            "sample": "%s: %d train steps at %.4f s/step + forward at %.2e s/row on a %d-cell sample, extrapolated to "
+                      "%d epochs x %d steps + validation + predict of %d cells. All timings: %s"
+                      % (which, cnt, t_step, t_row, n_sample, epochs, steps_per_epoch, n, "; ".join(notes))}
 
 
 def main():
@@ -212,7 +249,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
-    ap.add_argument("--epochs", type=int, default=20, help="fixed epoch count E of every fit (see DESIGN.md)")
+    ap.add_argument("--epochs", type=int, default=18, help="fixed epoch count E of every fit (see DESIGN.md)")
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)

@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -88,7 +89,8 @@ enum { kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0 };
 struct dimn_handle_s {
     dimn_config cfg;
     Dims dm;
-    int K, H, O, B, NT, OTW, HS;   // NT hidden tiles per wave; OTW out tiles per wave; HS = ceil(HT/2)
+    int K, H, O, B, NT, NT2, OTW, HS;   // NT/NT2 hidden tiles per wave (4-/8-wave kernels); OTW out tiles per wave; HS = ceil(HT/2)
+    int wg_per_cu = 1;
     int ncu = 256;
     std::vector<SubnetDev> sn;
     std::vector<Work> work;
@@ -149,7 +151,7 @@ static void build_work(dimn_handle h) {
     // per CU of near-equal bytes (the kernels are HBM-bound; balance = bandwidth).
     int64_t total_chunks = 0;
     for (auto& s : h->sn) total_chunks += s.nchunk;
-    const int target_wgs = h->ncu * 2;
+    const int target_wgs = h->ncu * h->wg_per_cu;
     const int per = (int)std::max<int64_t>(1, (total_chunks + target_wgs - 1) / target_wgs);
     h->work.clear();
     int slot = 0;
@@ -194,6 +196,7 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     dm.ldd = dm.Hp + ((dm.Hp % 32 == 0) ? 2 : 18);   // LDS row stride = 2 (mod 32) words: conflict-free b32 column reads
     dm.OS = ceil_div(dm.OT, 4);
     h->NT = ceil_div(dm.HT, 4);
+    h->NT2 = ceil_div(dm.HT, 8);
     h->OTW = ceil_div(dm.OT, 4);
     h->HS = ceil_div(dm.HT, 2);
     if (h->NT > 6) {
@@ -210,6 +213,7 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
         return fail(DIMN_ERR_HIP, "dimn_create: cannot select device %d", cfg->device_id);
     }
     h->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = getenv("DIMN_WG_PER_CU")) h->wg_per_cu = std::max(1, atoi(e));
 
     h->sn.resize(h->K);
     h->pred.resize(h->K); h->targ.resize(h->K);
@@ -483,10 +487,10 @@ static void launch_fwd1(dimn_handle h, const int32_t* rows, int b_act) {
     hipLaunchKernelGGL(k_fwd1<NT>, dim3((unsigned)h->work.size()), dim3(256), 0, h->stream, h->d_work, h->d_sn, h->d_X, h->d_W1,
                        rows, b_act, h->d_P, h->dm);
 }
-template <int NT>
-static void launch_w1(dimn_handle h, const int32_t* rows, int b_act, AdamP ap) {
-    hipLaunchKernelGGL(k_w1_update<NT>, dim3((unsigned)h->work.size()), dim3(256), 0, h->stream, h->d_work, h->d_sn, h->d_X,
-                       h->d_W1, h->d_M1, h->d_V1, rows, b_act, h->d_dA, h->dm, ap);
+template <int NT2>
+static void launch_w1(dimn_handle h, const int32_t* rows, int b_act, const int32_t* rows_n, int b_next, AdamP ap) {
+    hipLaunchKernelGGL(k_w1_update_fwd<NT2>, dim3((unsigned)h->work.size()), dim3(512), 0, h->stream, h->d_work, h->d_sn, h->d_X,
+                       h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
 }
 template <int NT>
 static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out, float* loss_part) {
@@ -504,9 +508,19 @@ static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, f
         case 5: fn<5>(__VA_ARGS__); break;            \
         default: fn<6>(__VA_ARGS__); break;           \
     }
+#define DISPATCH_NT2(fn, ...)                         \
+    switch (h->NT2) {                                 \
+        case 1: fn<1>(__VA_ARGS__); break;            \
+        case 2: fn<2>(__VA_ARGS__); break;            \
+        default: fn<3>(__VA_ARGS__); break;           \
+    }
 
-static int step_launch(dimn_handle h, const int32_t* d_rows, int b_act, const uint8_t* d_mask, uint32_t epoch_key,
-                       uint32_t step_key, double* d_loss_acc) {
+// One optimiser step on the handle's stream:
+//   [F1 if need_fwd]  ->  RED  ->  MF  ->  MB  ->  B1F1 (W1 Adam + forward partials of the NEXT batch)
+// need_fwd: the split-K partials of THIS batch are not in d_P yet (first step of an epoch,
+// or the single-step API); d_rows_n/b_next: the next batch (b_next = 0: none).
+static int step_launch(dimn_handle h, const int32_t* d_rows, int b_act, bool need_fwd, const int32_t* d_rows_n, int b_next,
+                       const uint8_t* d_mask, uint32_t epoch_key, uint32_t step_key, double* d_loss_acc) {
     const Dims& dm = h->dm;
     const int64_t t = h->t + 1;
     AdamP ap;
@@ -522,15 +536,16 @@ static int step_launch(dimn_handle h, const int32_t* d_rows, int b_act, const ui
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (h->profiling) { e0 = next_event(h); e1 = next_event(h); e2 = next_event(h); (void)hipEventRecord(e0, h->stream); }
 
-    DISPATCH_NT(launch_fwd1, h, d_rows, b_act);
+    if (need_fwd) { DISPATCH_NT(launch_fwd1, h, d_rows, b_act); }
+    hipLaunchKernelGGL(k_reduce_act, dim3((unsigned)ceil_div(DIMN_TB * dm.Hp, 1024), (unsigned)h->K), dim3(256), 0, h->stream,
+                       h->d_sn, h->d_P, h->d_b1, d_mask, h->d_Dd, dm, b_act, rate, scale, h->cfg.seed, epoch_key, step_key);
     hipLaunchKernelGGL(k_mid_fwd, dim3((unsigned)dm.OS, (unsigned)h->K), dim3(256), (size_t)DIMN_TB * dm.ldd * sizeof(float), h->stream,
-                       h->d_sn, h->d_P, h->d_b1, h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, d_mask,
-                       h->d_Dd, h->d_dZ, h->d_loss_step, d_loss_acc, dm, ap, rate, scale, inv_n, h->cfg.loss_binary, h->cfg.seed,
-                       epoch_key, step_key);
+                       h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_dZ,
+                       h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary);
     hipLaunchKernelGGL(k_mid_bwd, dim3((unsigned)h->HS, (unsigned)h->K), dim3(256), 0, h->stream, h->d_Dd, h->d_dZ, h->d_W2, h->d_M2,
                        h->d_V2, h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW);
     if (h->profiling) (void)hipEventRecord(e1, h->stream);
-    DISPATCH_NT(launch_w1, h, d_rows, b_act, ap);
+    DISPATCH_NT2(launch_w1, h, d_rows, b_act, d_rows_n, b_next, ap);
     if (h->profiling) (void)hipEventRecord(e2, h->stream);
     HIPCHK(hipGetLastError());
     h->t = t;
@@ -573,7 +588,7 @@ extern "C" int dimn_train_step(dimn_handle h, const int32_t* rows, int32_t b_act
         HIPCHK(hipMemcpyAsync(h->d_mask, padded.data(), padded.size(), hipMemcpyHostToDevice, h->stream));
         dmask = h->d_mask;
     }
-    CHK(step_launch(h, h->d_rows_step, b_act, dmask, (uint32_t)epoch_key, (uint32_t)step_key, nullptr));
+    CHK(step_launch(h, h->d_rows_step, b_act, true, nullptr, 0, dmask, (uint32_t)epoch_key, (uint32_t)step_key, nullptr));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->profiling) collect_timers(h);
     if (loss_out) {
@@ -619,7 +634,10 @@ extern "C" int dimn_train_epoch(dimn_handle h, int32_t epoch, const int32_t* per
     int step = 0;
     for (int64_t i0 = 0; i0 < h->n_tr; i0 += h->B, ++step) {
         const int b_act = (int)std::min<int64_t>(h->B, h->n_tr - i0);
-        CHK(step_launch(h, h->d_epoch_rows + i0, b_act, nullptr, (uint32_t)epoch, (uint32_t)step, h->d_loss_acc));
+        const int64_t i1 = i0 + h->B;
+        const int b_next = i1 < h->n_tr ? (int)std::min<int64_t>(h->B, h->n_tr - i1) : 0;
+        CHK(step_launch(h, h->d_epoch_rows + i0, b_act, step == 0, b_next ? h->d_epoch_rows + i1 : nullptr, b_next, nullptr,
+                        (uint32_t)epoch, (uint32_t)step, h->d_loss_acc));
     }
     HIPCHK(hipStreamSynchronize(h->stream));   // also keeps `rows` alive until the H2D copy is done
     if (h->profiling) collect_timers(h);

@@ -182,58 +182,73 @@ __global__ __launch_bounds__(256) void k_fwd1(const Work* __restrict__ work, con
 }
 
 // ---------------------------------------------------------------------------------------
+// RED: reduce the split-K partials ONCE per sub-net:  A = b1 + sum_slices P ; relu ; dropout
+// -> Dd[k][64][Hp].  grid (ceil(64*Hp/1024), K); each thread owns 4 consecutive hidden units.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_reduce_act(const SubnetDev* __restrict__ sn, const float* __restrict__ P,
+                                                    const float* __restrict__ b1, const uint8_t* __restrict__ mask,
+                                                    float* __restrict__ Dd, Dims dm, int b_act, float rate, float scale,
+                                                    uint64_t seed, uint32_t epoch_key, uint32_t step_key) {
+    const int k = blockIdx.y;
+    const SubnetDev s = sn[k];
+    const int Hp = dm.Hp;
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= DIMN_TB * Hp) return;
+    const int b = e / Hp, h = e - b * Hp;
+    const float* pk = P + (int64_t)s.slot0 * DIMN_TB * Hp + e;
+    const int64_t pstride = (int64_t)DIMN_TB * Hp;
+    f32x4 a = *(const f32x4*)(b1 + (int64_t)k * Hp + h);
+    for (int sl = 0; sl < s.nslice; ++sl) a += *(const f32x4*)(pk + sl * pstride);
+    bool keep[4];
+    if (mask) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) keep[r] = mask[((int64_t)k * DIMN_TB + b) * Hp + h + r] != 0;
+    } else if (rate > 0.f) {
+        if ((dm.H & 3) == 0) {
+            const dimn_u32x4 rnd = dimn_dropout_block(seed, (uint32_t)s.kg, epoch_key, step_key, (uint32_t)(b * dm.H + h) >> 2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) keep[r] = dimn_u01(rnd.v[r]) >= rate;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                keep[r] = (h + r < dm.H) && dimn_dropout_keep(seed, (uint32_t)s.kg, epoch_key, step_key, (uint32_t)(b * dm.H + h + r), rate);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) keep[r] = true;
+    }
+    f32x4 dd;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float relu = a[r] > 0.f ? a[r] : 0.f;
+        dd[r] = (keep[r] && b < b_act) ? relu * scale : 0.f;
+    }
+    *(f32x4*)(Dd + (int64_t)k * DIMN_TB * Hp + e) = dd;
+}
+
+// ---------------------------------------------------------------------------------------
 // MF: middle forward.  Workgroup = (sub-net k, output slice os of 64 columns).
-//  a) A = b1 + sum_slices P ; relu ; dropout -> Dd[64][Hp] into LDS (slice 0 also -> HBM)
+//  a) Dd[64][Hp] -> LDS
 //  b) Z[:,slice] = Dd W2[:,slice] + b2 ; yhat = softplus ; wMSE ; dZ ; gb2 -> Adam(b2)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mid_fwd(const SubnetDev* __restrict__ sn, const float* __restrict__ P,
-                                                 const float* __restrict__ b1, const float* __restrict__ W2,
+__global__ __launch_bounds__(256) void k_mid_fwd(const float* __restrict__ W2,
                                                  float* __restrict__ b2w, float* __restrict__ b2m, float* __restrict__ b2v,
                                                  const float* __restrict__ Y, int64_t n_cells,
                                                  const int32_t* __restrict__ rows, int b_act,
-                                                 const uint8_t* __restrict__ mask, float* __restrict__ Dd,
+                                                 const float* __restrict__ Dd,
                                                  float* __restrict__ dZ, float* __restrict__ loss_step,
-                                                 double* __restrict__ loss_acc, Dims dm, AdamP ap, float rate, float scale,
-                                                 float inv_n, int loss_binary, uint64_t seed, uint32_t epoch_key,
-                                                 uint32_t step_key) {
+                                                 double* __restrict__ loss_acc, Dims dm, AdamP ap, float inv_n, int loss_binary) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int os = blockIdx.x, k = blockIdx.y;
-    const SubnetDev s = sn[k];
     const int Hp = dm.Hp, ldd = dm.ldd;
 
-    // ---- a) reduce split-K partials, bias, relu, dropout ----
-    const float* pk = P + (int64_t)s.slot0 * DIMN_TB * Hp;
-    const int64_t pstride = (int64_t)DIMN_TB * Hp;
+    // ---- a) stage Dd[64][Hp] (written once per sub-net by k_reduce_act) into LDS ----
+    const float* ddk = Dd + (int64_t)k * DIMN_TB * Hp;
     for (int e = threadIdx.x * 4; e < DIMN_TB * Hp; e += 1024) {
         const int b = e / Hp, h = e - b * Hp;
-        f32x4 a = *(const f32x4*)(b1 + (int64_t)k * Hp + h);
-        for (int sl = 0; sl < s.nslice; ++sl) a += *(const f32x4*)(pk + sl * pstride + e);
-        f32x4 dd;
-        bool keep[4];
-        if (mask) {
+        const f32x4 dd = *(const f32x4*)(ddk + e);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) keep[r] = mask[((int64_t)k * DIMN_TB + b) * Hp + h + r] != 0;
-        } else if (rate > 0.f) {
-            if ((dm.H & 3) == 0) {
-                const dimn_u32x4 rnd = dimn_dropout_block(seed, (uint32_t)s.kg, epoch_key, step_key, (uint32_t)(b * dm.H + h) >> 2);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) keep[r] = dimn_u01(rnd.v[r]) >= rate;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    keep[r] = (h + r < dm.H) && dimn_dropout_keep(seed, (uint32_t)s.kg, epoch_key, step_key, (uint32_t)(b * dm.H + h + r), rate);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) keep[r] = true;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float relu = a[r] > 0.f ? a[r] : 0.f;
-            dd[r] = (keep[r] && b < b_act) ? relu * scale : 0.f;
-            lds[b * ldd + h + r] = dd[r];
-        }
-        if (os == 0) *(f32x4*)(Dd + (int64_t)k * DIMN_TB * Hp + e) = dd;
+        for (int r = 0; r < 4; ++r) lds[b * ldd + h + r] = dd[r];
     }
     __syncthreads();
 
@@ -451,6 +466,134 @@ __global__ __launch_bounds__(256) void k_w1_update(const Work* __restrict__ work
                 adam4(w, m, v, g[nt], ap);
                 *(f32x4*)(W1 + idx) = w; *(f32x4*)(M1 + idx) = m; *(f32x4*)(V1 + idx) = v;
             }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// B1F1: first-layer weight gradient + fused Keras-Adam + NEXT step's split-K forward.
+// 512 threads (8 waves, wave w owns hidden tiles [w*NT2, w*NT2+NT2)); one workgroup per CU.
+// Per 16-row chunk of W1:  g = X_t^T dA (K = batch) -> Adam on the lane's float4 of W1/m/v
+// -> the freshly updated W1 registers are the B operand of  P += X_{t+1}[:,chunk] W1new
+// (k-slot trick), so W1 is read ONCE per optimiser step (24 B/param instead of 28) and the
+// separate forward launch disappears.  X_t / X_{t+1} chunk tiles are staged through LDS by
+// one 16-byte load per thread; state and X for chunk c+1 are prefetched into registers while
+// chunk c computes (one barrier per chunk).
+// ---------------------------------------------------------------------------------------
+template <int NT2>
+__global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
+                                                       const float* __restrict__ X, float* __restrict__ W1,
+                                                       float* __restrict__ M1, float* __restrict__ V1,
+                                                       const int32_t* __restrict__ rows_t, int b_act,
+                                                       const int32_t* __restrict__ rows_n, int b_next,
+                                                       const float* __restrict__ dA, float* __restrict__ P, Dims dm, AdamP ap) {
+    constexpr int XT = DIMN_TB * 16, XN = DIMN_TB * 20;          // floats per staged tile
+    __shared__ __attribute__((aligned(16))) float sm[2 * (XT + XN)];
+    const Work wk = work[blockIdx.x];
+    const SubnetDev s = sn[wk.k];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    const int nt0 = wave * NT2;
+    const int Hp = dm.Hp;
+
+    float bfr[16][NT2];   // dA[b=4kb+lj][h=16(nt0+nt)+li]; rows >= b_act are zero
+    const float* dak = dA + (int64_t)wk.k * DIMN_TB * Hp;
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) bfr[kb][nt] = (nt0 + nt < dm.HT) ? dak[(4 * kb + lj) * Hp + 16 * (nt0 + nt) + li] : 0.f;
+
+    // staging role of this thread: tid<256 -> X_t tile, else X_{t+1} tile; row sb, 16-byte quarter sq
+    const bool stage_next = tid >= 256;
+    const int sb = (tid & 255) >> 2, sq = tid & 3;
+    const bool svalid = stage_next ? (sb < b_next) : (sb < b_act);
+    const float* xsrc = X + s.xoff + (svalid ? (int64_t)(stage_next ? rows_n[sb] : rows_t[sb]) * s.Dp : 0) + 4 * sq;
+    const int sdst = stage_next ? (2 * XT + sb * 20 + 4 * sq) : (sb * 16 + 4 * sq);
+    const int sbuf = stage_next ? XN : XT;                     // distance between the two buffers
+
+    const int64_t cstride = (int64_t)Hp * 16;
+    const int64_t wb = s.w1off + (int64_t)(16 * nt0 + li) * 16 + 4 * lj;
+
+    f32x4 pacc[4][NT2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) pacc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 w[NT2], m[NT2], v[NT2];
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+        const bool on = nt0 + nt < dm.HT;
+        const int64_t idx = wb + wk.c0 * cstride + nt * 256;
+        w[nt] = on ? *(const f32x4*)(W1 + idx) : zero4;
+        m[nt] = on ? *(const f32x4*)(M1 + idx) : zero4;
+        v[nt] = on ? *(const f32x4*)(V1 + idx) : zero4;
+    }
+    {
+        const f32x4 x0 = svalid ? *(const f32x4*)(xsrc + 16 * wk.c0) : zero4;
+        *(f32x4*)(sm + sdst) = x0;
+    }
+    __syncthreads();
+
+    for (int c = wk.c0; c < wk.c1; ++c) {
+        const int cur = (c - wk.c0) & 1;
+        const int cn = c + 1 < wk.c1 ? c + 1 : c;            // clamped prefetch (last one is a harmless re-read)
+        f32x4 wn[NT2], mn[NT2], vn[NT2];
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            const bool on = nt0 + nt < dm.HT;
+            const int64_t idx = wb + cn * cstride + nt * 256;
+            wn[nt] = on ? *(const f32x4*)(W1 + idx) : zero4;
+            mn[nt] = on ? *(const f32x4*)(M1 + idx) : zero4;
+            vn[nt] = on ? *(const f32x4*)(V1 + idx) : zero4;
+        }
+        const f32x4 xr = svalid ? *(const f32x4*)(xsrc + 16 * cn) : zero4;
+
+        // gW1 tile: A = X_t^T[d=li][b=4kb+lj] straight out of the linear LDS tile
+        const float* xt = sm + cur * XT;
+        f32x4 g[NT2];
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) g[nt] = zero4;
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            const float a = xt[64 * kb + lane];
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) g[nt] = MFMA16(a, bfr[kb][nt], g[nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt)
+            if (nt0 + nt < dm.HT) {
+                const int64_t idx = wb + c * cstride + nt * 256;
+                adam4(w[nt], m[nt], v[nt], g[nt], ap);
+                *(f32x4*)(W1 + idx) = w[nt]; *(f32x4*)(M1 + idx) = m[nt]; *(f32x4*)(V1 + idx) = v[nt];
+            }
+        if (b_next > 0) {
+            const float* xn = sm + 2 * XT + cur * XN;
+            f32x4 af[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) af[mt] = *(const f32x4*)(xn + (16 * mt + li) * 20 + 4 * lj);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT2; ++nt) pacc[mt][nt] = MFMA16(af[mt][r], w[nt][r], pacc[mt][nt]);
+        }
+        *(f32x4*)(sm + sdst + (cur ^ 1) * sbuf) = xr;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) { w[nt] = wn[nt]; m[nt] = mn[nt]; v[nt] = vn[nt]; }
+        __syncthreads();
+    }
+    if (b_next > 0) {
+        float* p = P + (int64_t)wk.slot * DIMN_TB * Hp;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt)
+                if (nt0 + nt < dm.HT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[(16 * mt + 4 * lj + r) * Hp + 16 * (nt0 + nt) + li] = pacc[mt][nt][r];
+                }
     }
 }
 

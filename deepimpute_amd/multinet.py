@@ -101,7 +101,7 @@ def _hidden_and_dropout(architecture):
 class MultiNet:
     def __init__(self, learning_rate=1e-4, batch_size=64, max_epochs=500, patience=5, ncores=-1,
                  loss="wMSE", output_prefix=_SCRATCH, sub_outputdim=512, verbose=1, seed=1234,
-                 architecture=None, device_id=0, engine_factory=None):
+                 architecture=None, device_id=0, engine_factory=None, comm=None):
         self.NN_parameters = dict(learning_rate=learning_rate, batch_size=batch_size, loss=loss,
                                   architecture=architecture, max_epochs=max_epochs, patience=patience)
         self.sub_outputdim = sub_outputdim
@@ -111,6 +111,10 @@ class MultiNet:
         self.device_id = device_id                 # extension: which GPU
         self._engine_factory = engine_factory      # extension (tests): None -> HipEngine, no fallback
         self._engine = None
+        # extension: a deepimpute_amd.sharded Comm (one process per GPU); the string "rccl" builds
+        # an RcclComm from RANK/WORLD_SIZE/LOCAL_RANK at fit time.  None = single process.
+        self._comm = comm
+        self._first_subnet = 0
         self.setCores(ncores)
 
     def setCores(self, ncores):
@@ -179,7 +183,8 @@ class MultiNet:
         """Translate gene labels of predictors/targets into column positions of the matrix."""
         where = pd.Index(columns)
         for k in range(engine.K):
-            cols_in, cols_out = where.get_indexer(self.predictors[k]), where.get_indexer(self.targets[k])
+            g = self._first_subnet + k                   # engine-local -> global sub-net
+            cols_in, cols_out = where.get_indexer(self.predictors[g]), where.get_indexer(self.targets[g])
             if (cols_in < 0).any() or (cols_out < 0).any():
                 raise KeyError("predictor/target genes missing from the data columns")
             engine.set_indices(k, cols_in, cols_out)
@@ -214,7 +219,12 @@ class MultiNet:
         if self._engine is not None:
             self._engine.close()
             self._engine = None
-        engine = self.build([len(p) for p in self.predictors])
+        comm, counts = self._resolve_comm(len(self.predictors))
+        self._first_subnet = sum(counts[:comm.rank])
+        mine = range(self._first_subnet, self._first_subnet + counts[comm.rank])
+        engine = self.build([len(self.predictors[k]) for k in mine], subnet_offset=self._first_subnet)
+        if isinstance(comm, str):
+            comm = self._comm = self._make_rccl(engine)
 
         held_out = np.random.choice(norm_data.index, int(_VALIDATION_FRACTION * norm_data.shape[0]), replace=False)
         kept = np.setdiff1d(norm_data.index, held_out)          # label-sorted, multinet.py:229
@@ -227,7 +237,12 @@ class MultiNet:
         engine.init_weights(0 if self.seed is None else self.seed)
 
         print("Fitting with {} cells".format(norm_data.shape[0]))
-        epochs, loss_curve, val_curve = engine.fit(self.NN_parameters["max_epochs"], self.NN_parameters["patience"])
+        if comm.world == 1:
+            epochs, loss_curve, val_curve = engine.fit(self.NN_parameters["max_epochs"], self.NN_parameters["patience"])
+        else:
+            from .sharded import fit_sharded
+            epochs, loss_curve, val_curve = fit_sharded(engine, comm, self.NN_parameters["max_epochs"],
+                                                        self.NN_parameters["patience"])
         self.history = {"loss": [float(x) for x in loss_curve], "val_loss": [float(x) for x in val_curve]}
         if self.verbose:
             for i, (a, b) in enumerate(zip(loss_curve, val_curve), start=1):
@@ -236,9 +251,45 @@ class MultiNet:
         print("Stopped fitting after {} epochs".format(self.trained_epochs))
 
         self._engine = engine
-        self.save(engine)
+        self._counts = counts
+        if comm.world == 1:
+            self.save(engine)
         self.test_metrics = self._held_out_metrics(engine, norm_data, held_out, rows_val)
         return self
+
+    def _resolve_comm(self, K):
+        from .sharded import SingleComm, shard_subnets
+        comm = self._comm
+        if comm is None:
+            comm = self._comm = SingleComm()
+        if isinstance(comm, str):
+            if comm.lower() != "rccl":
+                raise ValueError("comm must be a Comm object or 'rccl'")
+            world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+            self.device_id = int(os.environ.get("LOCAL_RANK", str(self.device_id)))
+            counts, _ = shard_subnets(K, world)
+
+            class _Pending(str):
+                pass
+            pending = _Pending("rccl")
+            pending.rank, pending.world = rank, world
+            return pending, counts
+        counts, _ = shard_subnets(K, comm.world)
+        if min(counts) < 1:
+            raise ValueError("more ranks (%d) than sub-networks (%d)" % (comm.world, K))
+        return comm, counts
+
+    def _make_rccl(self, engine):
+        from .sharded import RcclComm
+        return RcclComm(engine, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
+
+    def _predict_block(self, engine, rows=None):
+        """np.hstack of ALL sub-nets' outputs on rank 0 (None elsewhere when sharded)."""
+        comm = self._comm
+        if comm is None or comm.world == 1:
+            return engine.predict(rows)
+        from .sharded import predict_sharded
+        return predict_sharded(engine, comm, self._counts, rows)
 
     def _pad_gene_list(self, genes, gene_metric):
         """User-supplied gene list made a multiple of sub_outputdim (multinet.py:196-209)."""
@@ -254,8 +305,11 @@ class MultiNet:
 
     def _held_out_metrics(self, engine, norm_data, held_out, rows_val):
         """Pearson r and MSE on the positive entries of the validation targets (multinet.py:251-262)."""
+        guess = self._predict_block(engine, rows_val)
+        if guess is None:                     # sharded job: only rank 0 holds the gathered block
+            return None
         truth = np.hstack([norm_data.loc[held_out, genes].values for genes in self.targets]).flatten()
-        guess = engine.predict(rows_val).flatten()
+        guess = guess.flatten()
         positive = truth > 0
         truth, guess = truth[positive], guess[positive]
         return {'correlation': pearsonr(truth, guess)[0],
@@ -268,7 +322,9 @@ class MultiNet:
         engine.set_matrix(norm_raw.values.astype(np.float32))
         self._bind_columns(engine, norm_raw.columns)
         engine.gather(False)
-        block = engine.predict()                         # [cells, K*O], np.hstack of the K outputs
+        block = self._predict_block(engine)              # [cells, K*O], np.hstack of the K outputs
+        if block is None:
+            return None                                  # sharded job: rank 0 returns the frame
 
         # a gene may occupy several target slots: average them; columns come out label-sorted,
         # like the reference's groupby(columns).mean() (multinet.py:282-284)

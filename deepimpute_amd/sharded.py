@@ -1,0 +1,152 @@
+"""Sub-network sharding over the GPUs of one node (one process per GPU).
+
+The K sub-networks of a MultiNet share no parameters (reference deepimpute/multinet.py:132-146
+builds K disjoint branches); they are coupled only by the shared batch order and by ONE global
+early-stopping decision on the summed validation loss (multinet.py:242-243).  So the path shards
+by sub-network with no gradient traffic at all:
+
+  * every rank plans identically (same seed -> same targets / predictors / split) and owns a
+    contiguous block of sub-nets; Philox keys use the GLOBAL sub-net index, so the trained
+    weights do not depend on the number of ranks;
+  * per epoch: one all-reduce (sum) of two scalars -- validation and training loss -- so that
+    every rank takes the same stop/continue decision the single-process reference would take;
+  * at the end: the per-rank prediction blocks [cells, K_r*O] are gathered into the full
+    [cells, K*O] matrix on rank 0 (RCCL send/recv straight to root over xGMI on the GPU path).
+
+The collectives sit behind a tiny `Comm` interface with two implementations: `RcclComm`
+(libdimn's dimn_comm_* on the GPU data path; rendezvous through a file under /tmp, no torch in
+the process) and `TorchComm` (torch.distributed, e.g. gloo: the CPU test-suite, world_size 2).
+"""
+import os
+import time
+
+import numpy as np
+
+
+def shard_subnets(K, world):
+    """Contiguous balanced split: (counts[r], offsets[r]).  Ranks beyond K get zero sub-nets
+    (callers must have K >= world for a useful job)."""
+    counts = [K // world + (1 if r < K % world else 0) for r in range(world)]
+    offsets = [sum(counts[:r]) for r in range(world)]
+    return counts, offsets
+
+
+class SingleComm:
+    rank, world = 0, 1
+
+    def allreduce_sum(self, vec):
+        return np.asarray(vec, np.float64)
+
+    def gather_predictions(self, engine, local_block, n_rows, counts, out_dim):
+        return local_block() if callable(local_block) else local_block
+
+    def barrier(self):
+        pass
+
+
+class TorchComm:
+    """Collectives over an initialised torch.distributed process group (any backend; the
+    test-suite uses gloo on CPU).  Arrays travel as host tensors."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self._group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def allreduce_sum(self, vec):
+        import torch
+        t = torch.tensor(np.asarray(vec, np.float64))
+        self._dist.all_reduce(t, group=self._group)
+        return t.numpy()
+
+    def gather_predictions(self, engine, local_block, n_rows, counts, out_dim):
+        import torch
+        block = local_block() if callable(local_block) else local_block
+        mine = torch.from_numpy(np.ascontiguousarray(block, np.float32))
+        if self.rank == 0:
+            parts = [torch.empty((n_rows, c * out_dim), dtype=torch.float32) for c in counts]
+            self._dist.gather(mine, parts, dst=0, group=self._group)
+            return np.hstack([p.numpy() for p in parts])
+        self._dist.gather(mine, None, dst=0, group=self._group)
+        return None
+
+    def barrier(self):
+        self._dist.barrier(group=self._group)
+
+
+class RcclComm:
+    """RCCL over xGMI through libdimn (dimn_comm_*).  The 128-byte unique id is handed from
+    rank 0 to the others through a file in a directory named after the launcher's pid, so the
+    GPU processes never import torch."""
+
+    def __init__(self, engine, rank, world, tag=None, timeout=300.0):
+        self.rank, self.world, self._engine = rank, world, engine
+        tag = tag or "%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+        self._dir = os.path.join("/tmp", "dimn_rdzv_" + tag)
+        os.makedirs(self._dir, exist_ok=True)
+        path = os.path.join(self._dir, "uid")
+        if rank == 0:
+            uid = engine.comm_unique_id()
+            with open(path + ".tmp", "wb") as f:
+                f.write(uid.tobytes())
+            os.replace(path + ".tmp", path)
+        else:
+            t0 = time.time()
+            while not os.path.exists(path):
+                if time.time() - t0 > timeout:
+                    raise TimeoutError("RCCL rendezvous file %s never appeared" % path)
+                time.sleep(0.01)
+            with open(path, "rb") as f:
+                uid = np.frombuffer(f.read(), np.uint8)
+        engine.comm_init(uid, world, rank)
+
+    def allreduce_sum(self, vec):
+        return self._engine.comm_allreduce_sum(vec)
+
+    def gather_predictions(self, engine, local_block, n_rows, counts, out_dim):
+        # the local block is already in HBM (predict_device); root receives into HBM and copies out
+        return engine.comm_gather_predictions(n_rows, counts, root=0, is_root=self.rank == 0)
+
+    def barrier(self):
+        self._engine.comm_allreduce_sum(np.zeros(1))
+
+    def close(self):
+        self._engine.comm_destroy()
+        if self.rank == 0:
+            import shutil
+            shutil.rmtree(self._dir, ignore_errors=True)
+
+
+def fit_sharded(engine, comm, max_epochs, patience):
+    """model.fit with EarlyStopping(monitor='val_loss', patience) over a sharded job: each rank
+    trains its sub-nets; the monitored quantity is the sum over ALL sub-nets (one scalar
+    all-reduce per epoch), so every rank stops at the same epoch the single-process run would
+    (reference multinet.py:238-246; Keras: strict <, min_delta 0, last-epoch weights)."""
+    best, wait = np.inf, 0
+    loss_hist, val_hist = [], []
+    epoch = 0
+    while epoch < max_epochs:
+        tl = engine.train_epoch(epoch)
+        vl = engine.val_loss()
+        tot = comm.allreduce_sum(np.array([np.sum(tl), np.sum(vl)], np.float64))
+        loss_hist.append(float(tot[0]))
+        val_hist.append(float(tot[1]))
+        epoch += 1
+        if tot[1] < best:
+            best, wait = tot[1], 0
+        else:
+            wait += 1
+            if wait >= patience:
+                break
+    return epoch, np.array(loss_hist), np.array(val_hist)
+
+
+def predict_sharded(engine, comm, counts, rows=None, n_rows=None):
+    """model.predict over a sharded job: rank 0 gets np.hstack over ALL sub-nets, others None."""
+    if isinstance(comm, RcclComm):
+        engine.predict_device(rows, n_rows)
+        n = len(rows) if rows is not None else (n_rows if n_rows is not None else engine.n_cells)
+        return comm.gather_predictions(engine, None, n, counts, engine.O)
+    block = engine.predict(rows, n_rows)
+    return comm.gather_predictions(engine, block, block.shape[0], counts, engine.O)
