@@ -146,8 +146,9 @@ def impute_once(eng, epochs, comm=None, counts=None, n=None):
     eng.gather(True)
     eng.init_weights()
     vsum = 0.0
+    ident = np.arange(eng.n_train, dtype=np.int32) if os.environ.get("DIMN_BENCH_IDENTITY_PERM") else None   # diagnostic only
     for e in range(epochs):
-        eng.train_epoch(e)
+        eng.train_epoch(e, ident)
         v = eng.val_loss()
         if comm is not None:                       # global early-stopping quantity (multinet.py:242-243)
             v = eng.comm_allreduce_sum(np.array([v.sum()]))

@@ -90,7 +90,9 @@ struct dimn_handle_s {
     dimn_config cfg;
     Dims dm;
     int K, H, O, B, NT, NT2, OTW, HS;   // NT/NT2 hidden tiles per wave (4-/8-wave kernels); OTW out tiles per wave; HS = ceil(HT/2)
-    int wg_per_cu = 1;
+    int wg_per_cu = 2;
+    int dbg = 0;
+    int variant = 1;
     int ncu = 256;
     std::vector<SubnetDev> sn;
     std::vector<Work> work;
@@ -214,6 +216,8 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     }
     h->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("DIMN_WG_PER_CU")) h->wg_per_cu = std::max(1, atoi(e));
+    if (const char* e = getenv("DIMN_DBG")) h->dbg = atoi(e);
+    if (const char* e = getenv("DIMN_B1F1")) h->variant = atoi(e);
 
     h->sn.resize(h->K);
     h->pred.resize(h->K); h->targ.resize(h->K);
@@ -489,8 +493,28 @@ static void launch_fwd1(dimn_handle h, const int32_t* rows, int b_act) {
 }
 template <int NT2>
 static void launch_w1(dimn_handle h, const int32_t* rows, int b_act, const int32_t* rows_n, int b_next, AdamP ap) {
-    hipLaunchKernelGGL(k_w1_update_fwd<NT2>, dim3((unsigned)h->work.size()), dim3(512), 0, h->stream, h->d_work, h->d_sn, h->d_X,
-                       h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
+#define DBG_CASE(D) case D: hipLaunchKernelGGL((k_w1_update_fwd<2, true, D>), dim3((unsigned)h->work.size()), dim3(512), 0, h->stream, h->d_work, h->d_sn, \
+                           h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap); return;
+    if (NT2 == 2 && h->dm.HT == 16 && h->dbg) {   // ablation variants (diagnostics; DIMN_DBG=<bits>)
+        switch (h->dbg) { DBG_CASE(1) DBG_CASE(2) DBG_CASE(4) DBG_CASE(8) DBG_CASE(16) DBG_CASE(32) DBG_CASE(6) DBG_CASE(14) DBG_CASE(17) DBG_CASE(49) DBG_CASE(63) default: break; }
+    }
+#undef DBG_CASE
+    if (h->dm.HT == 16 && h->variant == 1) {
+        hipLaunchKernelGGL((k_w1_update_fwd_sh<16, 1>), dim3((unsigned)h->work.size()), dim3(1024), 0, h->stream, h->d_work, h->d_sn,
+                           h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
+        return;
+    }
+    if (h->dm.HT == 16 && h->variant == 2) {
+        hipLaunchKernelGGL((k_w1_update_fwd_sh<8, 2>), dim3((unsigned)h->work.size()), dim3(512), 0, h->stream, h->d_work, h->d_sn,
+                           h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
+        return;
+    }
+    if (h->dm.HT == 8 * NT2)
+        hipLaunchKernelGGL((k_w1_update_fwd<NT2, true>), dim3((unsigned)h->work.size()), dim3(512), 0, h->stream, h->d_work, h->d_sn,
+                           h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
+    else
+        hipLaunchKernelGGL((k_w1_update_fwd<NT2, false>), dim3((unsigned)h->work.size()), dim3(512), 0, h->stream, h->d_work, h->d_sn,
+                           h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
 }
 template <int NT>
 static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out, float* loss_part) {

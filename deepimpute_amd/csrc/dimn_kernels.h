@@ -61,7 +61,9 @@ __device__ __forceinline__ void adam4(f32x4& w, f32x4& m, f32x4& v, const f32x4 
     for (int r = 0; r < 4; ++r) {
         m[r] += (g[r] - m[r]) * a.omb1;
         v[r] += (g[r] * g[r] - v[r]) * a.omb2;
-        w[r] -= (m[r] * a.alpha) / (sqrtf(v[r]) + a.eps);
+        // 1-ulp hardware sqrt/rcp instead of the IEEE expansions (~3x fewer VALU ops); the update
+        // is <= lr in magnitude, so the extra ~2e-7 relative error is ~1e-11 absolute per step
+        w[r] -= (m[r] * a.alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v[r]) + a.eps);
     }
 }
 __device__ __forceinline__ void adam1(float& w, float& m, float& v, const float g, const AdamP a) {
@@ -471,15 +473,20 @@ __global__ __launch_bounds__(256) void k_w1_update(const Work* __restrict__ work
 
 // ---------------------------------------------------------------------------------------
 // B1F1: first-layer weight gradient + fused Keras-Adam + NEXT step's split-K forward.
-// 512 threads (8 waves, wave w owns hidden tiles [w*NT2, w*NT2+NT2)); one workgroup per CU.
+// 512 threads = 8 INDEPENDENT waves (wave w owns hidden tiles [w*NT2, w*NT2+NT2)); one
+// workgroup per CU; no barrier anywhere in the kernel.
 // Per 16-row chunk of W1:  g = X_t^T dA (K = batch) -> Adam on the lane's float4 of W1/m/v
 // -> the freshly updated W1 registers are the B operand of  P += X_{t+1}[:,chunk] W1new
 // (k-slot trick), so W1 is read ONCE per optimiser step (24 B/param instead of 28) and the
-// separate forward launch disappears.  X_t / X_{t+1} chunk tiles are staged through LDS by
-// one 16-byte load per thread; state and X for chunk c+1 are prefetched into registers while
-// chunk c computes (one barrier per chunk).
+// separate forward launch disappears.
+// Each wave stages the X_t / X_{t+1} chunk tiles it needs into its OWN LDS region (the tile
+// lines are shared through L1/L2); waves therefore drift apart freely, one wave's MFMAs
+// overlap another's Adam VALU work and memory waits (measured: a per-chunk workgroup barrier
+// cost ~2x).  State and X tiles of chunk c+1 are prefetched into registers while chunk c
+// computes.
 // ---------------------------------------------------------------------------------------
-template <int NT2>
+template <int NT2, bool FULL, int DBG = 0>   // FULL: every wave's NT2 tiles exist (HT == 8*NT2) -> no predicated memory ops in the loop
+                                              // DBG: ablation bits (diagnostics only): 1 no stores, 2 no g MFMAs, 4 no fwd MFMAs, 8 no Adam, 16 no state loads, 32 no X loads
 __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
                                                        const float* __restrict__ X, float* __restrict__ W1,
                                                        float* __restrict__ M1, float* __restrict__ V1,
@@ -487,69 +494,101 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
                                                        const int32_t* __restrict__ rows_n, int b_next,
                                                        const float* __restrict__ dA, float* __restrict__ P, Dims dm, AdamP ap) {
     constexpr int XT = DIMN_TB * 16, XN = DIMN_TB * 20;          // floats per staged tile
-    __shared__ __attribute__((aligned(16))) float sm[2 * (XT + XN)];
+    constexpr int WSZ = 2 * (XT + XN);                           // floats of LDS per wave
+    __shared__ __attribute__((aligned(16))) float sm_all[8 * WSZ];
     const Work wk = work[blockIdx.x];
     const SubnetDev s = sn[wk.k];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
     const int nt0 = wave * NT2;
     const int Hp = dm.Hp;
+    float* sm = sm_all + wave * WSZ;                             // [xt0 | xt1 | xn0 | xn1]
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float bfr[16][NT2];   // dA[b=4kb+lj][h=16(nt0+nt)+li]; rows >= b_act are zero
+    // Tiles beyond HT (ragged H) are handled without branches around loads: their addresses are
+    // clamped to tile 0 (always valid), their results are never stored.
+    bool on[NT2];
+    int tcl[NT2];
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) { on[nt] = FULL || (nt0 + nt < dm.HT); tcl[nt] = on[nt] ? nt0 + nt : 0; }
+
+    float bfr[16][NT2];   // dA[b=4kb+lj][h=16*tile+li]; rows >= b_act are zero
     const float* dak = dA + (int64_t)wk.k * DIMN_TB * Hp;
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) bfr[kb][nt] = (nt0 + nt < dm.HT) ? dak[(4 * kb + lj) * Hp + 16 * (nt0 + nt) + li] : 0.f;
+        for (int nt = 0; nt < NT2; ++nt) bfr[kb][nt] = dak[(4 * kb + lj) * Hp + 16 * tcl[nt] + li];
 
-    // staging role of this thread: tid<256 -> X_t tile, else X_{t+1} tile; row sb, 16-byte quarter sq
-    const bool stage_next = tid >= 256;
-    const int sb = (tid & 255) >> 2, sq = tid & 3;
-    const bool svalid = stage_next ? (sb < b_next) : (sb < b_act);
-    const float* xsrc = X + s.xoff + (svalid ? (int64_t)(stage_next ? rows_n[sb] : rows_t[sb]) * s.Dp : 0) + 4 * sq;
-    const int sdst = stage_next ? (2 * XT + sb * 20 + 4 * sq) : (sb * 16 + 4 * sq);
-    const int sbuf = stage_next ? XN : XT;                     // distance between the two buffers
-
+    // staging: pass i (0..3) of this lane moves row 16i + lane/4, 16-byte quarter lane%4
+    const float* xk = X + s.xoff + 4 * (lane & 3);
+    uint32_t xot[4], xon[4];
+    bool vt[4], vn[4];
+    const bool have_next = b_next > 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int b = 16 * i + (lane >> 2);
+        vt[i] = b < b_act;
+        vn[i] = b < b_next;
+        xot[i] = (uint32_t)rows_t[vt[i] ? b : 0] * (uint32_t)s.Dp;
+        xon[i] = have_next ? (uint32_t)rows_n[vn[i] ? b : 0] * (uint32_t)s.Dp : xot[i];
+    }
     const int64_t cstride = (int64_t)Hp * 16;
-    const int64_t wb = s.w1off + (int64_t)(16 * nt0 + li) * 16 + 4 * lj;
+    int64_t wb[NT2];
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) wb[nt] = s.w1off + (int64_t)(16 * tcl[nt] + li) * 16 + 4 * lj;
 
     f32x4 pacc[4][NT2];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) pacc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT2; ++nt) pacc[mt][nt] = zero4;
 
+    // prologue: state of chunk c0 into registers, X tiles of chunk c0 into LDS buffer 0
     f32x4 w[NT2], m[NT2], v[NT2];
-    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int nt = 0; nt < NT2; ++nt) {
-        const bool on = nt0 + nt < dm.HT;
-        const int64_t idx = wb + wk.c0 * cstride + nt * 256;
-        w[nt] = on ? *(const f32x4*)(W1 + idx) : zero4;
-        m[nt] = on ? *(const f32x4*)(M1 + idx) : zero4;
-        v[nt] = on ? *(const f32x4*)(V1 + idx) : zero4;
+        const int64_t i0 = wb[nt] + wk.c0 * cstride;
+        w[nt] = *(const f32x4*)(W1 + i0); m[nt] = *(const f32x4*)(M1 + i0); v[nt] = *(const f32x4*)(V1 + i0);
     }
-    {
-        const f32x4 x0 = svalid ? *(const f32x4*)(xsrc + 16 * wk.c0) : zero4;
-        *(f32x4*)(sm + sdst) = x0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x4 a = *(const f32x4*)(xk + xot[i] + 16 * wk.c0);
+        f32x4 b = *(const f32x4*)(xk + xon[i] + 16 * wk.c0);
+        *(f32x4*)(sm + 256 * i + 4 * lane) = vt[i] ? a : zero4;
+        *(f32x4*)(sm + 2 * XT + (16 * i + (lane >> 2)) * 20 + 4 * (lane & 3)) = vn[i] ? b : zero4;
     }
-    __syncthreads();
+    // Retire every prologue load before the loop: otherwise the waitcnt pass, merging the
+    // pre-header state into the loop header, drains the in-loop prefetch with vmcnt(0).
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) asm volatile("" : "+v"(bfr[kb][nt]));
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) asm volatile("" : "+v"(w[nt]), "+v"(m[nt]), "+v"(v[nt]));
 
+    const int clast = wk.c1 - 1;
     for (int c = wk.c0; c < wk.c1; ++c) {
         const int cur = (c - wk.c0) & 1;
-        const int cn = c + 1 < wk.c1 ? c + 1 : c;            // clamped prefetch (last one is a harmless re-read)
-        f32x4 wn[NT2], mn[NT2], vn[NT2];
+        const int cn = c < clast ? c + 1 : clast;            // clamped prefetch (the last one is a harmless re-read)
+        f32x4 xa[4], xb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (DBG & 32) { xa[i] = zero4; xb[i] = zero4; }
+            else {
+                xa[i] = *(const f32x4*)(xk + xot[i] + 16 * cn);
+                xb[i] = *(const f32x4*)(xk + xon[i] + 16 * cn);
+            }
+        }
+        f32x4 w1[NT2], m1[NT2], v1[NT2];
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
-            const bool on = nt0 + nt < dm.HT;
-            const int64_t idx = wb + cn * cstride + nt * 256;
-            wn[nt] = on ? *(const f32x4*)(W1 + idx) : zero4;
-            mn[nt] = on ? *(const f32x4*)(M1 + idx) : zero4;
-            vn[nt] = on ? *(const f32x4*)(V1 + idx) : zero4;
+            const int64_t idx = wb[nt] + cn * cstride;
+            if (DBG & 16) { w1[nt] = w[nt]; m1[nt] = m[nt]; v1[nt] = v[nt]; }
+            else { w1[nt] = *(const f32x4*)(W1 + idx); m1[nt] = *(const f32x4*)(M1 + idx); v1[nt] = *(const f32x4*)(V1 + idx); }
         }
-        const f32x4 xr = svalid ? *(const f32x4*)(xsrc + 16 * cn) : zero4;
+        __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch at the top of the iteration
 
-        // gW1 tile: A = X_t^T[d=li][b=4kb+lj] straight out of the linear LDS tile
+        // gW1 tile: A = X_t^T[d=li][b=4kb+lj] straight out of this wave's linear LDS tile
         const float* xt = sm + cur * XT;
         f32x4 g[NT2];
 #pragma unroll
@@ -558,16 +597,19 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
         for (int kb = 0; kb < 16; ++kb) {
             const float a = xt[64 * kb + lane];
 #pragma unroll
-            for (int nt = 0; nt < NT2; ++nt) g[nt] = MFMA16(a, bfr[kb][nt], g[nt]);
+            for (int nt = 0; nt < NT2; ++nt) { if (!(DBG & 2)) g[nt] = MFMA16(a, bfr[kb][nt], g[nt]); else g[nt][0] += a * bfr[kb][nt]; }
         }
 #pragma unroll
-        for (int nt = 0; nt < NT2; ++nt)
-            if (nt0 + nt < dm.HT) {
-                const int64_t idx = wb + c * cstride + nt * 256;
-                adam4(w[nt], m[nt], v[nt], g[nt], ap);
+        for (int nt = 0; nt < NT2; ++nt) { if (!(DBG & 8)) adam4(w[nt], m[nt], v[nt], g[nt], ap); else w[nt] += g[nt]; }
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            if (DBG & 1) { asm volatile("" :: "v"(w[nt]), "v"(m[nt]), "v"(v[nt])); }
+            else if (FULL || on[nt]) {
+                const int64_t idx = wb[nt] + c * cstride;
                 *(f32x4*)(W1 + idx) = w[nt]; *(f32x4*)(M1 + idx) = m[nt]; *(f32x4*)(V1 + idx) = v[nt];
             }
-        if (b_next > 0) {
+        }
+        if (have_next && !(DBG & 4)) {
             const float* xn = sm + 2 * XT + cur * XN;
             f32x4 af[4];
 #pragma unroll
@@ -579,21 +621,161 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
 #pragma unroll
                     for (int nt = 0; nt < NT2; ++nt) pacc[mt][nt] = MFMA16(af[mt][r], w[nt][r], pacc[mt][nt]);
         }
-        *(f32x4*)(sm + sdst + (cur ^ 1) * sbuf) = xr;
+        // stage the tiles of chunk c+1 into the other buffer (wave-private: LDS ops of one wave
+        // execute in order, no barrier needed)
 #pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) { w[nt] = wn[nt]; m[nt] = mn[nt]; v[nt] = vn[nt]; }
-        __syncthreads();
+        for (int i = 0; i < 4; ++i) {
+            *(f32x4*)(sm + (cur ^ 1) * XT + 256 * i + 4 * lane) = vt[i] ? xa[i] : zero4;
+            *(f32x4*)(sm + 2 * XT + (cur ^ 1) * XN + (16 * i + (lane >> 2)) * 20 + 4 * (lane & 3)) = vn[i] ? xb[i] : zero4;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) { w[nt] = w1[nt]; m[nt] = m1[nt]; v[nt] = v1[nt]; }
     }
-    if (b_next > 0) {
+    if (have_next) {
         float* p = P + (int64_t)wk.slot * DIMN_TB * Hp;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT2; ++nt)
-                if (nt0 + nt < dm.HT) {
+                if (FULL || on[nt]) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) p[(16 * mt + 4 * lj + r) * Hp + 16 * (nt0 + nt) + li] = pacc[mt][nt][r];
                 }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// B1F1 "shared staging" variant: WAVES waves (8 or 16) per workgroup, wave w owns NT2 =
+// HT/WAVES hidden tiles; the X_t / X_{t+1} chunk tiles are staged ONCE per workgroup through
+// LDS (one 16-byte load per staging thread) with one barrier per chunk.  With 16 waves of
+// <=128 VGPRs, four waves share each SIMD, so MFMA, Adam VALU work and memory waits of
+// different waves overlap inside every chunk.
+// ---------------------------------------------------------------------------------------
+template <int WAVES, int NT2>
+__global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_sh(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
+                                                                const float* __restrict__ X, float* __restrict__ W1,
+                                                                float* __restrict__ M1, float* __restrict__ V1,
+                                                                const int32_t* __restrict__ rows_t, int b_act,
+                                                                const int32_t* __restrict__ rows_n, int b_next,
+                                                                const float* __restrict__ dA, float* __restrict__ P, Dims dm, AdamP ap) {
+    constexpr int XT = DIMN_TB * 16, XN = DIMN_TB * 20;
+    __shared__ __attribute__((aligned(16))) float sm[2 * (XT + XN)];
+    const Work wk = work[blockIdx.x];
+    const SubnetDev s = sn[wk.k];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    const int nt0 = wave * NT2;
+    const int Hp = dm.Hp;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float bfr[16][NT2];
+    const float* dak = dA + (int64_t)wk.k * DIMN_TB * Hp;
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) bfr[kb][nt] = dak[(4 * kb + lj) * Hp + 16 * (nt0 + nt) + li];
+
+    // staging roles: threads 0..255 move the X_t tile, 256..511 the X_{t+1} tile (others none)
+    const bool stager = tid < 512;
+    const bool stage_next = tid >= 256;
+    const bool have_next = b_next > 0;
+    const int sb = (tid & 255) >> 2, sq = tid & 3;
+    const bool svalid = stager && (stage_next ? (sb < b_next) : (sb < b_act));
+    const int32_t* srows = (stage_next && have_next) ? rows_n : rows_t;
+    const float* xsrc = X + s.xoff + (int64_t)srows[svalid ? sb : 0] * s.Dp + 4 * sq;
+    const int sdst = stage_next ? (2 * XT + sb * 20 + 4 * sq) : (sb * 16 + 4 * sq);
+    const int sbuf = stage_next ? XN : XT;
+
+    const int64_t cstride = (int64_t)Hp * 16;
+    int64_t wb[NT2];
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) wb[nt] = s.w1off + (int64_t)(16 * (nt0 + nt) + li) * 16 + 4 * lj;
+
+    f32x4 pacc[4][NT2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) pacc[mt][nt] = zero4;
+
+    const int clast = wk.c1 - 1;
+    f32x4 w[NT2], m[NT2], v[NT2];
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+        const int64_t i0 = wb[nt] + wk.c0 * cstride;
+        w[nt] = *(const f32x4*)(W1 + i0); m[nt] = *(const f32x4*)(M1 + i0); v[nt] = *(const f32x4*)(V1 + i0);
+    }
+    f32x4 xa = zero4;
+    if (stager) {
+        f32x4 x0 = *(const f32x4*)(xsrc + 16 * wk.c0);
+        xa = *(const f32x4*)(xsrc + 16 * (wk.c0 < clast ? wk.c0 + 1 : clast));
+        *(f32x4*)(sm + sdst) = svalid ? x0 : zero4;
+    }
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) asm volatile("" : "+v"(bfr[kb][nt]));
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) asm volatile("" : "+v"(w[nt]), "+v"(m[nt]), "+v"(v[nt]));
+    asm volatile("" : "+v"(xa));
+    __syncthreads();
+
+    for (int c = wk.c0; c < wk.c1; ++c) {
+        const int cur = (c - wk.c0) & 1;
+        const int c1n = c < clast ? c + 1 : clast;
+        const int c2n = c + 2 < wk.c1 ? c + 2 : clast;
+        f32x4 xb = xa;
+        if (stager) xb = *(const f32x4*)(xsrc + 16 * c2n);          // X tile of chunk c+2
+        f32x4 w1[NT2], m1[NT2], v1[NT2];
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            const int64_t idx = wb[nt] + c1n * cstride;                // state of chunk c+1
+            w1[nt] = *(const f32x4*)(W1 + idx); m1[nt] = *(const f32x4*)(M1 + idx); v1[nt] = *(const f32x4*)(V1 + idx);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        const float* xt = sm + cur * XT;
+        f32x4 g[NT2];
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) g[nt] = zero4;
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            const float a = xt[64 * kb + lane];
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) g[nt] = MFMA16(a, bfr[kb][nt], g[nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) adam4(w[nt], m[nt], v[nt], g[nt], ap);
+        if (stager) *(f32x4*)(sm + sdst + (cur ^ 1) * sbuf) = svalid ? xa : zero4;      // tile of chunk c+1
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            const int64_t idx = wb[nt] + c * cstride;
+            *(f32x4*)(W1 + idx) = w[nt]; *(f32x4*)(M1 + idx) = m[nt]; *(f32x4*)(V1 + idx) = v[nt];
+        }
+        if (have_next) {
+            const float* xn = sm + 2 * XT + cur * XN;
+            f32x4 af[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) af[mt] = *(const f32x4*)(xn + (16 * mt + li) * 20 + 4 * lj);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT2; ++nt) pacc[mt][nt] = MFMA16(af[mt][r], w[nt][r], pacc[mt][nt]);
+        }
+        xa = xb;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) { w[nt] = w1[nt]; m[nt] = m1[nt]; v[nt] = v1[nt]; }
+        __syncthreads();
+    }
+    if (have_next) {
+        float* p = P + (int64_t)wk.slot * DIMN_TB * Hp;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[(16 * mt + 4 * lj + r) * Hp + 16 * (nt0 + nt) + li] = pacc[mt][nt][r];
     }
 }
 
