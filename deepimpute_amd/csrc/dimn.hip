@@ -90,7 +90,7 @@ struct dimn_handle_s {
     dimn_config cfg;
     Dims dm;
     int K, H, O, B, NT, NT2, OTW, HS;   // NT/NT2 hidden tiles per wave (4-/8-wave kernels); OTW out tiles per wave; HS = ceil(HT/2)
-    int wg_per_cu = 2;
+    int wg_per_cu = 3;
     int dbg = 0;
     int variant = 1;
     int ncu = 256;
@@ -117,7 +117,9 @@ struct dimn_handle_s {
     float* d_out = nullptr; int64_t out_cap = 0; int64_t out_rows = 0;
     float* d_loss_part = nullptr; int64_t loss_part_cap = 0;
     float *d_full = nullptr, *d_stage = nullptr; int64_t full_cap = 0;   // root's gathered predictions
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // lane 0's stream; also used by every non-training call
+    struct Lane { hipStream_t stream; int k0, k1, w0, w1; };   // sub-nets [k0,k1), work items [w0,w1)
+    std::vector<Lane> lanes;               // independent sub-net groups trained on concurrent streams
     int64_t t = 0;
     // profiling
     bool profiling = false;
@@ -199,7 +201,7 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     dm.OS = ceil_div(dm.OT, 4);
     h->NT = ceil_div(dm.HT, 4);
     h->NT2 = ceil_div(dm.HT, 8);
-    h->OTW = ceil_div(dm.OT, 4);
+    h->OTW = ceil_div(dm.OT, 8);   // output tiles per wave of the 8-wave middle-backward kernel
     h->HS = ceil_div(dm.HT, 2);
     if (h->NT > 6) {
         delete h;
@@ -235,13 +237,25 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     }
     h->w1_total = w1;
     build_work(h);
+    int n_lanes = 2;
+    if (const char* e = getenv("DIMN_LANES")) n_lanes = std::max(1, atoi(e));
+    n_lanes = std::min(n_lanes, h->K);
 
     const size_t w2n = (size_t)h->K * dm.Hp * dm.Op;
 #define TRY(expr) do { int rc_ = (expr); if (rc_) { dimn_destroy(h); return rc_; } } while (0)
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete h;
-        return fail(DIMN_ERR_HIP, "dimn_create: hipStreamCreate failed");
+    for (int l = 0; l < n_lanes; ++l) {
+        dimn_handle_s::Lane ln;
+        if (hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) != hipSuccess) {
+            delete h;
+            return fail(DIMN_ERR_HIP, "dimn_create: hipStreamCreate failed");
+        }
+        ln.k0 = (int)((int64_t)h->K * l / n_lanes);
+        ln.k1 = (int)((int64_t)h->K * (l + 1) / n_lanes);
+        ln.w0 = h->sn[ln.k0].slot0;
+        ln.w1 = ln.k1 < h->K ? h->sn[ln.k1].slot0 : h->nslots;
+        h->lanes.push_back(ln);
     }
+    h->stream = h->lanes[0].stream;
     TRY(dev_alloc(&h->d_sn, (size_t)h->K));
     TRY(dev_alloc(&h->d_work, h->work.size()));
     TRY(dev_alloc(&h->d_W1, (size_t)w1)); TRY(dev_alloc(&h->d_M1, (size_t)w1)); TRY(dev_alloc(&h->d_V1, (size_t)w1));
@@ -274,7 +288,7 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
 extern "C" int dimn_destroy(dimn_handle h) {
     if (!h) return DIMN_OK;
     (void)hipSetDevice(h->cfg.device_id);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& ln : h->lanes) (void)hipStreamSynchronize(ln.stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     DEV_FREE(h->d_sn); DEV_FREE(h->d_work); DEV_FREE(h->d_norm); DEV_FREE(h->d_X); DEV_FREE(h->d_Y);
@@ -284,7 +298,7 @@ extern "C" int dimn_destroy(dimn_handle h) {
     DEV_FREE(h->d_loss_step); DEV_FREE(h->d_loss_acc); DEV_FREE(h->d_mask); DEV_FREE(h->d_rows_step);
     DEV_FREE(h->d_epoch_rows); DEV_FREE(h->d_val_rows); DEV_FREE(h->d_pred_rows); DEV_FREE(h->d_out);
     DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (auto& ln : h->lanes) (void)hipStreamDestroy(ln.stream);
     delete h;
     return DIMN_OK;
 }
@@ -487,34 +501,24 @@ static hipEvent_t next_event(dimn_handle h) {
 }
 
 template <int NT>
-static void launch_fwd1(dimn_handle h, const int32_t* rows, int b_act) {
-    hipLaunchKernelGGL(k_fwd1<NT>, dim3((unsigned)h->work.size()), dim3(256), 0, h->stream, h->d_work, h->d_sn, h->d_X, h->d_W1,
+static void launch_fwd1(dimn_handle h, const dimn_handle_s::Lane& ln, const int32_t* rows, int b_act) {
+    hipLaunchKernelGGL(k_fwd1<NT>, dim3((unsigned)(ln.w1 - ln.w0)), dim3(256), 0, ln.stream, h->d_work + ln.w0, h->d_sn, h->d_X, h->d_W1,
                        rows, b_act, h->d_P, h->dm);
 }
 template <int NT2>
-static void launch_w1(dimn_handle h, const int32_t* rows, int b_act, const int32_t* rows_n, int b_next, AdamP ap) {
-#define DBG_CASE(D) case D: hipLaunchKernelGGL((k_w1_update_fwd<2, true, D>), dim3((unsigned)h->work.size()), dim3(512), 0, h->stream, h->d_work, h->d_sn, \
-                           h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap); return;
-    if (NT2 == 2 && h->dm.HT == 16 && h->dbg) {   // ablation variants (diagnostics; DIMN_DBG=<bits>)
-        switch (h->dbg) { DBG_CASE(1) DBG_CASE(2) DBG_CASE(4) DBG_CASE(8) DBG_CASE(16) DBG_CASE(32) DBG_CASE(6) DBG_CASE(14) DBG_CASE(17) DBG_CASE(49) DBG_CASE(63) default: break; }
-    }
-#undef DBG_CASE
-    if (h->dm.HT == 16 && h->variant == 1) {
-        hipLaunchKernelGGL((k_w1_update_fwd_sh<16, 1>), dim3((unsigned)h->work.size()), dim3(1024), 0, h->stream, h->d_work, h->d_sn,
-                           h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
-        return;
-    }
-    if (h->dm.HT == 16 && h->variant == 2) {
-        hipLaunchKernelGGL((k_w1_update_fwd_sh<8, 2>), dim3((unsigned)h->work.size()), dim3(512), 0, h->stream, h->d_work, h->d_sn,
-                           h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
-        return;
-    }
-    if (h->dm.HT == 8 * NT2)
-        hipLaunchKernelGGL((k_w1_update_fwd<NT2, true>), dim3((unsigned)h->work.size()), dim3(512), 0, h->stream, h->d_work, h->d_sn,
-                           h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
+static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, const int32_t* rows, int b_act, const int32_t* rows_n, int b_next,
+                      AdamP ap) {
+    const dim3 grid((unsigned)(ln.w1 - ln.w0));
+    const Work* wk = h->d_work + ln.w0;
+    if (h->dm.HT == 16 && h->variant == 1)        // H = 256: 16 waves x 1 hidden tile, X tiles staged once per workgroup
+        hipLaunchKernelGGL((k_w1_update_fwd_sh<16, 1>), grid, dim3(1024), 0, ln.stream, wk, h->d_sn, h->d_X, h->d_W1, h->d_M1, h->d_V1,
+                           rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
+    else if (h->dm.HT == 8 * NT2)
+        hipLaunchKernelGGL((k_w1_update_fwd<NT2, true>), grid, dim3(512), 0, ln.stream, wk, h->d_sn, h->d_X, h->d_W1, h->d_M1, h->d_V1,
+                           rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
     else
-        hipLaunchKernelGGL((k_w1_update_fwd<NT2, false>), dim3((unsigned)h->work.size()), dim3(512), 0, h->stream, h->d_work, h->d_sn,
-                           h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
+        hipLaunchKernelGGL((k_w1_update_fwd<NT2, false>), grid, dim3(512), 0, ln.stream, wk, h->d_sn, h->d_X, h->d_W1, h->d_M1, h->d_V1,
+                           rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
 }
 template <int NT>
 static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out, float* loss_part) {
@@ -543,10 +547,10 @@ static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, f
 //   [F1 if need_fwd]  ->  RED  ->  MF  ->  MB  ->  B1F1 (W1 Adam + forward partials of the NEXT batch)
 // need_fwd: the split-K partials of THIS batch are not in d_P yet (first step of an epoch,
 // or the single-step API); d_rows_n/b_next: the next batch (b_next = 0: none).
-static int step_launch(dimn_handle h, const int32_t* d_rows, int b_act, bool need_fwd, const int32_t* d_rows_n, int b_next,
-                       const uint8_t* d_mask, uint32_t epoch_key, uint32_t step_key, double* d_loss_acc) {
+static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed, const int32_t* d_rows, int b_act, bool need_fwd,
+                       const int32_t* d_rows_n, int b_next, const uint8_t* d_mask, uint32_t epoch_key, uint32_t step_key,
+                       double* d_loss_acc, int64_t t) {
     const Dims& dm = h->dm;
-    const int64_t t = h->t + 1;
     AdamP ap;
     const double b1 = h->cfg.beta1, b2 = h->cfg.beta2;
     ap.alpha = (float)((double)h->cfg.learning_rate * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t)));
@@ -557,22 +561,39 @@ static int step_launch(dimn_handle h, const int32_t* d_rows, int b_act, bool nee
     const float scale = 1.0f / (1.0f - rate);
     const float inv_n = (float)(1.0 / ((double)b_act * h->O));
     const size_t kh = (size_t)h->K * dm.Hp, ko = (size_t)h->K * dm.Op;
+    const unsigned nk = (unsigned)(ln.k1 - ln.k0);
+    hipStream_t st = ln.stream;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    if (h->profiling) { e0 = next_event(h); e1 = next_event(h); e2 = next_event(h); (void)hipEventRecord(e0, h->stream); }
+    timed = timed && h->profiling;
+    if (timed) { e0 = next_event(h); e1 = next_event(h); e2 = next_event(h); (void)hipEventRecord(e0, st); }
 
-    if (need_fwd) { DISPATCH_NT(launch_fwd1, h, d_rows, b_act); }
-    hipLaunchKernelGGL(k_reduce_act, dim3((unsigned)ceil_div(DIMN_TB * dm.Hp, 1024), (unsigned)h->K), dim3(256), 0, h->stream,
-                       h->d_sn, h->d_P, h->d_b1, d_mask, h->d_Dd, dm, b_act, rate, scale, h->cfg.seed, epoch_key, step_key);
-    hipLaunchKernelGGL(k_mid_fwd, dim3((unsigned)dm.OS, (unsigned)h->K), dim3(256), (size_t)DIMN_TB * dm.ldd * sizeof(float), h->stream,
-                       h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_dZ,
-                       h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary);
-    hipLaunchKernelGGL(k_mid_bwd, dim3((unsigned)h->HS, (unsigned)h->K), dim3(256), 0, h->stream, h->d_Dd, h->d_dZ, h->d_W2, h->d_M2,
-                       h->d_V2, h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW);
-    if (h->profiling) (void)hipEventRecord(e1, h->stream);
-    DISPATCH_NT2(launch_w1, h, d_rows, b_act, d_rows_n, b_next, ap);
-    if (h->profiling) (void)hipEventRecord(e2, h->stream);
+    if (need_fwd) { DISPATCH_NT(launch_fwd1, h, ln, d_rows, b_act); }
+    hipLaunchKernelGGL(k_reduce_act, dim3((unsigned)ceil_div(DIMN_TB * dm.Hp, 1024), nk), dim3(256), 0, st, h->d_sn, h->d_P, h->d_b1, d_mask,
+                       h->d_Dd, dm, b_act, rate, scale, h->cfg.seed, epoch_key, step_key, ln.k0);
+    {
+        const dim3 grid((unsigned)dm.OS, nk);
+        const size_t lds = (size_t)DIMN_TB * dm.ldd * sizeof(float);
+#define LAUNCH_MF(HTC) hipLaunchKernelGGL(k_mid_fwd<HTC>, grid, dim3(256), lds, st, h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, \
+                                          h->n, d_rows, b_act, h->d_Dd, h->d_dZ, h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary, ln.k0)
+        if (dm.HT == 16) LAUNCH_MF(16); else LAUNCH_MF(0);
+#undef LAUNCH_MF
+    }
+    // one hidden tile per workgroup: K*HT workgroups of <=128 VGPRs, two resident per CU
+    if (dm.OT == 8 * h->OTW)
+        hipLaunchKernelGGL((k_mid_bwd<true, 1>), dim3((unsigned)dm.HT, nk), dim3(512), 0, st, h->d_Dd, h->d_dZ, h->d_W2, h->d_M2, h->d_V2,
+                           h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0);
+    else
+        hipLaunchKernelGGL((k_mid_bwd<false, 1>), dim3((unsigned)dm.HT, nk), dim3(512), 0, st, h->d_Dd, h->d_dZ, h->d_W2, h->d_M2, h->d_V2,
+                           h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0);
+    if (timed) (void)hipEventRecord(e1, st);
+    DISPATCH_NT2(launch_w1, h, ln, d_rows, b_act, d_rows_n, b_next, ap);
+    if (timed) (void)hipEventRecord(e2, st);
     HIPCHK(hipGetLastError());
-    h->t = t;
+    return DIMN_OK;
+}
+
+static int sync_lanes(dimn_handle h) {
+    for (auto& ln : h->lanes) HIPCHK(hipStreamSynchronize(ln.stream));
     return DIMN_OK;
 }
 
@@ -612,8 +633,12 @@ extern "C" int dimn_train_step(dimn_handle h, const int32_t* rows, int32_t b_act
         HIPCHK(hipMemcpyAsync(h->d_mask, padded.data(), padded.size(), hipMemcpyHostToDevice, h->stream));
         dmask = h->d_mask;
     }
-    CHK(step_launch(h, h->d_rows_step, b_act, true, nullptr, 0, dmask, (uint32_t)epoch_key, (uint32_t)step_key, nullptr));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));     // rows / mask uploads done before any lane starts
+    for (size_t l = 0; l < h->lanes.size(); ++l)
+        CHK(step_launch(h, h->lanes[l], l == 0, h->d_rows_step, b_act, true, nullptr, 0, dmask, (uint32_t)epoch_key, (uint32_t)step_key,
+                        nullptr, h->t + 1));
+    h->t += 1;
+    CHK(sync_lanes(h));
     if (h->profiling) collect_timers(h);
     if (loss_out) {
         std::vector<float> ls((size_t)h->K * dm.OS);
@@ -650,9 +675,10 @@ extern "C" int dimn_train_epoch(dimn_handle h, int32_t epoch, const int32_t* per
         if (perm[i] < 0 || perm[i] >= h->n_tr) return fail(DIMN_ERR_ARG, "dimn_train_epoch: perm[%lld] out of range", (long long)i);
         rows[(size_t)i] = h->train_rows[(size_t)perm[i]];
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(sync_lanes(h));
     HIPCHK(hipMemcpyAsync(h->d_epoch_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(h->d_loss_acc, 0, (size_t)h->K * dm.OS * sizeof(double), h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));     // every lane reads the row list and accumulates into d_loss_acc
     // d_loss_acc accumulates sum(w e^2) per step; the per-step means are weighted by b_act,
     // i.e. sum_steps (sum/(b_act*O))*b_act / n_tr = total / (O*n_tr)
     int step = 0;
@@ -660,10 +686,14 @@ extern "C" int dimn_train_epoch(dimn_handle h, int32_t epoch, const int32_t* per
         const int b_act = (int)std::min<int64_t>(h->B, h->n_tr - i0);
         const int64_t i1 = i0 + h->B;
         const int b_next = i1 < h->n_tr ? (int)std::min<int64_t>(h->B, h->n_tr - i1) : 0;
-        CHK(step_launch(h, h->d_epoch_rows + i0, b_act, step == 0, b_next ? h->d_epoch_rows + i1 : nullptr, b_next, nullptr,
-                        (uint32_t)epoch, (uint32_t)step, h->d_loss_acc));
+        // the lanes (disjoint sub-net groups) are independent chains: issuing them to separate streams lets
+        // one group's small latency-bound kernels run under the other group's HBM-bound weight update
+        for (size_t l = 0; l < h->lanes.size(); ++l)
+            CHK(step_launch(h, h->lanes[l], l == 0, h->d_epoch_rows + i0, b_act, step == 0, b_next ? h->d_epoch_rows + i1 : nullptr,
+                            b_next, nullptr, (uint32_t)epoch, (uint32_t)step, h->d_loss_acc, h->t + 1));
+        h->t += 1;
     }
-    HIPCHK(hipStreamSynchronize(h->stream));   // also keeps `rows` alive until the H2D copy is done
+    CHK(sync_lanes(h));
     if (h->profiling) collect_timers(h);
     if (train_loss) {
         std::vector<double> acc((size_t)h->K * dm.OS);
@@ -767,7 +797,7 @@ extern "C" int dimn_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, 
 extern "C" int dimn_synchronize(dimn_handle h) {
     if (!h) return fail(DIMN_ERR_ARG, "null handle");
     CHK(use_device(h));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(sync_lanes(h));
     return DIMN_OK;
 }
 

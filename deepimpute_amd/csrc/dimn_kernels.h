@@ -69,7 +69,7 @@ __device__ __forceinline__ void adam4(f32x4& w, f32x4& m, f32x4& v, const f32x4 
 __device__ __forceinline__ void adam1(float& w, float& m, float& v, const float g, const AdamP a) {
     m += (g - m) * a.omb1;
     v += (g * g - v) * a.omb2;
-    w -= (m * a.alpha) / (sqrtf(v) + a.eps);
+    w -= (m * a.alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + a.eps);
 }
 
 __device__ __forceinline__ float softplus_f(float x) {
@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256) void k_fwd1(const Work* __restrict__ work, con
 __global__ __launch_bounds__(256) void k_reduce_act(const SubnetDev* __restrict__ sn, const float* __restrict__ P,
                                                     const float* __restrict__ b1, const uint8_t* __restrict__ mask,
                                                     float* __restrict__ Dd, Dims dm, int b_act, float rate, float scale,
-                                                    uint64_t seed, uint32_t epoch_key, uint32_t step_key) {
-    const int k = blockIdx.y;
+                                                    uint64_t seed, uint32_t epoch_key, uint32_t step_key, int k0) {
+    const int k = blockIdx.y + k0;
     const SubnetDev s = sn[k];
     const int Hp = dm.Hp;
     const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -200,7 +200,18 @@ __global__ __launch_bounds__(256) void k_reduce_act(const SubnetDev* __restrict_
     const float* pk = P + (int64_t)s.slot0 * DIMN_TB * Hp + e;
     const int64_t pstride = (int64_t)DIMN_TB * Hp;
     f32x4 a = *(const f32x4*)(b1 + (int64_t)k * Hp + h);
-    for (int sl = 0; sl < s.nslice; ++sl) a += *(const f32x4*)(pk + sl * pstride);
+    {   // S independent 16-byte loads, eight in flight at a time (a dependent add per load would
+        // serialise S memory latencies)
+        int sl = 0;
+        for (; sl + 8 <= s.nslice; sl += 8) {
+            f32x4 t[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = *(const f32x4*)(pk + (sl + i) * pstride);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a += t[i];
+        }
+        for (; sl < s.nslice; ++sl) a += *(const f32x4*)(pk + sl * pstride);
+    }
     bool keep[4];
     if (mask) {
 #pragma unroll
@@ -229,80 +240,113 @@ __global__ __launch_bounds__(256) void k_reduce_act(const SubnetDev* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------
-// MF: middle forward.  Workgroup = (sub-net k, output slice os of 64 columns).
-//  a) Dd[64][Hp] -> LDS
+// MF: middle forward.  Workgroup = (sub-net k, output slice os of 64 columns), 4 waves, wave w
+// owns output tile ot = 4*os + w.
+//  a) Dd[64][Hp] (from k_reduce_act) -> LDS
 //  b) Z[:,slice] = Dd W2[:,slice] + b2 ; yhat = softplus ; wMSE ; dZ ; gb2 -> Adam(b2)
+// HTC > 0 (compile-time hidden-tile count): every global load the wave needs -- its W2 column
+// block, the targets Y of the 64 batch rows, the bias -- is issued BEFORE the LDS staging, so
+// HBM/L2 latency overlaps the staging and the barrier instead of following it.
 // ---------------------------------------------------------------------------------------
+template <int HTC>
 __global__ __launch_bounds__(256) void k_mid_fwd(const float* __restrict__ W2,
                                                  float* __restrict__ b2w, float* __restrict__ b2m, float* __restrict__ b2v,
                                                  const float* __restrict__ Y, int64_t n_cells,
                                                  const int32_t* __restrict__ rows, int b_act,
                                                  const float* __restrict__ Dd,
                                                  float* __restrict__ dZ, float* __restrict__ loss_step,
-                                                 double* __restrict__ loss_acc, Dims dm, AdamP ap, float inv_n, int loss_binary) {
+                                                 double* __restrict__ loss_acc, Dims dm, AdamP ap, float inv_n, int loss_binary, int k0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int os = blockIdx.x, k = blockIdx.y;
+    const int os = blockIdx.x, k = blockIdx.y + k0;
     const int Hp = dm.Hp, ldd = dm.ldd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    const int ot = os * 4 + wave;
+    const bool act = ot < dm.OT;
+    const int otc = act ? ot : 0;                       // clamped tile: loads stay in bounds, results are dropped
+    const int o = 16 * otc + li;
+    const int HT = HTC > 0 ? HTC : dm.HT;
 
-    // ---- a) stage Dd[64][Hp] (written once per sub-net by k_reduce_act) into LDS ----
+    // ---- loads that depend on nothing: W2 operands, targets, bias ----
+    const float* w2 = W2 + (int64_t)k * Hp * dm.Op + (int64_t)otc * 256 + lj * 16 + li;
+    float bvr[HTC > 0 ? HTC : 1][4];
+    if (HTC > 0) {
+#pragma unroll
+        for (int ht = 0; ht < HTC; ++ht)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bvr[ht][q] = w2[(int64_t)ht * dm.OT * 256 + q * 64];   // W2[h=16ht+4q+lj][o]
+    }
+    float yv[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = 16 * mt + 4 * lj + r;
+            yv[mt][r] = Y[((int64_t)k * n_cells + rows[b < b_act ? b : 0]) * dm.Op + o];
+        }
+    const float bias = b2w[(int64_t)k * dm.Op + o];
+
+    // ---- a) stage Dd[64][Hp] into LDS (row stride ldd = 2 mod 32 words: conflict-free column reads) ----
     const float* ddk = Dd + (int64_t)k * DIMN_TB * Hp;
     for (int e = threadIdx.x * 4; e < DIMN_TB * Hp; e += 1024) {
         const int b = e / Hp, h = e - b * Hp;
         const f32x4 dd = *(const f32x4*)(ddk + e);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lds[b * ldd + h + r] = dd[r];
+        *(float2*)(lds + b * ldd + h) = make_float2(dd[0], dd[1]);
+        *(float2*)(lds + b * ldd + h + 2) = make_float2(dd[2], dd[3]);
     }
     __syncthreads();
 
-    // ---- b) second layer on this 64-column slice: wave w owns output tile ot ----
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane & 15, lj = lane >> 4;
-    const int ot = os * 4 + wave;
-    float lsum = 0.f;
-    if (ot < dm.OT) {
-        f32x4 acc[4];
+    // ---- b) second layer on this 64-column slice ----
+    f32x4 acc[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* w2 = W2 + (int64_t)k * Hp * dm.Op + (int64_t)ot * 256 + lj * 16 + li;
-        for (int ht = 0; ht < dm.HT; ++ht) {
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (HTC > 0) {
+#pragma unroll
+        for (int ht = 0; ht < HTC; ++ht)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt] = MFMA16(lds[(16 * mt + li) * ldd + 16 * ht + 4 * q + lj], bvr[ht][q], acc[mt]);
+    } else {
+        for (int ht = 0; ht < HT; ++ht) {
             const float* wt = w2 + (int64_t)ht * dm.OT * 256;
             float bv[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bv[q] = wt[q * 64];          // W2[h=16ht+4q+lj][o=16ot+li]
+            for (int q = 0; q < 4; ++q) bv[q] = wt[q * 64];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
                     acc[mt] = MFMA16(lds[(16 * mt + li) * ldd + 16 * ht + 4 * q + lj], bv[q], acc[mt]);
         }
-        const int o = 16 * ot + li;
-        const float bias = b2w[(int64_t)k * dm.Op + o];
-        float gb = 0.f;
+    }
+    float lsum = 0.f, gb = 0.f;
+    const bool col_ok = act && (16 * ot + li) < dm.O;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int b = 16 * mt + 4 * lj + r;
-                float dz = 0.f;
-                if (b < b_act && o < dm.O) {
-                    const float z = acc[mt][r] + bias;
-                    const float y = Y[((int64_t)k * n_cells + rows[b]) * dm.Op + o];
-                    const float w = loss_binary ? (y > 0.f ? 1.f : 0.f) : y;   // multinet.py:37-40
-                    const float e = y - softplus_f(z);
-                    lsum += w * e * e;
-                    dz = -2.f * w * e * inv_n * sigmoid_f(z);
-                }
-                dZ[((int64_t)k * DIMN_TB + b) * dm.Op + o] = dz;
-                gb += dz;
+        for (int r = 0; r < 4; ++r) {
+            const int b = 16 * mt + 4 * lj + r;
+            float dz = 0.f;
+            if (b < b_act && col_ok) {
+                const float z = acc[mt][r] + bias;
+                const float y = yv[mt][r];
+                const float w = loss_binary ? (y > 0.f ? 1.f : 0.f) : y;   // multinet.py:37-40
+                const float e = y - softplus_f(z);
+                lsum += w * e * e;
+                dz = -2.f * w * e * inv_n * sigmoid_f(z);
             }
-        gb += __shfl_xor(gb, 16);
-        gb += __shfl_xor(gb, 32);
-        if (lj == 0) {
-            const int64_t i = (int64_t)k * dm.Op + o;
-            float w = b2w[i], m = b2m[i], v = b2v[i];
-            adam1(w, m, v, gb, ap);
-            b2w[i] = w; b2m[i] = m; b2v[i] = v;
+            if (act) dZ[((int64_t)k * DIMN_TB + b) * dm.Op + o] = dz;
+            gb += dz;
         }
+    gb += __shfl_xor(gb, 16);
+    gb += __shfl_xor(gb, 32);
+    if (act && lj == 0) {
+        const int64_t i = (int64_t)k * dm.Op + o;
+        float w = bias, m = b2m[i], v = b2v[i];
+        adam1(w, m, v, gb, ap);
+        b2w[i] = w; b2m[i] = m; b2v[i] = v;
     }
     // block loss reduction -> one float per (k, slice)
 #pragma unroll
@@ -318,156 +362,145 @@ __global__ __launch_bounds__(256) void k_mid_fwd(const float* __restrict__ W2,
 }
 
 // ---------------------------------------------------------------------------------------
-// MB: middle backward.  Workgroup = (sub-net k, two hidden tiles = 32 rows of W2).
+// MB: middle backward.  Workgroup = (sub-net k, NH hidden tiles = 16*NH rows of W2), 8 waves;
+// wave w owns output tiles [w*otw, w*otw+otw).
 //  gW2^T tile = dZ^T Dd  (K = batch)  -> Adam on W2/m/v (tile-blocked, 1 KiB/tile)
-//  dD[:,32] = dZ W2^T (OLD W2, K = O split over the 4 waves, reduced through LDS)
+//  dD[:,16*NH] = dZ W2^T (OLD W2, K = O split over the 8 waves, reduced through LDS)
 //  dA = dD * scale * [Dd>0] ; gb1 -> Adam(b1)
+// Each wave stages the dZ tile [64 b][16 o] of its current output tile into a PRIVATE 4 KiB LDS
+// region (4 x 16-byte loads per lane): the linear image serves both operand forms -- dZ^T
+// (ds_read_b32, lane-linear) and dZ rows (ds_read_b128) -- without 64-byte strided gathers.
+// State and dZ of the next output tile are prefetched while the current one computes.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mid_bwd(const float* __restrict__ Dd, const float* __restrict__ dZ,
+template <bool FULL, int NH>   // NH hidden tiles (16 rows of W2 each) per workgroup; FULL: HT % NH == 0 and OT == 8*otw
+__global__ __launch_bounds__(512) void k_mid_bwd(const float* __restrict__ Dd, const float* __restrict__ dZ,
                                                  float* __restrict__ W2, float* __restrict__ M2, float* __restrict__ V2,
                                                  float* __restrict__ b1w, float* __restrict__ b1m, float* __restrict__ b1v,
-                                                 float* __restrict__ dA, Dims dm, AdamP ap, float scale, int otw) {
-    __shared__ __attribute__((aligned(16))) float red[4 * DIMN_TB * 33];
-    const int hs = blockIdx.x, k = blockIdx.y;
+                                                 float* __restrict__ dA, Dims dm, AdamP ap, float scale, int otw, int k0) {
+    constexpr int LDR = 16 * NH + 1;                             // padded row of the reduction buffer
+    constexpr int RED = (8 * DIMN_TB * LDR) > 8192 ? (8 * DIMN_TB * LDR) : 8192;                       // floats: cross-wave dD reduction buffer
+    __shared__ __attribute__((aligned(16))) float lds[RED];     // first 8 x 1024 floats double as the dZ tiles
+    const int hs = blockIdx.x, k = blockIdx.y + k0;
     const int Hp = dm.Hp, Op = dm.Op;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
-    const int ht0 = 2 * hs;
-    const int nht = (dm.HT - ht0) < 2 ? (dm.HT - ht0) : 2;
+    const int ht0 = NH * hs;
+    const int nht = FULL ? NH : ((dm.HT - ht0) < NH ? (dm.HT - ht0) : NH);
     const float* ddk = Dd + (int64_t)k * DIMN_TB * Hp;
     const float* dzk = dZ + (int64_t)k * DIMN_TB * Op;
+    float* tile = lds + wave * 1024;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float ddf[16][2];    // B operand of gW2: Dd[b=4kb+lj][h=16(ht0+ht)+li]
+    const int ot_beg = wave * otw;
+    const int ot_end = FULL ? ot_beg + otw : ((wave + 1) * otw < dm.OT ? (wave + 1) * otw : dm.OT);
+    const int ot_last = ot_end - 1;
+
+    float ddf[16][NH];    // B operand of gW2: Dd[b=4kb+lj][h=16(ht0+ht)+li] (second tile clamped when absent)
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht) ddf[kb][ht] = ht < nht ? ddk[(4 * kb + lj) * Hp + 16 * (ht0 + ht) + li] : 0.f;
+        for (int ht = 0; ht < NH; ++ht) ddf[kb][ht] = ddk[(4 * kb + lj) * Hp + 16 * (ht0 + (ht < nht ? ht : 0)) + li];
 
-    f32x4 dacc[4][2];
+    f32x4 dacc[4][NH];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht) dacc[mt][ht] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ht = 0; ht < NH; ++ht) dacc[mt][ht] = zero4;
 
-    const int ot_end = (wave + 1) * otw < dm.OT ? (wave + 1) * otw : dm.OT;
-    for (int ot = wave * otw; ot < ot_end; ++ot) {
-        f32x4 g[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    const int64_t tbase = (int64_t)k * Hp * Op + li * 16 + 4 * lj;
+    auto tidx = [&](int ht, int ot) { return tbase + ((int64_t)(ht0 + (ht < nht ? ht : 0)) * dm.OT + ot) * 256; };
+    // dZ tile staging: pass i moves row 16i + lane/4, quarter lane%4
+    const float* zsrc = dzk + (lane >> 2) * Op + 4 * (lane & 3);
+
+    if (ot_beg < ot_end) {
+        f32x4 w[NH], m[NH], v[NH], zt[4];
 #pragma unroll
-        for (int kb = 0; kb < 16; ++kb) {
-            const float az = dzk[(4 * kb + lj) * Op + 16 * ot + li];   // dZ^T[o=li][b=4kb+lj]
+        for (int ht = 0; ht < NH; ++ht) { const int64_t i = tidx(ht, ot_beg); w[ht] = *(const f32x4*)(W2 + i); m[ht] = *(const f32x4*)(M2 + i); v[ht] = *(const f32x4*)(V2 + i); }
 #pragma unroll
-            for (int ht = 0; ht < 2; ++ht) g[ht] = MFMA16(az, ddf[kb][ht], g[ht]);
-        }
-        f32x4 zf[4];
+        for (int i = 0; i < 4; ++i) zt[i] = *(const f32x4*)(zsrc + 16 * i * Op + 16 * ot_beg);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) zf[mt] = *(const f32x4*)(dzk + (16 * mt + li) * Op + 16 * ot + 4 * lj);
+        for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht) {
-            if (ht < nht) {
-                const int64_t idx = (int64_t)k * Hp * Op + ((int64_t)(ht0 + ht) * dm.OT + ot) * 256 + li * 16 + 4 * lj;
-                f32x4 w = *(const f32x4*)(W2 + idx), m = *(const f32x4*)(M2 + idx), v = *(const f32x4*)(V2 + idx);
+            for (int ht = 0; ht < NH; ++ht) asm volatile("" : "+v"(ddf[kb][ht]));
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) asm volatile("" : "+v"(w[ht]), "+v"(m[ht]), "+v"(v[ht]));
+
+        for (int ot = ot_beg; ot < ot_end; ++ot) {
+            // stage this tile (wave-private, in-order LDS), then request the next one
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(f32x4*)(tile + 256 * i + 4 * lane) = zt[i];
+            const int on = ot < ot_last ? ot + 1 : ot_last;
+            f32x4 w1[NH], m1[NH], v1[NH];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) zt[i] = *(const f32x4*)(zsrc + 16 * i * Op + 16 * on);
+#pragma unroll
+            for (int ht = 0; ht < NH; ++ht) { const int64_t i = tidx(ht, on); w1[ht] = *(const f32x4*)(W2 + i); m1[ht] = *(const f32x4*)(M2 + i); v1[ht] = *(const f32x4*)(V2 + i); }
+            __builtin_amdgcn_sched_barrier(0);
+
+            f32x4 g[NH];
+#pragma unroll
+            for (int ht = 0; ht < NH; ++ht) g[ht] = zero4;
+#pragma unroll
+            for (int kb = 0; kb < 16; ++kb) {
+                const float az = tile[64 * kb + lane];                       // dZ^T[o=li][b=4kb+lj]
+#pragma unroll
+                for (int ht = 0; ht < NH; ++ht) g[ht] = MFMA16(az, ddf[kb][ht], g[ht]);
+            }
+            f32x4 zf[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) zf[mt] = *(const f32x4*)(tile + (16 * mt + li) * 16 + 4 * lj);   // dZ[b][o=4lj+r]
+#pragma unroll
+            for (int ht = 0; ht < NH; ++ht) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) dacc[mt][ht] = MFMA16(zf[mt][r], w[r], dacc[mt][ht]);   // OLD W2
-                adam4(w, m, v, g[ht], ap);
-                *(f32x4*)(W2 + idx) = w; *(f32x4*)(M2 + idx) = m; *(f32x4*)(V2 + idx) = v;
+                    for (int mt = 0; mt < 4; ++mt) dacc[mt][ht] = MFMA16(zf[mt][r], w[ht][r], dacc[mt][ht]);   // OLD W2
+                adam4(w[ht], m[ht], v[ht], g[ht], ap);
+                if (FULL || ht < nht) {
+                    const int64_t i = tidx(ht, ot);
+                    *(f32x4*)(W2 + i) = w[ht]; *(f32x4*)(M2 + i) = m[ht]; *(f32x4*)(V2 + i) = v[ht];
+                }
             }
+#pragma unroll
+            for (int ht = 0; ht < NH; ++ht) { w[ht] = w1[ht]; m[ht] = m1[ht]; v[ht] = v1[ht]; }
         }
     }
+    __syncthreads();                                   // every wave is done with its private tile
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht)
+        for (int ht = 0; ht < NH; ++ht)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[(wave * DIMN_TB + 16 * mt + 4 * lj + r) * 33 + 16 * ht + li] = dacc[mt][ht][r];
+            for (int r = 0; r < 4; ++r) lds[(wave * DIMN_TB + 16 * mt + 4 * lj + r) * LDR + 16 * ht + li] = (FULL || ht < nht) ? dacc[mt][ht][r] : 0.f;
     __syncthreads();
-    // 64 x 32 outputs, 8 per thread: thread -> column hh = tid & 31, rows b = (tid>>5) + 8*i
-    const int hh = threadIdx.x & 31, b0 = threadIdx.x >> 5;
-    const int h = 32 * hs + hh;
+    // 64 x (16*NH) outputs: thread -> column hh = tid % (16*NH), rows b = tid / (16*NH) + RB*i
+    constexpr int CW = 16 * NH, RB = 512 / CW, NI = DIMN_TB / RB;
+    const int hh = tid % CW, b0 = tid / CW;
+    const int h = CW * hs + hh;
     float gsum = 0.f;
     if (h < Hp) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int b = b0 + 8 * i;
-            const float d = red[(0 * DIMN_TB + b) * 33 + hh] + red[(1 * DIMN_TB + b) * 33 + hh] +
-                            red[(2 * DIMN_TB + b) * 33 + hh] + red[(3 * DIMN_TB + b) * 33 + hh];
+        for (int i = 0; i < NI; ++i) {
+            const int b = b0 + RB * i;
+            float d = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 8; ++wv) d += lds[(wv * DIMN_TB + b) * LDR + hh];
             const float da = ddk[b * Hp + h] > 0.f ? d * scale : 0.f;
             dA[((int64_t)k * DIMN_TB + b) * Hp + h] = da;
             gsum += da;
         }
     }
     __syncthreads();
-    red[b0 * 33 + hh] = gsum;
+    lds[b0 * LDR + hh] = gsum;
     __syncthreads();
-    if (threadIdx.x < 32 && h < Hp) {
+    if (tid < CW && h < Hp) {
         float gb = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) gb += red[i * 33 + hh];
+        for (int i = 0; i < RB; ++i) gb += lds[i * LDR + hh];
         const int64_t idx = (int64_t)k * Hp + h;
         float w = b1w[idx], m = b1m[idx], v = b1v[idx];
         adam1(w, m, v, gb, ap);
         b1w[idx] = w; b1m[idx] = m; b1v[idx] = v;
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// B1: first-layer weight gradient + fused Keras-Adam.  Same work table as F1.
-//  gW1 tile[16 d][16 h] = X^T[d][b] dA[b][h]  (K = batch, dA fragments live in registers),
-//  accumulator (row = 4*lj + r = d, col = li = h) == the float4 the lane owns in the
-//  chunk-blocked W1/m/v -> read, update, write 1 KiB per wave instruction; dW never exists.
-// ---------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(256) void k_w1_update(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
-                                                   const float* __restrict__ X, float* __restrict__ W1,
-                                                   float* __restrict__ M1, float* __restrict__ V1,
-                                                   const int32_t* __restrict__ rows, int b_act,
-                                                   const float* __restrict__ dA, Dims dm, AdamP ap) {
-    const Work wk = work[blockIdx.x];
-    const SubnetDev s = sn[wk.k];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane & 15, lj = lane >> 4;
-    const int nt0 = wave * NT;
-    const int Hp = dm.Hp;
-
-    float bfr[16][NT];   // dA[b=4kb+lj][h=16(nt0+nt)+li]; rows >= b_act are zero
-    const float* dak = dA + (int64_t)wk.k * DIMN_TB * Hp;
-#pragma unroll
-    for (int kb = 0; kb < 16; ++kb)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bfr[kb][nt] = (nt0 + nt < dm.HT) ? dak[(4 * kb + lj) * Hp + 16 * (nt0 + nt) + li] : 0.f;
-
-    const float* xk = X + s.xoff;
-    uint32_t xo[16];
-    bool valid[16];
-#pragma unroll
-    for (int kb = 0; kb < 16; ++kb) {
-        const int b = 4 * kb + lj;
-        valid[kb] = b < b_act;
-        xo[kb] = valid[kb] ? (uint32_t)rows[b] * (uint32_t)s.Dp + (uint32_t)li : 0u;
-    }
-    const int64_t cstride = (int64_t)Hp * 16;
-    const int64_t wb = s.w1off + (int64_t)(16 * nt0 + li) * 16 + 4 * lj;
-
-    for (int c = wk.c0; c < wk.c1; ++c) {
-        float a[16];
-#pragma unroll
-        for (int kb = 0; kb < 16; ++kb) a[kb] = valid[kb] ? xk[xo[kb] + 16 * c] : 0.f;   // X^T[d=16c+li][b]
-        f32x4 g[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) g[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < 16; ++kb)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) g[nt] = MFMA16(a[kb], bfr[kb][nt], g[nt]);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            if (nt0 + nt < dm.HT) {
-                const int64_t idx = wb + c * cstride + nt * 256;
-                f32x4 w = *(const f32x4*)(W1 + idx), m = *(const f32x4*)(M1 + idx), v = *(const f32x4*)(V1 + idx);
-                adam4(w, m, v, g[nt], ap);
-                *(f32x4*)(W1 + idx) = w; *(f32x4*)(M1 + idx) = m; *(f32x4*)(V1 + idx) = v;
-            }
     }
 }
 
@@ -651,8 +684,8 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
 // <=128 VGPRs, four waves share each SIMD, so MFMA, Adam VALU work and memory waits of
 // different waves overlap inside every chunk.
 // ---------------------------------------------------------------------------------------
-template <int WAVES, int NT2>
-__global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_sh(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
+template <int WAVES, int NT2, int MINW = 1>
+__global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
                                                                 const float* __restrict__ X, float* __restrict__ W1,
                                                                 float* __restrict__ M1, float* __restrict__ V1,
                                                                 const int32_t* __restrict__ rows_t, int b_act,
@@ -767,6 +800,143 @@ __global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_sh(const Work* __r
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) { w[nt] = w1[nt]; m[nt] = m1[nt]; v[nt] = v1[nt]; }
         __syncthreads();
+    }
+    if (have_next) {
+        float* p = P + (int64_t)wk.slot * DIMN_TB * Hp;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[(16 * mt + 4 * lj + r) * Hp + 16 * (nt0 + nt) + li] = pacc[mt][nt][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// B1F1 "shared staging, deep ring": as k_w1_update_fwd_sh, but the chunk loop is unrolled three
+// times over three NAMED register sets (A, B, C), so that rotating the prefetch ring costs no
+// register copies -- a copy would force a wait on the load issued in the same iteration.  The
+// state of chunk c+2 and the X tile of chunk c+2 are requested while chunk c computes: two
+// chunks (~13 KB per wave) stay in flight.
+// ---------------------------------------------------------------------------------------
+template <int NT2>
+struct W1Set { f32x4 w[NT2], m[NT2], v[NT2]; f32x4 x; };
+
+template <int WAVES, int NT2>
+__global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_ring(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
+                                                                  const float* __restrict__ X, float* __restrict__ W1,
+                                                                  float* __restrict__ M1, float* __restrict__ V1,
+                                                                  const int32_t* __restrict__ rows_t, int b_act,
+                                                                  const int32_t* __restrict__ rows_n, int b_next,
+                                                                  const float* __restrict__ dA, float* __restrict__ P, Dims dm, AdamP ap) {
+    constexpr int XT = DIMN_TB * 16, XN = DIMN_TB * 20;
+    __shared__ __attribute__((aligned(16))) float sm[2 * (XT + XN)];
+    const Work wk = work[blockIdx.x];
+    const SubnetDev s = sn[wk.k];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    const int nt0 = wave * NT2;
+    const int Hp = dm.Hp;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float bfr[16][NT2];
+    const float* dak = dA + (int64_t)wk.k * DIMN_TB * Hp;
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) bfr[kb][nt] = dak[(4 * kb + lj) * Hp + 16 * (nt0 + nt) + li];
+
+    const bool stager = tid < 512;
+    const bool stage_next = tid >= 256;
+    const bool have_next = b_next > 0;
+    const int sb = (tid & 255) >> 2, sq = tid & 3;
+    const bool svalid = stager && (stage_next ? (sb < b_next) : (sb < b_act));
+    const int32_t* srows = (stage_next && have_next) ? rows_n : rows_t;
+    const float* xsrc = X + s.xoff + (int64_t)srows[svalid ? sb : 0] * s.Dp + 4 * sq;
+    const int sdst = stage_next ? (2 * XT + sb * 20 + 4 * sq) : (sb * 16 + 4 * sq);
+    const int sbuf = stage_next ? XN : XT;
+
+    const int64_t cstride = (int64_t)Hp * 16;
+    int64_t wb[NT2];
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) wb[nt] = s.w1off + (int64_t)(16 * (nt0 + nt) + li) * 16 + 4 * lj;
+
+    f32x4 pacc[4][NT2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) pacc[mt][nt] = zero4;
+
+    const int clast = wk.c1 - 1;
+    auto fetch = [&](W1Set<NT2>& st, int c) {               // issue the loads of chunk c (clamped)
+        const int cc = c < clast ? c : clast;
+        if (stager) st.x = *(const f32x4*)(xsrc + 16 * cc);
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            const int64_t idx = wb[nt] + cc * cstride;
+            st.w[nt] = *(const f32x4*)(W1 + idx); st.m[nt] = *(const f32x4*)(M1 + idx); st.v[nt] = *(const f32x4*)(V1 + idx);
+        }
+    };
+    // one chunk: `cur` holds chunk c, `nx1` chunk c+1 (its X tile is staged into LDS here),
+    // `nx2` receives the loads of chunk c+2
+    auto step = [&](W1Set<NT2>& cur, W1Set<NT2>& nx1, W1Set<NT2>& nx2, int c) {
+        const int par = (c - wk.c0) & 1;
+        fetch(nx2, c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* xt = sm + par * XT;
+        f32x4 g[NT2];
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) g[nt] = zero4;
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            const float a = xt[64 * kb + lane];
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) g[nt] = MFMA16(a, bfr[kb][nt], g[nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) adam4(cur.w[nt], cur.m[nt], cur.v[nt], g[nt], ap);
+        if (stager) *(f32x4*)(sm + sdst + (par ^ 1) * sbuf) = svalid ? nx1.x : zero4;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            const int64_t idx = wb[nt] + c * cstride;
+            *(f32x4*)(W1 + idx) = cur.w[nt]; *(f32x4*)(M1 + idx) = cur.m[nt]; *(f32x4*)(V1 + idx) = cur.v[nt];
+        }
+        if (have_next) {
+            const float* xn = sm + 2 * XT + par * XN;
+            f32x4 af[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) af[mt] = *(const f32x4*)(xn + (16 * mt + li) * 20 + 4 * lj);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT2; ++nt) pacc[mt][nt] = MFMA16(af[mt][r], cur.w[nt][r], pacc[mt][nt]);
+        }
+        __syncthreads();
+    };
+
+    W1Set<NT2> A, B, C;
+    A.x = B.x = C.x = zero4;
+    fetch(A, wk.c0);
+    fetch(B, wk.c0 + 1);
+    if (stager) *(f32x4*)(sm + sdst) = svalid ? A.x : zero4;
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) asm volatile("" : "+v"(bfr[kb][nt]));
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+        asm volatile("" : "+v"(A.w[nt]), "+v"(A.m[nt]), "+v"(A.v[nt]));
+        asm volatile("" : "+v"(B.w[nt]), "+v"(B.m[nt]), "+v"(B.v[nt]));
+    }
+    asm volatile("" : "+v"(B.x));
+    __syncthreads();
+
+    for (int c = wk.c0; c < wk.c1; c += 3) {
+        step(A, B, C, c);
+        if (c + 1 < wk.c1) step(B, C, A, c + 1);
+        if (c + 2 < wk.c1) step(C, A, B, c + 2);
     }
     if (have_next) {
         float* p = P + (int64_t)wk.slot * DIMN_TB * Hp;
