@@ -160,6 +160,23 @@ def impute_once(eng, epochs, comm=None, counts=None, n=None):
     return vsum
 
 
+def measured_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary
+    (profiles/*_traffic.json, made by tools/pmc_traffic.py from separate rocprofv3 --pmc passes);
+    None when no summary for this kernel is committed."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))):
+        try:
+            with open(path) as f:
+                for name, rec in json.load(f)["kernels"].items():
+                    if name.startswith(kernel_prefix):
+                        best = rec["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+    return best
+
+
 def w1_update_bytes(eng):
     """ALGORITHMIC HBM bytes of one k_w1_update launch: read+write of W1, m, v
     (24 B per first-layer parameter) + the batch's X rows (4*B*sum(D_k)) + dA (4*B*H*K)."""
@@ -323,8 +340,9 @@ def main():
             "config": {"workload": cfg["label"], "cells": n, "genes": g, "subnets": K, "epochs_per_fit": args.epochs,
                        "train_steps_per_epoch": steps_per_epoch, "parallelism": "subnets sharded x%d" % world,
                        "final_val_loss": vsum, "train_step_ms": timers[0] / max(1.0, timers[1])},
-            "roofline": {"bound": "hbm", "kernel": "k_w1_update", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_w1_update_fwd_sh<16,1> (W1 grad + Adam + next forward)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic("k_w1_update_fwd"),
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": w1_ms},
         }
         if args.early_stop_probe:
