@@ -120,12 +120,17 @@ struct dimn_handle_s {
     hipStream_t stream = nullptr;          // lane 0's stream; also used by every non-training call
     struct Lane { hipStream_t stream; int k0, k1, w0, w1; };   // sub-nets [k0,k1), work items [w0,w1)
     std::vector<Lane> lanes;               // independent sub-net groups trained on concurrent streams
+    // "W token": the HBM-saturating W1-update launches of the lanes are serialised through a ring of
+    // events (each waits for the previous one, whatever lane it ran on); a lane's small latency-bound
+    // kernels (RED/MF/MB) are free to run under the OTHER lane's W1 update.
+    std::vector<hipEvent_t> tokens; size_t token_seq = 0; bool use_token = false;   // measured: the cross-stream event latency costs more than the overlap gains
     int64_t t = 0;
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> ev;   // pairs around k_w1_update, plus step brackets
     size_t ev_used = 0;
-    double tm_step_ms = 0, tm_w1_ms = 0; int64_t tm_steps = 0, tm_w1 = 0;
+    double tm_step_ms = 0, tm_w1_ms = 0, tm_w1_bytes = 0; int64_t tm_steps = 0, tm_w1 = 0;
+    std::vector<double> ev_bytes;   // algorithmic bytes of the W1 launch bracketed by each event triple
     // comm
     ncclComm_t comm = nullptr; int n_ranks = 1, rank = 0;
 };
@@ -201,7 +206,7 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     dm.OS = ceil_div(dm.OT, 4);
     h->NT = ceil_div(dm.HT, 4);
     h->NT2 = ceil_div(dm.HT, 8);
-    h->OTW = ceil_div(dm.OT, 8);   // output tiles per wave of the 8-wave middle-backward kernel
+    h->OTW = ceil_div(dm.OT, 4);   // output tiles per wave of the 4-wave middle-backward kernel
     h->HS = ceil_div(dm.HT, 2);
     if (h->NT > 6) {
         delete h;
@@ -256,6 +261,13 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
         h->lanes.push_back(ln);
     }
     h->stream = h->lanes[0].stream;
+    if (const char* e = getenv("DIMN_TOKEN")) h->use_token = atoi(e) != 0;
+    if (h->lanes.size() > 1)
+        for (int i = 0; i < 16; ++i) {
+            hipEvent_t ev;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { delete h; return fail(DIMN_ERR_HIP, "dimn_create: hipEventCreate failed"); }
+            h->tokens.push_back(ev);
+        }
     TRY(dev_alloc(&h->d_sn, (size_t)h->K));
     TRY(dev_alloc(&h->d_work, h->work.size()));
     TRY(dev_alloc(&h->d_W1, (size_t)w1)); TRY(dev_alloc(&h->d_M1, (size_t)w1)); TRY(dev_alloc(&h->d_V1, (size_t)w1));
@@ -291,6 +303,7 @@ extern "C" int dimn_destroy(dimn_handle h) {
     for (auto& ln : h->lanes) (void)hipStreamSynchronize(ln.stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (auto e : h->ev) (void)hipEventDestroy(e);
+    for (auto e : h->tokens) (void)hipEventDestroy(e);
     DEV_FREE(h->d_sn); DEV_FREE(h->d_work); DEV_FREE(h->d_norm); DEV_FREE(h->d_X); DEV_FREE(h->d_Y);
     DEV_FREE(h->d_pred); DEV_FREE(h->d_targ); DEV_FREE(h->d_pred_off);
     DEV_FREE(h->d_W1); DEV_FREE(h->d_M1); DEV_FREE(h->d_V1); DEV_FREE(h->d_W2); DEV_FREE(h->d_M2); DEV_FREE(h->d_V2);
@@ -564,8 +577,17 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     const unsigned nk = (unsigned)(ln.k1 - ln.k0);
     hipStream_t st = ln.stream;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    timed = timed && h->profiling;
-    if (timed) { e0 = next_event(h); e1 = next_event(h); e2 = next_event(h); (void)hipEventRecord(e0, st); }
+    timed = h->profiling;            // every lane's launches are timed (HIP events on the lane's own stream)
+    if (timed) {
+        e0 = next_event(h); e1 = next_event(h); e2 = next_event(h);
+        (void)hipEventRecord(e0, st);
+        // ALGORITHMIC bytes of this W1 launch: 24 B per W1 parameter (read+write of
+        // w, m, v) + the X tiles of this and the next batch + dA, for the lane's sub-nets
+        double by = 0;
+        for (int k = ln.k0; k < ln.k1; ++k)
+            by += 24.0 * h->sn[k].D * h->H + 4.0 * (b_act + b_next) * h->sn[k].D + 4.0 * b_act * h->H;
+        h->ev_bytes.push_back(by);
+    }
 
     if (need_fwd) { DISPATCH_NT(launch_fwd1, h, ln, d_rows, b_act); }
     hipLaunchKernelGGL(k_reduce_act, dim3((unsigned)ceil_div(DIMN_TB * dm.Hp, 1024), nk), dim3(256), 0, st, h->d_sn, h->d_P, h->d_b1, d_mask,
@@ -575,19 +597,22 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
         const size_t lds = (size_t)DIMN_TB * dm.ldd * sizeof(float);
 #define LAUNCH_MF(HTC) hipLaunchKernelGGL(k_mid_fwd<HTC>, grid, dim3(256), lds, st, h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, \
                                           h->n, d_rows, b_act, h->d_Dd, h->d_dZ, h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary, ln.k0)
-        if (dm.HT == 16) LAUNCH_MF(16); else LAUNCH_MF(0);
+        LAUNCH_MF(0);        // <=128 VGPRs: a workgroup fits next to a resident W1-update workgroup (HTC=16 hoists W2, 162 VGPRs)
 #undef LAUNCH_MF
     }
-    // one hidden tile per workgroup: K*HT workgroups of <=128 VGPRs, two resident per CU
-    if (dm.OT == 8 * h->OTW)
-        hipLaunchKernelGGL((k_mid_bwd<true, 1>), dim3((unsigned)dm.HT, nk), dim3(512), 0, st, h->d_Dd, h->d_dZ, h->d_W2, h->d_M2, h->d_V2,
+    // one hidden tile per workgroup, 4 waves of <=128 VGPRs: fits next to a resident W1-update workgroup
+    if (dm.OT == 4 * h->OTW)
+        hipLaunchKernelGGL((k_mid_bwd<true, 1, 4>), dim3((unsigned)dm.HT, nk), dim3(256), 0, st, h->d_Dd, h->d_dZ, h->d_W2, h->d_M2, h->d_V2,
                            h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0);
     else
-        hipLaunchKernelGGL((k_mid_bwd<false, 1>), dim3((unsigned)dm.HT, nk), dim3(512), 0, st, h->d_Dd, h->d_dZ, h->d_W2, h->d_M2, h->d_V2,
+        hipLaunchKernelGGL((k_mid_bwd<false, 1, 4>), dim3((unsigned)dm.HT, nk), dim3(256), 0, st, h->d_Dd, h->d_dZ, h->d_W2, h->d_M2, h->d_V2,
                            h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0);
+    const bool ring = h->use_token && !h->tokens.empty();
+    if (ring && h->token_seq > 0) HIPCHK(hipStreamWaitEvent(st, h->tokens[(h->token_seq - 1) % h->tokens.size()], 0));
     if (timed) (void)hipEventRecord(e1, st);
     DISPATCH_NT2(launch_w1, h, ln, d_rows, b_act, d_rows_n, b_next, ap);
     if (timed) (void)hipEventRecord(e2, st);
+    if (ring) { HIPCHK(hipEventRecord(h->tokens[h->token_seq % h->tokens.size()], st)); h->token_seq++; }
     HIPCHK(hipGetLastError());
     return DIMN_OK;
 }
@@ -604,9 +629,11 @@ static int collect_timers(dimn_handle h) {
         if (hipEventElapsedTime(&a, h->ev[i], h->ev[i + 2]) == hipSuccess &&
             hipEventElapsedTime(&b, h->ev[i + 1], h->ev[i + 2]) == hipSuccess) {
             h->tm_step_ms += a; h->tm_w1_ms += b; h->tm_steps++; h->tm_w1++;
+            h->tm_w1_bytes += h->ev_bytes[i / 3];
         }
     }
     h->ev_used = 0;
+    h->ev_bytes.clear();
     return DIMN_OK;
 }
 
@@ -809,7 +836,8 @@ extern "C" int dimn_set_profiling(dimn_handle h, int32_t on) {
 extern "C" int dimn_get_timers(dimn_handle h, double* out4, int32_t reset) {
     if (!h || !out4) return fail(DIMN_ERR_ARG, "null argument");
     out4[0] = h->tm_step_ms; out4[1] = (double)h->tm_steps; out4[2] = h->tm_w1_ms; out4[3] = (double)h->tm_w1;
-    if (reset) { h->tm_step_ms = h->tm_w1_ms = 0; h->tm_steps = h->tm_w1 = 0; }
+    out4[4] = h->tm_w1_bytes; out4[5] = (double)h->lanes.size();
+    if (reset) { h->tm_step_ms = h->tm_w1_ms = h->tm_w1_bytes = 0; h->tm_steps = h->tm_w1 = 0; }
     return DIMN_OK;
 }
 

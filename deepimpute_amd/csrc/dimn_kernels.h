@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void k_reduce_act(const SubnetDev* __restrict_
 // HBM/L2 latency overlaps the staging and the barrier instead of following it.
 // ---------------------------------------------------------------------------------------
 template <int HTC>
-__global__ __launch_bounds__(256) void k_mid_fwd(const float* __restrict__ W2,
+__global__ __launch_bounds__(256, 4) void k_mid_fwd(const float* __restrict__ W2,
                                                  float* __restrict__ b2w, float* __restrict__ b2m, float* __restrict__ b2v,
                                                  const float* __restrict__ Y, int64_t n_cells,
                                                  const int32_t* __restrict__ rows, int b_act,
@@ -362,24 +362,24 @@ __global__ __launch_bounds__(256) void k_mid_fwd(const float* __restrict__ W2,
 }
 
 // ---------------------------------------------------------------------------------------
-// MB: middle backward.  Workgroup = (sub-net k, NH hidden tiles = 16*NH rows of W2), 8 waves;
+// MB: middle backward.  Workgroup = (sub-net k, NH hidden tiles = 16*NH rows of W2), WV waves;
 // wave w owns output tiles [w*otw, w*otw+otw).
 //  gW2^T tile = dZ^T Dd  (K = batch)  -> Adam on W2/m/v (tile-blocked, 1 KiB/tile)
-//  dD[:,16*NH] = dZ W2^T (OLD W2, K = O split over the 8 waves, reduced through LDS)
+//  dD[:,16*NH] = dZ W2^T (OLD W2, K = O split over the WV waves, reduced through LDS)
 //  dA = dD * scale * [Dd>0] ; gb1 -> Adam(b1)
 // Each wave stages the dZ tile [64 b][16 o] of its current output tile into a PRIVATE 4 KiB LDS
 // region (4 x 16-byte loads per lane): the linear image serves both operand forms -- dZ^T
 // (ds_read_b32, lane-linear) and dZ rows (ds_read_b128) -- without 64-byte strided gathers.
 // State and dZ of the next output tile are prefetched while the current one computes.
 // ---------------------------------------------------------------------------------------
-template <bool FULL, int NH>   // NH hidden tiles (16 rows of W2 each) per workgroup; FULL: HT % NH == 0 and OT == 8*otw
-__global__ __launch_bounds__(512) void k_mid_bwd(const float* __restrict__ Dd, const float* __restrict__ dZ,
+template <bool FULL, int NH, int WV>   // NH hidden tiles (16 rows of W2 each) per workgroup, WV waves; FULL: HT % NH == 0 and OT == WV*otw
+__global__ __launch_bounds__(WV * 64, 512 / (WV * 64) >= 2 ? 4 : 2) void k_mid_bwd(const float* __restrict__ Dd, const float* __restrict__ dZ,
                                                  float* __restrict__ W2, float* __restrict__ M2, float* __restrict__ V2,
                                                  float* __restrict__ b1w, float* __restrict__ b1m, float* __restrict__ b1v,
                                                  float* __restrict__ dA, Dims dm, AdamP ap, float scale, int otw, int k0) {
     constexpr int LDR = 16 * NH + 1;                             // padded row of the reduction buffer
-    constexpr int RED = (8 * DIMN_TB * LDR) > 8192 ? (8 * DIMN_TB * LDR) : 8192;                       // floats: cross-wave dD reduction buffer
-    __shared__ __attribute__((aligned(16))) float lds[RED];     // first 8 x 1024 floats double as the dZ tiles
+    constexpr int RED = (WV * DIMN_TB * LDR) > WV * 1024 ? (WV * DIMN_TB * LDR) : WV * 1024;                       // floats: cross-wave dD reduction buffer
+    __shared__ __attribute__((aligned(16))) float lds[RED];     // first WV x 1024 floats double as the dZ tiles
     const int hs = blockIdx.x, k = blockIdx.y + k0;
     const int Hp = dm.Hp, Op = dm.Op;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(512) void k_mid_bwd(const float* __restrict__ Dd, c
             for (int r = 0; r < 4; ++r) lds[(wave * DIMN_TB + 16 * mt + 4 * lj + r) * LDR + 16 * ht + li] = (FULL || ht < nht) ? dacc[mt][ht][r] : 0.f;
     __syncthreads();
     // 64 x (16*NH) outputs: thread -> column hh = tid % (16*NH), rows b = tid / (16*NH) + RB*i
-    constexpr int CW = 16 * NH, RB = 512 / CW, NI = DIMN_TB / RB;
+    constexpr int CW = 16 * NH, RB = (WV * 64) / CW, NI = DIMN_TB / RB;
     const int hh = tid % CW, b0 = tid / CW;
     const int h = CW * hs + hh;
     float gsum = 0.f;
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(512) void k_mid_bwd(const float* __restrict__ Dd, c
             const int b = b0 + RB * i;
             float d = 0.f;
 #pragma unroll
-            for (int wv = 0; wv < 8; ++wv) d += lds[(wv * DIMN_TB + b) * LDR + hh];
+            for (int wv = 0; wv < WV; ++wv) d += lds[(wv * DIMN_TB + b) * LDR + hh];
             const float da = ddk[b * Hp + h] > 0.f ? d * scale : 0.f;
             dA[((int64_t)k * DIMN_TB + b) * Hp + h] = da;
             gsum += da;

@@ -146,10 +146,11 @@ int dimn_epoch_permutation(uint64_t seed, int32_t epoch, int64_t n, int32_t* per
 
 /* Wait for all queued GPU work of this handle. */
 int dimn_synchronize(dimn_handle h);
-/* Times (ms, HIP events on the handle's own stream) accumulated since the last call with
- * reset != 0: [0] train-step kernels, [1] number of train steps, [2] w1-update kernel ms,
- * [3] w1-update launches.  Used by bench.py for the live roofline figure. */
-int dimn_get_timers(dimn_handle h, double* out4, int32_t reset);
+/* Times (ms, HIP events on the stream each launch went to) accumulated since the last call
+ * with reset != 0, over every sub-net lane: out6 = [0] sum of per-lane step times, [1] number of
+ * (lane, step) pairs, [2] sum of W1-update kernel times, [3] W1-update launches, [4] sum of the
+ * ALGORITHMIC bytes of those launches, [5] number of lanes.  bench.py's live roofline figure. */
+int dimn_get_timers(dimn_handle h, double* out6, int32_t reset);
 int dimn_set_profiling(dimn_handle h, int32_t on);
 
 /* ---- multi-GPU: sub-nets sharded over ranks, RCCL over xGMI (no reference analogue:

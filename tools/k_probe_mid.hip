@@ -1,0 +1,60 @@
+// k_probe_mid.hip -- standalone timing of the middle kernels (RED / MF / MB) on cfg3-shaped
+// synthetic state (K=40, H=256, O=512, n=50000).  Diagnostics only.
+#include "../deepimpute_amd/csrc/dimn_kernels.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+__global__ void k_fill(float* p, size_t n, float scale, unsigned seed) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned x = (unsigned)i * 2654435761u + seed; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        p[i] = scale * ((x >> 8) * (1.0f / 16777216.0f) - 0.5f);
+    }
+}
+template <typename F> static double timeit(F launch, int R = 30) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) launch();
+    CK(hipEventRecord(a));
+    for (int i = 0; i < R; ++i) launch();
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return 1e3 * ms / R;
+}
+static float* dalloc(size_t n, float scale, unsigned seed) {
+    float* p; CK(hipMalloc(&p, n * 4));
+    hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, p, n, scale, seed);
+    return p;
+}
+int main() {
+    const int K = 40, H = 256, O = 512, S = 19; const int64_t n = 50000;
+    Dims dm; dm.K = K; dm.H = H; dm.O = O; dm.Hp = 256; dm.Op = 512; dm.HT = 16; dm.OT = 32; dm.ldd = 258; dm.OS = 8;
+    std::vector<SubnetDev> sn(K);
+    for (int k = 0; k < K; ++k) { sn[k].D = 2400; sn[k].Dp = 2400; sn[k].nchunk = 150; sn[k].kg = k; sn[k].slot0 = k * S; sn[k].nslice = S; sn[k].xoff = 0; sn[k].w1off = 0; }
+    SubnetDev* dsn; CK(hipMalloc(&dsn, K * sizeof(SubnetDev))); CK(hipMemcpy(dsn, sn.data(), K * sizeof(SubnetDev), hipMemcpyHostToDevice));
+    float* P = dalloc((size_t)K * S * 64 * 256, 0.1f, 1);
+    float* b1 = dalloc((size_t)3 * K * 256, 0.01f, 2); float* b2 = dalloc((size_t)3 * K * 512, 0.01f, 3);
+    float* Dd = dalloc((size_t)K * 64 * 256, 1.f, 4); float* dZ = dalloc((size_t)K * 64 * 512, 1e-3f, 5); float* dA = dalloc((size_t)K * 64 * 256, 1e-3f, 6);
+    float* W2 = dalloc((size_t)K * 256 * 512, 0.1f, 7); float* M2 = dalloc((size_t)K * 256 * 512, 1e-6f, 8); float* V2 = dalloc((size_t)K * 256 * 512, 1e-6f, 9);
+    float* Y = dalloc((size_t)K * n * 512, 4.f, 10);
+    float* ls; CK(hipMalloc(&ls, K * 8 * 4)); double* la; CK(hipMalloc(&la, K * 8 * 8)); CK(hipMemset(la, 0, K * 8 * 8));
+    std::vector<int32_t> rows(64); for (int i = 0; i < 64; ++i) rows[i] = (int32_t)((i * 7919LL + 13) % n);
+    int32_t* drows; CK(hipMalloc(&drows, 256)); CK(hipMemcpy(drows, rows.data(), 256, hipMemcpyHostToDevice));
+    AdamP ap{1e-4f, 0.1f, 0.001f, 1e-7f};
+    const size_t kh = (size_t)K * 256, ko = (size_t)K * 512;
+    CK(hipDeviceSynchronize());
+#define T(name, ...) { double us = timeit([&] { hipLaunchKernelGGL(__VA_ARGS__); }); CK(hipGetLastError()); printf("%-34s %8.1f us\n", name, us); }
+    T("k_reduce_act", k_reduce_act, dim3(16, K), dim3(256), 0, 0, dsn, P, b1, (const uint8_t*)nullptr, Dd, dm, 64, 0.2f, 1.25f, 1234ull, 0u, 0u, 0)
+    T("k_mid_fwd<16>", k_mid_fwd<16>, dim3(8, K), dim3(256), 64 * 258 * 4, 0, W2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, dZ, ls, la, dm, ap, 1.f / (64 * 512), 0, 0)
+    T("k_mid_fwd<0>", k_mid_fwd<0>, dim3(8, K), dim3(256), 64 * 258 * 4, 0, W2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, dZ, ls, la, dm, ap, 1.f / (64 * 512), 0, 0)
+    T("k_mid_bwd<true,1>", (k_mid_bwd<true, 1, 8>), dim3(16, K), dim3(512), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 4, 0)
+    T("k_mid_bwd<true,1,4>", (k_mid_bwd<true, 1, 4>), dim3(16, K), dim3(256), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 8, 0)
+    T("k_mid_bwd<true,2>", (k_mid_bwd<true, 2, 8>), dim3(8, K), dim3(512), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 4, 0)
+    // chained like a real step
+    T("RED+MF+MB chain", k_reduce_act, dim3(16, K), dim3(256), 0, 0, dsn, P, b1, (const uint8_t*)nullptr, Dd, dm, 64, 0.2f, 1.25f, 1234ull, 0u, 0u, 0);
+    { double us = timeit([&] {
+        hipLaunchKernelGGL(k_reduce_act, dim3(16, K), dim3(256), 0, 0, dsn, P, b1, (const uint8_t*)nullptr, Dd, dm, 64, 0.2f, 1.25f, 1234ull, 0u, 0u, 0);
+        hipLaunchKernelGGL(k_mid_fwd<16>, dim3(8, K), dim3(256), 64 * 258 * 4, 0, W2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, dZ, ls, la, dm, ap, 1.f / (64 * 512), 0, 0);
+        hipLaunchKernelGGL((k_mid_bwd<true, 1, 8>), dim3(16, K), dim3(512), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 4, 0); });
+      printf("%-34s %8.1f us\n", "RED+MF+MB back-to-back", us); }
+    return 0;
+}
