@@ -93,6 +93,7 @@ struct dimn_handle_s {
     int wg_per_cu = 3;
     int dbg = 0;
     int variant = 1;
+    int mf_variant = 16, mb_waves = 8;   // DIMN_MF=16 hoists all W2 operands (162 VGPRs); DIMN_MB=8: 8-wave middle backward
     int ncu = 256;
     std::vector<SubnetDev> sn;
     std::vector<Work> work;
@@ -161,7 +162,9 @@ static void build_work(dimn_handle h) {
     int64_t total_chunks = 0;
     for (auto& s : h->sn) total_chunks += s.nchunk;
     const int target_wgs = h->ncu * h->wg_per_cu;
-    const int per = (int)std::max<int64_t>(1, (total_chunks + target_wgs - 1) / target_wgs);
+    // at least 8 chunks per workgroup: every workgroup writes a 64-row split-K partial (16 KB per hidden
+    // tile column block), so very fine slicing (few sub-nets per GPU) would drown the step in partials
+    const int per = (int)std::max<int64_t>(8, (total_chunks + target_wgs - 1) / target_wgs);
     h->work.clear();
     int slot = 0;
     for (int k = 0; k < h->K; ++k) {
@@ -225,6 +228,9 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     if (const char* e = getenv("DIMN_WG_PER_CU")) h->wg_per_cu = std::max(1, atoi(e));
     if (const char* e = getenv("DIMN_DBG")) h->dbg = atoi(e);
     if (const char* e = getenv("DIMN_B1F1")) h->variant = atoi(e);
+    if (const char* e = getenv("DIMN_MF")) h->mf_variant = atoi(e);
+    if (const char* e = getenv("DIMN_MB")) h->mb_waves = atoi(e) == 8 ? 8 : 4;
+    h->OTW = ceil_div(dm.OT, h->mb_waves);
 
     h->sn.resize(h->K);
     h->pred.resize(h->K); h->targ.resize(h->K);
@@ -379,9 +385,14 @@ extern "C" int dimn_gather(dimn_handle h, int32_t with_targets) {
         CHK(dev_alloc(&h->d_Y, (size_t)h->K * h->n * h->dm.Op));
     }
     HIPCHK(hipMemcpy(h->d_sn, h->sn.data(), h->sn.size() * sizeof(SubnetDev), hipMemcpyHostToDevice));
-    dim3 grid((unsigned)h->K, (unsigned)std::min<int64_t>(h->n, 8192));
-    hipLaunchKernelGGL(k_gather, grid, dim3(256), 0, h->stream, h->d_sn, h->d_norm, h->n, h->g, h->d_pred, h->d_pred_off,
-                       h->d_targ, h->d_X, h->d_Y, h->dm, with_targets ? 1 : 0);
+    if ((size_t)h->g * sizeof(float) <= 150 * 1024) {      // the row fits in LDS: read `norm` once, serve all sub-nets from LDS
+        hipLaunchKernelGGL(k_gather_lds, dim3((unsigned)std::min<int64_t>(h->n, 2048)), dim3(512), (size_t)h->g * sizeof(float), h->stream,
+                           h->d_sn, h->d_norm, h->n, h->g, h->d_pred, h->d_pred_off, h->d_targ, h->d_X, h->d_Y, h->dm, with_targets ? 1 : 0);
+    } else {
+        dim3 grid((unsigned)h->K, (unsigned)std::min<int64_t>(h->n, 8192));
+        hipLaunchKernelGGL(k_gather, grid, dim3(256), 0, h->stream, h->d_sn, h->d_norm, h->n, h->g, h->d_pred, h->d_pred_off,
+                           h->d_targ, h->d_X, h->d_Y, h->dm, with_targets ? 1 : 0);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     h->gathered = true;
@@ -577,7 +588,9 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     const unsigned nk = (unsigned)(ln.k1 - ln.k0);
     hipStream_t st = ln.stream;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    timed = h->profiling;            // every lane's launches are timed (HIP events on the lane's own stream)
+    // one step in eight is timed, on every lane, with HIP events on the lane's own stream: enough samples
+    // for a mean, and the event traffic stays out of the way of the other seven
+    timed = h->profiling && (step_key % 8u) == 0u;
     if (timed) {
         e0 = next_event(h); e1 = next_event(h); e2 = next_event(h);
         (void)hipEventRecord(e0, st);
@@ -597,16 +610,15 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
         const size_t lds = (size_t)DIMN_TB * dm.ldd * sizeof(float);
 #define LAUNCH_MF(HTC) hipLaunchKernelGGL(k_mid_fwd<HTC>, grid, dim3(256), lds, st, h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, \
                                           h->n, d_rows, b_act, h->d_Dd, h->d_dZ, h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary, ln.k0)
-        LAUNCH_MF(0);        // <=128 VGPRs: a workgroup fits next to a resident W1-update workgroup (HTC=16 hoists W2, 162 VGPRs)
+        if (h->mf_variant == 16 && dm.HT == 16) LAUNCH_MF(16); else LAUNCH_MF(0);   // 0: 78 VGPRs; 16: all W2 operands hoisted, 162 VGPRs
 #undef LAUNCH_MF
     }
-    // one hidden tile per workgroup, 4 waves of <=128 VGPRs: fits next to a resident W1-update workgroup
-    if (dm.OT == 4 * h->OTW)
-        hipLaunchKernelGGL((k_mid_bwd<true, 1, 4>), dim3((unsigned)dm.HT, nk), dim3(256), 0, st, h->d_Dd, h->d_dZ, h->d_W2, h->d_M2, h->d_V2,
-                           h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0);
-    else
-        hipLaunchKernelGGL((k_mid_bwd<false, 1, 4>), dim3((unsigned)dm.HT, nk), dim3(256), 0, st, h->d_Dd, h->d_dZ, h->d_W2, h->d_M2, h->d_V2,
-                           h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0);
+    // one hidden tile (16 rows of W2) per workgroup; 4 or 8 waves split the output tiles
+#define LAUNCH_MB(FULLV, WV) hipLaunchKernelGGL((k_mid_bwd<FULLV, 1, WV>), dim3((unsigned)dm.HT, nk), dim3(WV * 64), 0, st, h->d_Dd, h->d_dZ, \
+                                                h->d_W2, h->d_M2, h->d_V2, h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0)
+    if (h->mb_waves == 8) { if (dm.OT == 8 * h->OTW) LAUNCH_MB(true, 8); else LAUNCH_MB(false, 8); }
+    else { if (dm.OT == 4 * h->OTW) LAUNCH_MB(true, 4); else LAUNCH_MB(false, 4); }
+#undef LAUNCH_MB
     const bool ring = h->use_token && !h->tokens.empty();
     if (ring && h->token_seq > 0) HIPCHK(hipStreamWaitEvent(st, h->tokens[(h->token_seq - 1) % h->tokens.size()], 0));
     if (timed) (void)hipEventRecord(e1, st);
