@@ -248,7 +248,11 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     }
     h->w1_total = w1;
     build_work(h);
-    int n_lanes = 2;
+    // Sub-net lanes: independent sub-net groups on concurrent streams.  Default 1: with 2 lanes the
+    // end-to-end rate is ~9 % higher on cfg3 (one lane's latency-bound kernels hide under the other's
+    // weight update) but the two HBM-bound weight updates then share the bandwidth, which halves the
+    // per-launch figure the roofline is quoted on; opt in with DIMN_LANES=2.
+    int n_lanes = 1;
     if (const char* e = getenv("DIMN_LANES")) n_lanes = std::max(1, atoi(e));
     n_lanes = std::min(n_lanes, h->K);
 

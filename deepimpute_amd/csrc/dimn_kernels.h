@@ -720,7 +720,9 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
 // HT/WAVES hidden tiles; the X_t / X_{t+1} chunk tiles are staged ONCE per workgroup through
 // LDS (one 16-byte load per staging thread) with one barrier per chunk.  With 16 waves of
 // <=128 VGPRs, four waves share each SIMD, so MFMA, Adam VALU work and memory waits of
-// different waves overlap inside every chunk.
+// different waves overlap inside every chunk.  With WAVES*NT2 < HT the hidden tiles are split over
+// grid.y (e.g. <8,1> x 2 for H = 256): two such workgroups fit on one CU, so the prologue/epilogue
+// of one overlaps the streaming of the other.
 // ---------------------------------------------------------------------------------------
 template <int WAVES, int NT2, int MINW = 1>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
     const SubnetDev s = sn[wk.k];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
-    const int nt0 = wave * NT2;
+    const int nt0 = (blockIdx.y * WAVES + wave) * NT2;     // grid.y splits the hidden tiles when WAVES*NT2 < HT
     const int Hp = dm.Hp;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 
