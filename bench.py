@@ -337,7 +337,7 @@ def main():
                        "train_steps_per_epoch": steps_per_epoch, "parallelism": "subnets sharded x%d" % world,
                        "final_val_loss": vsum, "subnet_lanes": int(timers[5]),
                        "lane_step_ms": timers[0] / max(1.0, timers[1])},
-            "roofline": {"bound": "hbm", "kernel": "k_w1_update_fwd_sh<16,1> (W1 grad + Adam + next forward)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "k_w1_update_fwd_ring<16,1> (W1 grad + Adam + next forward)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic("k_w1_update_fwd"),
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": w1_ms, "launches": int(timers[3])},

@@ -90,7 +90,7 @@ struct dimn_handle_s {
     dimn_config cfg;
     Dims dm;
     int K, H, O, B, NT, NT2, OTW, HS;   // NT/NT2 hidden tiles per wave (4-/8-wave kernels); OTW out tiles per wave; HS = ceil(HT/2)
-    int wg_per_cu = 3;
+    int wg_per_cu = 1;
     int dbg = 0;
     int variant = 1;
     int mf_variant = 16, mb_waves = 8;   // DIMN_MF=16 hoists all W2 operands (162 VGPRs); DIMN_MB=8: 8-wave middle backward
@@ -157,26 +157,40 @@ static int dev_alloc(T** p, size_t count) {
     } while (0)
 
 static void build_work(dimn_handle h) {
-    // Split every sub-net's chunk range into slices so that the whole job is ~2 workgroups
-    // per CU of near-equal bytes (the kernels are HBM-bound; balance = bandwidth).
+    // Split every sub-net's chunk range into slices = workgroups of the W1 kernels.  The total is made
+    // EXACTLY ncu * wg_per_cu (a partially filled last round of workgroups costs a whole round), shared
+    // out in proportion to the chunk counts (largest remainder), subject to >= 8 chunks per slice: every
+    // workgroup writes a 64-row split-K partial, so very fine slicing (few sub-nets per GPU) would drown
+    // the step in partials.
     int64_t total_chunks = 0;
     for (auto& s : h->sn) total_chunks += s.nchunk;
-    const int target_wgs = h->ncu * h->wg_per_cu;
-    // at least 8 chunks per workgroup: every workgroup writes a 64-row split-K partial (16 KB per hidden
-    // tile column block), so very fine slicing (few sub-nets per GPU) would drown the step in partials
-    const int per = (int)std::max<int64_t>(8, (total_chunks + target_wgs - 1) / target_wgs);
+    const int64_t target = (int64_t)h->ncu * h->wg_per_cu;
+    std::vector<int> ns((size_t)h->K);
+    std::vector<std::pair<double, int>> frac;
+    int64_t assigned = 0;
+    for (int k = 0; k < h->K; ++k) {
+        const double share = (double)target * h->sn[k].nchunk / (double)total_chunks;
+        const int cap = std::max(1, h->sn[k].nchunk / 8);
+        ns[(size_t)k] = std::min(cap, std::max(1, (int)share));
+        assigned += ns[(size_t)k];
+        frac.push_back({share - (int)share, k});
+    }
+    std::sort(frac.begin(), frac.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
+    for (size_t i = 0; assigned < target && i < frac.size(); ++i) {
+        const int k = frac[i].second;
+        if (ns[(size_t)k] < std::max(1, h->sn[k].nchunk / 8)) { ns[(size_t)k]++; assigned++; }
+    }
     h->work.clear();
     int slot = 0;
     for (int k = 0; k < h->K; ++k) {
         SubnetDev& s = h->sn[k];
-        const int ns = std::max(1, ceil_div(s.nchunk, per));
         s.slot0 = slot;
-        s.nslice = ns;
-        for (int i = 0; i < ns; ++i) {
+        s.nslice = ns[(size_t)k];
+        for (int i = 0; i < s.nslice; ++i) {
             Work w;
             w.k = k;
-            w.c0 = (int)((int64_t)s.nchunk * i / ns);
-            w.c1 = (int)((int64_t)s.nchunk * (i + 1) / ns);
+            w.c0 = (int)((int64_t)s.nchunk * i / s.nslice);
+            w.c1 = (int)((int64_t)s.nchunk * (i + 1) / s.nslice);
             w.slot = slot++;
             h->work.push_back(w);
         }
@@ -538,7 +552,10 @@ static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, const int32_
                       AdamP ap) {
     const dim3 grid((unsigned)(ln.w1 - ln.w0));
     const Work* wk = h->d_work + ln.w0;
-    if (h->dm.HT == 16 && h->variant == 1)        // H = 256: 16 waves x 1 hidden tile, X tiles staged once per workgroup
+    if (h->dm.HT == 16 && h->variant == 1)        // H = 256: 16 waves x 1 hidden tile, X tiles staged once per workgroup, 3-set register ring
+        hipLaunchKernelGGL((k_w1_update_fwd_ring<16, 1>), grid, dim3(1024), 0, ln.stream, wk, h->d_sn, h->d_X, h->d_W1, h->d_M1, h->d_V1,
+                           rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
+    else if (h->dm.HT == 16 && h->variant == 2)
         hipLaunchKernelGGL((k_w1_update_fwd_sh<16, 1>), grid, dim3(1024), 0, ln.stream, wk, h->d_sn, h->d_X, h->d_W1, h->d_M1, h->d_V1,
                            rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
     else if (h->dm.HT == 8 * NT2)

@@ -870,12 +870,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_ring(const Work* _
                                                                   const int32_t* __restrict__ rows_n, int b_next,
                                                                   const float* __restrict__ dA, float* __restrict__ P, Dims dm, AdamP ap) {
     constexpr int XT = DIMN_TB * 16, XN = DIMN_TB * 20;
-    __shared__ __attribute__((aligned(16))) float sm[2 * (XT + XN)];
+    constexpr int DUMMY = 2 * (XT + XN);                       // LDS words nobody reads: target of non-staging threads
+    __shared__ __attribute__((aligned(16))) float sm[2 * (XT + XN) + 4 * WAVES * 64];
     const Work wk = work[blockIdx.x];
     const SubnetDev s = sn[wk.k];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
-    const int nt0 = wave * NT2;
+    const int nt0 = (blockIdx.y * WAVES + wave) * NT2;
     const int Hp = dm.Hp;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -886,15 +887,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_ring(const Work* _
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) bfr[kb][nt] = dak[(4 * kb + lj) * Hp + 16 * (nt0 + nt) + li];
 
+    // Every thread issues exactly one X load per chunk (no predicated VMEM op in the loop, so the
+    // compiler can count vmcnt exactly): threads 0..255 move the X_t tile, 256..511 the X_{t+1} tile,
+    // the others repeat those loads (L1 hits) and park the result in a dummy LDS word.
     const bool stager = tid < 512;
-    const bool stage_next = tid >= 256;
+    const bool stage_next = (tid & 511) >= 256;
     const bool have_next = b_next > 0;
     const int sb = (tid & 255) >> 2, sq = tid & 3;
-    const bool svalid = stager && (stage_next ? (sb < b_next) : (sb < b_act));
+    const bool svalid = stage_next ? (sb < b_next) : (sb < b_act);
     const int32_t* srows = (stage_next && have_next) ? rows_n : rows_t;
     const float* xsrc = X + s.xoff + (int64_t)srows[svalid ? sb : 0] * s.Dp + 4 * sq;
-    const int sdst = stage_next ? (2 * XT + sb * 20 + 4 * sq) : (sb * 16 + 4 * sq);
-    const int sbuf = stage_next ? XN : XT;
+    const int sdst0 = stage_next ? (2 * XT + sb * 20 + 4 * sq) : (sb * 16 + 4 * sq);
+    const int sbuf = stager ? (stage_next ? XN : XT) : 0;
+    const int sdst = stager ? sdst0 : DUMMY + 4 * tid;
 
     const int64_t cstride = (int64_t)Hp * 16;
     int64_t wb[NT2];
@@ -910,7 +915,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_ring(const Work* _
     const int clast = wk.c1 - 1;
     auto fetch = [&](W1Set<NT2>& st, int c) {               // issue the loads of chunk c (clamped)
         const int cc = c < clast ? c : clast;
-        if (stager) st.x = *(const f32x4*)(xsrc + 16 * cc);
+        // X tile first: one iteration later it is the oldest request of this wave, so waiting for it
+        // (in-order vmcnt) leaves the three state loads issued after it in flight
+        st.x = *(const f32x4*)(xsrc + 16 * cc);
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
             const int64_t idx = wb[nt] + cc * cstride;
@@ -935,7 +942,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_ring(const Work* _
         }
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) adam4(cur.w[nt], cur.m[nt], cur.v[nt], g[nt], ap);
-        if (stager) *(f32x4*)(sm + sdst + (par ^ 1) * sbuf) = svalid ? nx1.x : zero4;
+        *(f32x4*)(sm + sdst + (par ^ 1) * sbuf) = svalid ? nx1.x : zero4;
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
             const int64_t idx = wb[nt] + c * cstride;
@@ -957,10 +964,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_ring(const Work* _
     };
 
     W1Set<NT2> A, B, C;
-    A.x = B.x = C.x = zero4;
     fetch(A, wk.c0);
     fetch(B, wk.c0 + 1);
-    if (stager) *(f32x4*)(sm + sdst) = svalid ? A.x : zero4;
+    *(f32x4*)(sm + sdst) = svalid ? A.x : zero4;
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
@@ -973,10 +979,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_ring(const Work* _
     asm volatile("" : "+v"(B.x));
     __syncthreads();
 
-    for (int c = wk.c0; c < wk.c1; c += 3) {
+    int c = wk.c0;
+    for (; c + 3 <= wk.c1; c += 3) {                       // full triples: no conditional memory op inside
+        step(A, B, C, c);
+        step(B, C, A, c + 1);
+        step(C, A, B, c + 2);
+    }
+    if (c < wk.c1) {                                       // 1 or 2 chunks left
         step(A, B, C, c);
         if (c + 1 < wk.c1) step(B, C, A, c + 1);
-        if (c + 2 < wk.c1) step(C, A, B, c + 2);
     }
     if (have_next) {
         float* p = P + (int64_t)wk.slot * DIMN_TB * Hp;
