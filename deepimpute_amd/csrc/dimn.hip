@@ -93,7 +93,7 @@ struct dimn_handle_s {
     int wg_per_cu = 1;
     int dbg = 0;
     int variant = 1;
-    int mf_variant = 16, mb_waves = 8;   // DIMN_MF=16 hoists all W2 operands (162 VGPRs); DIMN_MB=8: 8-wave middle backward
+    int mf_variant = 16, mb_waves = 4;   // DIMN_MF=16 hoists all W2 operands (162 VGPRs); DIMN_MB=8: 8-wave middle backward
     int ncu = 256;
     std::vector<SubnetDev> sn;
     std::vector<Work> work;
@@ -629,7 +629,7 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     {
         const dim3 grid((unsigned)dm.OS, nk);
         const size_t lds = (size_t)DIMN_TB * dm.ldd * sizeof(float);
-#define LAUNCH_MF(HTC) hipLaunchKernelGGL(k_mid_fwd<HTC>, grid, dim3(256), lds, st, h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, \
+#define LAUNCH_MF(HTC) hipLaunchKernelGGL(k_mid_fwd<HTC>, grid, dim3(512), lds, st, h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, \
                                           h->n, d_rows, b_act, h->d_Dd, h->d_dZ, h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary, ln.k0)
         if (h->mf_variant == 16 && dm.HT == 16) LAUNCH_MF(16); else LAUNCH_MF(0);   // 0: 78 VGPRs; 16: all W2 operands hoisted, 162 VGPRs
 #undef LAUNCH_MF

@@ -81,6 +81,18 @@ __device__ __forceinline__ float softplus_f(float x) {
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Training-path versions on the hardware exp2/log2/rcp units (v_exp_f32, v_log_f32, v_rcp_f32):
+// t = exp(-|x|) in (0,1];  softplus = max(x,0) + log1p(t);  sigmoid = x>=0 ? 1/(1+t) : t/(1+t).
+// log1p(t) switches to its series below 2^-12 so tiny outputs keep their relative accuracy.  They feed
+// only the loss and dZ (absolute error ~1e-7), inference keeps libm's expf/log1pf (k_predict).
+__device__ __forceinline__ void softplus_sigmoid_fast(float x, float& sp, float& sg) {
+    const float t = __expf(-fabsf(x));
+    const float l = t < 2.44140625e-4f ? t * (1.0f - 0.5f * t) : __logf(1.0f + t);
+    sp = fmaxf(x, 0.f) + l;
+    const float r = __builtin_amdgcn_rcpf(1.0f + t);
+    sg = x >= 0.f ? r : t * r;
+}
+
 // ---------------------------------------------------------------------------------------
 // gather: X_k[i][d] = norm[i][pred_k[d]], Y_k[i][o] = norm[i][targ_k[o]]
 // (replaces the K pandas .loc gathers, multinet.py:231-235 / 273-274).  grid (K, rows)
@@ -267,16 +279,17 @@ __global__ __launch_bounds__(256) void k_reduce_act(const SubnetDev* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------
-// MF: middle forward.  Workgroup = (sub-net k, output slice os of 64 columns), 4 waves, wave w
-// owns output tile ot = 4*os + w.
+// MF: middle forward.  Workgroup = (sub-net k, output slice os of 64 columns), 8 waves: wave w
+// owns output tile ot = 4*os + (w&3) and the batch rows [32*(w>>2), +32) (two MFMA row tiles).
 //  a) Dd[64][Hp] (from k_reduce_act) -> LDS
 //  b) Z[:,slice] = Dd W2[:,slice] + b2 ; yhat = softplus ; wMSE ; dZ ; gb2 -> Adam(b2)
-// HTC > 0 (compile-time hidden-tile count): every global load the wave needs -- its W2 column
-// block, the targets Y of the 64 batch rows, the bias -- is issued BEFORE the LDS staging, so
-// HBM/L2 latency overlaps the staging and the barrier instead of following it.
+// The kernel is latency-bound (one workgroup's serial chain), so the chain is kept short: with
+// HTC > 0 (compile-time hidden-tile count) every global load a wave needs -- its W2 column block,
+// the targets Y of its batch rows, the bias -- is issued BEFORE the LDS staging; eight waves halve
+// the MFMA chain and the transcendental epilogue, which runs on the hardware exp/log/rcp units.
 // ---------------------------------------------------------------------------------------
 template <int HTC>
-__global__ __launch_bounds__(256) void k_mid_fwd(const float* __restrict__ W2,
+__global__ __launch_bounds__(512) void k_mid_fwd(const float* __restrict__ W2,
                                                  float* __restrict__ b2w, float* __restrict__ b2m, float* __restrict__ b2v,
                                                  const float* __restrict__ Y, int64_t n_cells,
                                                  const int32_t* __restrict__ rows, int b_act,
@@ -288,7 +301,7 @@ __global__ __launch_bounds__(256) void k_mid_fwd(const float* __restrict__ W2,
     const int Hp = dm.Hp, ldd = dm.ldd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lj = lane >> 4;
-    const int ot = os * 4 + wave;
+    const int ot = os * 4 + (wave & 3), mh = wave >> 2;
     const bool act = ot < dm.OT;
     const int otc = act ? ot : 0;                       // clamped tile: loads stay in bounds, results are dropped
     const int o = 16 * otc + li;
@@ -303,28 +316,28 @@ __global__ __launch_bounds__(256) void k_mid_fwd(const float* __restrict__ W2,
 #pragma unroll
             for (int q = 0; q < 4; ++q) bvr[ht][q] = w2[(int64_t)ht * dm.OT * 256 + q * 64];   // W2[h=16ht+4q+lj][o]
     }
-    float yv[4][4];
+    float yv[2][4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int b = 16 * mt + 4 * lj + r;
+            const int b = 32 * mh + 16 * mt + 4 * lj + r;
             yv[mt][r] = Y[((int64_t)k * n_cells + rows[b < b_act ? b : 0]) * dm.Op + o];
         }
     const float bias = b2w[(int64_t)k * dm.Op + o];
 
     // ---- a) stage Dd[64][Hp] into LDS (row stride ldd = 2 mod 32 words: conflict-free column reads) ----
     const float* ddk = Dd + (int64_t)k * DIMN_TB * Hp;
-    for (int e0 = threadIdx.x * 4; e0 < DIMN_TB * Hp; e0 += 8 * 1024) {     // eight independent 16-byte loads in flight
+    for (int e0 = threadIdx.x * 4; e0 < DIMN_TB * Hp; e0 += 8 * 2048) {     // eight independent 16-byte loads in flight
         f32x4 dd[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int e = e0 + i * 1024;
-            dd[i] = e < DIMN_TB * Hp ? *(const f32x4*)(ddk + (e < DIMN_TB * Hp ? e : 0)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int e = e0 + i * 2048;
+            dd[i] = *(const f32x4*)(ddk + (e < DIMN_TB * Hp ? e : 0));
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int e = e0 + i * 1024;
+            const int e = e0 + i * 2048;
             if (e < DIMN_TB * Hp) {
                 const int b = e / Hp, h = e - b * Hp;
                 *(float2*)(lds + b * ldd + h) = make_float2(dd[i][0], dd[i][1]);
@@ -334,18 +347,19 @@ __global__ __launch_bounds__(256) void k_mid_fwd(const float* __restrict__ W2,
     }
     __syncthreads();
 
-    // ---- b) second layer on this 64-column slice ----
-    f32x4 acc[4];
+    // ---- b) second layer: 32 batch rows x 16 outputs per wave ----
+    f32x4 acc[2];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < 2; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* arow = lds + (32 * mh + li) * ldd + lj;
     if (HTC > 0) {
 #pragma unroll
         for (int ht = 0; ht < HTC; ++ht)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[mt] = MFMA16(lds[(16 * mt + li) * ldd + 16 * ht + 4 * q + lj], bvr[ht][q], acc[mt]);
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt] = MFMA16(arow[16 * mt * ldd + 16 * ht + 4 * q], bvr[ht][q], acc[mt]);
     } else {
         for (int ht = 0; ht < HT; ++ht) {
             const float* wt = w2 + (int64_t)ht * dm.OT * 256;
@@ -355,45 +369,49 @@ __global__ __launch_bounds__(256) void k_mid_fwd(const float* __restrict__ W2,
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[mt] = MFMA16(lds[(16 * mt + li) * ldd + 16 * ht + 4 * q + lj], bv[q], acc[mt]);
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt] = MFMA16(arow[16 * mt * ldd + 16 * ht + 4 * q], bv[q], acc[mt]);
         }
     }
     float lsum = 0.f, gb = 0.f;
     const bool col_ok = act && (16 * ot + li) < dm.O;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int b = 16 * mt + 4 * lj + r;
+            const int b = 32 * mh + 16 * mt + 4 * lj + r;
             float dz = 0.f;
             if (b < b_act && col_ok) {
                 const float z = acc[mt][r] + bias;
                 const float y = yv[mt][r];
                 const float w = loss_binary ? (y > 0.f ? 1.f : 0.f) : y;   // multinet.py:37-40
-                const float e = y - softplus_f(z);
+                float sp, sg;
+                softplus_sigmoid_fast(z, sp, sg);
+                const float e = y - sp;
                 lsum += w * e * e;
-                dz = -2.f * w * e * inv_n * sigmoid_f(z);
+                dz = -2.f * w * e * inv_n * sg;
             }
             if (act) dZ[((int64_t)k * DIMN_TB + b) * dm.Op + o] = dz;
             gb += dz;
         }
     gb += __shfl_xor(gb, 16);
     gb += __shfl_xor(gb, 32);
-    if (act && lj == 0) {
-        const int64_t i = (int64_t)k * dm.Op + o;
-        float w = bias, m = b2m[i], v = b2v[i];
-        adam1(w, m, v, gb, ap);
-        b2w[i] = w; b2m[i] = m; b2v[i] = v;
-    }
-    // block loss reduction -> one float per (k, slice)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
-    __syncthreads();
+    __syncthreads();                                    // everybody is done reading Dd from LDS
+    if (lj == 0) lds[16 + wave * 16 + li] = gb;         // per-wave bias-gradient partials (32 rows each)
     if (lane == 0) lds[wave] = lsum;
     __syncthreads();
+    if (act && mh == 0 && lj == 0) {
+        const int64_t i = (int64_t)k * dm.Op + o;
+        float w = bias, m = b2m[i], v = b2v[i];
+        adam1(w, m, v, lds[16 + wave * 16 + li] + lds[16 + (wave + 4) * 16 + li], ap);
+        b2w[i] = w; b2m[i] = m; b2v[i] = v;
+    }
     if (threadIdx.x == 0) {
-        const float tot = lds[0] + lds[1] + lds[2] + lds[3];
+        float tot = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) tot += lds[wv];
         loss_step[k * dm.OS + os] = tot;
         if (loss_acc) loss_acc[k * dm.OS + os] += (double)tot;
     }
@@ -411,7 +429,7 @@ __global__ __launch_bounds__(256) void k_mid_fwd(const float* __restrict__ W2,
 // State and dZ of the next output tile are prefetched while the current one computes.
 // ---------------------------------------------------------------------------------------
 template <bool FULL, int NH, int WV>   // NH hidden tiles (16 rows of W2 each) per workgroup, WV waves; FULL: HT % NH == 0 and OT == WV*otw
-__global__ __launch_bounds__(WV * 64, 512 / (WV * 64) >= 2 ? 4 : 2) void k_mid_bwd(const float* __restrict__ Dd, const float* __restrict__ dZ,
+__global__ __launch_bounds__(WV * 64, WV == 4 ? 3 : 2) void k_mid_bwd(const float* __restrict__ Dd, const float* __restrict__ dZ,
                                                  float* __restrict__ W2, float* __restrict__ M2, float* __restrict__ V2,
                                                  float* __restrict__ b1w, float* __restrict__ b1m, float* __restrict__ b1v,
                                                  float* __restrict__ dA, Dims dm, AdamP ap, float scale, int otw, int k0) {
@@ -450,57 +468,69 @@ __global__ __launch_bounds__(WV * 64, 512 / (WV * 64) >= 2 ? 4 : 2) void k_mid_b
     // dZ tile staging: pass i moves row 16i + lane/4, quarter lane%4
     const float* zsrc = dzk + (lane >> 2) * Op + 4 * (lane & 3);
 
+    // Three NAMED register sets (state of one output tile + its dZ tile) rotate through the loop
+    // without copies: the loads of tile ot+2 are issued while tile ot computes, and no wait is ever
+    // placed on a load issued in the same iteration (a register copy would force exactly that).
+    struct Set { f32x4 w[NH], m[NH], v[NH], zt[4]; };
+    auto fetch = [&](Set& st, int ot) {
+        const int oc = ot < ot_last ? ot : ot_last;          // clamped: tail prefetches re-read the last tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st.zt[i] = *(const f32x4*)(zsrc + 16 * i * Op + 16 * oc);
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) { const int64_t i = tidx(ht, oc); st.w[ht] = *(const f32x4*)(W2 + i); st.m[ht] = *(const f32x4*)(M2 + i); st.v[ht] = *(const f32x4*)(V2 + i); }
+    };
+    auto step = [&](Set& cur, Set& nx2, int ot) {
+        // stage this tile (wave-private, in-order LDS), then request tile ot+2
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)(tile + 256 * i + 4 * lane) = cur.zt[i];
+        fetch(nx2, ot + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 g[NH];
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) g[ht] = zero4;
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            const float az = tile[64 * kb + lane];                       // dZ^T[o=li][b=4kb+lj]
+#pragma unroll
+            for (int ht = 0; ht < NH; ++ht) g[ht] = MFMA16(az, ddf[kb][ht], g[ht]);
+        }
+        f32x4 zf[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) zf[mt] = *(const f32x4*)(tile + (16 * mt + li) * 16 + 4 * lj);   // dZ[b][o=4lj+r]
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) dacc[mt][ht] = MFMA16(zf[mt][r], cur.w[ht][r], dacc[mt][ht]);   // OLD W2
+            adam4(cur.w[ht], cur.m[ht], cur.v[ht], g[ht], ap);
+            if (FULL || ht < nht) {
+                const int64_t i = tidx(ht, ot);
+                *(f32x4*)(W2 + i) = cur.w[ht]; *(f32x4*)(M2 + i) = cur.m[ht]; *(f32x4*)(V2 + i) = cur.v[ht];
+            }
+        }
+    };
     if (ot_beg < ot_end) {
-        f32x4 w[NH], m[NH], v[NH], zt[4];
-#pragma unroll
-        for (int ht = 0; ht < NH; ++ht) { const int64_t i = tidx(ht, ot_beg); w[ht] = *(const f32x4*)(W2 + i); m[ht] = *(const f32x4*)(M2 + i); v[ht] = *(const f32x4*)(V2 + i); }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) zt[i] = *(const f32x4*)(zsrc + 16 * i * Op + 16 * ot_beg);
+        Set A, B, C;
+        fetch(A, ot_beg);
+        fetch(B, ot_beg + 1);
 #pragma unroll
         for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
             for (int ht = 0; ht < NH; ++ht) asm volatile("" : "+v"(ddf[kb][ht]));
 #pragma unroll
-        for (int ht = 0; ht < NH; ++ht) asm volatile("" : "+v"(w[ht]), "+v"(m[ht]), "+v"(v[ht]));
-
-        for (int ot = ot_beg; ot < ot_end; ++ot) {
-            // stage this tile (wave-private, in-order LDS), then request the next one
+        for (int ht = 0; ht < NH; ++ht) asm volatile("" : "+v"(A.w[ht]), "+v"(A.m[ht]), "+v"(A.v[ht]));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *(f32x4*)(tile + 256 * i + 4 * lane) = zt[i];
-            const int on = ot < ot_last ? ot + 1 : ot_last;
-            f32x4 w1[NH], m1[NH], v1[NH];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) zt[i] = *(const f32x4*)(zsrc + 16 * i * Op + 16 * on);
-#pragma unroll
-            for (int ht = 0; ht < NH; ++ht) { const int64_t i = tidx(ht, on); w1[ht] = *(const f32x4*)(W2 + i); m1[ht] = *(const f32x4*)(M2 + i); v1[ht] = *(const f32x4*)(V2 + i); }
-            __builtin_amdgcn_sched_barrier(0);
-
-            f32x4 g[NH];
-#pragma unroll
-            for (int ht = 0; ht < NH; ++ht) g[ht] = zero4;
-#pragma unroll
-            for (int kb = 0; kb < 16; ++kb) {
-                const float az = tile[64 * kb + lane];                       // dZ^T[o=li][b=4kb+lj]
-#pragma unroll
-                for (int ht = 0; ht < NH; ++ht) g[ht] = MFMA16(az, ddf[kb][ht], g[ht]);
-            }
-            f32x4 zf[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) zf[mt] = *(const f32x4*)(tile + (16 * mt + li) * 16 + 4 * lj);   // dZ[b][o=4lj+r]
-#pragma unroll
-            for (int ht = 0; ht < NH; ++ht) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) dacc[mt][ht] = MFMA16(zf[mt][r], w[ht][r], dacc[mt][ht]);   // OLD W2
-                adam4(w[ht], m[ht], v[ht], g[ht], ap);
-                if (FULL || ht < nht) {
-                    const int64_t i = tidx(ht, ot);
-                    *(f32x4*)(W2 + i) = w[ht]; *(f32x4*)(M2 + i) = m[ht]; *(f32x4*)(V2 + i) = v[ht];
-                }
-            }
-#pragma unroll
-            for (int ht = 0; ht < NH; ++ht) { w[ht] = w1[ht]; m[ht] = m1[ht]; v[ht] = v1[ht]; }
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(A.zt[i]));
+        int ot = ot_beg;
+        for (; ot + 3 <= ot_end; ot += 3) {
+            step(A, C, ot);
+            step(B, A, ot + 1);
+            step(C, B, ot + 2);
+        }
+        if (ot < ot_end) {
+            step(A, C, ot);
+            if (ot + 1 < ot_end) step(B, A, ot + 1);
         }
     }
     __syncthreads();                                   // every wave is done with its private tile

@@ -25,8 +25,9 @@ static float* dalloc(size_t n, float scale, unsigned seed) {
     hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, p, n, scale, seed);
     return p;
 }
-int main() {
-    const int K = 40, H = 256, O = 512, S = 19; const int64_t n = 50000;
+int main(int argc, char** argv) {
+    const int K = argc > 1 ? atoi(argv[1]) : 40, H = 256, O = 512, S = 19; const int64_t n = 50000;
+    printf("K = %d\n", K);
     Dims dm; dm.K = K; dm.H = H; dm.O = O; dm.Hp = 256; dm.Op = 512; dm.HT = 16; dm.OT = 32; dm.ldd = 258; dm.OS = 8;
     std::vector<SubnetDev> sn(K);
     for (int k = 0; k < K; ++k) { sn[k].D = 2400; sn[k].Dp = 2400; sn[k].nchunk = 150; sn[k].kg = k; sn[k].slot0 = k * S; sn[k].nslice = S; sn[k].xoff = 0; sn[k].w1off = 0; }
@@ -44,8 +45,8 @@ int main() {
     CK(hipDeviceSynchronize());
 #define T(name, ...) { double us = timeit([&] { hipLaunchKernelGGL(__VA_ARGS__); }); CK(hipGetLastError()); printf("%-34s %8.1f us\n", name, us); }
     T("k_reduce_act", k_reduce_act, dim3(16, K), dim3(256), 0, 0, dsn, P, b1, (const uint8_t*)nullptr, Dd, dm, 64, 0.2f, 1.25f, 1234ull, 0u, 0u, 0)
-    T("k_mid_fwd<16>", k_mid_fwd<16>, dim3(8, K), dim3(256), 64 * 258 * 4, 0, W2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, dZ, ls, la, dm, ap, 1.f / (64 * 512), 0, 0)
-    T("k_mid_fwd<0>", k_mid_fwd<0>, dim3(8, K), dim3(256), 64 * 258 * 4, 0, W2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, dZ, ls, la, dm, ap, 1.f / (64 * 512), 0, 0)
+    T("k_mid_fwd<16>", k_mid_fwd<16>, dim3(8, K), dim3(512), 64 * 258 * 4, 0, W2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, dZ, ls, la, dm, ap, 1.f / (64 * 512), 0, 0)
+    T("k_mid_fwd<0>", k_mid_fwd<0>, dim3(8, K), dim3(512), 64 * 258 * 4, 0, W2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, dZ, ls, la, dm, ap, 1.f / (64 * 512), 0, 0)
     T("k_mid_bwd<true,1>", (k_mid_bwd<true, 1, 8>), dim3(16, K), dim3(512), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 4, 0)
     T("k_mid_bwd<true,1,4>", (k_mid_bwd<true, 1, 4>), dim3(16, K), dim3(256), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 8, 0)
     T("k_mid_bwd<true,2>", (k_mid_bwd<true, 2, 8>), dim3(8, K), dim3(512), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 4, 0)
@@ -53,7 +54,7 @@ int main() {
     T("RED+MF+MB chain", k_reduce_act, dim3(16, K), dim3(256), 0, 0, dsn, P, b1, (const uint8_t*)nullptr, Dd, dm, 64, 0.2f, 1.25f, 1234ull, 0u, 0u, 0);
     { double us = timeit([&] {
         hipLaunchKernelGGL(k_reduce_act, dim3(16, K), dim3(256), 0, 0, dsn, P, b1, (const uint8_t*)nullptr, Dd, dm, 64, 0.2f, 1.25f, 1234ull, 0u, 0u, 0);
-        hipLaunchKernelGGL(k_mid_fwd<16>, dim3(8, K), dim3(256), 64 * 258 * 4, 0, W2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, dZ, ls, la, dm, ap, 1.f / (64 * 512), 0, 0);
+        hipLaunchKernelGGL(k_mid_fwd<16>, dim3(8, K), dim3(512), 64 * 258 * 4, 0, W2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, dZ, ls, la, dm, ap, 1.f / (64 * 512), 0, 0);
         hipLaunchKernelGGL((k_mid_bwd<true, 1, 8>), dim3(16, K), dim3(512), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 4, 0); });
       printf("%-34s %8.1f us\n", "RED+MF+MB back-to-back", us); }
     return 0;
