@@ -99,7 +99,7 @@ struct dimn_handle_s {
     std::vector<Work> work;
     std::vector<std::vector<int32_t>> pred, targ;
     int nslots = 0;
-    int64_t w1_total = 0, x_total = 0;
+    int64_t w1_total = 0, x_total = 0, y_total = 0;
     int64_t n = 0, g = 0, n_tr = 0, n_val = 0;
     bool gathered = false, gathered_targets = false, have_idx = false;
     // device
@@ -383,8 +383,7 @@ extern "C" int dimn_gather(dimn_handle h, int32_t with_targets) {
         pflat.insert(pflat.end(), h->pred[k].begin(), h->pred[k].end());
         tflat.insert(tflat.end(), h->targ[k].begin(), h->targ[k].end());
     }
-    DEV_FREE(h->d_pred); DEV_FREE(h->d_targ); DEV_FREE(h->d_pred_off);
-    CHK(dev_alloc(&h->d_pred, pflat.size())); CHK(dev_alloc(&h->d_targ, tflat.size())); CHK(dev_alloc(&h->d_pred_off, (size_t)h->K));
+    if (!h->d_pred) { CHK(dev_alloc(&h->d_pred, pflat.size())); CHK(dev_alloc(&h->d_targ, tflat.size())); CHK(dev_alloc(&h->d_pred_off, (size_t)h->K)); }
     HIPCHK(hipMemcpy(h->d_pred, pflat.data(), pflat.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_targ, tflat.data(), tflat.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_pred_off, poff.data(), poff.size() * 8, hipMemcpyHostToDevice));
@@ -395,12 +394,17 @@ extern "C" int dimn_gather(dimn_handle h, int32_t with_targets) {
         h->sn[k].xoff = x;
         x += (int64_t)h->n * h->sn[k].Dp;
     }
-    DEV_FREE(h->d_X);
-    CHK(dev_alloc(&h->d_X, (size_t)x));
-    h->x_total = x;
-    if (with_targets) {
+    // the arenas are re-used across calls (19.5 GB at cfg3: a hipFree/hipMalloc pair costs up to a second)
+    if (!h->d_X || h->x_total != x) {
+        DEV_FREE(h->d_X);
+        CHK(dev_alloc(&h->d_X, (size_t)x));
+        h->x_total = x;
+    }
+    const int64_t y_need = (int64_t)h->K * h->n * h->dm.Op;
+    if (with_targets && (!h->d_Y || h->y_total != y_need)) {
         DEV_FREE(h->d_Y);
-        CHK(dev_alloc(&h->d_Y, (size_t)h->K * h->n * h->dm.Op));
+        CHK(dev_alloc(&h->d_Y, (size_t)y_need));
+        h->y_total = y_need;
     }
     HIPCHK(hipMemcpy(h->d_sn, h->sn.data(), h->sn.size() * sizeof(SubnetDev), hipMemcpyHostToDevice));
     if ((size_t)h->g * sizeof(float) <= 150 * 1024) {      // the row fits in LDS: read `norm` once, serve all sub-nets from LDS

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(512) void k_mid_fwd(const float* __restrict__ W2,
 // State and dZ of the next output tile are prefetched while the current one computes.
 // ---------------------------------------------------------------------------------------
 template <bool FULL, int NH, int WV>   // NH hidden tiles (16 rows of W2 each) per workgroup, WV waves; FULL: HT % NH == 0 and OT == WV*otw
-__global__ __launch_bounds__(WV * 64, WV == 4 ? 3 : 2) void k_mid_bwd(const float* __restrict__ Dd, const float* __restrict__ dZ,
+__global__ __launch_bounds__(WV * 64, WV == 4 ? 3 : (WV == 16 ? 4 : 2)) void k_mid_bwd(const float* __restrict__ Dd, const float* __restrict__ dZ,
                                                  float* __restrict__ W2, float* __restrict__ M2, float* __restrict__ V2,
                                                  float* __restrict__ b1w, float* __restrict__ b1m, float* __restrict__ b1v,
                                                  float* __restrict__ dA, Dims dm, AdamP ap, float scale, int otw, int k0) {
@@ -450,6 +450,19 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 3 : 2) void k_mid_bwd(const floa
     const int ot_beg = wave * otw;
     const int ot_end = FULL ? ot_beg + otw : ((wave + 1) * otw < dm.OT ? (wave + 1) * otw : dm.OT);
     const int ot_last = ot_end - 1;
+
+    // epilogue operands requested up front (they do not depend on the tile loop): the Dd values that gate
+    // dA = dD*scale*[Dd>0] for this thread's outputs, and the bias state for Adam(b1)
+    // 64 x (16*NH) outputs: thread -> column hh = tid % (16*NH), rows b = tid / (16*NH) + RB*i
+    constexpr int CW = 16 * NH, RB = (WV * 64) / CW, NI = DIMN_TB / RB;
+    const int hh = tid % CW, b0 = tid / CW;
+    const int h = CW * hs + hh;
+    const int hcl = h < Hp ? h : 0;
+    float ddv[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) ddv[i] = ddk[(b0 + RB * i) * Hp + hcl];
+    const int64_t bidx = (int64_t)k * Hp + (tid < CW ? hcl : 0);
+    float b1w0 = b1w[bidx], b1m0 = b1m[bidx], b1v0 = b1v[bidx];
 
     float ddf[16][NH];    // B operand of gW2: Dd[b=4kb+lj][h=16(ht0+ht)+li] (second tile clamped when absent)
 #pragma unroll
@@ -483,7 +496,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 3 : 2) void k_mid_bwd(const floa
         // stage this tile (wave-private, in-order LDS), then request tile ot+2
 #pragma unroll
         for (int i = 0; i < 4; ++i) *(f32x4*)(tile + 256 * i + 4 * lane) = cur.zt[i];
-        fetch(nx2, ot + 2);
+        if (WV < 16) fetch(nx2, ot + 2);                   // 16 waves: two tiles per wave, both requested up front
         __builtin_amdgcn_sched_barrier(0);
         f32x4 g[NH];
 #pragma unroll
@@ -541,10 +554,6 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 3 : 2) void k_mid_bwd(const floa
 #pragma unroll
             for (int r = 0; r < 4; ++r) lds[(wave * DIMN_TB + 16 * mt + 4 * lj + r) * LDR + 16 * ht + li] = (FULL || ht < nht) ? dacc[mt][ht][r] : 0.f;
     __syncthreads();
-    // 64 x (16*NH) outputs: thread -> column hh = tid % (16*NH), rows b = tid / (16*NH) + RB*i
-    constexpr int CW = 16 * NH, RB = (WV * 64) / CW, NI = DIMN_TB / RB;
-    const int hh = tid % CW, b0 = tid / CW;
-    const int h = CW * hs + hh;
     float gsum = 0.f;
     if (h < Hp) {
 #pragma unroll
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 3 : 2) void k_mid_bwd(const floa
             float d = 0.f;
 #pragma unroll
             for (int wv = 0; wv < WV; ++wv) d += lds[(wv * DIMN_TB + b) * LDR + hh];
-            const float da = ddk[b * Hp + h] > 0.f ? d * scale : 0.f;
+            const float da = ddv[i] > 0.f ? d * scale : 0.f;
             dA[((int64_t)k * DIMN_TB + b) * Hp + h] = da;
             gsum += da;
         }
@@ -565,10 +574,8 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 3 : 2) void k_mid_bwd(const floa
         float gb = 0.f;
 #pragma unroll
         for (int i = 0; i < RB; ++i) gb += lds[i * LDR + hh];
-        const int64_t idx = (int64_t)k * Hp + h;
-        float w = b1w[idx], m = b1m[idx], v = b1v[idx];
-        adam1(w, m, v, gb, ap);
-        b1w[idx] = w; b1m[idx] = m; b1v[idx] = v;
+        adam1(b1w0, b1m0, b1v0, gb, ap);
+        b1w[bidx] = b1w0; b1m[bidx] = b1m0; b1v[bidx] = b1v0;
     }
 }
 

@@ -49,6 +49,7 @@ int main(int argc, char** argv) {
     T("k_mid_fwd<0>", k_mid_fwd<0>, dim3(8, K), dim3(512), 64 * 258 * 4, 0, W2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, dZ, ls, la, dm, ap, 1.f / (64 * 512), 0, 0)
     T("k_mid_bwd<true,1>", (k_mid_bwd<true, 1, 8>), dim3(16, K), dim3(512), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 4, 0)
     T("k_mid_bwd<true,1,4>", (k_mid_bwd<true, 1, 4>), dim3(16, K), dim3(256), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 8, 0)
+    T("k_mid_bwd<true,1,16>", (k_mid_bwd<true, 1, 16>), dim3(16, K), dim3(1024), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 2, 0)
     T("k_mid_bwd<true,2>", (k_mid_bwd<true, 2, 8>), dim3(8, K), dim3(512), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 4, 0)
     // chained like a real step
     T("RED+MF+MB chain", k_reduce_act, dim3(16, K), dim3(256), 0, 0, dsn, P, b1, (const uint8_t*)nullptr, Dd, dm, 64, 0.2f, 1.25f, 1234ull, 0u, 0u, 0);
