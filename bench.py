@@ -264,6 +264,7 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--limit-subnets", type=int, default=0, help="diagnostic: keep only the first N sub-nets (what one rank of an N-GPU job sees)")
     ap.add_argument("--early-stop-probe", action="store_true", help="also run the early-stopped fit once and report its epoch count")
     args = ap.parse_args()
 
@@ -283,6 +284,8 @@ def main():
     norm = synth_counts(n, g, seed=0)
     targets, preds = synth_indices(g, cfg["O"], seed=0)
     train, val = split_rows(n, seed=0)
+    if args.limit_subnets:
+        targets, preds = targets[:args.limit_subnets], preds[:args.limit_subnets]
     K = targets.shape[0]
     counts, offs = shard(K, world)
     t_gen = time.time() - t_gen

@@ -159,18 +159,21 @@ static int dev_alloc(T** p, size_t count) {
 static void build_work(dimn_handle h) {
     // Split every sub-net's chunk range into slices = workgroups of the W1 kernels.  The total is made
     // EXACTLY ncu * wg_per_cu (a partially filled last round of workgroups costs a whole round), shared
-    // out in proportion to the chunk counts (largest remainder), subject to >= 8 chunks per slice: every
-    // workgroup writes a 64-row split-K partial, so very fine slicing (few sub-nets per GPU) would drown
-    // the step in partials.
+    // out in proportion to the chunk counts (largest remainder), subject to a minimum slice length: every
+    // workgroup writes a 64-row split-K partial, so very fine slicing would drown the step in partials.
     int64_t total_chunks = 0;
     for (auto& s : h->sn) total_chunks += s.nchunk;
     const int64_t target = (int64_t)h->ncu * h->wg_per_cu;
     std::vector<int> ns((size_t)h->K);
     std::vector<std::pair<double, int>> frac;
     int64_t assigned = 0;
+    // minimum chunks per slice: 8 when there is plenty of work per CU; down to 2 when a GPU owns only a
+    // few sub-nets (8-GPU sharding): the step is then latency-bound and parallelism beats partial traffic
+    int min_chunks = (int)std::min<int64_t>(8, std::max<int64_t>(2, total_chunks / std::max<int64_t>(1, target)));
+    if (const char* e = getenv("DIMN_MIN_CHUNKS")) min_chunks = std::max(1, atoi(e));
     for (int k = 0; k < h->K; ++k) {
         const double share = (double)target * h->sn[k].nchunk / (double)total_chunks;
-        const int cap = std::max(1, h->sn[k].nchunk / 8);
+        const int cap = std::max(1, h->sn[k].nchunk / min_chunks);
         ns[(size_t)k] = std::min(cap, std::max(1, (int)share));
         assigned += ns[(size_t)k];
         frac.push_back({share - (int)share, k});
@@ -178,7 +181,7 @@ static void build_work(dimn_handle h) {
     std::sort(frac.begin(), frac.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
     for (size_t i = 0; assigned < target && i < frac.size(); ++i) {
         const int k = frac[i].second;
-        if (ns[(size_t)k] < std::max(1, h->sn[k].nchunk / 8)) { ns[(size_t)k]++; assigned++; }
+        if (ns[(size_t)k] < std::max(1, h->sn[k].nchunk / min_chunks)) { ns[(size_t)k]++; assigned++; }
     }
     h->work.clear();
     int slot = 0;
