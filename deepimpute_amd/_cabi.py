@@ -75,6 +75,7 @@ GPU_ONLY = {
     "comm_allreduce_sum": [_H, _pd, _i32],
     "comm_gather_predictions": [_H, _i64, _pi, _i32, _pf],
     "comm_destroy": [_H],
+    "abs_corrcoef": [_i32, _pd, _i64, _i64, _pd],
 }
 
 

@@ -13,6 +13,7 @@
 
 #include "../../include/dimn.h"
 #include "dimn_kernels.h"
+#include "dimn_corr.h"
 
 #define DIMN_ABI_VERSION 1
 
@@ -963,4 +964,53 @@ extern "C" int dimn_comm_destroy(dimn_handle h) {
     if (!h) return fail(DIMN_ERR_ARG, "null handle");
     if (h->comm) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
     return DIMN_OK;
+}
+
+// ---- get_distance_matrix on the GPU (reference multinet.py:20-34) -------------------
+extern "C" int dimn_abs_corrcoef(int32_t device_id, const double* X, int64_t n, int64_t g, double* out) {
+    if (!X || !out || n < 2 || g < 1) return fail(DIMN_ERR_ARG, "dimn_abs_corrcoef: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(DIMN_ERR_HIP, "dimn_abs_corrcoef: no HIP device visible");
+    if (device_id < 0 || device_id >= ndev) return fail(DIMN_ERR_ARG, "dimn_abs_corrcoef: device_id out of range");
+    HIPCHK(hipSetDevice(device_id));
+    const int64_t gp = (g + CORR_BT - 1) / CORR_BT * CORR_BT, np_ = (n + CORR_KC - 1) / CORR_KC * CORR_KC;
+    const int nb = (int)(gp / CORR_BT);
+    double *dZ = nullptr, *dC = nullptr, *dOut = nullptr, *dMean = nullptr, *dPart = nullptr;
+    int2* dPairs = nullptr;
+    hipStream_t st = nullptr;
+    int rc = DIMN_OK;
+    std::vector<int2> pairs;
+    for (int i = 0; i < nb; ++i)
+        for (int j = i; j < nb; ++j) pairs.push_back(make_int2(i, j));
+    const int nparts = (int)std::min<int64_t>(64, (n + 255) / 256);
+    const int64_t rows_per_block = (n + nparts - 1) / nparts;
+#define CORR_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
+    CORR_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    CORR_TRY(hipMalloc((void**)&dZ, (size_t)np_ * gp * 8));
+    CORR_TRY(hipMalloc((void**)&dC, (size_t)gp * gp * 8));
+    CORR_TRY(hipMalloc((void**)&dOut, (size_t)g * g * 8));
+    CORR_TRY(hipMalloc((void**)&dMean, (size_t)gp * 8));
+    CORR_TRY(hipMalloc((void**)&dPart, (size_t)nparts * gp * 8));
+    CORR_TRY(hipMalloc((void**)&dPairs, pairs.size() * sizeof(int2)));
+    CORR_TRY(hipMemsetAsync(dZ, 0, (size_t)np_ * gp * 8, st));
+    CORR_TRY(hipMemcpy2DAsync(dZ, (size_t)gp * 8, X, (size_t)g * 8, (size_t)g * 8, (size_t)n, hipMemcpyHostToDevice, st));
+    CORR_TRY(hipMemcpyAsync(dPairs, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_corr_colsum, dim3((unsigned)((gp + 255) / 256), (unsigned)nparts), dim3(256), 0, st, dZ, n, gp, rows_per_block, dPart);
+    hipLaunchKernelGGL(k_corr_mean, dim3((unsigned)((gp + 255) / 256)), dim3(256), 0, st, dPart, nparts, n, gp, dMean);
+    hipLaunchKernelGGL(k_corr_center, dim3((unsigned)((g + 255) / 256), (unsigned)std::min<int64_t>(n, 1024)), dim3(256), 0, st, dZ, n, g, gp, dMean);
+    hipLaunchKernelGGL(k_corr_gemm, dim3((unsigned)pairs.size()), dim3(256), 0, st, dZ, np_, gp, dPairs, dC);
+    hipLaunchKernelGGL(k_corr_finish, dim3((unsigned)((g + 255) / 256), (unsigned)g), dim3(256), 0, st, dC, g, gp, 1.0 / (double)(n - 1), dOut);
+    CORR_TRY(hipGetLastError());
+    CORR_TRY(hipMemcpyAsync(out, dOut, (size_t)g * g * 8, hipMemcpyDeviceToHost, st));
+    CORR_TRY(hipStreamSynchronize(st));
+#undef CORR_TRY
+done:
+    if (dZ) (void)hipFree(dZ);
+    if (dC) (void)hipFree(dC);
+    if (dOut) (void)hipFree(dOut);
+    if (dMean) (void)hipFree(dMean);
+    if (dPart) (void)hipFree(dPart);
+    if (dPairs) (void)hipFree(dPairs);
+    if (st) (void)hipStreamDestroy(st);
+    return rc;
 }

@@ -35,9 +35,35 @@ _VALIDATION_FRACTION = 0.05     # multinet.py:228
 
 
 # --------------------------------------------------------------------------- module functions
-def get_distance_matrix(raw, n_pred=None):
+def _abs_corrcoef(values, backend="auto", device_id=0):
+    """|np.corrcoef| of the columns of `values` ([cells, genes] float64).  backend "hip": fp64 MFMA
+    kernel of libdimn (dimn_abs_corrcoef); "numpy": the reference's own host computation; "auto": hip
+    when a GPU is visible, numpy otherwise (host planning is not part of the accelerated hot path, so
+    unlike fit/predict it may run without a GPU)."""
+    if backend not in ("auto", "hip", "numpy"):
+        raise ValueError("backend must be 'auto', 'hip' or 'numpy'")
+    if backend != "numpy":
+        try:
+            from . import _cabi, _lib
+            fns = _lib.load()
+            x = np.ascontiguousarray(values, dtype=np.float64)
+            out = np.empty((x.shape[1], x.shape[1]), np.float64)
+            rc = fns["abs_corrcoef"](int(device_id), _cabi.p_f64(x), x.shape[0], x.shape[1], _cabi.p_f64(out))
+            if rc == 0:
+                return out
+            if backend == "hip":
+                raise RuntimeError("dimn_abs_corrcoef: " + fns["last_error"]().decode("utf-8", "replace"))
+        except ImportError:
+            if backend == "hip":
+                raise
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.abs(np.corrcoef(values.T))
+
+
+def get_distance_matrix(raw, n_pred=None, backend="auto", device_id=0):
     """Absolute Pearson correlation between candidate predictor genes (multinet.py:20-34).
-    Candidates: genes with std/mean > 0, or the `n_pred` genes with the largest ratio."""
+    Candidates: genes with std/mean > 0, or the `n_pred` genes with the largest ratio.  The g x g
+    float64 correlation itself runs on the GPU when one is visible (`backend`, see _abs_corrcoef)."""
     ratio = raw.std() / raw.mean()
     ratio[np.isinf(ratio)] = 0
     if n_pred is None:
@@ -45,7 +71,8 @@ def get_distance_matrix(raw, n_pred=None):
     else:
         print("Using {} predictors".format(n_pred))
         keep = ratio.sort_values(ascending=False).index[:n_pred]
-    table = pd.DataFrame(np.abs(np.corrcoef(raw.T.loc[keep])), index=keep, columns=keep)
+    corr = _abs_corrcoef(raw.loc[:, keep].values, backend=backend, device_id=device_id)
+    table = pd.DataFrame(corr, index=keep, columns=keep)
     return table.fillna(0)
 
 
@@ -207,7 +234,7 @@ class MultiNet:
         else:
             genes_to_impute = self._pad_gene_list(genes_to_impute, gene_metric)
 
-        correlations = get_distance_matrix(raw, n_pred=n_pred)
+        correlations = get_distance_matrix(raw, n_pred=n_pred, device_id=self.device_id)
         self.setTargets(raw.reindex(columns=genes_to_impute), mode=mode)
         self.setPredictors(correlations, ntop=ntop)
 
@@ -326,17 +353,18 @@ class MultiNet:
         if block is None:
             return None                                  # sharded job: rank 0 returns the frame
 
-        # a gene may occupy several target slots: average them; columns come out label-sorted,
+        # a gene may occupy several target slots: average them; the averaged columns are label-sorted,
         # like the reference's groupby(columns).mean() (multinet.py:282-284)
         slots = self.targets.flatten()
         genes, slot_gene = np.unique(slots, return_inverse=True)
         acc = np.zeros((len(genes), block.shape[0]), dtype=np.float32)
         np.add.at(acc, slot_gene, block.T)
         acc /= np.bincount(slot_gene, minlength=len(genes)).astype(np.float32)[:, None]
-        predicted = pd.DataFrame(acc.T, index=raw.index, columns=genes)
 
-        untouched = norm_raw.drop(genes, axis=1)
-        values = pd.concat([predicted, untouched], axis=1).loc[raw.index, raw.columns].values
+        # the reference concatenates predicted and untouched genes and re-orders them to raw's layout
+        # (multinet.py:285-289); writing the averaged columns into a copy of log1p(raw) is the same matrix
+        values = np.array(norm_raw.values, dtype=np.float64)
+        values[:, pd.Index(raw.columns).get_indexer(genes)] = acc.T
         ceiling = 2 * norm_raw.values.max()              # overflow guard, multinet.py:292
         values[(values > ceiling) | np.isnan(values)] = 0
         values = np.expm1(values)                        # back to counts
@@ -352,7 +380,7 @@ class MultiNet:
             values[keep_raw] = observed[keep_raw]
 
         imputed = pd.DataFrame(values, index=raw.index, columns=raw.columns)
-        return imputed.loc[:, predicted.columns] if imputed_only else imputed
+        return imputed.loc[:, genes] if imputed_only else imputed
 
     # -- planning helpers (public in the reference, so public here) --
     def filter_genes(self, gene_metric, threshold, NN_lim=None):
@@ -382,14 +410,19 @@ class MultiNet:
         row; picking the top-ntop by partial selection yields the same genes in the same order
         whenever the correlations involved are distinct."""
         pool = covariance_matrix.columns
-        self.predictors = []
+        table = covariance_matrix.values               # g x g float64; indexed by position below (pandas .loc
+        self.predictors = []                           # on a 20k x 20k frame costs seconds per sub-network)
         for net, targets in enumerate(self.targets):
-            outside = np.setdiff1d(pool, targets)
+            outside = np.setdiff1d(pool, targets)      # label-sorted, as in the reference
             if outside.size == 0:
                 warnings.warn('Warning: number of target genes lower than output dim. '
                               'Consider lowering down the sub_outputdim parameter', UserWarning)
-                outside = pool
-            scores = covariance_matrix.loc[targets, outside].values
+                outside = np.asarray(pool)
+            rows, cols = pool.get_indexer(targets), pool.get_indexer(outside)
+            if (rows < 0).any():
+                missing = [t for t, r in zip(targets, rows) if r < 0]
+                raise KeyError("{} not in index".format(missing[:5]))     # what .loc raises in the reference
+            scores = table[np.ix_(rows, cols)]
             width = min(ntop, scores.shape[1])
             if width < scores.shape[1]:
                 cand = np.argpartition(-scores, width - 1, axis=1)[:, :width]

@@ -169,6 +169,12 @@ int dimn_comm_gather_predictions(dimn_handle h, int64_t n_rows, const int32_t* c
                                  int32_t root, float* out);
 int dimn_comm_destroy(dimn_handle h);
 
+/* ---- next row: get_distance_matrix (multinet.py:20-34) ------------------------
+ * out[g][g] = np.abs(np.corrcoef(X.T)) with NaN -> 0, X host row-major fp64 [n][g] (the candidate
+ * predictor columns of the raw counts).  fp64 MFMA on the device, numpy's order of operations.
+ * Needs no handle (fit() calls it before the network exists). */
+int dimn_abs_corrcoef(int32_t device_id, const double* X, int64_t n, int64_t g, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -119,3 +119,42 @@ def test_error_paths_are_loud():
         e.train_epoch(0)                          # no split
     with pytest.raises(DimnError):
         e.train_step(np.array([99], np.int32))    # row out of range
+
+
+def test_abs_corrcoef_matches_numpy_and_selects_same_predictors():
+    """get_distance_matrix on the fp64 MFMA path vs the reference's numpy
+    computation (multinet.py:20-34) -- values to 1e-12 and the SAME predictor lists."""
+    import pandas as pd
+    from deepimpute_amd.multinet import MultiNet, get_distance_matrix
+    rng = np.random.default_rng(12)
+    n, g = 333, 700                                   # neither a multiple of the 16-row / 128-column tiles
+    mu = rng.lognormal(0.5, 1.2, size=g)
+    counts = rng.poisson(rng.gamma(2.0, mu / 2.0, size=(n, g))).astype(np.float64)
+    counts[:, 7] = 3.0                                # a constant gene: VMR = 0 -> dropped from the candidates
+    counts[:, 11] = 0.0
+    raw = pd.DataFrame(counts, index=["c%d" % i for i in range(n)], columns=["g%d" % j for j in range(g)])
+    a = get_distance_matrix(raw, backend="hip")
+    b = get_distance_matrix(raw, backend="numpy")
+    assert list(a.columns) == list(b.columns) and a.shape == b.shape and "g7" not in a.columns
+    np.testing.assert_allclose(a.values, b.values, rtol=0, atol=1e-12)
+    assert np.allclose(np.diag(a.values), 1.0, atol=1e-12) and (a.values <= 1.0).all() and (a.values >= 0).all()
+    np.testing.assert_allclose(a.values, a.values.T, rtol=0, atol=1e-15)   # like numpy's, symmetric to an ulp (c/s_i/s_j)
+    c = get_distance_matrix(raw, n_pred=200, backend="hip")
+    np.testing.assert_allclose(c.values, get_distance_matrix(raw, n_pred=200, backend="numpy").values, atol=1e-12)
+    # a constant column inside the matrix gives NaN in numpy (0/0) and 0 after fillna
+    from deepimpute_amd.multinet import _abs_corrcoef
+    x = counts[:, :40].copy(); x[:, 3] = 5.0
+    got = _abs_corrcoef(x, backend="hip")
+    ref = np.nan_to_num(_abs_corrcoef(x, backend="numpy"), nan=0.0)
+    np.testing.assert_allclose(got, ref, atol=1e-12)
+    assert (got[3] == 0).all()
+    # predictor selection consumes the matrix: identical lists from either backend
+    nets = []
+    for m in (a, b):
+        net = MultiNet(sub_outputdim=64, ncores=1, engine_factory=lambda *x, **k: None)
+        np.random.seed(5)
+        net.setTargets(raw.reindex(columns=list(a.columns[:256])), mode="random")
+        net.setPredictors(m, ntop=5)
+        nets.append(net)
+    for p, q in zip(nets[0].predictors, nets[1].predictors):
+        assert list(p) == list(q)

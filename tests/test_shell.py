@@ -178,3 +178,22 @@ def test_cli_digit_limit_and_subset_are_coerced(tmp_path, monkeypatch):
     net = MultiNet(engine_factory=FakeEngine, seed=99, sub_outputdim=32, ncores=1, verbose=0, output_prefix=str(tmp_path))
     net.fit(raw, NN_lim="64", cell_subset=90.0)
     assert net.targets.shape[1] == 32 and FakeEngine.instances[-1].norm.shape[0] == 90
+
+
+def test_distance_matrix_backends_without_gpu():
+    """No GPU here: 'auto' falls back to the reference's numpy computation, 'hip' is loud."""
+    raw = _raw("progressive")
+    a = get_distance_matrix(raw, backend="auto")
+    b = get_distance_matrix(raw, backend="numpy")
+    assert np.array_equal(a.values, b.values)
+    import subprocess, sys
+    code = ("import numpy as np\n"
+            "from deepimpute_amd.multinet import _abs_corrcoef\n"
+            "try:\n"
+            "    _abs_corrcoef(np.random.rand(20, 5), backend='hip'); print('RAN')\n"
+            "except Exception as e:\n"
+            "    print('LOUD', type(e).__name__)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout
+    assert "LOUD" in out, out
