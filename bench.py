@@ -218,7 +218,8 @@ def cpu_baseline(cfg, targets, preds, norm, train, val, epochs, lr, budget_s=20.
                 t0 = time.time(); port.predict(np.arange(512)); t_row = (time.time() - t0) / 512
             notes.append("np_port[blas=%d x pool=%d]: %.4f s/step, %.2e s/row" % (blas, min(K, cores), t_step, t_row))
             if best is None or t_step < best[0]:
-                best = (t_step, t_row, "oracle/np_port.py (OpenBLAS, %d BLAS threads x %d concurrent sub-nets)" % (blas, min(K, cores)), cnt)
+                best = (t_step, t_row, "oracle/np_port.py (OpenBLAS, %d BLAS threads x %d concurrent sub-nets)" % (blas, min(K, cores)), cnt,
+                        blas * min(K, cores))
         port.close()
     except Exception as e:
         notes.append("np_port failed: %r" % (e,))
@@ -238,7 +239,7 @@ def cpu_baseline(cfg, targets, preds, norm, train, val, epochs, lr, budget_s=20.
         t0 = time.time(); eng.predict(np.arange(256, dtype=np.int32)); t_row = (time.time() - t0) / 256
         notes.append("dimo.c[OpenMP %d threads]: %.4f s/step, %.2e s/row" % (cores, t_step, t_row))
         if best is None or t_step < best[0]:
-            best = (t_step, t_row, "oracle/dimo.c (OpenMP, %d threads)" % cores, cnt)
+            best = (t_step, t_row, "oracle/dimo.c (OpenMP, %d threads)" % cores, cnt, cores)
         eng.close()
     except Exception as e:
         notes.append("dimo.c failed: %r" % (e,))
@@ -246,9 +247,9 @@ def cpu_baseline(cfg, targets, preds, norm, train, val, epochs, lr, budget_s=20.
         os.remove(lib)
     if best is None:
         raise RuntimeError("; ".join(notes))
-    t_step, t_row, which, cnt = best
+    t_step, t_row, which, cnt, threads = best
     t_full = epochs * (steps_per_epoch * t_step + val.size * t_row) + n * t_row
-    return {"value": n / t_full, "unit": "cells/s", "cores": cores, "kind": "port",
+    return {"value": n / t_full, "unit": "cells/s", "cores": min(threads, cores), "kind": "port", "host_threads_available": cores,
             "sample": "%s: %d train steps at %.4f s/step + forward at %.2e s/row on a %d-cell sample, extrapolated to "
                       "%d epochs x %d steps + validation + predict of %d cells. All timings: %s"
                       % (which, cnt, t_step, t_row, n_sample, epochs, steps_per_epoch, n, "; ".join(notes))}

@@ -158,3 +158,75 @@ def test_abs_corrcoef_matches_numpy_and_selects_same_predictors():
         nets.append(net)
     for p, q in zip(nets[0].predictors, nets[1].predictors):
         assert list(p) == list(q)
+
+
+def test_binary_wmse_weights_match_oracle():
+    """wMSE(binary=True) (multinet.py:37-38): weights 1[y>0] instead of y."""
+    prob = make_problem(n=200, g=300, Ds=[48, 64], H=32, O=48, seed=31)
+    kw = dict(batch_size=64, dropout_rate=0.2, learning_rate=1e-3, seed=5, loss_binary=True)
+    a = load_problem(_hip(), prob, **kw)
+    b = load_problem(_oracle(), prob, **kw)
+    a.init_weights(); b.init_weights()
+    np.testing.assert_allclose(a.train_epoch(0), b.train_epoch(0), rtol=1e-4)
+    np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=1e-4, atol=1e-6)
+
+
+def test_full_size_properties():
+    """BASELINE configs[2] shapes (50k x 20k, K=40, H=256, O=512) are far too big for the CPU oracle,
+    so the full-size run is checked through size-independent properties:
+      * determinism: two runs from the same seed give bit-identical losses and predictions;
+      * row-permutation equivariance of predict;
+      * sharding invariance: sub-nets 0-19 / 20-39 trained in separate handles (what two ranks of a
+        2-GPU job do; Philox keys by GLOBAL sub-net index) reproduce the 40-sub-net run to fp32
+        rounding -- not bit for bit, because the split-K partition of the first layer (one slice per
+        workgroup, 256 workgroups per GPU) depends on how many sub-nets share the GPU;
+      * softplus(0) = ln 2 everywhere after zeroing the output layer."""
+    import bench
+    cfg = bench.CONFIGS["cfg3"]
+    n, g = cfg["n"], cfg["g"]
+    norm = bench.synth_counts(n, g, seed=0)
+    targets, preds = bench.synth_indices(g, cfg["O"], seed=0)
+    K = targets.shape[0]
+    rng = np.random.default_rng(1)
+    train = np.sort(rng.choice(n, 64 * 40 + 17, replace=False)).astype(np.int32)      # 41 steps, last one partial
+    val = np.setdiff1d(np.arange(n, dtype=np.int32), train)[:1000].astype(np.int32)
+    Hip = _hip()
+
+    def run(k0, k1):
+        e = Hip([len(preds[k]) for k in range(k0, k1)], cfg["H"], cfg["O"], batch_size=64, dropout_rate=0.2,
+                learning_rate=1e-4, seed=1234, subnet_offset=k0)
+        e.set_matrix(norm)
+        for i, k in enumerate(range(k0, k1)):
+            e.set_indices(i, preds[k], targets[k])
+        e.gather(True)
+        e.set_split(train, val)
+        e.init_weights()
+        tl = e.train_epoch(0)
+        vl = e.val_loss()
+        rows = np.arange(0, n, 97, dtype=np.int32)
+        return e, tl, vl, e.predict(rows), rows
+
+    full, tl, vl, pred, rows = run(0, K)
+    assert full.step_count() == 41 and np.isfinite(tl).all() and np.isfinite(vl).all() and np.isfinite(pred).all()
+    # row-permutation equivariance
+    perm = np.random.default_rng(2).permutation(rows.size)
+    assert np.array_equal(full.predict(rows[perm]), pred[perm])
+    # softplus(0) = ln 2 after zeroing the output layer of sub-net 3
+    W1, b1, W2, b2 = full.get_weights(3)
+    full.set_weights(3, W1, b1, np.zeros_like(W2), np.zeros_like(b2))
+    out = full.predict(rows[:64])
+    np.testing.assert_allclose(out[:, 3 * cfg["O"]:4 * cfg["O"]], np.log(2.0), rtol=1e-6)
+    full.close()
+    # determinism
+    again, tl2, vl2, pred2, _ = run(0, K)
+    assert np.array_equal(tl, tl2) and np.array_equal(vl, vl2) and np.array_equal(pred, pred2)
+    again.close()
+    # sharding invariance
+    O = cfg["O"]
+    for k0, k1 in ((0, 20), (20, K)):
+        part, tlp, vlp, predp, _ = run(k0, k1)
+        np.testing.assert_allclose(tlp, tl[k0:k1], rtol=1e-6)
+        np.testing.assert_allclose(vlp, vl[k0:k1], rtol=1e-6)
+        np.testing.assert_allclose(predp, pred[:, k0 * O:k1 * O], rtol=1e-5, atol=1e-7)
+        part.close()
