@@ -92,7 +92,6 @@ struct dimn_handle_s {
     Dims dm;
     int K, H, O, B, NT, NT2, OTW, HS;   // NT/NT2 hidden tiles per wave (4-/8-wave kernels); OTW out tiles per wave; HS = ceil(HT/2)
     int wg_per_cu = 1;
-    int dbg = 0;
     int variant = 1;
     int mf_variant = 16, mb_waves = 4;   // DIMN_MF=16 hoists all W2 operands (162 VGPRs); DIMN_MB=8: 8-wave middle backward
     int ncu = 256;
@@ -122,10 +121,6 @@ struct dimn_handle_s {
     hipStream_t stream = nullptr;          // lane 0's stream; also used by every non-training call
     struct Lane { hipStream_t stream; int k0, k1, w0, w1; };   // sub-nets [k0,k1), work items [w0,w1)
     std::vector<Lane> lanes;               // independent sub-net groups trained on concurrent streams
-    // "W token": the HBM-saturating W1-update launches of the lanes are serialised through a ring of
-    // events (each waits for the previous one, whatever lane it ran on); a lane's small latency-bound
-    // kernels (RED/MF/MB) are free to run under the OTHER lane's W1 update.
-    std::vector<hipEvent_t> tokens; size_t token_seq = 0; bool use_token = false;   // measured: the cross-stream event latency costs more than the overlap gains
     int64_t t = 0;
     // profiling
     bool profiling = false;
@@ -244,7 +239,6 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     }
     h->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("DIMN_WG_PER_CU")) h->wg_per_cu = std::max(1, atoi(e));
-    if (const char* e = getenv("DIMN_DBG")) h->dbg = atoi(e);
     if (const char* e = getenv("DIMN_B1F1")) h->variant = atoi(e);
     if (const char* e = getenv("DIMN_MF")) h->mf_variant = atoi(e);
     if (const char* e = getenv("DIMN_MB")) h->mb_waves = atoi(e) == 8 ? 8 : 4;
@@ -289,13 +283,6 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
         h->lanes.push_back(ln);
     }
     h->stream = h->lanes[0].stream;
-    if (const char* e = getenv("DIMN_TOKEN")) h->use_token = atoi(e) != 0;
-    if (h->lanes.size() > 1)
-        for (int i = 0; i < 16; ++i) {
-            hipEvent_t ev;
-            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { delete h; return fail(DIMN_ERR_HIP, "dimn_create: hipEventCreate failed"); }
-            h->tokens.push_back(ev);
-        }
     TRY(dev_alloc(&h->d_sn, (size_t)h->K));
     TRY(dev_alloc(&h->d_work, h->work.size()));
     TRY(dev_alloc(&h->d_W1, (size_t)w1)); TRY(dev_alloc(&h->d_M1, (size_t)w1)); TRY(dev_alloc(&h->d_V1, (size_t)w1));
@@ -331,7 +318,6 @@ extern "C" int dimn_destroy(dimn_handle h) {
     for (auto& ln : h->lanes) (void)hipStreamSynchronize(ln.stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (auto e : h->ev) (void)hipEventDestroy(e);
-    for (auto e : h->tokens) (void)hipEventDestroy(e);
     DEV_FREE(h->d_sn); DEV_FREE(h->d_work); DEV_FREE(h->d_norm); DEV_FREE(h->d_X); DEV_FREE(h->d_Y);
     DEV_FREE(h->d_pred); DEV_FREE(h->d_targ); DEV_FREE(h->d_pred_off);
     DEV_FREE(h->d_W1); DEV_FREE(h->d_M1); DEV_FREE(h->d_V1); DEV_FREE(h->d_W2); DEV_FREE(h->d_M2); DEV_FREE(h->d_V2);
@@ -648,12 +634,9 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     if (h->mb_waves == 8) { if (dm.OT == 8 * h->OTW) LAUNCH_MB(true, 8); else LAUNCH_MB(false, 8); }
     else { if (dm.OT == 4 * h->OTW) LAUNCH_MB(true, 4); else LAUNCH_MB(false, 4); }
 #undef LAUNCH_MB
-    const bool ring = h->use_token && !h->tokens.empty();
-    if (ring && h->token_seq > 0) HIPCHK(hipStreamWaitEvent(st, h->tokens[(h->token_seq - 1) % h->tokens.size()], 0));
     if (timed) (void)hipEventRecord(e1, st);
     DISPATCH_NT2(launch_w1, h, ln, d_rows, b_act, d_rows_n, b_next, ap);
     if (timed) (void)hipEventRecord(e2, st);
-    if (ring) { HIPCHK(hipEventRecord(h->tokens[h->token_seq % h->tokens.size()], st)); h->token_seq++; }
     HIPCHK(hipGetLastError());
     return DIMN_OK;
 }

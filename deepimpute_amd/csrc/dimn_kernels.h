@@ -593,8 +593,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 3 : (WV == 16 ? 4 : 2)) void k_m
 // cost ~2x).  State and X tiles of chunk c+1 are prefetched into registers while chunk c
 // computes.
 // ---------------------------------------------------------------------------------------
-template <int NT2, bool FULL, int DBG = 0>   // FULL: every wave's NT2 tiles exist (HT == 8*NT2) -> no predicated memory ops in the loop
-                                              // DBG: ablation bits (diagnostics only): 1 no stores, 2 no g MFMAs, 4 no fwd MFMAs, 8 no Adam, 16 no state loads, 32 no X loads
+template <int NT2, bool FULL>   // FULL: every wave's NT2 tiles exist (HT == 8*NT2) -> no predicated memory ops in the loop
 __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
                                                        const float* __restrict__ X, float* __restrict__ W1,
                                                        float* __restrict__ M1, float* __restrict__ V1,
@@ -681,18 +680,14 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
         f32x4 xa[4], xb[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (DBG & 32) { xa[i] = zero4; xb[i] = zero4; }
-            else {
-                xa[i] = *(const f32x4*)(xk + xot[i] + 16 * cn);
-                xb[i] = *(const f32x4*)(xk + xon[i] + 16 * cn);
-            }
+            xa[i] = *(const f32x4*)(xk + xot[i] + 16 * cn);
+            xb[i] = *(const f32x4*)(xk + xon[i] + 16 * cn);
         }
         f32x4 w1[NT2], m1[NT2], v1[NT2];
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
             const int64_t idx = wb[nt] + cn * cstride;
-            if (DBG & 16) { w1[nt] = w[nt]; m1[nt] = m[nt]; v1[nt] = v[nt]; }
-            else { w1[nt] = *(const f32x4*)(W1 + idx); m1[nt] = *(const f32x4*)(M1 + idx); v1[nt] = *(const f32x4*)(V1 + idx); }
+            w1[nt] = *(const f32x4*)(W1 + idx); m1[nt] = *(const f32x4*)(M1 + idx); v1[nt] = *(const f32x4*)(V1 + idx);
         }
         __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch at the top of the iteration
 
@@ -705,19 +700,18 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
         for (int kb = 0; kb < 16; ++kb) {
             const float a = xt[64 * kb + lane];
 #pragma unroll
-            for (int nt = 0; nt < NT2; ++nt) { if (!(DBG & 2)) g[nt] = MFMA16(a, bfr[kb][nt], g[nt]); else g[nt][0] += a * bfr[kb][nt]; }
+            for (int nt = 0; nt < NT2; ++nt) g[nt] = MFMA16(a, bfr[kb][nt], g[nt]);
         }
 #pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) { if (!(DBG & 8)) adam4(w[nt], m[nt], v[nt], g[nt], ap); else w[nt] += g[nt]; }
+        for (int nt = 0; nt < NT2; ++nt) adam4(w[nt], m[nt], v[nt], g[nt], ap);
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
-            if (DBG & 1) { asm volatile("" :: "v"(w[nt]), "v"(m[nt]), "v"(v[nt])); }
-            else if (FULL || on[nt]) {
+            if (FULL || on[nt]) {
                 const int64_t idx = wb[nt] + c * cstride;
                 *(f32x4*)(W1 + idx) = w[nt]; *(f32x4*)(M1 + idx) = m[nt]; *(f32x4*)(V1 + idx) = v[nt];
             }
         }
-        if (have_next && !(DBG & 4)) {
+        if (have_next) {
             const float* xn = sm + 2 * XT + cur * XN;
             f32x4 af[4];
 #pragma unroll
