@@ -339,6 +339,7 @@ extern "C" int dimn_set_matrix(dimn_handle h, const float* norm, int64_t n, int6
         DEV_FREE(h->d_norm);
         CHK(dev_alloc(&h->d_norm, (size_t)n * g));
         h->gathered = false;
+        if (n != h->n) { h->n_tr = 0; h->n_val = 0; h->train_rows.clear(); h->val_rows.clear(); }   // row indices of another matrix
     }
     HIPCHK(hipMemcpy(h->d_norm, norm, (size_t)n * g * sizeof(float), hipMemcpyHostToDevice));
     h->n = n; h->g = g;
@@ -414,6 +415,10 @@ extern "C" int dimn_gather(dimn_handle h, int32_t with_targets) {
 
 extern "C" int dimn_set_split(dimn_handle h, const int32_t* tr, int64_t n_tr, const int32_t* va, int64_t n_val) {
     if (!h || n_tr < 0 || n_val < 0 || (n_tr > 0 && !tr) || (n_val > 0 && !va)) return fail(DIMN_ERR_ARG, "dimn_set_split: bad argument");
+    if (h->n > 0) {
+        for (int64_t i = 0; i < n_tr; ++i) if (tr[i] < 0 || tr[i] >= h->n) return fail(DIMN_ERR_ARG, "dimn_set_split: train row %d out of range", tr[i]);
+        for (int64_t i = 0; i < n_val; ++i) if (va[i] < 0 || va[i] >= h->n) return fail(DIMN_ERR_ARG, "dimn_set_split: validation row %d out of range", va[i]);
+    }
     CHK(use_device(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->train_rows.assign(tr, tr + n_tr);
@@ -725,6 +730,7 @@ extern "C" int dimn_train_epoch(dimn_handle h, int32_t epoch, const int32_t* per
     for (int64_t i = 0; i < h->n_tr; ++i) {
         if (perm[i] < 0 || perm[i] >= h->n_tr) return fail(DIMN_ERR_ARG, "dimn_train_epoch: perm[%lld] out of range", (long long)i);
         rows[(size_t)i] = h->train_rows[(size_t)perm[i]];
+        if (rows[(size_t)i] < 0 || rows[(size_t)i] >= h->n) return fail(DIMN_ERR_ARG, "dimn_train_epoch: train row %d outside the matrix", rows[(size_t)i]);
     }
     CHK(sync_lanes(h));
     HIPCHK(hipMemcpyAsync(h->d_epoch_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, h->stream));
@@ -762,6 +768,7 @@ extern "C" int dimn_val_loss(dimn_handle h, double* val_loss) {
     if (!h || !val_loss) return fail(DIMN_ERR_ARG, "dimn_val_loss: null argument");
     CHK(ready_for_training(h, "dimn_val_loss"));
     if (h->n_val < 1) return fail(DIMN_ERR_STATE, "dimn_val_loss: no validation rows (dimn_set_split)");
+    for (int32_t r : h->val_rows) if (r < 0 || r >= h->n) return fail(DIMN_ERR_ARG, "dimn_val_loss: validation row %d outside the matrix", r);
     CHK(use_device(h));
     const int64_t tiles = (h->n_val + DIMN_TB - 1) / DIMN_TB;
     if (h->loss_part_cap < tiles * h->K) {

@@ -21,6 +21,19 @@
 //   W2_k [Hp/16][Op/16][16h][16o]  tile-blocked, 1 KiB per tile; same for m, v
 //   b1 [Hp], b2 [Op]; workspaces P (split-K partials), Dd, dZ, dA: [64][Hp|Op] per sub-net
 // Padded rows/columns are zero and provably stay zero under Adam (g=0, m=v=0 -> dw=0).
+//
+// Kernels (one optimiser step = RED -> MF -> MB -> B1F1; see DESIGN.md section 2 for measurements):
+//   k_gather_lds / k_gather   device gather of X_k, Y_k from the shared log1p matrix
+//   k_init_weights            Glorot-uniform Philox init into the blocked layouts
+//   k_fwd1                    split-K first layer (first step of an epoch, single-step API)
+//   k_reduce_act     RED      sum of split-K partials + bias + ReLU + Philox dropout -> Dd
+//   k_mid_fwd        MF       second layer, softplus, wMSE, dZ, Adam(b2)
+//   k_mid_bwd        MB       W2 gradient + Adam in registers, dD with the old W2, dA, Adam(b1)
+//   k_w1_update_fwd_ring      B1F1 for H = 256: W1 gradient + Adam in registers + next step's split-K
+//                             forward; 16 waves, LDS-staged X tiles, three-set register ring
+//   k_w1_update_fwd_sh        the same with a two-set ring (kept as DIMN_B1F1=2 for A/B measurements)
+//   k_w1_update_fwd           B1F1 for any H (8 independent waves, wave-private staging, no barrier)
+//   k_predict                 fused forward for model.predict and the validation loss
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

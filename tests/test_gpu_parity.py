@@ -102,6 +102,16 @@ def test_fit_early_stopping_matches_oracle():
     np.testing.assert_allclose(la, lb, rtol=2e-4)
 
 
+def test_wide_matrix_uses_fallback_gather():
+    """g*4 bytes > the LDS budget of k_gather_lds -> the per-sub-net gather kernel; same numbers."""
+    prob = make_problem(n=70, g=40000, Ds=[120, 90], H=32, O=32, seed=17)
+    a = load_problem(_hip(), prob, seed=2)
+    b = load_problem(_oracle(), prob, seed=2)
+    a.init_weights(); b.init_weights()
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(a.train_epoch(0), b.train_epoch(0), rtol=1e-4)
+
+
 def test_error_paths_are_loud():
     from deepimpute_amd.engine import DimnError
     Hip = _hip()
@@ -119,6 +129,13 @@ def test_error_paths_are_loud():
         e.train_epoch(0)                          # no split
     with pytest.raises(DimnError):
         e.train_step(np.array([99], np.int32))    # row out of range
+    with pytest.raises(DimnError):
+        e.set_split(np.array([0, 1, 8], np.int32), np.array([2], np.int32))   # row 8 of an 8-row matrix
+    e.set_split(np.arange(6), np.array([6, 7]))
+    e.set_matrix(np.ones((4, 20), np.float32))    # a smaller matrix invalidates the old split
+    e.gather(True)
+    with pytest.raises(DimnError):
+        e.train_epoch(0)
 
 
 def test_abs_corrcoef_matches_numpy_and_selects_same_predictors():
