@@ -906,7 +906,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
 template <int NT2>
 struct W1Set { f32x4 w[NT2], m[NT2], v[NT2]; f32x4 x; };
 
-template <int WAVES, int NT2>
+template <int WAVES, int NT2, int DEPTH = 3>   // DEPTH named register sets = DEPTH-1 chunks in flight
 __global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_ring(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
                                                                   const float* __restrict__ X, float* __restrict__ W1,
                                                                   float* __restrict__ M1, float* __restrict__ V1,
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_ring(const Work* _
     // `nx2` receives the loads of chunk c+2
     auto step = [&](W1Set<NT2>& cur, W1Set<NT2>& nx1, W1Set<NT2>& nx2, int c) {
         const int par = (c - wk.c0) & 1;
-        fetch(nx2, c + 2);
+        fetch(nx2, c + DEPTH - 1);                            // nx2 = the set that is free again (chunk c-1's)
         __builtin_amdgcn_sched_barrier(0);
         const float* xt = sm + par * XT;
         f32x4 g[NT2];
@@ -1007,9 +1007,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_ring(const Work* _
         __syncthreads();
     };
 
-    W1Set<NT2> A, B, C;
+    W1Set<NT2> A, B, C, D4;
     fetch(A, wk.c0);
     fetch(B, wk.c0 + 1);
+    if (DEPTH == 4) fetch(C, wk.c0 + 2);
     *(f32x4*)(sm + sdst) = svalid ? A.x : zero4;
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb)
@@ -1024,14 +1025,29 @@ __global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_ring(const Work* _
     __syncthreads();
 
     int c = wk.c0;
-    for (; c + 3 <= wk.c1; c += 3) {                       // full triples: no conditional memory op inside
-        step(A, B, C, c);
-        step(B, C, A, c + 1);
-        step(C, A, B, c + 2);
-    }
-    if (c < wk.c1) {                                       // 1 or 2 chunks left
-        step(A, B, C, c);
-        if (c + 1 < wk.c1) step(B, C, A, c + 1);
+    if (DEPTH == 4) {
+        asm volatile("" : "+v"(C.x));
+        for (; c + 4 <= wk.c1; c += 4) {                   // full groups: no conditional memory op inside
+            step(A, B, D4, c);
+            step(B, C, A, c + 1);
+            step(C, D4, B, c + 2);
+            step(D4, A, C, c + 3);
+        }
+        if (c < wk.c1) {                                   // 1..3 chunks left
+            step(A, B, D4, c);
+            if (c + 1 < wk.c1) step(B, C, A, c + 1);
+            if (c + 2 < wk.c1) step(C, D4, B, c + 2);
+        }
+    } else {
+        for (; c + 3 <= wk.c1; c += 3) {                   // full triples: no conditional memory op inside
+            step(A, B, C, c);
+            step(B, C, A, c + 1);
+            step(C, A, B, c + 2);
+        }
+        if (c < wk.c1) {                                   // 1 or 2 chunks left
+            step(A, B, C, c);
+            if (c + 1 < wk.c1) step(B, C, A, c + 1);
+        }
     }
     if (have_next) {
         float* p = P + (int64_t)wk.slot * DIMN_TB * Hp;
