@@ -297,9 +297,25 @@ def main():
     comm = None
     if world > 1:
         rdzv = FileRendezvous(rank, world)
-        uid = eng.comm_unique_id().tobytes() if rank == 0 else None
+        sys.stdout.flush()
+        saved0 = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            uid = eng.comm_unique_id().tobytes() if rank == 0 else None
+        finally:
+            os.dup2(saved0, 1)
+            os.close(saved0)
         uid = rdzv.broadcast_bytes("uid", uid)
-        eng.comm_init(np.frombuffer(uid, np.uint8), world, rank)
+        # RCCL prints a version banner on stdout at init; stdout must carry exactly one JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            eng.comm_init(np.frombuffer(uid, np.uint8), world, rank)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         comm = True
 
     def barrier():
