@@ -1,0 +1,84 @@
+"""Thread-pool helpers for the host-side planning around the GPU path.
+
+The reference does its planning (per-gene statistics, log1p, predictor selection, post-processing of the
+predictions; deepimpute/multinet.py:20-34, 191-216, 282-310) with whole-matrix pandas/numpy calls on one
+core.  Every one of those is independent per gene column or per cell row, so here the SAME pandas/numpy
+routine runs on column / row blocks from a thread pool (numpy releases the GIL inside its loops): the
+per-element arithmetic -- and therefore every value, to the bit -- is what the whole-matrix call gives
+(tests/test_shell.py checks that), only the wall time changes.  Nothing here touches the GPU.
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pandas as pd
+
+
+def n_workers():
+    n = int(os.environ.get("DIMN_HOST_THREADS", "0") or 0)
+    if n <= 0:
+        n = min(32, os.cpu_count() or 1)
+    return max(1, n)
+
+
+def spans(total, block):
+    """[(start, stop)] covering range(total) in pieces of `block`."""
+    block = max(1, int(block))
+    return [(a, min(a + block, total)) for a in range(0, total, block)]
+
+
+def pmap(fn, items):
+    """[fn(x) for x in items], evaluated on the pool, results in order."""
+    items = list(items)
+    if len(items) <= 1 or n_workers() == 1:
+        return [fn(x) for x in items]
+    with ThreadPoolExecutor(n_workers()) as pool:
+        return list(pool.map(fn, items))
+
+
+def _block_for(frame_or_shape, axis, target_bytes=32 << 20):
+    shape = getattr(frame_or_shape, "shape", frame_or_shape)
+    other = shape[1 - axis]
+    return max(16, int(target_bytes // max(1, 8 * other)))
+
+
+def column_var_mean(frame):
+    """(frame.var(), frame.mean()) -- pandas' own reductions on column blocks."""
+    def one(ab):
+        part = frame.iloc[:, ab[0]:ab[1]]
+        return part.var(), part.mean()
+    parts = pmap(one, spans(frame.shape[1], _block_for(frame, 1)))
+    if not parts:
+        return frame.var(), frame.mean()
+    return pd.concat([p[0] for p in parts]), pd.concat([p[1] for p in parts])
+
+
+def log1p_float32(frame):
+    """np.log1p(frame).astype(np.float32) as a frame (multinet.py:216), by row blocks."""
+    values = frame.values
+    out = np.empty(values.shape, np.float32)
+
+    def one(ab):
+        out[ab[0]:ab[1]] = np.log1p(values[ab[0]:ab[1]])      # log1p in the input dtype, then the cast
+    pmap(one, spans(values.shape[0], _block_for(values, 0)))
+    return pd.DataFrame(out, index=frame.index, columns=frame.columns, copy=False)
+
+
+def zero_nans_inplace(square):
+    """square[np.isnan(square)] = 0 by row blocks (== DataFrame.fillna(0) on a float matrix)."""
+    def one(ab):
+        part = square[ab[0]:ab[1]]
+        part[np.isnan(part)] = 0
+    pmap(one, spans(square.shape[0], _block_for(square, 0)))
+    return square
+
+
+def take_columns(values, positions):
+    """values[:, positions] (a C-ordered copy) by row blocks."""
+    positions = np.asarray(positions)
+    out = np.empty((values.shape[0], len(positions)), values.dtype)
+
+    def one(ab):
+        np.take(values[ab[0]:ab[1]], positions, axis=1, out=out[ab[0]:ab[1]])
+    pmap(one, spans(values.shape[0], _block_for(out, 0)))
+    return out

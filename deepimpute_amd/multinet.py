@@ -28,10 +28,13 @@ import numpy as np
 import pandas as pd
 from scipy.stats import pearsonr
 
+from . import _hostpar
+
 # one scratch directory per process, shared by every instance that does not pass its own
 # (the reference evaluates tempfile.mkdtemp() once, as a default argument: multinet.py:74)
 _SCRATCH = tempfile.mkdtemp()
 _VALIDATION_FRACTION = 0.05     # multinet.py:228
+_POST_ROWS = 256                # cells per host-pool task in predict()'s post-processing
 
 
 # --------------------------------------------------------------------------- module functions
@@ -60,20 +63,26 @@ def _abs_corrcoef(values, backend="auto", device_id=0):
         return np.abs(np.corrcoef(values.T))
 
 
-def get_distance_matrix(raw, n_pred=None, backend="auto", device_id=0):
+def get_distance_matrix(raw, n_pred=None, backend="auto", device_id=0, _var_mean=None):
     """Absolute Pearson correlation between candidate predictor genes (multinet.py:20-34).
     Candidates: genes with std/mean > 0, or the `n_pred` genes with the largest ratio.  The g x g
-    float64 correlation itself runs on the GPU when one is visible (`backend`, see _abs_corrcoef)."""
-    ratio = raw.std() / raw.mean()
+    float64 correlation itself runs on the GPU when one is visible (`backend`, see _abs_corrcoef).
+    `_var_mean`: (raw.var(), raw.mean()) when the caller already holds them (std = sqrt(var), as in
+    pandas)."""
+    var, mean = _var_mean if _var_mean is not None else _hostpar.column_var_mean(raw)
+    ratio = np.sqrt(var) / mean
     ratio[np.isinf(ratio)] = 0
     if n_pred is None:
         keep = raw.columns[ratio > 0]
     else:
         print("Using {} predictors".format(n_pred))
         keep = ratio.sort_values(ascending=False).index[:n_pred]
-    corr = _abs_corrcoef(raw.loc[:, keep].values, backend=backend, device_id=device_id)
-    table = pd.DataFrame(corr, index=keep, columns=keep)
-    return table.fillna(0)
+    if keep.equals(raw.columns):
+        candidates = raw.values
+    else:
+        candidates = _hostpar.take_columns(raw.values, raw.columns.get_indexer(keep))
+    corr = _abs_corrcoef(candidates, backend=backend, device_id=device_id)
+    return pd.DataFrame(_hostpar.zero_nans_inplace(corr), index=keep, columns=keep, copy=False)   # .fillna(0)
 
 
 def wMSE(y_true, y_pred, binary=False):
@@ -227,19 +236,22 @@ class MultiNet:
             raw = raw.sample(frac=cell_subset) if cell_subset < 1 else raw.sample(int(cell_subset))
 
         # variance over (1 + mean), most variable first, strictly positive (multinet.py:191-192)
-        gene_metric = (raw.var() / (1 + raw.mean())).sort_values(ascending=False)
+        var, mean = _hostpar.column_var_mean(raw)
+        gene_metric = (var / (1 + mean)).sort_values(ascending=False)
         gene_metric = gene_metric[gene_metric > 0]
         if genes_to_impute is None:
             genes_to_impute = self.filter_genes(gene_metric, minVMR, NN_lim=NN_lim)
         else:
             genes_to_impute = self._pad_gene_list(genes_to_impute, gene_metric)
 
-        correlations = get_distance_matrix(raw, n_pred=n_pred, device_id=self.device_id)
-        self.setTargets(raw.reindex(columns=genes_to_impute), mode=mode)
+        correlations = get_distance_matrix(raw, n_pred=n_pred, device_id=self.device_id, _var_mean=(var, mean))
+        # setTargets only looks at the column labels; the reference hands it raw.reindex(columns=...),
+        # a full copy of the matrix (multinet.py:212) -- an empty frame has the same labels
+        self.setTargets(pd.DataFrame(columns=pd.Index(genes_to_impute)), mode=mode)
         self.setPredictors(correlations, ntop=ntop)
 
         print("Normalization")
-        norm_data = np.log1p(raw).astype(np.float32)
+        norm_data = _hostpar.log1p_float32(raw)
         np.random.seed(self.seed)                      # second seeding, multinet.py:219
 
         print("Building network")
@@ -335,7 +347,8 @@ class MultiNet:
         guess = self._predict_block(engine, rows_val)
         if guess is None:                     # sharded job: only rank 0 holds the gathered block
             return None
-        truth = np.hstack([norm_data.loc[held_out, genes].values for genes in self.targets]).flatten()
+        table, where = norm_data.values, norm_data.columns
+        truth = np.hstack([table[np.ix_(rows_val, where.get_indexer(genes))] for genes in self.targets]).flatten()
         guess = guess.flatten()
         positive = truth > 0
         truth, guess = truth[positive], guess[positive]
@@ -344,10 +357,9 @@ class MultiNet:
 
     # -- predict: forward on the GPU, post-processing as multinet.py:282-310 --
     def predict(self, raw, imputed_only=False, policy="restore"):
-        norm_raw = np.log1p(raw)
         engine = self.load()
-        engine.set_matrix(norm_raw.values.astype(np.float32))
-        self._bind_columns(engine, norm_raw.columns)
+        engine.set_matrix(_hostpar.log1p_float32(raw).values)     # float32(log1p(raw)): what Keras is fed
+        self._bind_columns(engine, raw.columns)
         engine.gather(False)
         block = self._predict_block(engine)              # [cells, K*O], np.hstack of the K outputs
         if block is None:
@@ -357,27 +369,44 @@ class MultiNet:
         # like the reference's groupby(columns).mean() (multinet.py:282-284)
         slots = self.targets.flatten()
         genes, slot_gene = np.unique(slots, return_inverse=True)
-        acc = np.zeros((len(genes), block.shape[0]), dtype=np.float32)
-        np.add.at(acc, slot_gene, block.T)
-        acc /= np.bincount(slot_gene, minlength=len(genes)).astype(np.float32)[:, None]
-
-        # the reference concatenates predicted and untouched genes and re-orders them to raw's layout
-        # (multinet.py:285-289); writing the averaged columns into a copy of log1p(raw) is the same matrix
-        values = np.array(norm_raw.values, dtype=np.float64)
-        values[:, pd.Index(raw.columns).get_indexer(genes)] = acc.T
-        ceiling = 2 * norm_raw.values.max()              # overflow guard, multinet.py:292
-        values[(values > ceiling) | np.isnan(values)] = 0
-        values = np.expm1(values)                        # back to counts
-
-        observed = raw.values
+        per_gene = np.bincount(slot_gene, minlength=len(genes)).astype(np.float32)
+        first_slot = np.full(len(genes), -1, np.int64)
+        first_slot[slot_gene[::-1]] = np.arange(len(slots) - 1, -1, -1)     # lowest slot of each gene
+        later = np.flatnonzero(first_slot[slot_gene] != np.arange(len(slots)))   # the repeats, ascending
+        where = pd.Index(raw.columns).get_indexer(genes)
         if policy == "restore":
             print("Filling zeros")
-            keep_raw = observed > 0
-            values[keep_raw] = observed[keep_raw]
         elif policy == "max":
             print("Imputing data with 'max' policy")
-            keep_raw = observed > values
-            values[keep_raw] = observed[keep_raw]
+
+        # the reference concatenates predicted and untouched genes and re-orders them to raw's layout
+        # (multinet.py:285-289); writing the averaged columns into a copy of log1p(raw) is the same
+        # matrix.  Every step below is per cell, so it runs on row blocks from the host pool.
+        observed = raw.values
+        ceiling = 2 * np.log1p(observed.max())           # overflow guard, multinet.py:292 (log1p is monotonic)
+        values = np.empty(observed.shape, dtype=np.float64)
+        untouched = len(where) < observed.shape[1]       # genes no sub-network predicts keep log1p(raw)
+
+        def finish(ab):
+            part = block[ab[0]:ab[1]]
+            acc = part[:, first_slot]                    # float32 sums in slot order, as np.add.at would
+            for s in later:
+                acc[:, slot_gene[s]] += part[:, s]
+            acc /= per_gene
+            v = values[ab[0]:ab[1]]
+            if untouched:
+                v[...] = np.log1p(observed[ab[0]:ab[1]])
+            v[:, where] = acc
+            v[(v > ceiling) | np.isnan(v)] = 0
+            np.expm1(v, out=v)                           # back to counts
+            seen = observed[ab[0]:ab[1]]
+            if policy == "restore":
+                keep_raw = seen > 0
+                v[keep_raw] = seen[keep_raw]
+            elif policy == "max":
+                keep_raw = seen > v
+                v[keep_raw] = seen[keep_raw]
+        _hostpar.pmap(finish, _hostpar.spans(len(values), _POST_ROWS))
 
         imputed = pd.DataFrame(values, index=raw.index, columns=raw.columns)
         return imputed.loc[:, genes] if imputed_only else imputed
@@ -411,17 +440,22 @@ class MultiNet:
         whenever the correlations involved are distinct."""
         pool = covariance_matrix.columns
         table = covariance_matrix.values               # g x g float64; indexed by position below (pandas .loc
-        self.predictors = []                           # on a 20k x 20k frame costs seconds per sub-network)
-        for net, targets in enumerate(self.targets):
-            outside = np.setdiff1d(pool, targets)      # label-sorted, as in the reference
-            if outside.size == 0:
-                warnings.warn('Warning: number of target genes lower than output dim. '
-                              'Consider lowering down the sub_outputdim parameter', UserWarning)
-                outside = np.asarray(pool)
-            rows, cols = pool.get_indexer(targets), pool.get_indexer(outside)
+                                                       # on a 20k x 20k frame costs seconds per sub-network)
+        by_label = np.argsort(pool.values, kind="stable")   # np.setdiff1d(pool, targets) is label-sorted
+        if not pool.is_unique:
+            by_label = by_label[np.unique(pool.values[by_label], return_index=True)[1]]
+
+        def plan(targets):
+            rows = pool.get_indexer(targets)
             if (rows < 0).any():
                 missing = [t for t, r in zip(targets, rows) if r < 0]
                 raise KeyError("{} not in index".format(missing[:5]))     # what .loc raises in the reference
+            inside = np.zeros(len(pool), bool)
+            inside[rows] = True
+            cols = by_label[~inside[by_label]]         # positions of setdiff1d(pool, targets), same order
+            starved = cols.size == 0
+            if starved:
+                cols = np.arange(len(pool))
             scores = table[np.ix_(rows, cols)]
             width = min(ntop, scores.shape[1])
             if width < scores.shape[1]:
@@ -430,9 +464,16 @@ class MultiNet:
                 cand = np.broadcast_to(np.arange(scores.shape[1]), scores.shape).copy()
             rank = np.argsort(-np.take_along_axis(scores, cand, axis=1), axis=1, kind="stable")
             best = np.take_along_axis(cand, rank, axis=1)
-            picked = pd.Index(outside)[best.flatten()]
-            self.predictors.append(picked.unique())
-            print("Net {}: {} predictors, {} targets".format(net, len(np.unique(picked)), len(targets)))
+            return pool[pd.unique(cols[best.flatten()])], starved     # first-occurrence order
+
+        # the sub-networks are independent: plan them on the host pool, report in order
+        self.predictors = []
+        for net, (chosen, starved) in enumerate(_hostpar.pmap(plan, self.targets)):
+            if starved:
+                warnings.warn('Warning: number of target genes lower than output dim. '
+                              'Consider lowering down the sub_outputdim parameter', UserWarning)
+            self.predictors.append(chosen)
+            print("Net {}: {} predictors, {} targets".format(net, len(chosen), len(self.targets[net])))
 
     def score(self, data, policy=None):
         warnings.warn("This method is deprecated. Please use model.test_metrics to measure model accuracy instead",

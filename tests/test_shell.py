@@ -197,3 +197,40 @@ def test_distance_matrix_backends_without_gpu():
     env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1", PYTHONPATH=root)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout
     assert "LOUD" in out, out
+
+
+def test_host_pool_blocks_are_bit_identical(monkeypatch):
+    """The host pool runs the reference's own pandas/numpy calls on column / row blocks: every value must
+    be what the whole-matrix call gives, to the bit (so the plan -- gene order, predictors -- is the same)."""
+    from deepimpute_amd import _hostpar
+    monkeypatch.setenv("DIMN_HOST_THREADS", "4")
+    monkeypatch.setattr(_hostpar, "_block_for", lambda *a, **k: 16)
+    rng = np.random.default_rng(5)
+    v = rng.poisson(rng.gamma(0.4, 4.0, size=(1, 75)), size=(301, 75)).astype(np.float64)
+    v[:, 3] = 0.0                                          # a constant gene: std/mean = nan
+    for dtype in (np.float64, np.float32, np.int64):
+        raw = pd.DataFrame(v.astype(dtype), index=["c%d" % i for i in range(301)], columns=["g%d" % j for j in range(75)])
+        var, mean = _hostpar.column_var_mean(raw)
+        assert var.index.equals(raw.var().index)
+        assert np.array_equal(var.values, raw.var().values, equal_nan=True)
+        assert np.array_equal(mean.values, raw.mean().values, equal_nan=True)
+        assert np.array_equal(np.sqrt(var).values, raw.std().values, equal_nan=True)
+        got, want = _hostpar.log1p_float32(raw), np.log1p(raw).astype(np.float32)
+        assert got.values.dtype == np.float32 and np.array_equal(got.values, want.values)
+        assert got.index.equals(raw.index) and got.columns.equals(raw.columns)
+    pos = rng.permutation(75)[:40]
+    assert np.array_equal(_hostpar.take_columns(v, pos), v[:, pos])
+    sq = rng.normal(size=(70, 70)); sq[rng.random((70, 70)) < 0.1] = np.nan
+    assert np.array_equal(_hostpar.zero_nans_inplace(sq.copy()), pd.DataFrame(sq).fillna(0).values)
+
+
+def test_predict_row_blocks_do_not_change_the_result(monkeypatch):
+    from deepimpute_amd import multinet as mn
+    raw = _raw("default64")
+    net = MultiNet(engine_factory=FakeEngine, seed=123, sub_outputdim=64, ncores=1, verbose=0)
+    net.fit(raw)
+    whole = {p: net.predict(raw, policy=p).values for p in ("restore", "max", None)}
+    monkeypatch.setattr(mn, "_POST_ROWS", 7)
+    monkeypatch.setenv("DIMN_HOST_THREADS", "3")
+    for p, want in whole.items():
+        assert np.array_equal(net.predict(raw, policy=p).values, want, equal_nan=True)

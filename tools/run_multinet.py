@@ -24,16 +24,21 @@ def main():
     counts = np.expm1(bench.synth_counts(args.cells, args.genes, seed=0)).round()
     raw = pd.DataFrame(counts, index=["c%d" % i for i in range(args.cells)], columns=["g%d" % j for j in range(args.genes)])
     marks = {}
-    for name in ("get_distance_matrix",):
-        fn = getattr(multinet, name)
-        def timed(*a, _fn=fn, _name=name, **k):
-            t = time.time(); out = _fn(*a, **k); marks[_name] = time.time() - t; return out
-        setattr(multinet, name, timed)
+
+    def clock(owner, name, label=None):
+        fn = getattr(owner, name)
+        def timed(*a, **k):
+            t = time.time(); out = fn(*a, **k); marks[label or name] = marks.get(label or name, 0.0) + time.time() - t; return out
+        setattr(owner, name, timed)
+
+    from deepimpute_amd import _hostpar, engine as eng_mod
+    clock(multinet, "get_distance_matrix"); clock(multinet, "_abs_corrcoef"); clock(multinet, "inspect_data")
+    for name in ("column_var_mean", "log1p_float32", "zero_nans_inplace", "take_columns"):
+        clock(_hostpar, name)
+    for name in ("set_matrix", "gather", "fit", "predict", "get_weights", "init_weights"):
+        clock(eng_mod.HipEngine, name, "engine." + name)
     net = multinet.MultiNet(verbose=0, max_epochs=args.max_epochs)
-    orig_sp = net.setPredictors
-    def sp(*a, **k):
-        t = time.time(); out = orig_sp(*a, **k); marks["setPredictors"] = time.time() - t; return out
-    net.setPredictors = sp
+    clock(net, "setPredictors"); clock(net, "save"); clock(net, "_held_out_metrics")
     t0 = time.time()
     net.fit(raw, NN_lim=args.genes)
     t_fit = time.time() - t0
@@ -41,8 +46,8 @@ def main():
     out = net.predict(raw)
     t_pred = time.time() - t0
     print("cells=%d genes=%d K=%d epochs=%d" % (args.cells, args.genes, len(net.predictors), net.trained_epochs))
-    print("fit total %.2fs (corr matrix %.2fs, setPredictors %.2fs)  predict total %.2fs" %
-          (t_fit, marks.get("get_distance_matrix", 0), marks.get("setPredictors", 0), t_pred))
+    print("fit total %.2fs  predict total %.2fs" % (t_fit, t_pred))
+    print("  " + "  ".join("%s %.2f" % kv for kv in sorted(marks.items(), key=lambda kv: -kv[1])))
     print("test_metrics", net.test_metrics, "val_loss first/last %.4f %.4f" % (net.history["val_loss"][0], net.history["val_loss"][-1]))
     print("cells/s end to end (drop-in, incl. host planning): %.1f" % (args.cells / (t_fit + t_pred)))
     assert out.shape == raw.shape
