@@ -97,6 +97,9 @@ struct dimn_handle_s {
     int ncu = 256;
     std::vector<SubnetDev> sn;
     std::vector<Work> work;
+    std::vector<MidWork> midwork;          // work table of the fused second-layer kernel (k_mid_fused)
+    int mid_fused = 0, mid_slices = 0;     // 1: RED -> MFB -> RED2 -> B1F1; 0: RED -> MF -> MB -> B1F1
+    MidWork* d_midwork = nullptr; int32_t* d_midk = nullptr; float* d_P2 = nullptr;
     std::vector<std::vector<int32_t>> pred, targ;
     int nslots = 0;
     int64_t w1_total = 0, x_total = 0, y_total = 0;
@@ -197,6 +200,29 @@ static void build_work(dimn_handle h) {
     h->nslots = slot;
 }
 
+static void build_mid(dimn_handle h) {
+    // Fused second layer (H = 256): every sub-net's OT output tiles are cut into S slices, S*K <= ncu so that
+    // each CU runs exactly one workgroup; a slice holds at most DIMN_MID_TMAX tiles (LDS) and a sub-net at
+    // most OS slices (loss slots).  DIMN_MID=0 keeps the two-kernel path (MF + MB).
+    const Dims& dm = h->dm;
+    h->mid_fused = 0;
+    if (dm.HT != 16) return;
+    if (const char* e = getenv("DIMN_MID")) { if (atoi(e) == 0) return; }
+    int S = std::max(1, std::min(h->ncu / std::max(1, h->K), std::min((int)dm.OS, (int)dm.OT)));
+    S = std::max(S, ceil_div(dm.OT, DIMN_MID_TMAX));
+    if (S > dm.OS || S > dm.OT) return;
+    h->mid_slices = S;
+    h->midwork.clear();
+    int slot = 0;
+    for (int k = 0; k < h->K; ++k)
+        for (int i = 0; i < S; ++i) {
+            MidWork m;
+            m.k = k; m.ot0 = dm.OT * i / S; m.ot1 = dm.OT * (i + 1) / S; m.slot = slot++; m.sidx = i;
+            h->midwork.push_back(m);
+        }
+    h->mid_fused = 1;
+}
+
 extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle* out) {
     if (!cfg || !D || !out) return fail(DIMN_ERR_ARG, "dimn_create: null argument");
     if (cfg->n_subnets < 1 || cfg->hidden < 1 || cfg->out_dim < 1)
@@ -260,6 +286,7 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     }
     h->w1_total = w1;
     build_work(h);
+    build_mid(h);
     // Sub-net lanes: independent sub-net groups on concurrent streams.  Default 1: with 2 lanes the
     // end-to-end rate is ~9 % higher on cfg3 (one lane's latency-bound kernels hide under the other's
     // weight update) but the two HBM-bound weight updates then share the bandwidth, which halves the
@@ -296,12 +323,26 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     TRY(dev_alloc(&h->d_loss_acc, (size_t)h->K * dm.OS));
     TRY(dev_alloc(&h->d_mask, (size_t)h->K * DIMN_TB * dm.Hp));
     TRY(dev_alloc(&h->d_rows_step, (size_t)DIMN_TB));
+    if (h->mid_fused) {
+        std::vector<int32_t> midk((size_t)2 * h->K);
+        for (int k = 0; k < h->K; ++k) { midk[2 * k] = k * h->mid_slices; midk[2 * k + 1] = h->mid_slices; }
+        TRY(dev_alloc(&h->d_midwork, h->midwork.size()));
+        TRY(dev_alloc(&h->d_midk, midk.size()));
+        TRY(dev_alloc(&h->d_P2, h->midwork.size() * DIMN_TB * dm.Hp));
+        if (hipMemcpy(h->d_midwork, h->midwork.data(), h->midwork.size() * sizeof(MidWork), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->d_midk, midk.data(), midk.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            dimn_destroy(h);
+            return fail(DIMN_ERR_HIP, "dimn_create: descriptor upload failed");
+        }
+        (void)hipFuncSetAttribute((const void*)k_mid_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     auto zero = [&](void* p, size_t bytes) { return hipMemset(p, 0, bytes) == hipSuccess ? 0 : fail(DIMN_ERR_HIP, "hipMemset failed"); };
     TRY(zero(h->d_W1, w1 * 4)); TRY(zero(h->d_M1, w1 * 4)); TRY(zero(h->d_V1, w1 * 4));
     TRY(zero(h->d_W2, w2n * 4)); TRY(zero(h->d_M2, w2n * 4)); TRY(zero(h->d_V2, w2n * 4));
     TRY(zero(h->d_b1, (size_t)3 * h->K * dm.Hp * 4)); TRY(zero(h->d_b2, (size_t)3 * h->K * dm.Op * 4));
     TRY(zero(h->d_Dd, (size_t)h->K * DIMN_TB * dm.Hp * 4)); TRY(zero(h->d_dA, (size_t)h->K * DIMN_TB * dm.Hp * 4));
     TRY(zero(h->d_dZ, (size_t)h->K * DIMN_TB * dm.Op * 4));
+    TRY(zero(h->d_loss_step, (size_t)h->K * dm.OS * 4)); TRY(zero(h->d_loss_acc, (size_t)h->K * dm.OS * 8));
     if (hipMemcpy(h->d_work, h->work.data(), h->work.size() * sizeof(Work), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->d_sn, h->sn.data(), h->sn.size() * sizeof(SubnetDev), hipMemcpyHostToDevice) != hipSuccess) {
         dimn_destroy(h);
@@ -323,6 +364,7 @@ extern "C" int dimn_destroy(dimn_handle h) {
     DEV_FREE(h->d_W1); DEV_FREE(h->d_M1); DEV_FREE(h->d_V1); DEV_FREE(h->d_W2); DEV_FREE(h->d_M2); DEV_FREE(h->d_V2);
     DEV_FREE(h->d_b1); DEV_FREE(h->d_b2); DEV_FREE(h->d_P); DEV_FREE(h->d_Dd); DEV_FREE(h->d_dZ); DEV_FREE(h->d_dA);
     DEV_FREE(h->d_loss_step); DEV_FREE(h->d_loss_acc); DEV_FREE(h->d_mask); DEV_FREE(h->d_rows_step);
+    DEV_FREE(h->d_midwork); DEV_FREE(h->d_midk); DEV_FREE(h->d_P2);
     DEV_FREE(h->d_epoch_rows); DEV_FREE(h->d_val_rows); DEV_FREE(h->d_pred_rows); DEV_FREE(h->d_out);
     DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage);
     for (auto& ln : h->lanes) (void)hipStreamDestroy(ln.stream);
@@ -625,6 +667,15 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     if (need_fwd) { DISPATCH_NT(launch_fwd1, h, ln, d_rows, b_act); }
     hipLaunchKernelGGL(k_reduce_act, dim3((unsigned)ceil_div(DIMN_TB * dm.Hp, 1024), nk), dim3(256), 0, st, h->d_sn, h->d_P, h->d_b1, d_mask,
                        h->d_Dd, dm, b_act, rate, scale, h->cfg.seed, epoch_key, step_key, ln.k0);
+    if (h->mid_fused) {
+        // RED -> MFB (whole second layer, W2 streamed once) -> RED2 (dD partials -> dA, Adam(b1))
+        const size_t lds = ((size_t)DIMN_TB * dm.ldd + DIMN_MID_TMAX * 1024 + 8 * 1024 + 8) * sizeof(float);
+        hipLaunchKernelGGL(k_mid_fused, dim3(nk * (unsigned)h->mid_slices), dim3(512), lds, st, h->d_midwork + (size_t)ln.k0 * h->mid_slices,
+                           h->d_W2, h->d_M2, h->d_V2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_P2,
+                           h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary);
+        hipLaunchKernelGGL(k_reduce_dd, dim3((unsigned)ceil_div(dm.Hp, 64), nk), dim3(256), 0, st, h->d_midk, h->d_P2, h->d_Dd,
+                           h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, ln.k0);
+    } else {
     {
         const dim3 grid((unsigned)dm.OS, nk);
         const size_t lds = (size_t)DIMN_TB * dm.ldd * sizeof(float);
@@ -639,6 +690,7 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     if (h->mb_waves == 8) { if (dm.OT == 8 * h->OTW) LAUNCH_MB(true, 8); else LAUNCH_MB(false, 8); }
     else { if (dm.OT == 4 * h->OTW) LAUNCH_MB(true, 4); else LAUNCH_MB(false, 4); }
 #undef LAUNCH_MB
+    }
     if (timed) (void)hipEventRecord(e1, st);
     DISPATCH_NT2(launch_w1, h, ln, d_rows, b_act, d_rows_n, b_next, ap);
     if (timed) (void)hipEventRecord(e2, st);

@@ -593,6 +593,274 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 3 : (WV == 16 ? 4 : 2)) void k_m
 }
 
 // ---------------------------------------------------------------------------------------
+// MFB: the whole second layer in ONE pass over W2 (H = 256 only: 8 waves x 2 hidden tiles).
+// Workgroup = (sub-net k, output tiles [ot0, ot1)), one workgroup per CU (<= ncu items, T = ot1-ot0 <= 8).
+// wMSE is element-wise, so dZ of an output slice needs only Z of that slice:
+//   phase 1  wave = one output tile: Z = Dd W2[:,tile] + b2 ; softplus ; wMSE ; dZ -> LDS ; gb2 -> Adam(b2)
+//   phase 2  per output tile: gW2^T = dZ^T Dd -> Adam on W2/m/v in registers ; dD[:, 32 h of this wave] += dZ W2old^T
+//   epilogue the slice's dD partial [64][Hp] -> P2[slot]  (summed over the slices by k_reduce_dd)
+// vs MF + MB: W2 is streamed once (24 B/param, no separate 4 B/param forward read), dZ never goes to
+// memory, one launch instead of two, and the work table gives every CU one workgroup.
+// ---------------------------------------------------------------------------------------
+struct MidWork { int32_t k, ot0, ot1, slot, sidx; };   // slot: P2 partial; sidx: slice number inside the sub-net (loss slot)
+#define DIMN_MID_TMAX 8
+#ifdef DIMN_MID_TL   // tools/k_probe_mid.hip: per-wave phase stamps (shader clock)
+__device__ unsigned long long g_mid_tl[512 * 8 * 8];
+#define MID_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_mid_tl[(blockIdx.x * 8 + wave) * 8 + (i)] = t_; }
+#else
+#define MID_STAMP(i)
+#endif
+
+__global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ mwork,
+                                                   float* __restrict__ W2, float* __restrict__ M2, float* __restrict__ V2,
+                                                   float* __restrict__ b2w, float* __restrict__ b2m, float* __restrict__ b2v,
+                                                   const float* __restrict__ Y, int64_t n_cells,
+                                                   const int32_t* __restrict__ rows, int b_act,
+                                                   const float* __restrict__ Dd, float* __restrict__ P2,
+                                                   float* __restrict__ loss_step, double* __restrict__ loss_acc,
+                                                   Dims dm, AdamP ap, float inv_n, int loss_binary) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const MidWork mw = mwork[blockIdx.x];
+    const int k = mw.k, ot0 = mw.ot0, ot1 = mw.ot1, ot_last = mw.ot1 - 1;
+    const int Hp = dm.Hp, ldd = dm.ldd, OT = dm.OT, Op = dm.Op;
+    float* ddl = lds;                                        // Dd [64][ldd]
+    float* dzl = lds + DIMN_TB * ldd;                        // dZ tiles [T][64 b][16 o]
+    float* wsl = dzl + DIMN_MID_TMAX * 1024;                 // per-wave W2 transpose buffers [8][4 tiles]
+    float* lsl = wsl + 8 * 1024;                             // loss partials [8 waves]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    MID_STAMP(0)
+
+    // Loads are issued in the order they are needed (VMEM returns in order): batch rows, Dd, this wave's
+    // W2 column block and targets (phase 1), then the state of the first two output tiles (phase 2).
+    // All are 16-byte-per-lane, fully coalesced (47 requests per lane; dword-strided operand loads
+    // would be 119 and overflow the 6-bit vmcnt).
+    // phase 1: wave w -> output tile ot0 + w (all 64 batch rows), so every W2 column block is loaded once
+    // per workgroup; waves beyond the slice's tile count idle until phase 2.
+    const int ot1w = ot0 + wave;
+    const bool p1 = ot1w < ot1;
+    const int oc = p1 ? ot1w : ot_last;                      // clamped: loads stay in bounds
+    int rid[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int b = 16 * i + (lane >> 2); rid[i] = rows[b < b_act ? b : 0]; }
+    const float* ddk = Dd + (int64_t)k * DIMN_TB * Hp;
+    f32x4 ddv[8];                                            // 64 x 256 floats = 8 float4 per thread
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ddv[i] = *(const f32x4*)(ddk + tid * 4 + i * 2048);
+    f32x4 wt[16], yt[4];
+    const float* w2 = W2 + (int64_t)k * Hp * Op + (int64_t)oc * 256 + lane * 4;
+#pragma unroll
+    for (int ht = 0; ht < 16; ++ht) wt[ht] = *(const f32x4*)(w2 + (int64_t)ht * OT * 256);       // tile (ht, oc), natural layout
+#pragma unroll
+    for (int i = 0; i < 4; ++i) yt[i] = *(const f32x4*)(Y + ((int64_t)k * n_cells + rid[i]) * Op + 16 * oc + 4 * (lane & 3));
+    const int64_t bi = (int64_t)k * Op + 16 * oc + li;
+    float bias = b2w[bi], b2m0 = b2m[bi], b2v0 = b2v[bi];
+
+    struct Set { f32x4 w[2], m[2], v[2]; };
+    const int64_t tbase = (int64_t)k * Hp * Op + li * 16 + 4 * lj;
+    auto tidx = [&](int ht, int ot) { return tbase + ((int64_t)(2 * wave + ht) * OT + ot) * 256; };
+    auto fetch = [&](Set& st, int ot) {
+        const int o2 = ot < ot_last ? ot : ot_last;
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) { const int64_t i = tidx(ht, o2); st.w[ht] = *(const f32x4*)(W2 + i); st.m[ht] = *(const f32x4*)(M2 + i); st.v[ht] = *(const f32x4*)(V2 + i); }
+    };
+    Set A, B, C, D;                                          // four named sets: three tiles in flight
+    fetch(A, ot0);
+    fetch(B, ot0 + 1);
+    fetch(C, ot0 + 2);
+
+    // Dd[64][Hp] -> LDS (row stride ldd = 2 mod 32 words: conflict-free column reads)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid * 4 + i * 2048, b = e >> 8, h = e & 255;
+        *(float2*)(ddl + b * ldd + h) = make_float2(ddv[i][0], ddv[i][1]);
+        *(float2*)(ddl + b * ldd + h + 2) = make_float2(ddv[i][2], ddv[i][3]);
+    }
+    float* zb = dzl + wave * 1024;                           // this wave's [64 b][16 o] tile: targets first, dZ later
+    float* ws = wsl + wave * 1024;                           // this wave's W2 transpose buffer (4 tiles)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(f32x4*)(zb + (16 * i + (lane >> 2)) * 16 + 4 * (lane & 3)) = yt[i];
+    __syncthreads();
+    MID_STAMP(1)
+
+    float lsum = 0.f;
+    if (p1) {
+        float yv[4][4];
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yv[m4][r] = zb[(16 * m4 + 4 * lj + r) * 16 + li];
+        f32x4 acc[4] = {zero4, zero4, zero4, zero4};
+        const float* arow = ddl + li * ldd + lj;
+#pragma unroll
+        for (int rd = 0; rd < 4; ++rd) {                     // four hidden tiles per round through the wave-private buffer
+#pragma unroll
+            for (int t = 0; t < 4; ++t) *(f32x4*)(ws + t * 256 + lane * 4) = wt[4 * rd + t];
+            float bq[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bq[t][q] = ws[t * 256 + 64 * q + lane];              // W2[h = 16ht+4q+lj][o = li]
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int m4 = 0; m4 < 4; ++m4)
+                        acc[m4] = MFMA16(arow[16 * m4 * ldd + 16 * (4 * rd + t) + 4 * q], bq[t][q], acc[m4]);
+        }
+        const bool col_ok = (16 * oc + li) < dm.O;
+        float gb = 0.f;
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = 16 * m4 + 4 * lj + r;
+                float dz = 0.f;
+                if (b < b_act && col_ok) {
+                    const float z = acc[m4][r] + bias;
+                    const float y = yv[m4][r];
+                    const float w = loss_binary ? (y > 0.f ? 1.f : 0.f) : y;   // multinet.py:37-40
+                    float sp, sg;
+                    softplus_sigmoid_fast(z, sp, sg);
+                    const float e = y - sp;
+                    lsum += w * e * e;
+                    dz = -2.f * w * e * inv_n * sg;
+                }
+                zb[b * 16 + li] = dz;
+                gb += dz;
+            }
+        gb += __shfl_xor(gb, 16);                            // the wave holds all 64 rows of its 16 columns
+        gb += __shfl_xor(gb, 32);
+        if (lj == 0) {                                       // Adam(b2)
+            adam1(bias, b2m0, b2v0, gb, ap);
+            b2w[bi] = bias; b2m[bi] = b2m0; b2v[bi] = b2v0;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
+    }
+    if (lane == 0) lsl[wave] = lsum;
+    MID_STAMP(2)
+    __syncthreads();                                         // dZ tiles and loss partials are in LDS
+    MID_STAMP(3)
+    if (tid == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) tot += lsl[wv];
+        loss_step[k * dm.OS + mw.sidx] = tot;
+        if (loss_acc) loss_acc[k * dm.OS + mw.sidx] += (double)tot;
+    }
+
+    // ---- phase 2: wave w owns hidden tiles 2w, 2w+1 for every output tile of the slice ----
+    float ddf[16][2];    // B operand of gW2^T: Dd[b = 4kb+lj][h = 16(2w+ht)+li]
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) ddf[kb][ht] = ddl[(4 * kb + lj) * ldd + 16 * (2 * wave + ht) + li];
+    f32x4 dacc[4][2];
+#pragma unroll
+    for (int m4 = 0; m4 < 4; ++m4)
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) dacc[m4][ht] = zero4;
+
+    auto step = [&](Set& cur, Set& nx3, int ot) {
+        fetch(nx3, ot + 3);                                  // into the set the previous tile has just released
+        __builtin_amdgcn_sched_barrier(0);
+        const float* zb = dzl + (ot - ot0) * 1024;
+        f32x4 g[2] = {zero4, zero4};
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            const float az = zb[64 * kb + lane];                             // dZ^T[o = li][b = 4kb+lj]
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht) g[ht] = MFMA16(az, ddf[kb][ht], g[ht]);
+        }
+        f32x4 zf[4];
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) zf[m4] = *(const f32x4*)(zb + (16 * m4 + li) * 16 + 4 * lj);   // dZ[b][o = 4lj+r]
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m4 = 0; m4 < 4; ++m4) dacc[m4][ht] = MFMA16(zf[m4][r], cur.w[ht][r], dacc[m4][ht]);   // OLD W2
+            adam4(cur.w[ht], cur.m[ht], cur.v[ht], g[ht], ap);
+            const int64_t i = tidx(ht, ot);
+            *(f32x4*)(W2 + i) = cur.w[ht]; *(f32x4*)(M2 + i) = cur.m[ht]; *(f32x4*)(V2 + i) = cur.v[ht];
+        }
+    };
+#pragma unroll
+    for (int ht = 0; ht < 2; ++ht) {
+        asm volatile("" : "+v"(A.w[ht]), "+v"(A.m[ht]), "+v"(A.v[ht]));
+        asm volatile("" : "+v"(B.w[ht]), "+v"(B.m[ht]), "+v"(B.v[ht]));
+        asm volatile("" : "+v"(C.w[ht]), "+v"(C.m[ht]), "+v"(C.v[ht]));
+    }
+    MID_STAMP(4)
+    int ot = ot0;
+    for (; ot + 4 <= ot1; ot += 4) {
+        step(A, D, ot);
+        step(B, A, ot + 1);
+        step(C, B, ot + 2);
+        step(D, C, ot + 3);
+    }
+    if (ot < ot1) {
+        step(A, D, ot);
+        if (ot + 1 < ot1) step(B, A, ot + 1);
+        if (ot + 2 < ot1) step(C, B, ot + 2);
+    }
+    MID_STAMP(5)
+    float* p2 = P2 + (int64_t)mw.slot * DIMN_TB * Hp;
+#pragma unroll
+    for (int m4 = 0; m4 < 4; ++m4)
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p2[(16 * m4 + 4 * lj + r) * Hp + 16 * (2 * wave + ht) + li] = dacc[m4][ht][r];
+    MID_STAMP(6)
+}
+
+// RED2: dA = (sum over the sub-net's slices of the dD partials) * scale * [Dd > 0] ; gb1 -> Adam(b1).
+// grid (ceil(Hp/64), K), 256 threads: thread -> hidden unit h, 16 batch rows.
+__global__ __launch_bounds__(256) void k_reduce_dd(const int32_t* __restrict__ midk, const float* __restrict__ P2,
+                                                   const float* __restrict__ Dd,
+                                                   float* __restrict__ b1w, float* __restrict__ b1m, float* __restrict__ b1v,
+                                                   float* __restrict__ dA, Dims dm, AdamP ap, float scale, int k0) {
+    __shared__ float gs[4][64];
+    const int k = blockIdx.y + k0, Hp = dm.Hp;
+    const int tid = threadIdx.x, hh = tid & 63, rg = tid >> 6;
+    const int h = 64 * blockIdx.x + hh;
+    const int slot0 = midk[2 * k], ns = midk[2 * k + 1];
+    float gsum = 0.f;
+    if (h < Hp) {
+        const float* p = P2 + ((int64_t)slot0 * DIMN_TB + 16 * rg) * Hp + h;
+        const float* dd = Dd + ((int64_t)k * DIMN_TB + 16 * rg) * Hp + h;
+        float* da = dA + ((int64_t)k * DIMN_TB + 16 * rg) * Hp + h;
+        float d[16], gate[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { d[i] = 0.f; gate[i] = dd[i * Hp]; }
+        for (int sl = 0; sl < ns; ++sl) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d[i] += p[((int64_t)sl * DIMN_TB + i) * Hp];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = gate[i] > 0.f ? d[i] * scale : 0.f;
+            da[i * Hp] = v;
+            gsum += v;
+        }
+    }
+    gs[rg][hh] = gsum;
+    __syncthreads();
+    if (tid < 64 && h < Hp) {
+        const float gb = ((gs[0][hh] + gs[1][hh]) + gs[2][hh]) + gs[3][hh];
+        const int64_t i = (int64_t)k * Hp + h;
+        float w = b1w[i], m = b1m[i], v = b1v[i];
+        adam1(w, m, v, gb, ap);
+        b1w[i] = w; b1m[i] = m; b1v[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // B1F1: first-layer weight gradient + fused Keras-Adam + NEXT step's split-K forward.
 // 512 threads = 8 INDEPENDENT waves (wave w owns hidden tiles [w*NT2, w*NT2+NT2)); one
 // workgroup per CU; no barrier anywhere in the kernel.

@@ -1,9 +1,11 @@
 // k_probe_mid.hip -- standalone timing of the middle kernels (RED / MF / MB) on cfg3-shaped
 // synthetic state (K=40, H=256, O=512, n=50000).  Diagnostics only.
+#define DIMN_MID_TL 1
 #include "../deepimpute_amd/csrc/dimn_kernels.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <algorithm>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 __global__ void k_fill(float* p, size_t n, float scale, unsigned seed) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -51,6 +53,49 @@ int main(int argc, char** argv) {
     T("k_mid_bwd<true,1,4>", (k_mid_bwd<true, 1, 4>), dim3(16, K), dim3(256), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 8, 0)
     T("k_mid_bwd<true,1,16>", (k_mid_bwd<true, 1, 16>), dim3(16, K), dim3(1024), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 2, 0)
     T("k_mid_bwd<true,2>", (k_mid_bwd<true, 2, 8>), dim3(8, K), dim3(512), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 4, 0)
+    {   // fused second layer: work table as dimn.hip's build_mid
+        const int Sm = std::max(4, std::min(8, 256 / K));
+        std::vector<MidWork> mw; std::vector<int32_t> midk(2 * K);
+        for (int k = 0; k < K; ++k) { midk[2 * k] = k * Sm; midk[2 * k + 1] = Sm;
+            for (int i = 0; i < Sm; ++i) mw.push_back(MidWork{k, 32 * i / Sm, 32 * (i + 1) / Sm, k * Sm + i, i}); }
+        MidWork* dmw; int32_t* dmk; CK(hipMalloc(&dmw, mw.size() * sizeof(MidWork))); CK(hipMalloc(&dmk, midk.size() * 4));
+        CK(hipMemcpy(dmw, mw.data(), mw.size() * sizeof(MidWork), hipMemcpyHostToDevice)); CK(hipMemcpy(dmk, midk.data(), midk.size() * 4, hipMemcpyHostToDevice));
+        float* P2 = dalloc(mw.size() * 64 * 256, 0.f, 11);
+        const size_t ldsb = ((size_t)64 * 258 + 8 * 1024 + 8 * 1024 + 8) * 4;
+        CK(hipFuncSetAttribute((const void*)k_mid_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        printf("fused: %zu workgroups (%d slices per sub-net)\n", mw.size(), Sm);
+        T("k_mid_fused (warm)", k_mid_fused, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0)
+        T("k_reduce_dd", k_reduce_dd, dim3(4, K), dim3(256), 0, 0, dmk, P2, Dd, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 0)
+        // cold: 1 GB of unrelated traffic between launches, as the W1 update does in a real step
+        float* big = dalloc((size_t)256 << 20, 1.f, 12);
+        hipEvent_t ea, eb; CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
+        double cold_f = 0, cold_mf = 0, cold_mb = 0; const int R = 10;
+        for (int it = 0; it < R; ++it) {
+            float ms;
+            hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, big, (size_t)256 << 20, 1.f, 13u + it);
+            CK(hipEventRecord(ea));
+            hipLaunchKernelGGL(k_mid_fused, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
+            CK(hipEventRecord(eb)); CK(hipEventSynchronize(eb)); CK(hipEventElapsedTime(&ms, ea, eb)); cold_f += ms;
+            hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, big, (size_t)256 << 20, 1.f, 33u + it);
+            CK(hipEventRecord(ea));
+            hipLaunchKernelGGL(k_mid_fwd<16>, dim3(8, K), dim3(512), 64 * 258 * 4, 0, W2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, dZ, ls, la, dm, ap, 1.f / (64 * 512), 0, 0);
+            CK(hipEventRecord(eb)); CK(hipEventSynchronize(eb)); CK(hipEventElapsedTime(&ms, ea, eb)); cold_mf += ms;
+            hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, big, (size_t)256 << 20, 1.f, 53u + it);
+            CK(hipEventRecord(ea));
+            hipLaunchKernelGGL((k_mid_bwd<true, 1, 4>), dim3(16, K), dim3(256), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 8, 0);
+            CK(hipEventRecord(eb)); CK(hipEventSynchronize(eb)); CK(hipEventElapsedTime(&ms, ea, eb)); cold_mb += ms;
+        }
+        printf("cold (after 1 GB of other traffic): k_mid_fused %.1f us   k_mid_fwd<16> %.1f us   k_mid_bwd<1,4> %.1f us\n", 1e3 * cold_f / R, 1e3 * cold_mf / R, 1e3 * cold_mb / R);
+        // phase timeline of one cold launch
+        hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, big, (size_t)256 << 20, 1.f, 99u);
+        hipLaunchKernelGGL(k_mid_fused, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> tl(512 * 8 * 8); CK(hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_mid_tl), tl.size() * 8));
+        double ph[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tmin = ~0ull, tmax = 0; const size_t nw = mw.size() * 8;
+        for (size_t i = 0; i < nw; ++i) { const unsigned long long* o = &tl[i * 8]; for (int j = 0; j < 6; ++j) ph[j] += (double)(o[j + 1] - o[j]); if (o[0] < tmin) tmin = o[0]; if (o[6] > tmax) tmax = o[6]; }
+        printf("timeline, mean clk per wave: prologue+Dd stage %.0f | phase1 %.0f | barrier %.0f | Adam(b2)+ddf %.0f | phase2 %.0f | P2 store %.0f | first start -> last end %.0f clk\n",
+               ph[0] / nw, ph[1] / nw, ph[2] / nw, ph[3] / nw, ph[4] / nw, ph[5] / nw, (double)(tmax - tmin));
+    }
     // chained like a real step
     T("RED+MF+MB chain", k_reduce_act, dim3(16, K), dim3(256), 0, 0, dsn, P, b1, (const uint8_t*)nullptr, Dd, dm, 64, 0.2f, 1.25f, 1234ull, 0u, 0u, 0);
     { double us = timeit([&] {
