@@ -64,6 +64,37 @@ def test_two_epochs_match_oracle(H, O, B, Ds, p):
     np.testing.assert_allclose(pa, pb, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("mid", ["1", "0"])
+@pytest.mark.parametrize("O,B,Ds,p", [
+    (512, 64, [300, 150, 77], 0.2),     # the default architecture: H = 256, O = 512
+    (500, 37, [97, 260], 0.3),          # ragged output width and partial batches
+    (96, 64, [64], 0.0),                # fewer output tiles than waves
+])
+def test_h256_both_second_layer_paths_match_oracle(O, B, Ds, p, mid, monkeypatch):
+    """H = 256 takes the ring B1F1 kernel and, by default only when the GPU is well filled, the fused
+    second-layer kernel (k_mid_fused + k_reduce_dd); DIMN_MID forces either path (read at dimn_create)."""
+    monkeypatch.setenv("DIMN_MID", mid)
+    prob = make_problem(n=330, g=700, Ds=Ds, H=256, O=O, seed=17)
+    kw = dict(batch_size=B, dropout_rate=p, learning_rate=1e-3, seed=99)
+    a = load_problem(_hip(), prob, **kw)
+    b = load_problem(_oracle(), prob, **kw)
+    a.init_weights(); b.init_weights()
+    for epoch in range(2):
+        np.testing.assert_allclose(a.train_epoch(epoch), b.train_epoch(epoch), rtol=1e-4)
+        np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
+    for k in range(a.K):
+        for x, y, name in zip(a.get_weights(k), b.get_weights(k), ("W1", "b1", "W2", "b2")):
+            np.testing.assert_allclose(x, y, rtol=1e-3, atol=2e-5, err_msg="%s k=%d" % (name, k))
+        for which in (0, 1):
+            for x, y, name in zip(a.get_adam_state(k, which), b.get_adam_state(k, which), ("W1", "b1", "W2", "b2")):
+                np.testing.assert_allclose(x, y, rtol=2e-3, atol=1e-7 if which == 0 else 1e-10, err_msg="adam %d %s k=%d" % (which, name, k))
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=1e-4, atol=1e-6)
+    # a single step with an injected keep-mask reports the same per-sub-net loss
+    rows = prob["train"][:B]
+    mask = (np.random.default_rng(1).random((a.K, len(rows), 256)) > p).astype(np.uint8)
+    np.testing.assert_allclose(a.train_step(rows, keep_mask=mask), b.train_step(rows, keep_mask=mask), rtol=1e-4)
+
+
 def test_single_forward_tight():
     prob = make_problem(n=200, g=500, Ds=[300, 150], H=256, O=512, seed=3)
     a = load_problem(_hip(), prob, seed=1)
