@@ -649,13 +649,18 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
 #pragma unroll
     for (int i = 0; i < 8; ++i) ddv[i] = *(const f32x4*)(ddk + tid * 4 + i * 2048);
     f32x4 wt[16], yt[4];
-    const float* w2 = W2 + (int64_t)k * Hp * Op + (int64_t)oc * 256 + lane * 4;
-#pragma unroll
-    for (int ht = 0; ht < 16; ++ht) wt[ht] = *(const f32x4*)(w2 + (int64_t)ht * OT * 256);       // tile (ht, oc), natural layout
-#pragma unroll
-    for (int i = 0; i < 4; ++i) yt[i] = *(const f32x4*)(Y + ((int64_t)k * n_cells + rid[i]) * Op + 16 * oc + 4 * (lane & 3));
     const int64_t bi = (int64_t)k * Op + 16 * oc + li;
-    float bias = b2w[bi], b2m0 = b2m[bi], b2v0 = b2v[bi];
+    float bias = 0.f, b2m0 = 0.f, b2v0 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) yt[i] = zero4;
+    if (p1) {                                                // wave-uniform: idle waves request nothing
+        const float* w2 = W2 + (int64_t)k * Hp * Op + (int64_t)oc * 256 + lane * 4;
+#pragma unroll
+        for (int ht = 0; ht < 16; ++ht) wt[ht] = *(const f32x4*)(w2 + (int64_t)ht * OT * 256);   // tile (ht, oc), natural layout
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yt[i] = *(const f32x4*)(Y + ((int64_t)k * n_cells + rid[i]) * Op + 16 * oc + 4 * (lane & 3));
+        bias = b2w[bi]; b2m0 = b2m[bi]; b2v0 = b2v[bi];
+    }
 
     struct Set { f32x4 w[2], m[2], v[2]; };
     const int64_t tbase = (int64_t)k * Hp * Op + li * 16 + 4 * lj;
