@@ -679,7 +679,7 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
         hipLaunchKernelGGL(k_mid_fused, dim3(nk * (unsigned)h->mid_slices), dim3(512), lds, st, h->d_midwork + (size_t)ln.k0 * h->mid_slices,
                            h->d_W2, h->d_M2, h->d_V2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_P2,
                            h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary);
-        hipLaunchKernelGGL(k_reduce_dd, dim3((unsigned)ceil_div(dm.Hp, 64), nk), dim3(256), 0, st, h->d_midk, h->d_P2, h->d_Dd,
+        hipLaunchKernelGGL(k_reduce_dd, dim3((unsigned)ceil_div(dm.Hp, 64), nk), dim3(1024), 0, st, h->d_midk, h->d_P2, h->d_Dd,
                            h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, ln.k0);
     } else {
     {

@@ -825,30 +825,41 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
 }
 
 // RED2: dA = (sum over the sub-net's slices of the dD partials) * scale * [Dd > 0] ; gb1 -> Adam(b1).
-// grid (ceil(Hp/64), K), 256 threads: thread -> hidden unit h, 16 batch rows.
-__global__ __launch_bounds__(256) void k_reduce_dd(const int32_t* __restrict__ midk, const float* __restrict__ P2,
-                                                   const float* __restrict__ Dd,
-                                                   float* __restrict__ b1w, float* __restrict__ b1m, float* __restrict__ b1v,
-                                                   float* __restrict__ dA, Dims dm, AdamP ap, float scale, int k0) {
-    __shared__ float gs[4][64];
+// grid (ceil(Hp/64), K), 1024 threads: thread -> hidden unit h, 4 batch rows (a latency-bound kernel:
+// 16 waves per workgroup keep ~24 independent loads per thread in flight).
+__global__ __launch_bounds__(1024) void k_reduce_dd(const int32_t* __restrict__ midk, const float* __restrict__ P2,
+                                                    const float* __restrict__ Dd,
+                                                    float* __restrict__ b1w, float* __restrict__ b1m, float* __restrict__ b1v,
+                                                    float* __restrict__ dA, Dims dm, AdamP ap, float scale, int k0) {
+    __shared__ float gs[16][64];
     const int k = blockIdx.y + k0, Hp = dm.Hp;
     const int tid = threadIdx.x, hh = tid & 63, rg = tid >> 6;
     const int h = 64 * blockIdx.x + hh;
     const int slot0 = midk[2 * k], ns = midk[2 * k + 1];
     float gsum = 0.f;
+    float b1w0 = 0.f, b1m0 = 0.f, b1v0 = 0.f;
+    const int64_t bi = (int64_t)k * Hp + h;
+    if (tid < 64 && h < Hp) { b1w0 = b1w[bi]; b1m0 = b1m[bi]; b1v0 = b1v[bi]; }
     if (h < Hp) {
-        const float* p = P2 + ((int64_t)slot0 * DIMN_TB + 16 * rg) * Hp + h;
-        const float* dd = Dd + ((int64_t)k * DIMN_TB + 16 * rg) * Hp + h;
-        float* da = dA + ((int64_t)k * DIMN_TB + 16 * rg) * Hp + h;
-        float d[16], gate[16];
+        const float* p = P2 + ((int64_t)slot0 * DIMN_TB + 4 * rg) * Hp + h;
+        const float* dd = Dd + ((int64_t)k * DIMN_TB + 4 * rg) * Hp + h;
+        float* da = dA + ((int64_t)k * DIMN_TB + 4 * rg) * Hp + h;
+        float d[4], gate[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { d[i] = 0.f; gate[i] = dd[i * Hp]; }
-        for (int sl = 0; sl < ns; ++sl) {
+        for (int i = 0; i < 4; ++i) { d[i] = 0.f; gate[i] = dd[i * Hp]; }
+        int sl = 0;
+        for (; sl + 2 <= ns; sl += 2) {                      // slices in ascending order: the sum is order-exact
+            float t0[4], t1[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) d[i] += p[((int64_t)sl * DIMN_TB + i) * Hp];
+            for (int i = 0; i < 4; ++i) { t0[i] = p[((int64_t)sl * DIMN_TB + i) * Hp]; t1[i] = p[((int64_t)(sl + 1) * DIMN_TB + i) * Hp]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] = (d[i] + t0[i]) + t1[i];
         }
+        for (; sl < ns; ++sl)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 4; ++i) d[i] += p[((int64_t)sl * DIMN_TB + i) * Hp];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
             const float v = gate[i] > 0.f ? d[i] * scale : 0.f;
             da[i * Hp] = v;
             gsum += v;
@@ -857,11 +868,11 @@ __global__ __launch_bounds__(256) void k_reduce_dd(const int32_t* __restrict__ m
     gs[rg][hh] = gsum;
     __syncthreads();
     if (tid < 64 && h < Hp) {
-        const float gb = ((gs[0][hh] + gs[1][hh]) + gs[2][hh]) + gs[3][hh];
-        const int64_t i = (int64_t)k * Hp + h;
-        float w = b1w[i], m = b1m[i], v = b1v[i];
-        adam1(w, m, v, gb, ap);
-        b1w[i] = w; b1m[i] = m; b1v[i] = v;
+        float gb = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gb += gs[i][hh];
+        adam1(b1w0, b1m0, b1v0, gb, ap);
+        b1w[bi] = b1w0; b1m[bi] = b1m0; b1v[bi] = b1v0;
     }
 }
 

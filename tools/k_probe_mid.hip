@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
         CK(hipFuncSetAttribute((const void*)k_mid_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         printf("fused: %zu workgroups (%d slices per sub-net)\n", mw.size(), Sm);
         T("k_mid_fused (warm)", k_mid_fused, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0)
-        T("k_reduce_dd", k_reduce_dd, dim3(4, K), dim3(256), 0, 0, dmk, P2, Dd, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 0)
+        T("k_reduce_dd", k_reduce_dd, dim3(4, K), dim3(1024), 0, 0, dmk, P2, Dd, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 0)
         // cold: 1 GB of unrelated traffic between launches, as the W1 update does in a real step
         float* big = dalloc((size_t)256 << 20, 1.f, 12);
         hipEvent_t ea, eb; CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
