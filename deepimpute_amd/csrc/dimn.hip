@@ -579,7 +579,7 @@ extern "C" int dimn_get_adam_state(dimn_handle h, int32_t k, int32_t which, floa
     return io_weights(h, k, which ? h->d_V1 : h->d_M1, h->d_b1, which ? h->d_V2 : h->d_M2, h->d_b2, 1 + which, W1, b1, W2, b2, false);
 }
 
-// ---- one optimiser step: F1 -> MF -> MB -> B1 on the handle's stream ----------------------
+// ---- one optimiser step: [F1] -> RED -> (MFB -> RED2 | MF -> MB) -> B1F1 on the lane's stream ----
 static hipEvent_t next_event(dimn_handle h) {
     if (h->ev_used == h->ev.size()) {
         hipEvent_t e;
@@ -636,7 +636,8 @@ static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, f
     }
 
 // One optimiser step on the handle's stream:
-//   [F1 if need_fwd]  ->  RED  ->  MF  ->  MB  ->  B1F1 (W1 Adam + forward partials of the NEXT batch)
+//   [F1 if need_fwd]  ->  RED  ->  MFB -> RED2 (fused second layer) or MF -> MB  ->  B1F1 (W1 Adam + forward
+//   partials of the NEXT batch)
 // need_fwd: the split-K partials of THIS batch are not in d_P yet (first step of an epoch,
 // or the single-step API); d_rows_n/b_next: the next batch (b_next = 0: none).
 static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed, const int32_t* d_rows, int b_act, bool need_fwd,
