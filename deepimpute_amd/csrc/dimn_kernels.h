@@ -604,6 +604,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 3 : (WV == 16 ? 4 : 2)) void k_m
 // ---------------------------------------------------------------------------------------
 struct MidWork { int32_t k, ot0, ot1, slot, sidx; };   // slot: P2 partial; sidx: slice number inside the sub-net (loss slot)
 #define DIMN_MID_TMAX 8
+#define DIMN_MID_LDD 260   // LDS row stride of Dd in k_mid_fused: 16-byte aligned rows, 4 mod 32 words (conflict-free b128 row reads)
 #ifdef DIMN_MID_TL   // tools/k_probe_mid.hip: per-wave phase stamps (shader clock)
 __device__ unsigned long long g_mid_tl[512 * 8 * 8];
 #define MID_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_mid_tl[(blockIdx.x * 8 + wave) * 8 + (i)] = t_; }
@@ -622,7 +623,8 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const MidWork mw = mwork[blockIdx.x];
     const int k = mw.k, ot0 = mw.ot0, ot1 = mw.ot1, ot_last = mw.ot1 - 1;
-    const int Hp = dm.Hp, ldd = dm.ldd, OT = dm.OT, Op = dm.Op;
+    const int Hp = dm.Hp, OT = dm.OT, Op = dm.Op;
+    constexpr int ldd = DIMN_MID_LDD;
     float* ddl = lds;                                        // Dd [64][ldd]
     float* dzl = lds + DIMN_TB * ldd;                        // dZ tiles [T][64 b][16 o]
     float* wsl = dzl + DIMN_MID_TMAX * 1024;                 // per-wave W2 transpose buffers [8][4 tiles]
@@ -675,12 +677,11 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
     fetch(B, ot0 + 1);
     fetch(C, ot0 + 2);
 
-    // Dd[64][Hp] -> LDS (row stride ldd = 2 mod 32 words: conflict-free column reads)
+    // Dd[64][Hp] -> LDS
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int e = tid * 4 + i * 2048, b = e >> 8, h = e & 255;
-        *(float2*)(ddl + b * ldd + h) = make_float2(ddv[i][0], ddv[i][1]);
-        *(float2*)(ddl + b * ldd + h + 2) = make_float2(ddv[i][2], ddv[i][3]);
+        *(f32x4*)(ddl + b * ldd + h) = ddv[i];
     }
     float* zb = dzl + wave * 1024;                           // this wave's [64 b][16 o] tile: targets first, dZ later
     float* ws = wsl + wave * 1024;                           // this wave's W2 transpose buffer (4 tiles)
@@ -697,7 +698,9 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
 #pragma unroll
             for (int r = 0; r < 4; ++r) yv[m4][r] = zb[(16 * m4 + 4 * lj + r) * 16 + li];
         f32x4 acc[4] = {zero4, zero4, zero4, zero4};
-        const float* arow = ddl + li * ldd + lj;
+        // k-slot form: MFMA r of a hidden tile takes k = 4*lj + r, so one 16-byte LDS read of a Dd row feeds
+        // four MFMAs (A) and the W2 operand is the transposed tile read at row 4*lj + r (B)
+        const float* arow = ddl + li * ldd + 4 * lj;
 #pragma unroll
         for (int rd = 0; rd < 4; ++rd) {                     // four hidden tiles per round through the wave-private buffer
 #pragma unroll
@@ -706,14 +709,17 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bq[t][q] = ws[t * 256 + 64 * q + lane];              // W2[h = 16ht+4q+lj][o = li]
+                for (int r = 0; r < 4; ++r) bq[t][r] = ws[t * 256 + (4 * lj + r) * 16 + li];     // W2[h = 16ht+4lj+r][o = li]
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t) {
+                f32x4 a4[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int m4 = 0; m4 < 4; ++m4) a4[m4] = *(const f32x4*)(arow + 16 * m4 * ldd + 16 * (4 * rd + t));
 #pragma unroll
-                    for (int m4 = 0; m4 < 4; ++m4)
-                        acc[m4] = MFMA16(arow[16 * m4 * ldd + 16 * (4 * rd + t) + 4 * q], bq[t][q], acc[m4]);
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int m4 = 0; m4 < 4; ++m4) acc[m4] = MFMA16(a4[m4][r], bq[t][r], acc[m4]);
+            }
         }
         const bool col_ok = (16 * oc + li) < dm.O;
         float gb = 0.f;
