@@ -21,8 +21,9 @@
  * PARITY STATUS: the NN arithmetic is "parity unpinned" against Keras itself:
  * TensorFlow/Keras are not installable here and the reference's tests hold no numeric
  * vector for this path (tests/multinet_test.py:29-33 asserts nothing).  The oracle is
- * pinned instead against torch.autograd in fp64 (tests/golden/kat_*.npz, generated by
- * tests/golden/make_kat.py) and analytic known answers; the host shell around it is
+ * pinned instead against torch.autograd in fp64 (tests/golden/kat_steps.npz: single steps,
+ * make_kat.py; kat_epochs.npz: a three-epoch trajectory with the Philox streams restated in
+ * numpy and checked against the Random123 vectors, make_epochs.py) and analytic known answers; the host shell around it is
  * pinned by fixtures captured from the imported reference (tests/golden/make_shell.py).
  *
  * Build: gcc -O2 -fopenmp -shared -fPIC [-DDIMO_REAL=double] (oracle/Makefile).

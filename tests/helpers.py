@@ -84,3 +84,46 @@ def load_problem(cls, prob, **kw):
     eng.gather(True)
     eng.set_split(prob["train"], prob["val"])
     return eng
+
+
+def load_epochs():
+    return np.load(os.path.join(GOLDEN, "kat_epochs.npz"))
+
+
+def check_epoch_trajectory(cls, rtol_loss, rtol_w, atol_w, **kw):
+    """Three epochs of a tiny MultiNet against tests/golden/kat_epochs.npz (torch fp64 autograd + a numpy
+    restatement of the Philox streams; generator: tests/golden/make_epochs.py): initial weights and the
+    per-epoch permutations bit-exact, losses / weights / Adam state / predictions within the tolerances."""
+    z = load_epochs()
+    Ds = [int(d) for d in z["Ds"]]
+    K = len(Ds)
+    eng = cls(Ds, int(z["H"]), int(z["O"]), batch_size=int(z["B"]), dropout_rate=float(z["p"]),
+              learning_rate=float(z["lr"]), beta1=float(z["beta1"]), beta2=float(z["beta2"]), eps=float(z["eps"]),
+              seed=int(z["seed"]), subnet_offset=int(z["subnet_offset"]), **kw)
+    eng.set_matrix(z["norm"])
+    for k in range(K):
+        eng.set_indices(k, z["pred%d" % k], z["targ%d" % k])
+    eng.gather(True)
+    eng.set_split(z["train_rows"], z["val_rows"])
+    eng.init_weights()
+    for k in range(K):
+        for got, name in zip(eng.get_weights(k), ("W1", "b1", "W2", "b2")):
+            assert np.array_equal(got, z["init_%s_%d" % (name, k)]), "init %s k=%d" % (name, k)
+    for e in range(int(z["epochs"])):
+        assert np.array_equal(eng.epoch_permutation(e), z["perms"][e])
+        tr = eng.train_epoch(e)                      # library-generated permutation and dropout masks
+        va = eng.val_loss()
+        for k in range(K):
+            np.testing.assert_allclose(tr[k], z["train_loss_%d" % k][e], rtol=rtol_loss, err_msg="train loss epoch %d k=%d" % (e, k))
+            np.testing.assert_allclose(va[k], z["val_loss_%d" % k][e], rtol=rtol_loss, err_msg="val loss epoch %d k=%d" % (e, k))
+    assert eng.step_count() == int(z["steps"])
+    pred = eng.predict()
+    O = int(z["O"])
+    for k in range(K):
+        W, M, V = eng.get_weights(k), eng.get_adam_state(k, 0), eng.get_adam_state(k, 1)
+        for i, name in enumerate(("W1", "b1", "W2", "b2")):
+            np.testing.assert_allclose(W[i], z["out_%s_%d" % (name, k)], rtol=rtol_w, atol=atol_w, err_msg="%s k=%d" % (name, k))
+            np.testing.assert_allclose(M[i], z["m_%s_%d" % (name, k)], rtol=rtol_w, atol=atol_w * 1e-2, err_msg="m %s k=%d" % (name, k))
+            np.testing.assert_allclose(V[i], z["v_%s_%d" % (name, k)], rtol=rtol_w, atol=atol_w * 1e-4, err_msg="v %s k=%d" % (name, k))
+        np.testing.assert_allclose(pred[:, k * O:(k + 1) * O], z["predict_%d" % k], rtol=rtol_w, atol=atol_w)
+    eng.close()

@@ -28,6 +28,12 @@ def test_kat_steps_match_autograd_golden():
     check_kat(eng, kat, rtol=RTOL, atol=ATOL)
 
 
+def test_three_epochs_match_autograd_golden():
+    """The HIP path against the independent torch-fp64 + numpy-Philox trajectory (not via the oracle)."""
+    from helpers import check_epoch_trajectory
+    check_epoch_trajectory(_hip(), rtol_loss=5e-5, rtol_w=2e-3, atol_w=3e-6)
+
+
 def test_init_weights_bit_exact_vs_oracle():
     prob = make_problem(n=150, g=400, Ds=[70, 33, 128], H=48, O=32, seed=5)
     a = load_problem(_hip(), prob, seed=99)
