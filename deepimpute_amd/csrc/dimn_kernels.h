@@ -43,6 +43,33 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// Streamed optimiser state (read once, written once per step).  DIMN_NT bit 0 marks its loads, bit 1 its
+// stores non-temporal; bit 2 the split-K partial stores of B1F1, bit 3 the dD partial stores of MFB.
+// Measured (tools/ab_nt.sh, one box, cfg3): non-temporal STATE STORES keep the X tiles / dA / partials in L2:
+// step 0.1864 -> 0.1731 ms, B1F1 121 -> 113 us; non-temporal state LOADS cost +4 us.  Default: stores only.
+#ifndef DIMN_NT
+#define DIMN_NT 2
+#endif
+#if DIMN_NT & 1
+#define DIMN_LD_STATE(p) __builtin_nontemporal_load((const f32x4*)(p))
+#else
+#define DIMN_LD_STATE(p) (*(const f32x4*)(p))
+#endif
+#if DIMN_NT & 2
+#define DIMN_ST_STATE(p, v) __builtin_nontemporal_store((v), (f32x4*)(p))
+#else
+#define DIMN_ST_STATE(p, v) (*(f32x4*)(p) = (v))
+#endif
+#if DIMN_NT & 4
+#define DIMN_ST_P(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define DIMN_ST_P(p, v) (*(p) = (v))
+#endif
+#if DIMN_NT & 8
+#define DIMN_ST_P2(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define DIMN_ST_P2(p, v) (*(p) = (v))
+#endif
 #define DIMN_TB 64  // batch rows per optimiser step tile (4 MFMA M-tiles)
 
 struct SubnetDev {
@@ -532,7 +559,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 3 : (WV == 16 ? 4 : 2)) void k_m
             adam4(cur.w[ht], cur.m[ht], cur.v[ht], g[ht], ap);
             if (FULL || ht < nht) {
                 const int64_t i = tidx(ht, ot);
-                *(f32x4*)(W2 + i) = cur.w[ht]; *(f32x4*)(M2 + i) = cur.m[ht]; *(f32x4*)(V2 + i) = cur.v[ht];
+                DIMN_ST_STATE(W2 + i, cur.w[ht]); DIMN_ST_STATE(M2 + i, cur.m[ht]); DIMN_ST_STATE(V2 + i, cur.v[ht]);
             }
         }
     };
@@ -797,7 +824,7 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
                 for (int m4 = 0; m4 < 4; ++m4) dacc[m4][ht] = MFMA16(zf[m4][r], cur.w[ht][r], dacc[m4][ht]);   // OLD W2
             adam4(cur.w[ht], cur.m[ht], cur.v[ht], g[ht], ap);
             const int64_t i = tidx(ht, ot);
-            *(f32x4*)(W2 + i) = cur.w[ht]; *(f32x4*)(M2 + i) = cur.m[ht]; *(f32x4*)(V2 + i) = cur.v[ht];
+            DIMN_ST_STATE(W2 + i, cur.w[ht]); DIMN_ST_STATE(M2 + i, cur.m[ht]); DIMN_ST_STATE(V2 + i, cur.v[ht]);
         }
     };
 #pragma unroll
@@ -826,7 +853,7 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p2[(16 * m4 + 4 * lj + r) * Hp + 16 * (2 * wave + ht) + li] = dacc[m4][ht][r];
+            for (int r = 0; r < 4; ++r) DIMN_ST_P2(&p2[(16 * m4 + 4 * lj + r) * Hp + 16 * (2 * wave + ht) + li], dacc[m4][ht][r]);
     MID_STAMP(6)
 }
 
@@ -1255,7 +1282,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_ring(const Work* _
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
             const int64_t idx = wb[nt] + cc * cstride;
-            st.w[nt] = *(const f32x4*)(W1 + idx); st.m[nt] = *(const f32x4*)(M1 + idx); st.v[nt] = *(const f32x4*)(V1 + idx);
+            st.w[nt] = DIMN_LD_STATE(W1 + idx); st.m[nt] = DIMN_LD_STATE(M1 + idx); st.v[nt] = DIMN_LD_STATE(V1 + idx);
         }
     };
     // one chunk: `cur` holds chunk c, `nx1` chunk c+1 (its X tile is staged into LDS here),
@@ -1280,7 +1307,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_ring(const Work* _
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
             const int64_t idx = wb[nt] + c * cstride;
-            *(f32x4*)(W1 + idx) = cur.w[nt]; *(f32x4*)(M1 + idx) = cur.m[nt]; *(f32x4*)(V1 + idx) = cur.v[nt];
+            DIMN_ST_STATE(W1 + idx, cur.w[nt]); DIMN_ST_STATE(M1 + idx, cur.m[nt]); DIMN_ST_STATE(V1 + idx, cur.v[nt]);
         }
         if (have_next) {
             const float* xn = sm + 2 * XT + par * XN;
@@ -1346,7 +1373,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_ring(const Work* _
 #pragma unroll
             for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p[(16 * mt + 4 * lj + r) * Hp + 16 * (nt0 + nt) + li] = pacc[mt][nt][r];
+                for (int r = 0; r < 4; ++r) DIMN_ST_P(&p[(16 * mt + 4 * lj + r) * Hp + 16 * (nt0 + nt) + li], pacc[mt][nt][r]);
     }
 }
 
