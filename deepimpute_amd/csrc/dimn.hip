@@ -676,7 +676,7 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
                        h->d_Dd, dm, b_act, rate, scale, h->cfg.seed, epoch_key, step_key, ln.k0);
     if (h->mid_fused) {
         // RED -> MFB (whole second layer, W2 streamed once) -> RED2 (dD partials -> dA, Adam(b1))
-        const size_t lds = ((size_t)DIMN_TB * DIMN_MID_LDD + DIMN_MID_TMAX * 1024 + 8 * 1024 + 8) * sizeof(float);
+        const size_t lds = ((size_t)DIMN_TB * DIMN_MID_LDD + DIMN_MID_TMAX * 1024 + 8 * 1024 + 8 + 64) * sizeof(float);
         hipLaunchKernelGGL(k_mid_fused, dim3(nk * (unsigned)h->mid_slices), dim3(512), lds, st, h->d_midwork + (size_t)ln.k0 * h->mid_slices,
                            h->d_W2, h->d_M2, h->d_V2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_P2,
                            h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary);

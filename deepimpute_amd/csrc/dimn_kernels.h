@@ -36,6 +36,7 @@
 //   k_predict                 fused forward for model.predict and the validation loss
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "../../include/dimn_rng.h"
@@ -656,6 +657,7 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
     float* dzl = lds + DIMN_TB * ldd;                        // dZ tiles [T][64 b][16 o]
     float* wsl = dzl + DIMN_MID_TMAX * 1024;                 // per-wave W2 transpose buffers [8][4 tiles]
     float* lsl = wsl + 8 * 1024;                             // loss partials [8 waves]
+    float* gbl = lsl + 8;                                    // bias-gradient halves of the shared units [4 waves][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -667,12 +669,22 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
     // would be 119 and overflow the 6-bit vmcnt).
     // phase 1: wave w -> output tile ot0 + w (all 64 batch rows), so every W2 column block is loaded once
     // per workgroup; waves beyond the slice's tile count idle until phase 2.
-    const int ot1w = ot0 + wave;
-    const bool p1 = ot1w < ot1;
-    const int oc = p1 ? ot1w : ot_last;                      // clamped: loads stay in bounds
+    // Unit u = output tile ot0 + u.  Waves 0..3 (one per SIMD) take units 0..3 whole; with 5 or 6 tiles the
+    // remaining units are shared by two waves, 32 batch rows each, so that every SIMD's MFMA pipe carries the
+    // same load (two whole units on one SIMD made phase 1 1.4x longer); 7 or 8 tiles: one unit per wave.
+    const int T = ot1 - ot0;
+    const bool split = (T == 5 || T == 6) && wave >= 4;
+    const int u = split ? 4 + ((wave - 4) >> 1) : wave;
+    const int m0 = split ? 2 * ((wave - 4) & 1) : 0;         // first 16-row tile of this wave
+    const int nm = split ? 2 : 4;                            // 16-row tiles of this wave
+    const bool p1 = u < T;
+    const int oc = p1 ? ot0 + u : ot_last;                   // clamped: loads stay in bounds
     int rid[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int b = 16 * i + (lane >> 2); rid[i] = rows[b < b_act ? b : 0]; }
+    for (int i = 0; i < 4; ++i) {                            // a split wave repeats its two tiles (same loads, same LDS words)
+        const int b = 16 * (m0 + (i < nm ? i : i - nm)) + (lane >> 2);
+        rid[i] = rows[b < b_act ? b : 0];
+    }
     const float* ddk = Dd + (int64_t)k * DIMN_TB * Hp;
     f32x4 ddv[8];                                            // 64 x 256 floats = 8 float4 per thread
 #pragma unroll
@@ -710,24 +722,27 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
         const int e = tid * 4 + i * 2048, b = e >> 8, h = e & 255;
         *(f32x4*)(ddl + b * ldd + h) = ddv[i];
     }
-    float* zb = dzl + wave * 1024;                           // this wave's [64 b][16 o] tile: targets first, dZ later
+    float* zb = dzl + (p1 ? u : wave) * 1024;                // the unit's [64 b][16 o] tile: targets first, dZ later
     float* ws = wsl + wave * 1024;                           // this wave's W2 transpose buffer (4 tiles)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(f32x4*)(zb + (16 * i + (lane >> 2)) * 16 + 4 * (lane & 3)) = yt[i];
+    for (int i = 0; i < 4; ++i) *(f32x4*)(zb + (16 * (m0 + (i < nm ? i : i - nm)) + (lane >> 2)) * 16 + 4 * (lane & 3)) = yt[i];
     __syncthreads();
     MID_STAMP(1)
 
     float lsum = 0.f;
-    if (p1) {
-        float yv[4][4];
+    auto phase1 = [&](auto nmc) {
+        constexpr int NM = decltype(nmc)::value;
+        float yv[NM][4];
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4)
+        for (int j = 0; j < NM; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) yv[m4][r] = zb[(16 * m4 + 4 * lj + r) * 16 + li];
-        f32x4 acc[4] = {zero4, zero4, zero4, zero4};
+            for (int r = 0; r < 4; ++r) yv[j][r] = zb[(16 * (m0 + j) + 4 * lj + r) * 16 + li];
+        f32x4 acc[NM];
+#pragma unroll
+        for (int j = 0; j < NM; ++j) acc[j] = zero4;
         // k-slot form: MFMA r of a hidden tile takes k = 4*lj + r, so one 16-byte LDS read of a Dd row feeds
         // four MFMAs (A) and the W2 operand is the transposed tile read at row 4*lj + r (B)
-        const float* arow = ddl + li * ldd + 4 * lj;
+        const float* arow = ddl + (16 * m0 + li) * ldd + 4 * lj;
 #pragma unroll
         for (int rd = 0; rd < 4; ++rd) {                     // four hidden tiles per round through the wave-private buffer
 #pragma unroll
@@ -739,26 +754,26 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
                 for (int r = 0; r < 4; ++r) bq[t][r] = ws[t * 256 + (4 * lj + r) * 16 + li];     // W2[h = 16ht+4lj+r][o = li]
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                f32x4 a4[4];
+                f32x4 a4[NM];
 #pragma unroll
-                for (int m4 = 0; m4 < 4; ++m4) a4[m4] = *(const f32x4*)(arow + 16 * m4 * ldd + 16 * (4 * rd + t));
+                for (int j = 0; j < NM; ++j) a4[j] = *(const f32x4*)(arow + 16 * j * ldd + 16 * (4 * rd + t));
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int m4 = 0; m4 < 4; ++m4) acc[m4] = MFMA16(a4[m4][r], bq[t][r], acc[m4]);
+                    for (int j = 0; j < NM; ++j) acc[j] = MFMA16(a4[j][r], bq[t][r], acc[j]);
             }
         }
         const bool col_ok = (16 * oc + li) < dm.O;
         float gb = 0.f;
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4)
+        for (int j = 0; j < NM; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int b = 16 * m4 + 4 * lj + r;
+                const int b = 16 * (m0 + j) + 4 * lj + r;
                 float dz = 0.f;
                 if (b < b_act && col_ok) {
-                    const float z = acc[m4][r] + bias;
-                    const float y = yv[m4][r];
+                    const float z = acc[j][r] + bias;
+                    const float y = yv[j][r];
                     const float w = loss_binary ? (y > 0.f ? 1.f : 0.f) : y;   // multinet.py:37-40
                     float sp, sg;
                     softplus_sigmoid_fast(z, sp, sg);
@@ -769,14 +784,21 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
                 zb[b * 16 + li] = dz;
                 gb += dz;
             }
-        gb += __shfl_xor(gb, 16);                            // the wave holds all 64 rows of its 16 columns
+        gb += __shfl_xor(gb, 16);                            // column sums over this wave's rows
         gb += __shfl_xor(gb, 32);
-        if (lj == 0) {                                       // Adam(b2)
-            adam1(bias, b2m0, b2v0, gb, ap);
-            b2w[bi] = bias; b2m[bi] = b2m0; b2v[bi] = b2v0;
+        if (lj == 0) {
+            if (NM == 4) {                                   // the wave holds all 64 rows: Adam(b2) here
+                adam1(bias, b2m0, b2v0, gb, ap);
+                b2w[bi] = bias; b2m[bi] = b2m0; b2v[bi] = b2v0;
+            } else {
+                gbl[(wave - 4) * 16 + li] = gb;              // half of the rows: finished after the barrier
+            }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
+    };
+    if (p1) {
+        if (split) phase1(std::integral_constant<int, 2>{}); else phase1(std::integral_constant<int, 4>{});
     }
     if (lane == 0) lsl[wave] = lsum;
     MID_STAMP(2)
@@ -788,6 +810,11 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
         for (int wv = 0; wv < 8; ++wv) tot += lsl[wv];
         loss_step[k * dm.OS + mw.sidx] = tot;
         if (loss_acc) loss_acc[k * dm.OS + mw.sidx] += (double)tot;
+    }
+    if (split && p1 && m0 == 0 && lj == 0) {                 // Adam(b2) of a shared unit: rows 0..31 + rows 32..63
+        const float gb = gbl[(wave - 4) * 16 + li] + gbl[(wave - 3) * 16 + li];
+        adam1(bias, b2m0, b2v0, gb, ap);
+        b2w[bi] = bias; b2m[bi] = b2m0; b2v[bi] = b2v0;
     }
 
     // ---- phase 2: wave w owns hidden tiles 2w, 2w+1 for every output tile of the slice ----

@@ -61,7 +61,7 @@ int main(int argc, char** argv) {
         MidWork* dmw; int32_t* dmk; CK(hipMalloc(&dmw, mw.size() * sizeof(MidWork))); CK(hipMalloc(&dmk, midk.size() * 4));
         CK(hipMemcpy(dmw, mw.data(), mw.size() * sizeof(MidWork), hipMemcpyHostToDevice)); CK(hipMemcpy(dmk, midk.data(), midk.size() * 4, hipMemcpyHostToDevice));
         float* P2 = dalloc(mw.size() * 64 * 256, 0.f, 11);
-        const size_t ldsb = ((size_t)64 * DIMN_MID_LDD + 8 * 1024 + 8 * 1024 + 8) * 4;
+        const size_t ldsb = ((size_t)64 * DIMN_MID_LDD + 8 * 1024 + 8 * 1024 + 8 + 64) * 4;
         CK(hipFuncSetAttribute((const void*)k_mid_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         printf("fused: %zu workgroups (%d slices per sub-net)\n", mw.size(), Sm);
         T("k_mid_fused (warm)", k_mid_fused, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0)
