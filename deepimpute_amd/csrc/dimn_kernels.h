@@ -698,11 +698,25 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
         const float* w2 = W2 + (int64_t)k * Hp * Op + (int64_t)oc * 256 + lane * 4;
 #pragma unroll
         for (int ht = 0; ht < 16; ++ht) wt[ht] = *(const f32x4*)(w2 + (int64_t)ht * OT * 256);   // tile (ht, oc), natural layout
+    }
+
+    // Dd[64][Hp] -> LDS
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid * 4 + i * 2048, b = e >> 8, h = e & 255;
+        *(f32x4*)(ddl + b * ldd + h) = ddv[i];
+    }
+    float* zb = dzl + (p1 ? u : wave) * 1024;                // the unit's [64 b][16 o] tile: targets first, dZ later
+    float* ws = wsl + wave * 1024;                           // this wave's W2 transpose buffer (4 tiles)
+    __syncthreads();                                         // only Dd and the W2 column block were requested so far: a
+    MID_STAMP(1)                                             // wave reaches this barrier as soon as ITS requests are issued
+
+    // requested after the barrier, consumed later: targets and bias state (end of phase 1), phase-2 state
+    if (p1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) yt[i] = *(const f32x4*)(Y + ((int64_t)k * n_cells + rid[i]) * Op + 16 * oc + 4 * (lane & 3));
         bias = b2w[bi]; b2m0 = b2m[bi]; b2v0 = b2v[bi];
     }
-
     struct Set { f32x4 w[2], m[2], v[2]; };
     const int64_t tbase = (int64_t)k * Hp * Op + li * 16 + 4 * lj;
     auto tidx = [&](int ht, int ot) { return tbase + ((int64_t)(2 * wave + ht) * OT + ot) * 256; };
@@ -716,27 +730,9 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
     fetch(B, ot0 + 1);
     fetch(C, ot0 + 2);
 
-    // Dd[64][Hp] -> LDS
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int e = tid * 4 + i * 2048, b = e >> 8, h = e & 255;
-        *(f32x4*)(ddl + b * ldd + h) = ddv[i];
-    }
-    float* zb = dzl + (p1 ? u : wave) * 1024;                // the unit's [64 b][16 o] tile: targets first, dZ later
-    float* ws = wsl + wave * 1024;                           // this wave's W2 transpose buffer (4 tiles)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *(f32x4*)(zb + (16 * (m0 + (i < nm ? i : i - nm)) + (lane >> 2)) * 16 + 4 * (lane & 3)) = yt[i];
-    __syncthreads();
-    MID_STAMP(1)
-
     float lsum = 0.f;
     auto phase1 = [&](auto nmc) {
         constexpr int NM = decltype(nmc)::value;
-        float yv[NM][4];
-#pragma unroll
-        for (int j = 0; j < NM; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) yv[j][r] = zb[(16 * (m0 + j) + 4 * lj + r) * 16 + li];
         f32x4 acc[NM];
 #pragma unroll
         for (int j = 0; j < NM; ++j) acc[j] = zero4;
@@ -763,6 +759,15 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
                     for (int j = 0; j < NM; ++j) acc[j] = MFMA16(a4[j][r], bq[t][r], acc[j]);
             }
         }
+        // targets: row-major float4 pieces -> this wave's rows of the unit tile -> MFMA C layout (the rows are
+        // private to the wave, LDS is in order per wave: no barrier)
+#pragma unroll
+        for (int i = 0; i < NM; ++i) *(f32x4*)(zb + (16 * (m0 + i) + (lane >> 2)) * 16 + 4 * (lane & 3)) = yt[i];
+        float yv[NM][4];
+#pragma unroll
+        for (int j = 0; j < NM; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yv[j][r] = zb[(16 * (m0 + j) + 4 * lj + r) * 16 + li];
         const bool col_ok = (16 * oc + li) < dm.O;
         float gb = 0.f;
 #pragma unroll
