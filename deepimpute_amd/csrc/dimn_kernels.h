@@ -71,6 +71,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #else
 #define DIMN_ST_P2(p, v) (*(p) = (v))
 #endif
+#ifndef DIMN_W_PEEL
+#define DIMN_W_PEEL 1   // B1F1 ring: first chunk triple peeled out of the loop (0: wait for two chunks before the loop)
+#endif
 #define DIMN_TB 64  // batch rows per optimiser step tile (4 MFMA M-tiles)
 
 struct SubnetDev {
@@ -1365,15 +1368,36 @@ __global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_ring(const Work* _
     for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) asm volatile("" : "+v"(bfr[kb][nt]));
+#if !DIMN_W_PEEL
 #pragma unroll
     for (int nt = 0; nt < NT2; ++nt) {
         asm volatile("" : "+v"(A.w[nt]), "+v"(A.m[nt]), "+v"(A.v[nt]));
         asm volatile("" : "+v"(B.w[nt]), "+v"(B.m[nt]), "+v"(B.v[nt]));
     }
+#endif
+#if DIMN_W_PEEL
+    __syncthreads();
+    int c = wk.c0;
+    if (DEPTH == 3 && c + 3 <= wk.c1) {
+        // first triple peeled out of the loop: in straight-line code the waits are placed per use, so chunk c0
+        // computes while chunk c0+1 is still arriving (a wait for BOTH before the loop cost part of the burst)
+        step(A, B, C, c);
+        step(B, C, A, c + 1);
+        step(C, A, B, c + 2);
+        c += 3;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {                     // what the loop header inherits is retired here
+        asm volatile("" : "+v"(A.w[nt]), "+v"(A.m[nt]), "+v"(A.v[nt]));
+        asm volatile("" : "+v"(B.w[nt]), "+v"(B.m[nt]), "+v"(B.v[nt]));
+    }
+    asm volatile("" : "+v"(A.x), "+v"(B.x));
+#else
     asm volatile("" : "+v"(B.x));
     __syncthreads();
 
     int c = wk.c0;
+#endif
     if (DEPTH == 4) {
         asm volatile("" : "+v"(C.x));
         for (; c + 4 <= wk.c1; c += 4) {                   // full groups: no conditional memory op inside
