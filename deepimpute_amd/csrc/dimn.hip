@@ -214,9 +214,9 @@ static void build_mid(dimn_handle h) {
     S = std::max(S, ceil_div(dm.OT, DIMN_MID_TMAX));
     if (S > dm.OS || S > dm.OT) return;
     // a GPU that owns only a few sub-nets (8-GPU sharding) cannot fill its CUs with <= OS slices per sub-net,
-    // and the fused kernel's serial phases then cost more than MF + MB (measured: K=5 65 vs 54 us per step,
-    // K=20 equal, K=40 186 vs 197): take the fused path when it occupies at least 3/4 of the CUs
-    if (force < 0 && 4 * S * h->K < 3 * h->ncu) return;
+    // and the fused kernel's serial phases then cost more than MF + MB (measured per step: K=5 62 vs 54 us,
+    // K=10 77 vs 68, K=20 106 vs 107, K=40 170 vs 186): take the fused path from ~0.6 workgroups per CU up
+    if (force < 0 && 5 * S * h->K < 3 * h->ncu) return;
     h->mid_slices = S;
     h->midwork.clear();
     int slot = 0;
