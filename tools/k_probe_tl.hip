@@ -11,6 +11,7 @@
 //   VAR bit0: no gradient MFMAs   bit1: no forward MFMAs   bit2: no forward LDS reads
 //       bit3: no Adam arithmetic  bit4: no per-chunk barrier (racy, timing only)  bit5: stamps
 //       bit6: no P store          bit7: P stored in the MFMA-fragment-native layout (float4 per lane)
+//       bit8: barrier only after every second chunk (racy, timing only)
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/k_probe_tl.hip -o /tmp/k_probe_tl && /tmp/k_probe_tl
 #include "../deepimpute_amd/csrc/dimn_kernels.h"
 #include <stdio.h>
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(1024) void k_ring_var(const Work* __restrict__ work
         STAMP(1)                                              // wait for the chunk's state + Adam
         *(f32x4*)(sm + sdst + (par ^ 1) * sbuf) = svalid ? nx1.x : zero4;
         const int64_t idx = wb + c * cstride;
-        *(f32x4*)(W1 + idx) = cur.w[0]; *(f32x4*)(M1 + idx) = cur.m[0]; *(f32x4*)(V1 + idx) = cur.v[0];
+        DIMN_ST_STATE(W1 + idx, cur.w[0]); DIMN_ST_STATE(M1 + idx, cur.m[0]); DIMN_ST_STATE(V1 + idx, cur.v[0]);
         STAMP(2)                                              // wait for next X tile, LDS staging, stores issued
         if (have_next) {
             const float* xn = sm + 2 * XT + par * XN;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(1024) void k_ring_var(const Work* __restrict__ work
             if (VAR & 32) { asm volatile("" : "+v"(pacc[0]), "+v"(pacc[1]), "+v"(pacc[2]), "+v"(pacc[3])); }
         }
         STAMP(3)                                              // forward: LDS reads + 16 MFMAs
-        if (!(VAR & 16)) __syncthreads();
+        if (!(VAR & 16) && (!(VAR & 256) || ((c - wk.c0) & 1))) __syncthreads();
         STAMP(4)                                              // barrier
     };
 
@@ -208,6 +209,9 @@ int main(int argc, char** argv) {
     T("next  -fwdMFMA -fwdLDS", 6, drows + 64, 64)
     T("next  -Adam", 8, drows + 64, 64)
     T("next  -barrier", 16, drows + 64, 64)
+    T("next  barrier every 2nd chunk (racy, timing only)", 256, drows + 64, 64)
+    T("next  baseline again", 0, drows + 64, 64)
+    T("next  barrier every 2nd chunk again", 256, drows + 64, 64)
     T("next  -gradMFMA -fwdMFMA -fwdLDS -Adam (stream+barrier)", 15, drows + 64, 64)
     T("next  everything off incl. barrier", 31, drows + 64, 64)
     T("next  no P store", 64, drows + 64, 64)
