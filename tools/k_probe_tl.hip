@@ -8,6 +8,9 @@
 // P store (16.8 MB at the kernel's tail, layout-insensitive) and ~2 us of compute; staging the X tiles as
 // 128-byte chunk PAIRS (whole L2 lines) was built and A/B-ed in one process: no change, reverted; the
 // prologue (work -> sub-net -> rows -> first loads: three dependent round trips) is ~9 us per launch.
+// With the non-temporal state stores (DIMN_NT=2, also used by this copy): next 109 us vs no-next 102 us on one
+// box -- the fused forward now costs ~7 us (X_{t+1} rows 4, P store 2, MFMAs 2); a barrier only after every
+// second chunk (bit 8, racy): no gain.
 //   VAR bit0: no gradient MFMAs   bit1: no forward MFMAs   bit2: no forward LDS reads
 //       bit3: no Adam arithmetic  bit4: no per-chunk barrier (racy, timing only)  bit5: stamps
 //       bit6: no P store          bit7: P stored in the MFMA-fragment-native layout (float4 per lane)
