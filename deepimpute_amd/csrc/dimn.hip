@@ -202,22 +202,24 @@ static void build_work(dimn_handle h) {
 
 static void build_mid(dimn_handle h) {
     // Fused second layer (H = 256): every sub-net's OT output tiles are cut into S slices, S*K <= ncu so that
-    // each CU runs exactly one workgroup; a slice holds at most DIMN_MID_TMAX tiles (LDS) and a sub-net at
-    // most OS slices (loss slots).  DIMN_MID=0 keeps the two-kernel path (MF + MB).
+    // each CU runs at most one workgroup (S <= OT: one tile per slice when a GPU owns few sub-nets); a slice
+    // holds at most DIMN_MID_TMAX tiles (LDS).  DIMN_MID=0 keeps the two-kernel path (MF + MB).
     const Dims& dm = h->dm;
     h->mid_fused = 0;
     if (dm.HT != 16) return;
     int force = -1;
     if (const char* e = getenv("DIMN_MID")) force = atoi(e) != 0;
     if (force == 0) return;
-    int S = std::max(1, std::min(h->ncu / std::max(1, h->K), std::min((int)dm.OS, (int)dm.OT)));
+    // S <= 8: finer slices (down to one tile per workgroup) were measured for GPUs that own few sub-nets and
+    // bring nothing (K=5: MFB 12.8 + RED2 8.5 us vs MF 11.3 + MB 10.6), so small K keeps the two-kernel path:
+    // fused from ~0.6 workgroups per CU up (per step: K=5 62 vs 54 us, K=10 77 vs 68, K=20 106 vs 107, K=40 170 vs 186)
+    int S = std::max(1, std::min(h->ncu / std::max(1, h->K), std::min(8, (int)dm.OT)));
     S = std::max(S, ceil_div(dm.OT, DIMN_MID_TMAX));
-    if (S > dm.OS || S > dm.OT) return;
-    // a GPU that owns only a few sub-nets (8-GPU sharding) cannot fill its CUs with <= OS slices per sub-net,
-    // and the fused kernel's serial phases then cost more than MF + MB (measured per step: K=5 62 vs 54 us,
-    // K=10 77 vs 68, K=20 106 vs 107, K=40 170 vs 186): take the fused path from ~0.6 workgroups per CU up
+    if (const char* e = getenv("DIMN_MID_SLICES")) S = std::max(ceil_div(dm.OT, DIMN_MID_TMAX), std::min(atoi(e), (int)dm.OT));   // tests
+    if (S > dm.OT) return;
     if (force < 0 && 5 * S * h->K < 3 * h->ncu) return;
     h->mid_slices = S;
+    h->dm.LS = std::max((int)dm.OS, S);
     h->midwork.clear();
     int slot = 0;
     for (int k = 0; k < h->K; ++k)
@@ -252,6 +254,7 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     dm.Op = ceil_div(h->O, 16) * 16; dm.OT = dm.Op / 16;
     dm.ldd = dm.Hp + ((dm.Hp % 32 == 0) ? 2 : 18);   // LDS row stride = 2 (mod 32) words: conflict-free b32 column reads
     dm.OS = ceil_div(dm.OT, 4);
+    dm.LS = dm.OS;
     h->NT = ceil_div(dm.HT, 4);
     h->NT2 = ceil_div(dm.HT, 8);
     h->OTW = ceil_div(dm.OT, 4);   // output tiles per wave of the 4-wave middle-backward kernel
@@ -325,8 +328,8 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     TRY(dev_alloc(&h->d_Dd, (size_t)h->K * DIMN_TB * dm.Hp));
     TRY(dev_alloc(&h->d_dA, (size_t)h->K * DIMN_TB * dm.Hp));
     TRY(dev_alloc(&h->d_dZ, (size_t)h->K * DIMN_TB * dm.Op));
-    TRY(dev_alloc(&h->d_loss_step, (size_t)h->K * dm.OS));
-    TRY(dev_alloc(&h->d_loss_acc, (size_t)h->K * dm.OS));
+    TRY(dev_alloc(&h->d_loss_step, (size_t)h->K * dm.LS));
+    TRY(dev_alloc(&h->d_loss_acc, (size_t)h->K * dm.LS));
     TRY(dev_alloc(&h->d_mask, (size_t)h->K * DIMN_TB * dm.Hp));
     TRY(dev_alloc(&h->d_rows_step, (size_t)DIMN_TB));
     if (h->mid_fused) {
@@ -348,7 +351,7 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     TRY(zero(h->d_b1, (size_t)3 * h->K * dm.Hp * 4)); TRY(zero(h->d_b2, (size_t)3 * h->K * dm.Op * 4));
     TRY(zero(h->d_Dd, (size_t)h->K * DIMN_TB * dm.Hp * 4)); TRY(zero(h->d_dA, (size_t)h->K * DIMN_TB * dm.Hp * 4));
     TRY(zero(h->d_dZ, (size_t)h->K * DIMN_TB * dm.Op * 4));
-    TRY(zero(h->d_loss_step, (size_t)h->K * dm.OS * 4)); TRY(zero(h->d_loss_acc, (size_t)h->K * dm.OS * 8));
+    TRY(zero(h->d_loss_step, (size_t)h->K * dm.LS * 4)); TRY(zero(h->d_loss_acc, (size_t)h->K * dm.LS * 8));
     if (hipMemcpy(h->d_work, h->work.data(), h->work.size() * sizeof(Work), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->d_sn, h->sn.data(), h->sn.size() * sizeof(SubnetDev), hipMemcpyHostToDevice) != hipSuccess) {
         dimn_destroy(h);
@@ -756,11 +759,11 @@ extern "C" int dimn_train_step(dimn_handle h, const int32_t* rows, int32_t b_act
     CHK(sync_lanes(h));
     if (h->profiling) collect_timers(h);
     if (loss_out) {
-        std::vector<float> ls((size_t)h->K * dm.OS);
+        std::vector<float> ls((size_t)h->K * dm.LS);
         HIPCHK(hipMemcpy(ls.data(), h->d_loss_step, ls.size() * 4, hipMemcpyDeviceToHost));
         for (int k = 0; k < h->K; ++k) {
             double s = 0;
-            for (int j = 0; j < dm.OS; ++j) s += ls[(size_t)k * dm.OS + j];
+            for (int j = 0; j < dm.LS; ++j) s += ls[(size_t)k * dm.LS + j];
             loss_out[k] = (float)(s / ((double)b_act * h->O));
         }
     }
@@ -793,7 +796,7 @@ extern "C" int dimn_train_epoch(dimn_handle h, int32_t epoch, const int32_t* per
     }
     CHK(sync_lanes(h));
     HIPCHK(hipMemcpyAsync(h->d_epoch_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemsetAsync(h->d_loss_acc, 0, (size_t)h->K * dm.OS * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_loss_acc, 0, (size_t)h->K * dm.LS * sizeof(double), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));     // every lane reads the row list and accumulates into d_loss_acc
     // d_loss_acc accumulates sum(w e^2) per step; the per-step means are weighted by b_act,
     // i.e. sum_steps (sum/(b_act*O))*b_act / n_tr = total / (O*n_tr)
@@ -812,11 +815,11 @@ extern "C" int dimn_train_epoch(dimn_handle h, int32_t epoch, const int32_t* per
     CHK(sync_lanes(h));
     if (h->profiling) collect_timers(h);
     if (train_loss) {
-        std::vector<double> acc((size_t)h->K * dm.OS);
+        std::vector<double> acc((size_t)h->K * dm.LS);
         HIPCHK(hipMemcpy(acc.data(), h->d_loss_acc, acc.size() * sizeof(double), hipMemcpyDeviceToHost));
         for (int k = 0; k < h->K; ++k) {
             double s = 0;
-            for (int j = 0; j < dm.OS; ++j) s += acc[(size_t)k * dm.OS + j];
+            for (int j = 0; j < dm.LS; ++j) s += acc[(size_t)k * dm.LS + j];
             train_loss[k] = s / ((double)h->O * (double)h->n_tr);
         }
     }

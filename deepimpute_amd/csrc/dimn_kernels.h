@@ -90,9 +90,9 @@ struct Work {               // one workgroup of the split-K / weight-update kern
 };
 
 struct Dims {
-    int32_t K, H, O, Hp, Op, HT, OT, ldd, OS;
+    int32_t K, H, O, Hp, Op, HT, OT, ldd, OS, LS;
     // Hp = ceil16(H), HT = Hp/16, Op = ceil16(O), OT = Op/16, ldd = LDS row stride of Dd,
-    // OS = ceil(OT/4) output slices of 64 columns
+    // OS = ceil(OT/4) output slices of 64 columns; LS = loss slots per sub-net (>= OS, >= slices of the fused kernel)
 };
 
 struct AdamP {
@@ -456,8 +456,8 @@ __global__ __launch_bounds__(512) void k_mid_fwd(const float* __restrict__ W2,
         float tot = 0.f;
 #pragma unroll
         for (int wv = 0; wv < 8; ++wv) tot += lds[wv];
-        loss_step[k * dm.OS + os] = tot;
-        if (loss_acc) loss_acc[k * dm.OS + os] += (double)tot;
+        loss_step[k * dm.LS + os] = tot;
+        if (loss_acc) loss_acc[k * dm.LS + os] += (double)tot;
     }
 }
 
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
     float* dzl = lds + DIMN_TB * ldd;                        // dZ tiles [T][64 b][16 o]
     float* wsl = dzl + DIMN_MID_TMAX * 1024;                 // per-wave W2 transpose buffers [8][4 tiles]
     float* lsl = wsl + 8 * 1024;                             // loss partials [8 waves]
-    float* gbl = lsl + 8;                                    // bias-gradient halves of the shared units [4 waves][16]
+    float* gbl = lsl + 8;                                    // bias-gradient row parts of the shared units [8 waves][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -672,20 +672,25 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
     // would be 119 and overflow the 6-bit vmcnt).
     // phase 1: wave w -> output tile ot0 + w (all 64 batch rows), so every W2 column block is loaded once
     // per workgroup; waves beyond the slice's tile count idle until phase 2.
-    // Unit u = output tile ot0 + u.  Waves 0..3 (one per SIMD) take units 0..3 whole; with 5 or 6 tiles the
-    // remaining units are shared by two waves, 32 batch rows each, so that every SIMD's MFMA pipe carries the
-    // same load (two whole units on one SIMD made phase 1 1.4x longer); 7 or 8 tiles: one unit per wave.
+    // Unit u = output tile ot0 + u, shared by `ways` waves (64/ways batch rows each) so that all eight waves --
+    // and all four SIMDs' MFMA pipes -- carry phase 1:  T <= 2: 4 waves per unit;  T = 3, 4: 2 waves per unit;
+    // T = 5, 6: units 0..3 whole on waves 0..3 (one per SIMD), units 4, 5 halved over waves 4..7 (two whole
+    // units on one SIMD made phase 1 1.4x longer);  T = 7, 8: one unit per wave.
     const int T = ot1 - ot0;
-    const bool split = (T == 5 || T == 6) && wave >= 4;
-    const int u = split ? 4 + ((wave - 4) >> 1) : wave;
-    const int m0 = split ? 2 * ((wave - 4) & 1) : 0;         // first 16-row tile of this wave
-    const int nm = split ? 2 : 4;                            // 16-row tiles of this wave
+    int ways, u, part;
+    if (T <= 2) { ways = 4; u = wave >> 2; part = wave & 3; }
+    else if (T <= 4) { ways = 2; u = wave >> 1; part = wave & 1; }
+    else if (T <= 6 && wave >= 4) { ways = 2; u = 4 + ((wave - 4) >> 1); part = (wave - 4) & 1; }
+    else { ways = 1; u = wave; part = 0; }
+    const bool split = ways > 1;
+    const int nm = 4 / ways;                                 // 16-row tiles of this wave
+    const int m0 = part * nm;                                // its first one
     const bool p1 = u < T;
     const int oc = p1 ? ot0 + u : ot_last;                   // clamped: loads stay in bounds
     int rid[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                            // a split wave repeats its two tiles (same loads, same LDS words)
-        const int b = 16 * (m0 + (i < nm ? i : i - nm)) + (lane >> 2);
+        const int b = 16 * (m0 + i % nm) + (lane >> 2);
         rid[i] = rows[b < b_act ? b : 0];
     }
     const float* ddk = Dd + (int64_t)k * DIMN_TB * Hp;
@@ -799,14 +804,16 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
                 adam1(bias, b2m0, b2v0, gb, ap);
                 b2w[bi] = bias; b2m[bi] = b2m0; b2v[bi] = b2v0;
             } else {
-                gbl[(wave - 4) * 16 + li] = gb;              // half of the rows: finished after the barrier
+                gbl[wave * 16 + li] = gb;                    // part of the rows: finished after the barrier
             }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
     };
     if (p1) {
-        if (split) phase1(std::integral_constant<int, 2>{}); else phase1(std::integral_constant<int, 4>{});
+        if (ways == 4) phase1(std::integral_constant<int, 1>{});
+        else if (ways == 2) phase1(std::integral_constant<int, 2>{});
+        else phase1(std::integral_constant<int, 4>{});
     }
     if (lane == 0) lsl[wave] = lsum;
     MID_STAMP(2)
@@ -816,11 +823,12 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
         float tot = 0.f;
 #pragma unroll
         for (int wv = 0; wv < 8; ++wv) tot += lsl[wv];
-        loss_step[k * dm.OS + mw.sidx] = tot;
-        if (loss_acc) loss_acc[k * dm.OS + mw.sidx] += (double)tot;
+        loss_step[k * dm.LS + mw.sidx] = tot;
+        if (loss_acc) loss_acc[k * dm.LS + mw.sidx] += (double)tot;
     }
-    if (split && p1 && m0 == 0 && lj == 0) {                 // Adam(b2) of a shared unit: rows 0..31 + rows 32..63
-        const float gb = gbl[(wave - 4) * 16 + li] + gbl[(wave - 3) * 16 + li];
+    if (split && p1 && part == 0 && lj == 0) {               // Adam(b2) of a shared unit: its waves' row parts, in order
+        float gb = gbl[wave * 16 + li];
+        for (int j = 1; j < ways; ++j) gb += gbl[(wave + j) * 16 + li];
         adam1(bias, b2m0, b2v0, gb, ap);
         b2w[bi] = bias; b2m[bi] = b2m0; b2v[bi] = b2v0;
     }

@@ -25,7 +25,7 @@ template <typename F> static double timeit(F launch, int R = 20) {
 int main(int argc, char** argv) {
     const int K = 40, D = 2400, H = 256, O = 512; const int64_t n = argc > 1 ? atoll(argv[1]) : 50000;
     const float vscale = argc > 2 ? atof(argv[2]) : 1e-6f;
-    Dims dm; dm.K = K; dm.H = H; dm.O = O; dm.Hp = 256; dm.Op = 512; dm.HT = 16; dm.OT = 32; dm.ldd = 258; dm.OS = 8;
+    Dims dm; dm.K = K; dm.H = H; dm.O = O; dm.Hp = 256; dm.Op = 512; dm.HT = 16; dm.OT = 32; dm.ldd = 258; dm.OS = 8; dm.LS = 8;
     std::vector<SubnetDev> sn(K);
     int64_t w1 = 0, x = 0;
     for (int k = 0; k < K; ++k) { sn[k].D = D; sn[k].Dp = D; sn[k].nchunk = D / 16; sn[k].kg = k; sn[k].xoff = x; sn[k].w1off = w1; w1 += (int64_t)D * 256; x += n * D; }

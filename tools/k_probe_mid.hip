@@ -30,7 +30,7 @@ static float* dalloc(size_t n, float scale, unsigned seed) {
 int main(int argc, char** argv) {
     const int K = argc > 1 ? atoi(argv[1]) : 40, H = 256, O = 512, S = 19; const int64_t n = 50000;
     printf("K = %d\n", K);
-    Dims dm; dm.K = K; dm.H = H; dm.O = O; dm.Hp = 256; dm.Op = 512; dm.HT = 16; dm.OT = 32; dm.ldd = 258; dm.OS = 8;
+    Dims dm; dm.K = K; dm.H = H; dm.O = O; dm.Hp = 256; dm.Op = 512; dm.HT = 16; dm.OT = 32; dm.ldd = 258; dm.OS = 8; dm.LS = 8;
     std::vector<SubnetDev> sn(K);
     for (int k = 0; k < K; ++k) { sn[k].D = 2400; sn[k].Dp = 2400; sn[k].nchunk = 150; sn[k].kg = k; sn[k].slot0 = k * S; sn[k].nslice = S; sn[k].xoff = 0; sn[k].w1off = 0; }
     SubnetDev* dsn; CK(hipMalloc(&dsn, K * sizeof(SubnetDev))); CK(hipMemcpy(dsn, sn.data(), K * sizeof(SubnetDev), hipMemcpyHostToDevice));
