@@ -56,6 +56,10 @@ int main(int argc, char** argv) {
         T("ring4<16,1> next", (k_w1_update_fwd_ring<16, 1, 4>), dim3(g), dim3(1024), 0, 0, dwk, dsn, X, W, M, V, drows, 64, drows + 64, 64, dA, P, dm, ap)
         T("ring4<16,1> no-next", (k_w1_update_fwd_ring<16, 1, 4>), dim3(g), dim3(1024), 0, 0, dwk, dsn, X, W, M, V, drows, 64, (const int32_t*)nullptr, 0, dA, P, dm, ap)
         T("ring<16,1> no-next", (k_w1_update_fwd_ring<16, 1>), dim3(g), dim3(1024), 0, 0, dwk, dsn, X, W, M, V, drows, 64, (const int32_t*)nullptr, 0, dA, P, dm, ap)
+        // half of the sub-nets on half of the CUs (what one of two lanes launches; the GB/s column assumes the full byte count):
+        // measured 82 us for 320 MB = 3.9 TB/s -- 128 CUs cannot pull the whole HBM rate, so two serialised half launches
+        // (164 us) lose to one full launch (110-120 us) and sub-net lanes cannot pay off
+        T("ring<16,1> next, first 128 WGs only", (k_w1_update_fwd_ring<16, 1>), dim3(g / 2), dim3(1024), 0, 0, dwk, dsn, X, W, M, V, drows, 64, drows + 64, 64, dA, P, dm, ap)
         T("ring<8,1> x2 halves next", (k_w1_update_fwd_ring<8, 1>), dim3(g, 2), dim3(512), 0, 0, dwk, dsn, X, W, M, V, drows, 64, drows + 64, 64, dA, P, dm, ap)
         // T("ring<8,2> next", (k_w1_update_fwd_ring<8, 2>), dim3(g), dim3(512), 0, 0, dwk, dsn, X, W, M, V, drows, 64, drows + 64, 64, dA, P, dm, ap)
         T("sh<8,1> x2 halves next", (k_w1_update_fwd_sh<8, 1>), dim3(g, 2), dim3(512), 0, 0, dwk, dsn, X, W, M, V, drows, 64, drows + 64, 64, dA, P, dm, ap)
