@@ -266,6 +266,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--limit-subnets", type=int, default=0, help="diagnostic: keep only the first N sub-nets (what one rank of an N-GPU job sees)")
+    ap.add_argument("--hidden", type=int, default=0, help="diagnostic: hidden width (default: the config's 256; the reference CLI defaults to 300)")
     ap.add_argument("--early-stop-probe", action="store_true", help="also run the early-stopped fit once and report its epoch count")
     args = ap.parse_args()
 
@@ -281,7 +282,10 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     from deepimpute_amd.engine import HipEngine
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.hidden:
+        cfg["H"] = args.hidden
+        cfg["label"] += " [hidden=%d]" % args.hidden
     n, g = cfg["n"], cfg["g"]
     t_gen = time.time()
     norm = synth_counts(n, g, seed=0)

@@ -1266,8 +1266,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
 template <int NT2>
 struct W1Set { f32x4 w[NT2], m[NT2], v[NT2]; f32x4 x; };
 
-template <int WAVES, int NT2, int DEPTH = 3>   // DEPTH named register sets = DEPTH-1 chunks in flight
-__global__ __launch_bounds__(WAVES * 64) void k_w1_update_fwd_ring(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
+template <int WAVES, int NT2, int DEPTH = 3, int WPS = 1>   // DEPTH named register sets = DEPTH-1 chunks in flight; WPS: waves per SIMD to fit (co-resident workgroups)
+__global__ __launch_bounds__(WAVES * 64, WPS) void k_w1_update_fwd_ring(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
                                                                   const float* __restrict__ X, float* __restrict__ W1,
                                                                   float* __restrict__ M1, float* __restrict__ V1,
                                                                   const int32_t* __restrict__ rows_t, int b_act,
