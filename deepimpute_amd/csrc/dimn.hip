@@ -699,7 +699,9 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
         const size_t lds = (size_t)DIMN_TB * dm.ldd * sizeof(float);
 #define LAUNCH_MF(HTC) hipLaunchKernelGGL(k_mid_fwd<HTC>, grid, dim3(512), lds, st, h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, \
                                           h->n, d_rows, b_act, h->d_Dd, h->d_dZ, h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary, ln.k0)
-        if (h->mf_variant == 16 && dm.HT == 16) LAUNCH_MF(16); else LAUNCH_MF(0);   // 0: 78 VGPRs; 16: all W2 operands hoisted, 162 VGPRs
+        if (h->mf_variant == 16 && dm.HT == 16) LAUNCH_MF(16);                      // all W2 operands hoisted, 162 VGPRs
+        else if (h->mf_variant == 16 && dm.HT == 20) LAUNCH_MF(20);                 // hidden = 300 (padded to 320)
+        else LAUNCH_MF(0);                                                          // generic: 78 VGPRs
 #undef LAUNCH_MF
     }
     // one hidden tile (16 rows of W2) per workgroup; 4 or 8 waves split the output tiles
