@@ -1,0 +1,60 @@
+"""CPU checks of bench.py's workload generator and sharding helpers (the GPU legs are exercised by the
+driver; these make sure every rank builds the same problem and that the shards cover it)."""
+import os
+import sys
+import threading
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def test_synthetic_matrix_is_a_pure_function_of_its_seed():
+    a = bench.synth_counts(700, 90, seed=3, threads=1)
+    b = bench.synth_counts(700, 90, seed=3, threads=5)          # every rank may use a different pool size
+    assert a.dtype == np.float32 and np.array_equal(a, b)
+    assert not np.array_equal(a, bench.synth_counts(700, 90, seed=4, threads=2))
+    counts = np.expm1(a.astype(np.float64))
+    assert np.allclose(counts, np.round(counts), atol=1e-3) and counts.max() >= 10     # raw counts, passes inspect_data
+
+
+def test_index_lists_have_the_reference_shapes():
+    g, O = 1300, 128
+    targets, preds = bench.synth_indices(g, O, seed=0)
+    K = -(-g // O)
+    assert targets.shape == (K, O) and len(preds) == K
+    assert set(targets[:g // O].ravel()) <= set(range(g))
+    assert np.unique(targets.ravel()[:g]).size == g             # every gene is a target once before the random fill
+    for k in range(K):
+        assert np.unique(preds[k]).size == preds[k].size        # first-occurrence unique, like setPredictors
+        assert not set(preds[k]) & set(targets[k])              # predictors exclude the sub-net's own targets
+    t2, p2 = bench.synth_indices(g, O, seed=0)
+    assert np.array_equal(targets, t2) and all(np.array_equal(a, b) for a, b in zip(preds, p2))
+
+
+def test_split_and_shards_cover_everything():
+    train, val = bench.split_rows(1000, seed=0)
+    assert val.size == 50 and np.array_equal(np.sort(np.concatenate([train, val])), np.arange(1000))
+    assert np.array_equal(train, np.sort(train))               # np.setdiff1d order, multinet.py:229
+    for K, world in ((40, 1), (40, 8), (10, 4), (7, 3)):
+        counts, offs = bench.shard(K, world)
+        assert sum(counts) == K and offs[0] == 0 and max(counts) - min(counts) <= 1
+        assert all(offs[r + 1] == offs[r] + counts[r] for r in range(world - 1))
+
+
+def test_file_rendezvous_hands_the_payload_to_every_rank(monkeypatch, tmp_path):
+    monkeypatch.setenv("MASTER_PORT", "4%d" % (os.getpid() % 10000))
+    ranks = [bench.FileRendezvous(r, 3) for r in range(3)]
+    got = {}
+
+    def run(r):
+        got[r] = ranks[r].broadcast_bytes("uid", b"\x01\x02payload" if r == 0 else None, timeout=20.0)
+    th = [threading.Thread(target=run, args=(r,)) for r in (2, 1, 0)]     # root arrives last
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert got == {0: b"\x01\x02payload", 1: b"\x01\x02payload", 2: b"\x01\x02payload"}
+    ranks[0].cleanup()
+    assert not os.path.exists(ranks[0].dir)
