@@ -2,6 +2,7 @@
 // in dimn_kernels.h.  One handle = one GPU = one HIP stream; RCCL is bound lazily (dlopen).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -604,24 +605,25 @@ static void launch_fwd1(dimn_handle h, const dimn_handle_s::Lane& ln, const int3
 }
 template <int NT2>
 static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, const int32_t* rows, int b_act, const int32_t* rows_n, int b_next,
-                      AdamP ap) {
+                      AdamP ap, hipEvent_t ev_begin, hipEvent_t ev_end) {
     const dim3 grid((unsigned)(ln.w1 - ln.w0));
     const Work* wk = h->d_work + ln.w0;
+    // ev_begin/ev_end (timed launches only): hipExtLaunchKernelGGL stamps them with the kernel's own begin and end,
+    // so the elapsed time is the launch's duration without the dispatch latency an event pair around it would add
+#define W1_LAUNCH(KERNEL, THREADS) hipExtLaunchKernelGGL((KERNEL), grid, dim3(THREADS), 0, ln.stream, ev_begin, ev_end, 0, wk, h->d_sn,      \
+                                                         (const float*)h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, \
+                                                         (const float*)h->d_dA, h->d_P, h->dm, ap)
     if (h->dm.HT == 20 && h->variant == 1)        // H = 300 (padded to 320): 10 waves x 2 hidden tiles, two-set shared-staging variant
-        hipLaunchKernelGGL((k_w1_update_fwd_sh<10, 2, 1>), grid, dim3(640), 0, ln.stream, wk, h->d_sn, h->d_X, h->d_W1, h->d_M1, h->d_V1,
-                           rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
+        W1_LAUNCH((k_w1_update_fwd_sh<10, 2, 1>), 640);
     else if (h->dm.HT == 16 && h->variant == 1)   // H = 256: 16 waves x 1 hidden tile, X tiles staged once per workgroup, 3-set register ring
-        hipLaunchKernelGGL((k_w1_update_fwd_ring<16, 1>), grid, dim3(1024), 0, ln.stream, wk, h->d_sn, h->d_X, h->d_W1, h->d_M1, h->d_V1,
-                           rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
+        W1_LAUNCH((k_w1_update_fwd_ring<16, 1>), 1024);
     else if (h->dm.HT == 16 && h->variant == 2)
-        hipLaunchKernelGGL((k_w1_update_fwd_sh<16, 1>), grid, dim3(1024), 0, ln.stream, wk, h->d_sn, h->d_X, h->d_W1, h->d_M1, h->d_V1,
-                           rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
+        W1_LAUNCH((k_w1_update_fwd_sh<16, 1>), 1024);
     else if (h->dm.HT == 8 * NT2)
-        hipLaunchKernelGGL((k_w1_update_fwd<NT2, true>), grid, dim3(512), 0, ln.stream, wk, h->d_sn, h->d_X, h->d_W1, h->d_M1, h->d_V1,
-                           rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
+        W1_LAUNCH((k_w1_update_fwd<NT2, true>), 512);
     else
-        hipLaunchKernelGGL((k_w1_update_fwd<NT2, false>), grid, dim3(512), 0, ln.stream, wk, h->d_sn, h->d_X, h->d_W1, h->d_M1, h->d_V1,
-                           rows, b_act, rows_n, b_next, h->d_dA, h->d_P, h->dm, ap);
+        W1_LAUNCH((k_w1_update_fwd<NT2, false>), 512);
+#undef W1_LAUNCH
 }
 template <int NT>
 static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out, float* loss_part) {
@@ -711,9 +713,7 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     else { if (dm.OT == 4 * h->OTW) LAUNCH_MB(true, 4); else LAUNCH_MB(false, 4); }
 #undef LAUNCH_MB
     }
-    if (timed) (void)hipEventRecord(e1, st);
-    DISPATCH_NT2(launch_w1, h, ln, d_rows, b_act, d_rows_n, b_next, ap);
-    if (timed) (void)hipEventRecord(e2, st);
+    DISPATCH_NT2(launch_w1, h, ln, d_rows, b_act, d_rows_n, b_next, ap, e1, e2);   // e1/e2 (timed steps): the kernel's own begin/end
     HIPCHK(hipGetLastError());
     return DIMN_OK;
 }
