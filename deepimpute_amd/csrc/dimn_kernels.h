@@ -177,11 +177,11 @@ __global__ __launch_bounds__(512) void k_gather_lds(const SubnetDev* __restrict_
             const SubnetDev s = sn[k];
             const int32_t* pk = pred + pred_off[k];
             float* xr = X + s.xoff + i * s.Dp;
-            for (int d = threadIdx.x; d < s.Dp; d += 512) xr[d] = d < s.D ? rowbuf[pk[d]] : 0.f;
+            for (int d = threadIdx.x; d < s.Dp; d += 512) __builtin_nontemporal_store(d < s.D ? rowbuf[pk[d]] : 0.f, &xr[d]);   // written once, read much later
             if (with_targets) {
                 float* yr = Y + ((int64_t)k * n + i) * dm.Op;
                 const int32_t* tk = targ + (int64_t)k * dm.O;
-                for (int o = threadIdx.x; o < dm.Op; o += 512) yr[o] = o < dm.O ? rowbuf[tk[o]] : 0.f;
+                for (int o = threadIdx.x; o < dm.Op; o += 512) __builtin_nontemporal_store(o < dm.O ? rowbuf[tk[o]] : 0.f, &yr[o]);
             }
         }
     }
@@ -1537,7 +1537,7 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
                     const int64_t i = r0 + 16 * mt + 4 * lj + r;
                     if (i < n_rows) {
                         const float yh = softplus_f(z[mt][r] + bias);
-                        if (out) out[(i * dm.K + k) * dm.O + o] = yh;
+                        if (out) __builtin_nontemporal_store(yh, &out[(i * dm.K + k) * dm.O + o]);
                         if (loss_part) {
                             const int64_t row = rows ? (int64_t)rows[i] : i;
                             const float y = Y[((int64_t)k * n_cells + row) * dm.Op + o];
