@@ -1477,23 +1477,41 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
         const int64_t row = valid[mt] ? (rows ? (int64_t)rows[i] : i) : 0;
         xo[mt] = row * s.Dp + 4 * lj;
     }
-    const float* wb = W1 + s.w1off + (int64_t)(16 * nt0 + li) * 16 + 4 * lj;
     const int64_t cstride = (int64_t)Hp * 16;
-    for (int c = 0; c < s.nchunk; ++c) {
-        f32x4 a[4], b[NT];
+    const float* wbt[NT];                                    // tiles past HT are clamped: loaded, never used
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-            a[mt] = valid[mt] ? *(const f32x4*)(xk + xo[mt] + 16 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt) {
+        const int t = (nt0 + nt) < dm.HT ? (nt0 + nt) : (dm.HT - 1);
+        wbt[nt] = W1 + s.w1off + (int64_t)(16 * t + li) * 16 + 4 * lj;
+    }
+    // Two named operand sets, loop unrolled x2: the loads of chunk c+1 are in flight while chunk c feeds the
+    // MFMAs (rows past n_rows read row 0 and are dropped at the end, so every load is unconditional).
+    struct Ops { f32x4 a[4], b[NT]; };
+    auto fetch = [&](Ops& o, int c) {
+        const int cc = c < s.nchunk ? c : s.nchunk - 1;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            b[nt] = (nt0 + nt < dm.HT) ? *(const f32x4*)(wb + c * cstride + nt * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < 4; ++mt) o.a[mt] = *(const f32x4*)(xk + xo[mt] + 16 * cc);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) o.b[nt] = *(const f32x4*)(wbt[nt] + cc * cstride);
+    };
+    auto mma = [&](const Ops& o) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA16(a[mt][r], b[nt][r], acc[mt][nt]);
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA16(o.a[mt][r], o.b[nt][r], acc[mt][nt]);
+    };
+    Ops P0, P1;
+    fetch(P0, 0);
+    int c = 0;
+    for (; c + 2 <= s.nchunk; c += 2) {
+        fetch(P1, c + 1);
+        mma(P0);
+        fetch(P0, c + 2);
+        mma(P1);
     }
+    if (c < s.nchunk) mma(P0);
     // bias + relu -> LDS (dropout is identity at inference, S3/S12)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
