@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
         for (int nt = 0; nt < NT2; ++nt) {
             if (FULL || on[nt]) {
                 const int64_t idx = wb[nt] + c * cstride;
-                *(f32x4*)(W1 + idx) = w[nt]; *(f32x4*)(M1 + idx) = m[nt]; *(f32x4*)(V1 + idx) = v[nt];
+                DIMN_ST_STATE(W1 + idx, w[nt]); DIMN_ST_STATE(M1 + idx, m[nt]); DIMN_ST_STATE(V1 + idx, v[nt]);
             }
         }
         if (have_next) {
@@ -1226,7 +1226,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
             const int64_t idx = wb[nt] + c * cstride;
-            *(f32x4*)(W1 + idx) = w[nt]; *(f32x4*)(M1 + idx) = m[nt]; *(f32x4*)(V1 + idx) = v[nt];
+            DIMN_ST_STATE(W1 + idx, w[nt]); DIMN_ST_STATE(M1 + idx, m[nt]); DIMN_ST_STATE(V1 + idx, v[nt]);
         }
         if (have_next) {
             const float* xn = sm + 2 * XT + cur * XN;
