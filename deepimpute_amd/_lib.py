@@ -19,6 +19,9 @@ def library():
                 "deepimpute_amd: %s is not built. Run `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (needs hipcc, --offload-arch=gfx950). There is no CPU fallback."
                 % LIB_PATH)
+        # multi-process GPU work (RCCL between ranks) needs dmabuf IPC on this driver stack; the variable is read when
+        # the HSA runtime initialises, i.e. at the first HIP call after this load
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     return _lib
 
