@@ -12,6 +12,8 @@ import numpy as np
 ABI_VERSION = 1
 MAX_BATCH = 64
 COMM_ID_BYTES = 128
+# hidden-layer activations the kernels implement (ids = DIMN_ACT_* of include/dimn.h; Keras names)
+ACTIVATIONS = {"relu": 0, "linear": 1, "sigmoid": 2, "tanh": 3, "elu": 4, "softplus": 5}
 
 
 class Config(C.Structure):
@@ -54,6 +56,7 @@ SIGNATURES = {
     "set_weights": [_H, _i32, _pf, _pf, _pf, _pf],
     "get_weights": [_H, _i32, _pf, _pf, _pf, _pf],
     "get_adam_state": [_H, _i32, _i32, _pf, _pf, _pf, _pf],
+    "set_activation": [_H, _i32],
     "reset_optimizer": [_H],
     "get_step_count": [_H, C.POINTER(_i64)],
     "train_step": [_H, _pi, _i32, _pu8, _i32, _i32, _pf],

@@ -114,6 +114,7 @@ struct dimn_handle_s {
     float *d_W2 = nullptr, *d_M2 = nullptr, *d_V2 = nullptr;
     float *d_b1 = nullptr, *d_b2 = nullptr;   // [3][K][Hp|Op]: w, m, v
     float *d_P = nullptr, *d_Dd = nullptr, *d_dZ = nullptr, *d_dA = nullptr;
+    int act = 0; float* d_G = nullptr;     // hidden activation (DIMN_ACT_*), gate buffer f'(A)*keep*scale for act != relu
     float* d_loss_step = nullptr; double* d_loss_acc = nullptr;
     uint8_t* d_mask = nullptr;
     int32_t *d_rows_step = nullptr, *d_epoch_rows = nullptr, *d_val_rows = nullptr, *d_pred_rows = nullptr;
@@ -201,6 +202,7 @@ static void build_work(dimn_handle h) {
     h->nslots = slot;
 }
 
+static int sync_lanes_fwd(dimn_handle h);
 static void build_mid(dimn_handle h) {
     // Fused second layer (H = 256): every sub-net's OT output tiles are cut into S slices, S*K <= ncu so that
     // each CU runs at most one workgroup (S <= OT: one tile per slice when a GPU owns few sub-nets); a slice
@@ -379,7 +381,7 @@ extern "C" int dimn_destroy(dimn_handle h) {
     DEV_FREE(h->d_W1); DEV_FREE(h->d_M1); DEV_FREE(h->d_V1); DEV_FREE(h->d_W2); DEV_FREE(h->d_M2); DEV_FREE(h->d_V2);
     DEV_FREE(h->d_b1); DEV_FREE(h->d_b2); DEV_FREE(h->d_P); DEV_FREE(h->d_Dd); DEV_FREE(h->d_dZ); DEV_FREE(h->d_dA);
     DEV_FREE(h->d_loss_step); DEV_FREE(h->d_loss_acc); DEV_FREE(h->d_mask); DEV_FREE(h->d_rows_step);
-    DEV_FREE(h->d_midwork); DEV_FREE(h->d_midk); DEV_FREE(h->d_P2);
+    DEV_FREE(h->d_midwork); DEV_FREE(h->d_midk); DEV_FREE(h->d_P2); DEV_FREE(h->d_G);
     DEV_FREE(h->d_epoch_rows); DEV_FREE(h->d_val_rows); DEV_FREE(h->d_pred_rows); DEV_FREE(h->d_out);
     DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage);
     for (auto& ln : h->lanes) (void)hipStreamDestroy(ln.stream);
@@ -498,6 +500,20 @@ static int zero_opt(dimn_handle h) {
     HIPCHK(hipMemsetAsync(h->d_b1 + (size_t)h->K * dm.Hp, 0, (size_t)2 * h->K * dm.Hp * 4, h->stream));
     HIPCHK(hipMemsetAsync(h->d_b2 + (size_t)h->K * dm.Op, 0, (size_t)2 * h->K * dm.Op * 4, h->stream));
     h->t = 0;
+    return DIMN_OK;
+}
+
+extern "C" int dimn_set_activation(dimn_handle h, int32_t activation) {
+    if (!h) return fail(DIMN_ERR_ARG, "null handle");
+    if (activation < DIMN_ACT_RELU || activation > DIMN_ACT_SOFTPLUS) return fail(DIMN_ERR_UNSUP, "dimn_set_activation: unknown activation %d", activation);
+    CHK(use_device(h));
+    CHK(sync_lanes_fwd(h));
+    if (activation != DIMN_ACT_RELU && !h->d_G) {
+        CHK(dev_alloc(&h->d_G, (size_t)h->K * DIMN_TB * h->dm.Hp));
+        HIPCHK(hipMemset(h->d_G, 0, (size_t)h->K * DIMN_TB * h->dm.Hp * 4));
+    }
+    if (activation == DIMN_ACT_RELU) DEV_FREE(h->d_G);     // relu derives its gate from Dd > 0
+    h->act = activation;
     return DIMN_OK;
 }
 
@@ -630,7 +646,7 @@ static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, f
     const unsigned tiles = (unsigned)((n_rows + DIMN_TB - 1) / DIMN_TB);
     const size_t lds = (size_t)DIMN_TB * h->dm.ldd * sizeof(float);
     hipLaunchKernelGGL(k_predict<NT>, dim3(tiles, (unsigned)h->K), dim3(256), lds, h->stream, h->d_sn, h->d_X, h->d_W1, h->d_b1,
-                       h->d_W2, h->d_b2, rows, n_rows, out, h->d_Y, h->n, loss_part, h->dm, h->cfg.loss_binary);
+                       h->d_W2, h->d_b2, rows, n_rows, out, h->d_Y, h->n, loss_part, h->dm, h->cfg.loss_binary, h->act);
 }
 #define DISPATCH_NT(fn, ...)                          \
     switch (h->NT) {                                  \
@@ -686,7 +702,7 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
 
     if (need_fwd) { DISPATCH_NT(launch_fwd1, h, ln, d_rows, b_act); }
     hipLaunchKernelGGL(k_reduce_act, dim3((unsigned)ceil_div(DIMN_TB * dm.Hp, 1024), nk), dim3(256), 0, st, h->d_sn, h->d_P, h->d_b1, d_mask,
-                       h->d_Dd, dm, b_act, rate, scale, h->cfg.seed, epoch_key, step_key, ln.k0);
+                       h->d_Dd, dm, b_act, rate, scale, h->cfg.seed, epoch_key, step_key, ln.k0, h->act, h->d_G);
     if (h->mid_fused) {
         // RED -> MFB (whole second layer, W2 streamed once) -> RED2 (dD partials -> dA, Adam(b1))
         const size_t lds = ((size_t)DIMN_TB * DIMN_MID_LDD + DIMN_MID_TMAX * 1024 + 8 * 1024 + 8 + 64) * sizeof(float);
@@ -694,7 +710,7 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
                            h->d_W2, h->d_M2, h->d_V2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_P2,
                            h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary);
         hipLaunchKernelGGL(k_reduce_dd, dim3((unsigned)ceil_div(dm.Hp, 64), nk), dim3(1024), 0, st, h->d_midk, h->d_P2, h->d_Dd,
-                           h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, ln.k0);
+                           h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, ln.k0, (const float*)h->d_G);
     } else {
     {
         const dim3 grid((unsigned)dm.OS, nk);
@@ -708,7 +724,7 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     }
     // one hidden tile (16 rows of W2) per workgroup; 4 or 8 waves split the output tiles
 #define LAUNCH_MB(FULLV, WV) hipLaunchKernelGGL((k_mid_bwd<FULLV, 1, WV>), dim3((unsigned)dm.HT, nk), dim3(WV * 64), 0, st, h->d_Dd, h->d_dZ, \
-                                                h->d_W2, h->d_M2, h->d_V2, h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0)
+                                                h->d_W2, h->d_M2, h->d_V2, h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0, (const float*)h->d_G)
     if (h->mb_waves == 8) { if (dm.OT == 8 * h->OTW) LAUNCH_MB(true, 8); else LAUNCH_MB(false, 8); }
     else { if (dm.OT == 4 * h->OTW) LAUNCH_MB(true, 4); else LAUNCH_MB(false, 4); }
 #undef LAUNCH_MB
@@ -718,6 +734,8 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     return DIMN_OK;
 }
 
+static int sync_lanes(dimn_handle h);
+static int sync_lanes_fwd(dimn_handle h) { return sync_lanes(h); }
 static int sync_lanes(dimn_handle h) {
     for (auto& ln : h->lanes) HIPCHK(hipStreamSynchronize(ln.stream));
     return DIMN_OK;

@@ -125,6 +125,19 @@ __device__ __forceinline__ float softplus_f(float x) {
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Hidden activation f and derivative f' at pre-activation a (multinet.py:137; ids = DIMN_ACT_* of dimn.h, elu alpha = 1).
+// relu is handled inline by the kernels (bit-identical to the path that has no activation switch).
+__device__ __forceinline__ void hidden_act(int act, float a, float& f, float& df) {
+    switch (act) {
+        case 1: f = a; df = 1.f; break;
+        case 2: { const float s = sigmoid_f(a); f = s; df = s * (1.f - s); break; }
+        case 3: { const float t = tanhf(a); f = t; df = 1.f - t * t; break; }
+        case 4: { const float e = expm1f(a); f = a > 0.f ? a : e; df = a > 0.f ? 1.f : e + 1.f; break; }
+        case 5: f = softplus_f(a); df = sigmoid_f(a); break;
+        default: f = a > 0.f ? a : 0.f; df = a > 0.f ? 1.f : 0.f; break;
+    }
+}
+
 // Training-path versions on the hardware exp2/log2/rcp units (v_exp_f32, v_log_f32, v_rcp_f32):
 // t = exp(-|x|) in (0,1];  softplus = max(x,0) + log1p(t);  sigmoid = x>=0 ? 1/(1+t) : t/(1+t).
 // log1p(t) switches to its series below 2^-12 so tiny outputs keep their relative accuracy.  They feed
@@ -273,7 +286,8 @@ __global__ __launch_bounds__(256) void k_fwd1(const Work* __restrict__ work, con
 __global__ __launch_bounds__(256) void k_reduce_act(const SubnetDev* __restrict__ sn, const float* __restrict__ P,
                                                     const float* __restrict__ b1, const uint8_t* __restrict__ mask,
                                                     float* __restrict__ Dd, Dims dm, int b_act, float rate, float scale,
-                                                    uint64_t seed, uint32_t epoch_key, uint32_t step_key, int k0) {
+                                                    uint64_t seed, uint32_t epoch_key, uint32_t step_key, int k0,
+                                                    int act, float* __restrict__ G) {   // act != relu: G[k][64][Hp] = f'(A) * keep * scale
     const int k = blockIdx.y + k0;
     const SubnetDev s = sn[k];
     const int Hp = dm.Hp;
@@ -314,10 +328,23 @@ __global__ __launch_bounds__(256) void k_reduce_act(const SubnetDev* __restrict_
         for (int r = 0; r < 4; ++r) keep[r] = true;
     }
     f32x4 dd;
+    if (act == 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float relu = a[r] > 0.f ? a[r] : 0.f;
-        dd[r] = (keep[r] && b < b_act) ? relu * scale : 0.f;
+        for (int r = 0; r < 4; ++r) {
+            const float relu = a[r] > 0.f ? a[r] : 0.f;
+            dd[r] = (keep[r] && b < b_act) ? relu * scale : 0.f;
+        }
+    } else {
+        f32x4 gg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float f, df;
+            hidden_act(act, a[r], f, df);
+            const bool on = keep[r] && b < b_act && (h + r) < dm.H;      // padded hidden units stay exactly zero
+            dd[r] = on ? f * scale : 0.f;
+            gg[r] = on ? df * scale : 0.f;
+        }
+        *(f32x4*)(G + (int64_t)k * DIMN_TB * Hp + e) = gg;
     }
     *(f32x4*)(Dd + (int64_t)k * DIMN_TB * Hp + e) = dd;
 }
@@ -476,7 +503,8 @@ template <bool FULL, int NH, int WV>   // NH hidden tiles (16 rows of W2 each) p
 __global__ __launch_bounds__(WV * 64, WV == 4 ? 3 : (WV == 16 ? 4 : 2)) void k_mid_bwd(const float* __restrict__ Dd, const float* __restrict__ dZ,
                                                  float* __restrict__ W2, float* __restrict__ M2, float* __restrict__ V2,
                                                  float* __restrict__ b1w, float* __restrict__ b1m, float* __restrict__ b1v,
-                                                 float* __restrict__ dA, Dims dm, AdamP ap, float scale, int otw, int k0) {
+                                                 float* __restrict__ dA, Dims dm, AdamP ap, float scale, int otw, int k0,
+                                                 const float* __restrict__ G) {   // G != NULL: dA = dD * G (activation other than relu)
     constexpr int LDR = 16 * NH + 1;                             // padded row of the reduction buffer
     constexpr int RED = (WV * DIMN_TB * LDR) > WV * 1024 ? (WV * DIMN_TB * LDR) : WV * 1024;                       // floats: cross-wave dD reduction buffer
     __shared__ __attribute__((aligned(16))) float lds[RED];     // first WV x 1024 floats double as the dZ tiles
@@ -504,7 +532,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 3 : (WV == 16 ? 4 : 2)) void k_m
     const int hcl = h < Hp ? h : 0;
     float ddv[NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) ddv[i] = ddk[(b0 + RB * i) * Hp + hcl];
+    for (int i = 0; i < NI; ++i) ddv[i] = (G ? G + (int64_t)k * DIMN_TB * Hp : ddk)[(b0 + RB * i) * Hp + hcl];
     const int64_t bidx = (int64_t)k * Hp + (tid < CW ? hcl : 0);
     float b1w0 = b1w[bidx], b1m0 = b1m[bidx], b1v0 = b1v[bidx];
 
@@ -606,7 +634,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 3 : (WV == 16 ? 4 : 2)) void k_m
             float d = 0.f;
 #pragma unroll
             for (int wv = 0; wv < WV; ++wv) d += lds[(wv * DIMN_TB + b) * LDR + hh];
-            const float da = ddv[i] > 0.f ? d * scale : 0.f;
+            const float da = G ? d * ddv[i] : (ddv[i] > 0.f ? d * scale : 0.f);
             dA[((int64_t)k * DIMN_TB + b) * Hp + h] = da;
             gsum += da;
         }
@@ -906,7 +934,8 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
 __global__ __launch_bounds__(1024) void k_reduce_dd(const int32_t* __restrict__ midk, const float* __restrict__ P2,
                                                     const float* __restrict__ Dd,
                                                     float* __restrict__ b1w, float* __restrict__ b1m, float* __restrict__ b1v,
-                                                    float* __restrict__ dA, Dims dm, AdamP ap, float scale, int k0) {
+                                                    float* __restrict__ dA, Dims dm, AdamP ap, float scale, int k0,
+                                                    const float* __restrict__ G) {   // G != NULL: dA = dD * G
     __shared__ float gs[16][64];
     const int k = blockIdx.y + k0, Hp = dm.Hp;
     const int tid = threadIdx.x, hh = tid & 63, rg = tid >> 6;
@@ -918,7 +947,7 @@ __global__ __launch_bounds__(1024) void k_reduce_dd(const int32_t* __restrict__ 
     if (tid < 64 && h < Hp) { b1w0 = b1w[bi]; b1m0 = b1m[bi]; b1v0 = b1v[bi]; }
     if (h < Hp) {
         const float* p = P2 + ((int64_t)slot0 * DIMN_TB + 4 * rg) * Hp + h;
-        const float* dd = Dd + ((int64_t)k * DIMN_TB + 4 * rg) * Hp + h;
+        const float* dd = (G ? G : Dd) + ((int64_t)k * DIMN_TB + 4 * rg) * Hp + h;
         float* da = dA + ((int64_t)k * DIMN_TB + 4 * rg) * Hp + h;
         float d[4], gate[4];
 #pragma unroll
@@ -936,7 +965,7 @@ __global__ __launch_bounds__(1024) void k_reduce_dd(const int32_t* __restrict__ 
             for (int i = 0; i < 4; ++i) d[i] += p[((int64_t)sl * DIMN_TB + i) * Hp];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float v = gate[i] > 0.f ? d[i] * scale : 0.f;
+            const float v = G ? d[i] * gate[i] : (gate[i] > 0.f ? d[i] * scale : 0.f);
             da[i * Hp] = v;
             gsum += v;
         }
@@ -1452,7 +1481,7 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
                                                  const float* __restrict__ W2, const float* __restrict__ b2,
                                                  const int32_t* __restrict__ rows, int64_t n_rows,
                                                  float* __restrict__ out, const float* __restrict__ Y, int64_t n_cells,
-                                                 float* __restrict__ loss_part, Dims dm, int loss_binary) {
+                                                 float* __restrict__ loss_part, Dims dm, int loss_binary, int act) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int k = blockIdx.y;
     const int64_t r0 = (int64_t)blockIdx.x * DIMN_TB;
@@ -1523,7 +1552,9 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = acc[mt][nt][r] + bias;
-                    lds[(16 * mt + 4 * lj + r) * ldd + h] = v > 0.f ? v : 0.f;
+                    float f = v > 0.f ? v : 0.f, df;
+                    if (act != 0) { hidden_act(act, v, f, df); if (h >= dm.H) f = 0.f; }
+                    lds[(16 * mt + 4 * lj + r) * ldd + h] = f;
                 }
         }
     __syncthreads();

@@ -23,7 +23,7 @@ class Engine:
 
     def __init__(self, fns, D, hidden, out_dim, batch_size=64, dropout_rate=0.2,
                  learning_rate=1e-4, beta1=0.9, beta2=0.999, eps=1e-7, loss_binary=False,
-                 seed=1234, device_id=0, subnet_offset=0):
+                 seed=1234, device_id=0, subnet_offset=0, activation="relu"):
         self._f = fns
         self.D = [int(d) for d in D]
         self.K = len(self.D)
@@ -42,6 +42,11 @@ class Engine:
         self.n_val = 0
         Darr = i32(self.D)
         self._check(self._f["create"](C.byref(self.cfg), p_i32(Darr), C.byref(self._h)))
+        self.activation = "linear" if activation is None else str(activation).lower()
+        if self.activation not in _cabi.ACTIVATIONS:
+            raise NotImplementedError("hidden activation %r: implemented are %s" % (activation, sorted(_cabi.ACTIVATIONS)))
+        if self.activation != "relu":
+            self._check(self._f["set_activation"](self._h, _cabi.ACTIVATIONS[self.activation]))
 
     # -- plumbing ---------------------------------------------------------
     def _check(self, rc):

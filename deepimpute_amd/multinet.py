@@ -111,26 +111,29 @@ def inspect_data(data):
 
 
 def _hidden_and_dropout(architecture):
-    """(H, p) of an architecture list.  The kernels implement Dense(H, relu) [-> Dropout(p)]
-    -> Dense(O, softplus): the form of loadDefaultArchitecture (multinet.py:99-103) and of every
-    caller in the reference tree (deepImpute.py:24-26, tests/multinet_test.py:17-20)."""
-    hidden, rate, dropped = None, 0.0, False
+    """(H, p, activation) of an architecture list.  The kernels implement Dense(H, act) [-> Dropout(p)]
+    -> Dense(O, softplus) with act in relu / linear / sigmoid / tanh / elu / softplus: the form of
+    loadDefaultArchitecture (multinet.py:99-103) and of every caller in the reference tree
+    (deepImpute.py:24-26, tests/multinet_test.py:17-20), which all use relu."""
+    from ._cabi import ACTIVATIONS
+    hidden, rate, dropped, act = None, 0.0, False, "relu"
     for spec in architecture:
         kind = str(spec.get("type", "")).lower()
         if kind == "dense" and hidden is None and not dropped:
-            act = str(spec.get("activation", "relu")).lower()
-            if act != "relu":
-                raise NotImplementedError("hidden activation %r: only 'relu' has a gfx950 kernel" % act)
+            name = spec.get("activation", "relu")
+            act = "linear" if name is None else str(name).lower()
+            if act not in ACTIVATIONS:
+                raise NotImplementedError("hidden activation %r: the gfx950 kernels implement %s" % (name, sorted(ACTIVATIONS)))
             hidden = int(spec["neurons"])
         elif kind == "dropout" and hidden is not None and not dropped:
             rate, dropped = float(spec["rate"]), True
         elif kind in ("dense", "dropout"):
-            raise NotImplementedError("only [dense(relu), dropout] architectures are implemented, got %r" % (architecture,))
+            raise NotImplementedError("only [dense, dropout] architectures are implemented, got %r" % (architecture,))
         else:
             print("Unknown layer type.")       # the reference skips such entries (multinet.py:142-143)
     if hidden is None:
         raise NotImplementedError("architecture needs a hidden dense layer")
-    return hidden, rate
+    return hidden, rate, act
 
 
 # ------------------------------------------------------------------------------- the estimator
@@ -170,7 +173,7 @@ class MultiNet:
         if self.NN_parameters['architecture'] is None:
             self.loadDefaultArchitecture()
         print(self.NN_parameters['architecture'])
-        hidden, rate = _hidden_and_dropout(self.NN_parameters['architecture'])
+        hidden, rate, act = _hidden_and_dropout(self.NN_parameters['architecture'])
         loss = self.NN_parameters['loss']
         loss = getattr(loss, "__name__", loss)
         if str(loss).lower() != "wmse":
@@ -183,12 +186,12 @@ class MultiNet:
                     batch_size=self.NN_parameters["batch_size"], dropout_rate=rate,
                     learning_rate=self.NN_parameters["learning_rate"],
                     seed=0 if self.seed is None else self.seed,
-                    device_id=self.device_id, subnet_offset=subnet_offset)
+                    device_id=self.device_id, subnet_offset=subnet_offset, **({} if act == "relu" else {"activation": act}))
 
     # -- persistence (reference: model.json + model.h5, multinet.py:105-124) --
     def save(self, model):
         os.makedirs(self.outputdir, exist_ok=True)
-        hidden, rate = _hidden_and_dropout(self.NN_parameters['architecture'])
+        hidden, rate, _ = _hidden_and_dropout(self.NN_parameters['architecture'])
         with open(os.path.join(self.outputdir, "model.json"), "w") as fh:
             json.dump({"format": "deepimpute_amd-1", "inputdims": list(model.D), "hidden": hidden,
                        "dropout_rate": rate, "sub_outputdim": self.sub_outputdim,

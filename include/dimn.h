@@ -98,6 +98,17 @@ int dimn_get_weights(dimn_handle h, int32_t k, float* W1, float* b1, float* W2, 
 /* Adam moments (which: 0 = m, 1 = v) in the same layout; test/checkpoint hook. */
 int dimn_get_adam_state(dimn_handle h, int32_t k, int32_t which, float* W1, float* b1,
                         float* W2, float* b2);
+/* Hidden-layer activation (reference deepimpute/multinet.py:137: Dense(neurons, activation=layer['activation']);
+ * the default architecture, the CLI and every reference test use 'relu').  Call before training / inference;
+ * a handle starts as DIMN_ACT_RELU.  Returns DIMN_ERR_UNSUP for an unknown id. */
+#define DIMN_ACT_RELU 0
+#define DIMN_ACT_LINEAR 1
+#define DIMN_ACT_SIGMOID 2
+#define DIMN_ACT_TANH 3
+#define DIMN_ACT_ELU 4       /* alpha = 1 (Keras default) */
+#define DIMN_ACT_SOFTPLUS 5
+int dimn_set_activation(dimn_handle h, int32_t activation);
+
 int dimn_reset_optimizer(dimn_handle h);
 /* Adam step counter t (shared by all variables, as in Keras). */
 int dimn_get_step_count(dimn_handle h, int64_t* t);

@@ -68,6 +68,7 @@ struct dimo_handle_s {
     float* norm; int64_t n, g;
     int32_t *train_rows, *val_rows; int64_t n_tr, n_val;
     int64_t t;                        /* Adam step counter */
+    int act;                          /* hidden activation, DIMN_ACT_* (multinet.py:137) */
 };
 typedef struct dimo_handle_s* dimo_handle;
 
@@ -220,6 +221,25 @@ static inline real softplus_r(real x) {
 }
 static inline real sigmoid_r(real x) { return (real)(1.0 / (1.0 + exp(-(double)x))); }
 
+/* Hidden activation f and its derivative f' at pre-activation a (Keras definitions; elu alpha = 1). */
+static inline void hidden_act(int act, real a, real* f, real* df) {
+    switch (act) {
+        case DIMN_ACT_LINEAR: *f = a; *df = 1; break;
+        case DIMN_ACT_SIGMOID: { const real s = sigmoid_r(a); *f = s; *df = s * (1 - s); break; }
+        case DIMN_ACT_TANH: { const real t = (real)tanh((double)a); *f = t; *df = 1 - t * t; break; }
+        case DIMN_ACT_ELU: { const real e = (real)expm1((double)a); *f = a > 0 ? a : e; *df = a > 0 ? (real)1 : e + 1; break; }
+        case DIMN_ACT_SOFTPLUS: *f = softplus_r(a); *df = sigmoid_r(a); break;
+        default: *f = a > 0 ? a : 0; *df = a > 0 ? (real)1 : (real)0; break;     /* relu */
+    }
+}
+
+int dimo_set_activation(dimo_handle h, int32_t activation) {
+    if (!h) return fail(DIMN_ERR_ARG, "null handle");
+    if (activation < DIMN_ACT_RELU || activation > DIMN_ACT_SOFTPLUS) return fail(DIMN_ERR_UNSUP, "unknown activation id");
+    h->act = activation;
+    return DIMN_OK;
+}
+
 /* Forward of one row of one sub-net.  x[D] in; a[H] pre-activation, dd[H] hidden output
  * after relu(+dropout when keep != NULL), z[O] pre-softplus out. */
 static void forward_row(const struct dimo_handle_s* h, const subnet* s, const real* x,
@@ -234,7 +254,8 @@ static void forward_row(const struct dimo_handle_s* h, const subnet* s, const re
     }
     for (int j = 0; j < H; ++j) {
         a[j] += s->b1[j];
-        const real r = a[j] > 0 ? a[j] : 0;             /* S2: relu */
+        real r, dr;
+        hidden_act(h->act, a[j], &r, &dr);              /* S2: relu (or the configured activation) */
         dd[j] = keep ? (keep[j] ? r * scale : 0) : r;   /* S3: dropout (train) / identity */
     }
     for (int o = 0; o < O; ++o) z[o] = 0;
@@ -335,7 +356,13 @@ int dimo_train_step(dimo_handle h, const int32_t* rows, int32_t b_act, const uin
                 const real* w = s->W2 + (size_t)j * O;
                 real acc = 0;
                 for (int o = 0; o < O; ++o) acc += dz[o] * w[o];
-                dA[j] = (keep[j] && a[j] > 0) ? acc * scale : 0;
+                if (h->act == DIMN_ACT_RELU) {
+                    dA[j] = (keep[j] && a[j] > 0) ? acc * scale : 0;
+                } else {
+                    real f, df;
+                    hidden_act(h->act, a[j], &f, &df);
+                    dA[j] = keep[j] ? acc * scale * df : 0;
+                }
             }
         }
     /* gW2 = dd^T dz ; Adam */

@@ -127,3 +127,26 @@ def check_epoch_trajectory(cls, rtol_loss, rtol_w, atol_w, **kw):
             np.testing.assert_allclose(V[i], z["v_%s_%d" % (name, k)], rtol=rtol_w, atol=atol_w * 1e-4, err_msg="v %s k=%d" % (name, k))
         np.testing.assert_allclose(pred[:, k * O:(k + 1) * O], z["predict_%d" % k], rtol=rtol_w, atol=atol_w)
     eng.close()
+
+
+def check_activation_kat(cls, name, rtol, atol, **kw):
+    """Two optimiser steps + predict of a tiny sub-net with hidden activation `name` against
+    tests/golden/kat_act.npz (torch fp64 autograd; generator tests/golden/make_act.py)."""
+    z = np.load(os.path.join(GOLDEN, "kat_act.npz"))
+    eng = cls([int(z["D"])], int(z["H"]), int(z["O"]), batch_size=int(z["B"]), dropout_rate=float(z["p"]),
+              learning_rate=float(z["lr"]), beta1=float(z["beta1"]), beta2=float(z["beta2"]), eps=float(z["eps"]),
+              seed=1, activation=name, **kw)
+    eng.set_matrix(z["norm"])
+    eng.set_indices(0, z["pred"], z["targ"])
+    eng.gather(True)
+    n = z["norm"].shape[0]
+    eng.set_split(np.arange(n - 8, dtype=np.int32), np.arange(n - 8, n, dtype=np.int32))
+    eng.reset_optimizer()
+    eng.set_weights(0, z["init_W1"], z["init_b1"], z["init_W2"], z["init_b2"])
+    for t in range(2):
+        loss = eng.train_step(z["rows_%d" % t], keep_mask=z["mask_%d" % t])
+        np.testing.assert_allclose(loss[0], z[name + "/loss"][t], rtol=rtol, err_msg="%s loss step %d" % (name, t))
+    for got, nm in zip(eng.get_weights(0), ("W1", "b1", "W2", "b2")):
+        np.testing.assert_allclose(got, z["%s/%s" % (name, nm)], rtol=rtol, atol=atol, err_msg="%s %s" % (name, nm))
+    np.testing.assert_allclose(eng.predict(), z[name + "/predict"], rtol=rtol, atol=atol, err_msg=name + " predict")
+    eng.close()

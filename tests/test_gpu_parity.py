@@ -103,6 +103,31 @@ def test_h256_both_second_layer_paths_match_oracle(O, B, Ds, p, mid, monkeypatch
     np.testing.assert_allclose(a.train_step(rows, keep_mask=mask), b.train_step(rows, keep_mask=mask), rtol=1e-4)
 
 
+@pytest.mark.parametrize("name", ["linear", "sigmoid", "tanh", "elu", "softplus"])
+def test_hidden_activations_match_autograd_golden(name):
+    from helpers import check_activation_kat
+    check_activation_kat(_hip(), name, rtol=2e-3, atol=3e-6)
+
+
+@pytest.mark.parametrize("name,mid", [("tanh", "1"), ("sigmoid", "0"), ("elu", "1"), ("linear", "0")])
+def test_hidden_activation_training_matches_oracle_h256(name, mid, monkeypatch):
+    """Other activations carry their gate f'(A)*keep*scale in a buffer (relu derives it from Dd > 0): both
+    second-layer paths of the H = 256 kernels, two epochs against the oracle."""
+    monkeypatch.setenv("DIMN_MID", mid)
+    prob = make_problem(n=200, g=400, Ds=[130, 61], H=256, O=96, seed=23)
+    kw = dict(batch_size=48, dropout_rate=0.2, learning_rate=1e-3, seed=7, activation=name)
+    a = load_problem(_hip(), prob, **kw)
+    b = load_problem(_oracle(), prob, **kw)
+    a.init_weights(); b.init_weights()
+    for epoch in range(2):
+        np.testing.assert_allclose(a.train_epoch(epoch), b.train_epoch(epoch), rtol=1e-4)
+        np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
+    for k in range(a.K):
+        for x, y, nm in zip(a.get_weights(k), b.get_weights(k), ("W1", "b1", "W2", "b2")):
+            np.testing.assert_allclose(x, y, rtol=1e-3, atol=2e-5, err_msg="%s %s k=%d" % (name, nm, k))
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=1e-4, atol=1e-6)
+
+
 def test_single_forward_tight():
     prob = make_problem(n=200, g=500, Ds=[300, 150], H=256, O=512, seed=3)
     a = load_problem(_hip(), prob, seed=1)

@@ -154,9 +154,15 @@ def test_module_functions():
 
 def test_unsupported_architecture_is_loud():
     net = MultiNet(engine_factory=FakeEngine, ncores=1,
-                   architecture=[{"type": "dense", "neurons": 8, "activation": "tanh"}])
+                   architecture=[{"type": "dense", "neurons": 8, "activation": "swish"}])
     with pytest.raises(NotImplementedError):
         net.build([10])
+    with pytest.raises(NotImplementedError):           # two hidden layers: not implemented
+        MultiNet(engine_factory=FakeEngine, ncores=1, architecture=[{"type": "dense", "neurons": 8, "activation": "relu"},
+                                                                    {"type": "dense", "neurons": 8, "activation": "relu"}]).build([10])
+    eng = MultiNet(engine_factory=FakeEngine, ncores=1,
+                   architecture=[{"type": "dense", "neurons": 8, "activation": "tanh"}, {"type": "dropout", "rate": 0.1}]).build([10])
+    assert eng.kw["activation"] == "tanh" and eng.H == 8 and abs(eng.kw["dropout_rate"] - 0.1) < 1e-12
     with pytest.raises(SystemExit):
         MultiNet(engine_factory=FakeEngine, ncores=1, loss="mse").build([10])
 

@@ -46,13 +46,13 @@ int main(int argc, char** argv) {
     const size_t kh = (size_t)K * 256, ko = (size_t)K * 512;
     CK(hipDeviceSynchronize());
 #define T(name, ...) { double us = timeit([&] { hipLaunchKernelGGL(__VA_ARGS__); }); CK(hipGetLastError()); printf("%-34s %8.1f us\n", name, us); }
-    T("k_reduce_act", k_reduce_act, dim3(16, K), dim3(256), 0, 0, dsn, P, b1, (const uint8_t*)nullptr, Dd, dm, 64, 0.2f, 1.25f, 1234ull, 0u, 0u, 0)
+    T("k_reduce_act", k_reduce_act, dim3(16, K), dim3(256), 0, 0, dsn, P, b1, (const uint8_t*)nullptr, Dd, dm, 64, 0.2f, 1.25f, 1234ull, 0u, 0u, 0, 0, (float*)nullptr)
     T("k_mid_fwd<16>", k_mid_fwd<16>, dim3(8, K), dim3(512), 64 * 258 * 4, 0, W2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, dZ, ls, la, dm, ap, 1.f / (64 * 512), 0, 0)
     T("k_mid_fwd<0>", k_mid_fwd<0>, dim3(8, K), dim3(512), 64 * 258 * 4, 0, W2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, dZ, ls, la, dm, ap, 1.f / (64 * 512), 0, 0)
-    T("k_mid_bwd<true,1>", (k_mid_bwd<true, 1, 8>), dim3(16, K), dim3(512), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 4, 0)
-    T("k_mid_bwd<true,1,4>", (k_mid_bwd<true, 1, 4>), dim3(16, K), dim3(256), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 8, 0)
-    T("k_mid_bwd<true,1,16>", (k_mid_bwd<true, 1, 16>), dim3(16, K), dim3(1024), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 2, 0)
-    T("k_mid_bwd<true,2>", (k_mid_bwd<true, 2, 8>), dim3(8, K), dim3(512), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 4, 0)
+    T("k_mid_bwd<true,1>", (k_mid_bwd<true, 1, 8>), dim3(16, K), dim3(512), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 4, 0, (const float*)nullptr)
+    T("k_mid_bwd<true,1,4>", (k_mid_bwd<true, 1, 4>), dim3(16, K), dim3(256), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 8, 0, (const float*)nullptr)
+    T("k_mid_bwd<true,1,16>", (k_mid_bwd<true, 1, 16>), dim3(16, K), dim3(1024), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 2, 0, (const float*)nullptr)
+    T("k_mid_bwd<true,2>", (k_mid_bwd<true, 2, 8>), dim3(8, K), dim3(512), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 4, 0, (const float*)nullptr)
     {   // fused second layer: work table as dimn.hip's build_mid
         const int Sm = std::max(4, std::min(8, 256 / K));
         std::vector<MidWork> mw; std::vector<int32_t> midk(2 * K);
@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
         CK(hipFuncSetAttribute((const void*)k_mid_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         printf("fused: %zu workgroups (%d slices per sub-net)\n", mw.size(), Sm);
         T("k_mid_fused (warm)", k_mid_fused, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0)
-        T("k_reduce_dd", k_reduce_dd, dim3(4, K), dim3(1024), 0, 0, dmk, P2, Dd, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 0)
+        T("k_reduce_dd", k_reduce_dd, dim3(4, K), dim3(1024), 0, 0, dmk, P2, Dd, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 0, (const float*)nullptr)
         // cold: 1 GB of unrelated traffic between launches, as the W1 update does in a real step
         float* big = dalloc((size_t)256 << 20, 1.f, 12);
         hipEvent_t ea, eb; CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
@@ -82,7 +82,7 @@ int main(int argc, char** argv) {
             CK(hipEventRecord(eb)); CK(hipEventSynchronize(eb)); CK(hipEventElapsedTime(&ms, ea, eb)); cold_mf += ms;
             hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, big, (size_t)256 << 20, 1.f, 53u + it);
             CK(hipEventRecord(ea));
-            hipLaunchKernelGGL((k_mid_bwd<true, 1, 4>), dim3(16, K), dim3(256), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 8, 0);
+            hipLaunchKernelGGL((k_mid_bwd<true, 1, 4>), dim3(16, K), dim3(256), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 8, 0, (const float*)nullptr);
             CK(hipEventRecord(eb)); CK(hipEventSynchronize(eb)); CK(hipEventElapsedTime(&ms, ea, eb)); cold_mb += ms;
         }
         printf("cold (after 1 GB of other traffic): k_mid_fused %.1f us   k_mid_fwd<16> %.1f us   k_mid_bwd<1,4> %.1f us\n", 1e3 * cold_f / R, 1e3 * cold_mf / R, 1e3 * cold_mb / R);
@@ -97,11 +97,11 @@ int main(int argc, char** argv) {
                ph[0] / nw, ph[1] / nw, ph[2] / nw, ph[3] / nw, ph[4] / nw, ph[5] / nw, (double)(tmax - tmin));
     }
     // chained like a real step
-    T("RED+MF+MB chain", k_reduce_act, dim3(16, K), dim3(256), 0, 0, dsn, P, b1, (const uint8_t*)nullptr, Dd, dm, 64, 0.2f, 1.25f, 1234ull, 0u, 0u, 0);
+    T("RED+MF+MB chain", k_reduce_act, dim3(16, K), dim3(256), 0, 0, dsn, P, b1, (const uint8_t*)nullptr, Dd, dm, 64, 0.2f, 1.25f, 1234ull, 0u, 0u, 0, 0, (float*)nullptr);
     { double us = timeit([&] {
-        hipLaunchKernelGGL(k_reduce_act, dim3(16, K), dim3(256), 0, 0, dsn, P, b1, (const uint8_t*)nullptr, Dd, dm, 64, 0.2f, 1.25f, 1234ull, 0u, 0u, 0);
+        hipLaunchKernelGGL(k_reduce_act, dim3(16, K), dim3(256), 0, 0, dsn, P, b1, (const uint8_t*)nullptr, Dd, dm, 64, 0.2f, 1.25f, 1234ull, 0u, 0u, 0, 0, (float*)nullptr);
         hipLaunchKernelGGL(k_mid_fwd<16>, dim3(8, K), dim3(512), 64 * 258 * 4, 0, W2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, dZ, ls, la, dm, ap, 1.f / (64 * 512), 0, 0);
-        hipLaunchKernelGGL((k_mid_bwd<true, 1, 8>), dim3(16, K), dim3(512), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 4, 0); });
+        hipLaunchKernelGGL((k_mid_bwd<true, 1, 8>), dim3(16, K), dim3(512), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 4, 0, (const float*)nullptr); });
       printf("%-34s %8.1f us\n", "RED+MF+MB back-to-back", us); }
     return 0;
 }
