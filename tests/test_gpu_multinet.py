@@ -64,6 +64,22 @@ def test_shell_on_hip_matches_shell_on_oracle(tmp_path):
     np.testing.assert_allclose(a.test_metrics["MSE"], b.test_metrics["MSE"], rtol=1e-3)
 
 
+def test_shell_with_tanh_architecture_on_hip_matches_oracle(tmp_path):
+    """A non-relu architecture through the whole shell (build -> engine activation -> save/load -> predict)."""
+    from deepimpute_amd.multinet import MultiNet
+    from oracle.dimo import OracleEngine
+    raw = _raw(n=200, g=300, seed=9)
+    kw = dict(sub_outputdim=64, seed=11, ncores=1, verbose=0, max_epochs=3, patience=3, learning_rate=1e-3,
+              architecture=[{"type": "dense", "neurons": 40, "activation": "tanh"}, {"type": "dropout", "rate": 0.2}])
+    a = MultiNet(output_prefix=str(tmp_path / "a"), **kw).fit(raw, NN_lim=128)
+    b = MultiNet(output_prefix=str(tmp_path / "b"), engine_factory=OracleEngine, **kw).fit(raw, NN_lim=128)
+    np.testing.assert_allclose(a.history["val_loss"], b.history["val_loss"], rtol=1e-4)
+    np.testing.assert_allclose(a.predict(raw).values, b.predict(raw).values, rtol=1e-4, atol=1e-6)
+    fresh = MultiNet(output_prefix=str(tmp_path / "a"), sub_outputdim=64, seed=11, ncores=1, verbose=0)   # reload: model.json carries the architecture
+    fresh.predictors, fresh.targets = a.predictors, a.targets
+    np.testing.assert_allclose(fresh.predict(raw).values, a.predict(raw).values, rtol=1e-6)
+
+
 def test_cli_end_to_end(tmp_path):
     """The reference's deepImpute_test: parse_args mocked with a fixed Namespace, output None."""
     from deepimpute_amd.deepImpute import deepImpute
