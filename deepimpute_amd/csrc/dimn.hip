@@ -726,6 +726,9 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
 #define LAUNCH_MB(FULLV, WV) hipLaunchKernelGGL((k_mid_bwd<FULLV, 1, WV>), dim3((unsigned)dm.HT, nk), dim3(WV * 64), 0, st, h->d_Dd, h->d_dZ, \
                                                 h->d_W2, h->d_M2, h->d_V2, h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0, (const float*)h->d_G)
     if (h->mb_waves == 8) { if (dm.OT == 8 * h->OTW) LAUNCH_MB(true, 8); else LAUNCH_MB(false, 8); }
+    else if (dm.OT == 4 * h->OTW && (int64_t)dm.HT * nk <= 2 * (int64_t)h->ncu)   // few workgroups (a GPU that owns few sub-nets):
+        hipLaunchKernelGGL((k_mid_bwd<true, 1, 4, 2>), dim3((unsigned)dm.HT, nk), dim3(256), 0, st, h->d_Dd, h->d_dZ,   // 2 per CU fit anyway -> no register cap, no spills
+                           h->d_W2, h->d_M2, h->d_V2, h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0, (const float*)h->d_G);
     else { if (dm.OT == 4 * h->OTW) LAUNCH_MB(true, 4); else LAUNCH_MB(false, 4); }
 #undef LAUNCH_MB
     }

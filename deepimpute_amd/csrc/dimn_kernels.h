@@ -499,8 +499,8 @@ __global__ __launch_bounds__(512) void k_mid_fwd(const float* __restrict__ W2,
 // (ds_read_b32, lane-linear) and dZ rows (ds_read_b128) -- without 64-byte strided gathers.
 // State and dZ of the next output tile are prefetched while the current one computes.
 // ---------------------------------------------------------------------------------------
-template <bool FULL, int NH, int WV>   // NH hidden tiles (16 rows of W2 each) per workgroup, WV waves; FULL: HT % NH == 0 and OT == WV*otw
-__global__ __launch_bounds__(WV * 64, WV == 4 ? 3 : (WV == 16 ? 4 : 2)) void k_mid_bwd(const float* __restrict__ Dd, const float* __restrict__ dZ,
+template <bool FULL, int NH, int WV, int WPS = (WV == 4 ? 3 : (WV == 16 ? 4 : 2))>   // NH hidden tiles (16 rows of W2 each) per workgroup, WV waves; FULL: HT % NH == 0 and OT == WV*otw; WPS: waves per SIMD to fit
+__global__ __launch_bounds__(WV * 64, WPS) void k_mid_bwd(const float* __restrict__ Dd, const float* __restrict__ dZ,
                                                  float* __restrict__ W2, float* __restrict__ M2, float* __restrict__ V2,
                                                  float* __restrict__ b1w, float* __restrict__ b1m, float* __restrict__ b1v,
                                                  float* __restrict__ dA, Dims dm, AdamP ap, float scale, int otw, int k0,
