@@ -44,17 +44,24 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// Streamed optimiser state (read once, written once per step).  DIMN_NT bit 0 marks its loads, bit 1 its
-// stores non-temporal; bit 2 the split-K partial stores of B1F1, bit 3 the dD partial stores of MFB.
-// Measured (tools/ab_nt.sh, one box, cfg3): non-temporal STATE STORES keep the X tiles / dA / partials in L2:
-// step 0.1864 -> 0.1731 ms, B1F1 121 -> 113 us; non-temporal state LOADS cost +4 us.  Default: stores only.
+// Streamed optimiser state (read once, written once per step).  DIMN_NT bit 0 marks all of B1F1's state loads, bit 4
+// only its m and v loads, bit 1 the state stores non-temporal; bit 2 the split-K partial stores of B1F1, bit 3 the dD
+// partial stores of MFB.  Measured (tools/ab_nt.sh / ab_def.sh, one box, cfg3): non-temporal STATE STORES keep the X
+// tiles / dA / partials in L2: step 0.1864 -> 0.1731 ms, B1F1 121 -> 113 us; non-temporal loads of m and v (not of w):
+// B1F1 120.8 -> 114.1 us, step 0.1776 -> 0.1709 ms (four A/B pairs); all three loads non-temporal: no better than none.
+// Default: stores + m, v loads.
 #ifndef DIMN_NT
-#define DIMN_NT 2
+#define DIMN_NT 18
 #endif
 #if DIMN_NT & 1
 #define DIMN_LD_STATE(p) __builtin_nontemporal_load((const f32x4*)(p))
 #else
 #define DIMN_LD_STATE(p) (*(const f32x4*)(p))
+#endif
+#if DIMN_NT & 16
+#define DIMN_LD_STATE_MV(p) __builtin_nontemporal_load((const f32x4*)(p))
+#else
+#define DIMN_LD_STATE_MV(p) DIMN_LD_STATE(p)
 #endif
 #if DIMN_NT & 2
 #define DIMN_ST_STATE(p, v) __builtin_nontemporal_store((v), (f32x4*)(p))
@@ -70,6 +77,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define DIMN_ST_P2(p, v) __builtin_nontemporal_store((v), (p))
 #else
 #define DIMN_ST_P2(p, v) (*(p) = (v))
+#endif
+// m and v of the second layer are read once per step by the fused kernel (W2 itself twice: phases 1 and 2): non-temporal
+// loads keep them out of the caches' way -- step 0.1693 -> 0.1656 ms, both weight kernels gain (tools/ab_def.sh)
+#ifndef DIMN_MFB_NT_MV
+#define DIMN_MFB_NT_MV 1
+#endif
+#if DIMN_MFB_NT_MV
+#define DIMN_LD_MV(p) __builtin_nontemporal_load((const f32x4*)(p))
+#else
+#define DIMN_LD_MV(p) (*(const f32x4*)(p))
 #endif
 #ifndef DIMN_W_PEEL
 #define DIMN_W_PEEL 1   // B1F1 ring: first chunk triple peeled out of the loop (0: wait for two chunks before the loop)
@@ -759,7 +776,7 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
     auto fetch = [&](Set& st, int ot) {
         const int o2 = ot < ot_last ? ot : ot_last;
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht) { const int64_t i = tidx(ht, o2); st.w[ht] = *(const f32x4*)(W2 + i); st.m[ht] = *(const f32x4*)(M2 + i); st.v[ht] = *(const f32x4*)(V2 + i); }
+        for (int ht = 0; ht < 2; ++ht) { const int64_t i = tidx(ht, o2); st.w[ht] = *(const f32x4*)(W2 + i); st.m[ht] = DIMN_LD_MV(M2 + i); st.v[ht] = DIMN_LD_MV(V2 + i); }
     };
     Set A, B, C, D;                                          // four named sets: three tiles in flight
     fetch(A, ot0);
@@ -1354,7 +1371,7 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void k_w1_update_fwd_ring(const Wo
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
             const int64_t idx = wb[nt] + cc * cstride;
-            st.w[nt] = DIMN_LD_STATE(W1 + idx); st.m[nt] = DIMN_LD_STATE(M1 + idx); st.v[nt] = DIMN_LD_STATE(V1 + idx);
+            st.w[nt] = DIMN_LD_STATE(W1 + idx); st.m[nt] = DIMN_LD_STATE_MV(M1 + idx); st.v[nt] = DIMN_LD_STATE_MV(V1 + idx);
         }
     };
     // one chunk: `cur` holds chunk c, `nx1` chunk c+1 (its X tile is staged into LDS here),
