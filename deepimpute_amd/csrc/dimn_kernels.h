@@ -579,7 +579,7 @@ __global__ __launch_bounds__(WV * 64, WPS) void k_mid_bwd(const float* __restric
 #pragma unroll
         for (int i = 0; i < 4; ++i) st.zt[i] = *(const f32x4*)(zsrc + 16 * i * Op + 16 * oc);
 #pragma unroll
-        for (int ht = 0; ht < NH; ++ht) { const int64_t i = tidx(ht, oc); st.w[ht] = *(const f32x4*)(W2 + i); st.m[ht] = *(const f32x4*)(M2 + i); st.v[ht] = *(const f32x4*)(V2 + i); }
+        for (int ht = 0; ht < NH; ++ht) { const int64_t i = tidx(ht, oc); st.w[ht] = *(const f32x4*)(W2 + i); st.m[ht] = DIMN_LD_MV(M2 + i); st.v[ht] = DIMN_LD_MV(V2 + i); }
     };
     auto step = [&](Set& cur, Set& nx2, int ot) {
         // stage this tile (wave-private, in-order LDS), then request tile ot+2
@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
 #pragma unroll
     for (int nt = 0; nt < NT2; ++nt) {
         const int64_t i0 = wb[nt] + wk.c0 * cstride;
-        w[nt] = *(const f32x4*)(W1 + i0); m[nt] = *(const f32x4*)(M1 + i0); v[nt] = *(const f32x4*)(V1 + i0);
+        w[nt] = *(const f32x4*)(W1 + i0); m[nt] = DIMN_LD_STATE_MV(M1 + i0); v[nt] = DIMN_LD_STATE_MV(V1 + i0);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1106,7 +1106,7 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
             const int64_t idx = wb[nt] + cn * cstride;
-            w1[nt] = *(const f32x4*)(W1 + idx); m1[nt] = *(const f32x4*)(M1 + idx); v1[nt] = *(const f32x4*)(V1 + idx);
+            w1[nt] = *(const f32x4*)(W1 + idx); m1[nt] = DIMN_LD_STATE_MV(M1 + idx); v1[nt] = DIMN_LD_STATE_MV(V1 + idx);
         }
         __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch at the top of the iteration
 
@@ -1225,7 +1225,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
 #pragma unroll
     for (int nt = 0; nt < NT2; ++nt) {
         const int64_t i0 = wb[nt] + wk.c0 * cstride;
-        w[nt] = *(const f32x4*)(W1 + i0); m[nt] = *(const f32x4*)(M1 + i0); v[nt] = *(const f32x4*)(V1 + i0);
+        w[nt] = *(const f32x4*)(W1 + i0); m[nt] = DIMN_LD_STATE_MV(M1 + i0); v[nt] = DIMN_LD_STATE_MV(V1 + i0);
     }
     f32x4 xa = zero4;
     if (stager) {
@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
             const int64_t idx = wb[nt] + c1n * cstride;                // state of chunk c+1
-            w1[nt] = *(const f32x4*)(W1 + idx); m1[nt] = *(const f32x4*)(M1 + idx); v1[nt] = *(const f32x4*)(V1 + idx);
+            w1[nt] = *(const f32x4*)(W1 + idx); m1[nt] = DIMN_LD_STATE_MV(M1 + idx); v1[nt] = DIMN_LD_STATE_MV(V1 + idx);
         }
         __builtin_amdgcn_sched_barrier(0);
 
