@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_BATCH = 64
 COMM_ID_BYTES = 128
 # hidden-layer activations the kernels implement (ids = DIMN_ACT_* of include/dimn.h; Keras names)
@@ -69,6 +69,7 @@ SIGNATURES = {
 # entry points only the GPU library has
 GPU_ONLY = {
     "abi_version": [],
+    "device_count": [C.POINTER(C.c_int32)],
     "predict_device": [_H, _pi, _i64, C.POINTER(C.c_void_p)],
     "synchronize": [_H],
     "get_timers": [_H, _pd, _i32],

@@ -37,3 +37,10 @@ def load():
                               % (ver, _cabi.ABI_VERSION))
         _fns = fns
     return _fns
+
+
+def device_count():
+    """HIP devices visible to this process (0 without a GPU)."""
+    n = C.c_int32(0)
+    load()["device_count"](C.byref(n))
+    return n.value

@@ -16,7 +16,7 @@
 #include "dimn_kernels.h"
 #include "dimn_corr.h"
 
-#define DIMN_ABI_VERSION 1
+#define DIMN_ABI_VERSION 2
 
 static thread_local char g_err[1024];
 static int fail(int code, const char* fmt, ...) {
@@ -40,6 +40,13 @@ static int fail(int code, const char* fmt, ...) {
 
 extern "C" const char* dimn_last_error(void) { return g_err; }
 extern "C" int dimn_abi_version(void) { return DIMN_ABI_VERSION; }
+extern "C" int dimn_device_count(int32_t* n) {
+    if (!n) return fail(DIMN_ERR_ARG, "dimn_device_count: null argument");
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess) nd = 0;
+    *n = nd;
+    return DIMN_OK;
+}
 
 // ---- RCCL, bound at first use so that the library loads on machines without it ----------
 typedef struct ncclComm* ncclComm_t;
@@ -123,6 +130,7 @@ struct dimn_handle_s {
     float* d_out = nullptr; int64_t out_cap = 0; int64_t out_rows = 0;
     float* d_loss_part = nullptr; int64_t loss_part_cap = 0;
     float *d_full = nullptr, *d_stage = nullptr; int64_t full_cap = 0;   // root's gathered predictions
+    double* d_red = nullptr; int red_cap = 0;                            // all-reduce scratch
     hipStream_t stream = nullptr;          // lane 0's stream; also used by every non-training call
     struct Lane { hipStream_t stream; int k0, k1, w0, w1; };   // sub-nets [k0,k1), work items [w0,w1)
     std::vector<Lane> lanes;               // independent sub-net groups trained on concurrent streams
@@ -383,7 +391,7 @@ extern "C" int dimn_destroy(dimn_handle h) {
     DEV_FREE(h->d_loss_step); DEV_FREE(h->d_loss_acc); DEV_FREE(h->d_mask); DEV_FREE(h->d_rows_step);
     DEV_FREE(h->d_midwork); DEV_FREE(h->d_midk); DEV_FREE(h->d_P2); DEV_FREE(h->d_G);
     DEV_FREE(h->d_epoch_rows); DEV_FREE(h->d_val_rows); DEV_FREE(h->d_pred_rows); DEV_FREE(h->d_out);
-    DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage);
+    DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage); DEV_FREE(h->d_red);
     for (auto& ln : h->lanes) (void)hipStreamDestroy(ln.stream);
     delete h;
     return DIMN_OK;
@@ -607,8 +615,8 @@ extern "C" int dimn_get_adam_state(dimn_handle h, int32_t k, int32_t which, floa
 // ---- one optimiser step: [F1] -> RED -> (MFB -> RED2 | MF -> MB) -> B1F1 on the lane's stream ----
 static hipEvent_t next_event(dimn_handle h) {
     if (h->ev_used == h->ev.size()) {
-        hipEvent_t e;
-        (void)hipEventCreate(&e);
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;   // caller falls back to an untimed launch
         h->ev.push_back(e);
     }
     return h->ev[h->ev_used++];
@@ -691,12 +699,16 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     timed = h->profiling && (step_key % 8u) == 0u;
     if (timed) {
         e0 = next_event(h); e1 = next_event(h); e2 = next_event(h);
+        if (!e0 || !e1 || !e2) { timed = false; e0 = e1 = e2 = nullptr; h->ev_used -= h->ev_used % 3; }
+    }
+    if (timed) {
         (void)hipEventRecord(e0, st);
-        // ALGORITHMIC bytes of this W1 launch: 24 B per W1 parameter (read+write of
-        // w, m, v) + the X tiles of this and the next batch + dA, for the lane's sub-nets
+        // ALGORITHMIC bytes of this W1 launch: 24 B per W1 parameter (read+write
+        // of w, m, v) + the batch rows of X ONCE per step (the launch reads X_t and X_{t+1}; the second read is
+        // the kernel's own choice, not the algorithm's) + dA, for the lane's sub-nets
         double by = 0;
         for (int k = ln.k0; k < ln.k1; ++k)
-            by += 24.0 * h->sn[k].D * h->H + 4.0 * (b_act + b_next) * h->sn[k].D + 4.0 * b_act * h->H;
+            by += 24.0 * h->sn[k].D * h->H + 4.0 * b_act * h->sn[k].D + 4.0 * b_act * h->H;
         h->ev_bytes.push_back(by);
     }
 
@@ -866,7 +878,7 @@ extern "C" int dimn_val_loss(dimn_handle h, double* val_loss) {
     const int64_t tiles = (h->n_val + DIMN_TB - 1) / DIMN_TB;
     if (h->loss_part_cap < tiles * h->K) {
         HIPCHK(hipStreamSynchronize(h->stream));
-        DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage);
+        DEV_FREE(h->d_loss_part);
         CHK(dev_alloc(&h->d_loss_part, (size_t)(tiles * h->K)));
         h->loss_part_cap = tiles * h->K;
     }
@@ -989,13 +1001,17 @@ extern "C" int dimn_comm_allreduce_sum(dimn_handle h, double* v, int32_t n) {
     if (!h || !v || n < 1) return fail(DIMN_ERR_ARG, "dimn_comm_allreduce_sum: bad argument");
     if (!h->comm) return fail(DIMN_ERR_STATE, "dimn_comm_allreduce_sum: dimn_comm_init first");
     CHK(use_device(h));
-    double* d = nullptr;
-    CHK(dev_alloc(&d, (size_t)n));
+    if (h->red_cap < n) {                                   // scratch kept across calls (one all-reduce per epoch)
+        HIPCHK(hipStreamSynchronize(h->stream));
+        DEV_FREE(h->d_red);
+        CHK(dev_alloc(&h->d_red, (size_t)std::max(n, 16)));
+        h->red_cap = std::max(n, 16);
+    }
+    double* d = h->d_red;
     HIPCHK(hipMemcpyAsync(d, v, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
     NCCLCHK(g_rccl.AllReduce(d, d, (size_t)n, kNcclFloat64, kNcclSum, h->comm, h->stream));
     HIPCHK(hipMemcpyAsync(v, d, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    (void)hipFree(d);
     return DIMN_OK;
 }
 extern "C" int dimn_comm_gather_predictions(dimn_handle h, int64_t n_rows, const int32_t* counts, int32_t root, float* out) {

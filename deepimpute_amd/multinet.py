@@ -19,6 +19,7 @@ same plan; tests/golden/shell_*.npz (captured from the imported reference) pin t
 
 There is no CPU fallback: without libdimn.so and a GPU, fit()/predict() raise.
 """
+import glob
 import json
 import os
 import tempfile
@@ -54,8 +55,11 @@ def _abs_corrcoef(values, backend="auto", device_id=0):
             rc = fns["abs_corrcoef"](int(device_id), _cabi.p_f64(x), x.shape[0], x.shape[1], _cabi.p_f64(out))
             if rc == 0:
                 return out
-            if backend == "hip":
-                raise RuntimeError("dimn_abs_corrcoef: " + fns["last_error"]().decode("utf-8", "replace"))
+            msg = fns["last_error"]().decode("utf-8", "replace")
+            # "auto" may run on the host only when NO GPU is visible; a failing GPU (out of memory, HIP error)
+            # is an error, not a reason to spend minutes in float64 numpy without a word
+            if backend == "hip" or "no HIP device visible" not in msg:
+                raise RuntimeError("dimn_abs_corrcoef: " + msg)
         except ImportError:
             if backend == "hip":
                 raise
@@ -152,8 +156,12 @@ class MultiNet:
         self._engine = None
         # extension: a deepimpute_amd.sharded Comm (one process per GPU); the string "rccl" builds
         # an RcclComm from RANK/WORLD_SIZE/LOCAL_RANK at fit time.  None = single process.
-        self._comm = comm
+        self._comm_spec = comm                     # what the caller asked for
+        self._comm = None                          # the live communicator of the current engine
         self._first_subnet = 0
+        if isinstance(comm, str) and comm.lower() == "rccl":
+            # one process per GPU: the rank's device is known before any planning touches a GPU
+            self.device_id = int(os.environ.get("LOCAL_RANK", str(device_id)))
         self.setCores(ncores)
 
     def setCores(self, ncores):
@@ -190,17 +198,29 @@ class MultiNet:
 
     # -- persistence (reference: model.json + model.h5, multinet.py:105-124) --
     def save(self, model):
+        """model.json (rank 0) + the weights of this rank's sub-nets in Keras layout, keyed by GLOBAL sub-net
+        index: model.npz for a single process, model.rank<r>.npz per rank of a sharded job (one node, one
+        file system), so a fresh MultiNet under any world size can load() them."""
         os.makedirs(self.outputdir, exist_ok=True)
         hidden, rate, _ = _hidden_and_dropout(self.NN_parameters['architecture'])
-        with open(os.path.join(self.outputdir, "model.json"), "w") as fh:
-            json.dump({"format": "deepimpute_amd-1", "inputdims": list(model.D), "hidden": hidden,
-                       "dropout_rate": rate, "sub_outputdim": self.sub_outputdim,
-                       "architecture": self.NN_parameters['architecture']}, fh)
+        comm = self._comm
+        rank, world = (comm.rank, comm.world) if comm is not None else (0, 1)
+        if rank == 0:
+            dims = [len(p) for p in self.predictors] if getattr(self, "predictors", None) is not None else list(model.D)
+            with open(os.path.join(self.outputdir, "model.json"), "w") as fh:
+                json.dump({"format": "deepimpute_amd-1", "inputdims": dims, "hidden": hidden,
+                           "dropout_rate": rate, "sub_outputdim": self.sub_outputdim,
+                           "architecture": self.NN_parameters['architecture']}, fh)
         blobs = {}
         for k in range(model.K):
             for name, arr in zip(("W1", "b1", "W2", "b2"), model.get_weights(k)):
-                blobs["%s_%d" % (name, k)] = arr
-        np.savez(os.path.join(self.outputdir, "model.npz"), **blobs)
+                blobs["%s_%d" % (name, self._first_subnet + k)] = arr
+        if world == 1:
+            for stale in glob.glob(os.path.join(self.outputdir, "model.rank*.npz")):
+                os.remove(stale)
+        np.savez(os.path.join(self.outputdir, "model.npz" if world == 1 else "model.rank%d.npz" % rank), **blobs)
+        if comm is not None:
+            comm.barrier()                               # every shard is on disk when any rank returns
         print("Saved model to disk in {}".format(self.outputdir))
 
     def load(self):
@@ -211,11 +231,19 @@ class MultiNet:
                 meta = json.load(fh)
             self.NN_parameters['architecture'] = meta["architecture"]
             self.sub_outputdim = meta["sub_outputdim"]
-            engine = self.build(meta["inputdims"])
-            with np.load(os.path.join(self.outputdir, "model.npz")) as z:
-                for k in range(engine.K):
-                    engine.set_weights(k, *(z["%s_%d" % (nm, k)] for nm in ("W1", "b1", "W2", "b2")))
+            engine, _, counts = self._build_shard(meta["inputdims"])
+            files = sorted(glob.glob(os.path.join(self.outputdir, "model.rank*.npz"))) or [os.path.join(self.outputdir, "model.npz")]
+            wanted = set(range(self._first_subnet, self._first_subnet + engine.K))
+            for path in files:
+                with np.load(path) as z:
+                    for g in sorted(wanted):
+                        if "W1_%d" % g in z.files:
+                            engine.set_weights(g - self._first_subnet, *(z["%s_%d" % (nm, g)] for nm in ("W1", "b1", "W2", "b2")))
+                            wanted.discard(g)
+            if wanted:
+                raise FileNotFoundError("weights of sub-networks %s not found in %s" % (sorted(wanted), self.outputdir))
             self._engine = engine
+            self._counts = counts
         return self._engine
 
     def _bind_columns(self, engine, columns):
@@ -258,15 +286,8 @@ class MultiNet:
         np.random.seed(self.seed)                      # second seeding, multinet.py:219
 
         print("Building network")
-        if self._engine is not None:
-            self._engine.close()
-            self._engine = None
-        comm, counts = self._resolve_comm(len(self.predictors))
-        self._first_subnet = sum(counts[:comm.rank])
-        mine = range(self._first_subnet, self._first_subnet + counts[comm.rank])
-        engine = self.build([len(self.predictors[k]) for k in mine], subnet_offset=self._first_subnet)
-        if isinstance(comm, str):
-            comm = self._comm = self._make_rccl(engine)
+        self._release_engine()
+        engine, comm, counts = self._build_shard([len(p) for p in self.predictors])
 
         held_out = np.random.choice(norm_data.index, int(_VALIDATION_FRACTION * norm_data.shape[0]), replace=False)
         kept = np.setdiff1d(norm_data.index, held_out)          # label-sorted, multinet.py:229
@@ -294,36 +315,57 @@ class MultiNet:
 
         self._engine = engine
         self._counts = counts
-        if comm.world == 1:
-            self.save(engine)
+        self.save(engine)
         self.test_metrics = self._held_out_metrics(engine, norm_data, held_out, rows_val)
         return self
 
-    def _resolve_comm(self, K):
-        from .sharded import SingleComm, shard_subnets
-        comm = self._comm
-        if comm is None:
-            comm = self._comm = SingleComm()
-        if isinstance(comm, str):
-            if comm.lower() != "rccl":
+    def _release_engine(self):
+        """Close the live communicator (a collective: every rank of a sharded job calls fit/close alike),
+        then the engine it was bound to."""
+        if self._comm is not None:
+            self._comm.close()
+            self._comm = None
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
+    def close(self):
+        """Extension: release the GPU (and, in a sharded job, the RCCL communicator) now instead of at exit."""
+        self._release_engine()
+
+    def _shard_plan(self, K):
+        """(rank, world, counts) of this process for K sub-networks under the caller's comm spec."""
+        from .sharded import shard_subnets
+        spec = self._comm_spec
+        if spec is None:
+            rank, world = 0, 1
+        elif isinstance(spec, str):
+            if spec.lower() != "rccl":
                 raise ValueError("comm must be a Comm object or 'rccl'")
-            world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-            self.device_id = int(os.environ.get("LOCAL_RANK", str(self.device_id)))
-            counts, _ = shard_subnets(K, world)
-
-            class _Pending(str):
-                pass
-            pending = _Pending("rccl")
-            pending.rank, pending.world = rank, world
-            return pending, counts
-        counts, _ = shard_subnets(K, comm.world)
+            rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        else:
+            rank, world = spec.rank, spec.world
+        counts, _ = shard_subnets(K, world)
         if min(counts) < 1:
-            raise ValueError("more ranks (%d) than sub-networks (%d)" % (comm.world, K))
-        return comm, counts
+            raise ValueError("more ranks (%d) than sub-networks (%d)" % (world, K))
+        return rank, world, counts
 
-    def _make_rccl(self, engine):
-        from .sharded import RcclComm
-        return RcclComm(engine, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
+    def _build_shard(self, inputdims):
+        """The engine of this rank's contiguous block of sub-nets + the communicator bound to it."""
+        from .sharded import RcclComm, SingleComm
+        rank, world, counts = self._shard_plan(len(inputdims))
+        self._first_subnet = sum(counts[:rank])
+        mine = range(self._first_subnet, self._first_subnet + counts[rank])
+        engine = self.build([inputdims[k] for k in mine], subnet_offset=self._first_subnet)
+        spec = self._comm_spec
+        if spec is None:
+            comm = SingleComm()
+        elif isinstance(spec, str):
+            comm = RcclComm(engine, rank, world)       # bound to THIS engine's handle; closed with it
+        else:
+            comm = spec
+        self._comm = comm
+        return engine, comm, counts
 
     def _predict_block(self, engine, rows=None):
         """np.hstack of ALL sub-nets' outputs on rank 0 (None elsewhere when sharded)."""

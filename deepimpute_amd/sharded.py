@@ -13,9 +13,10 @@ by sub-network with no gradient traffic at all:
   * at the end: the per-rank prediction blocks [cells, K_r*O] are gathered into the full
     [cells, K*O] matrix on rank 0 (RCCL send/recv straight to root over xGMI on the GPU path).
 
-The collectives sit behind a tiny `Comm` interface with two implementations: `RcclComm`
-(libdimn's dimn_comm_* on the GPU data path; rendezvous through a file under /tmp, no torch in
-the process) and `TorchComm` (torch.distributed, e.g. gloo: the CPU test-suite, world_size 2).
+The collectives sit behind a tiny `Comm` interface (rank, world, allreduce_sum, gather_predictions,
+barrier, close).  The product implementation is `RcclComm` (libdimn's dimn_comm_* on the GPU data
+path; rendezvous through a private file under /tmp, no torch in the process); the CPU test-suite
+plugs a gloo implementation of the same interface in (tests/torch_comm.py, world_size 2 and 3).
 """
 import os
 import time
@@ -43,48 +44,37 @@ class SingleComm:
     def barrier(self):
         pass
 
+    def close(self):
+        pass
 
-class TorchComm:
-    """Collectives over an initialised torch.distributed process group (any backend; the
-    test-suite uses gloo on CPU).  Arrays travel as host tensors."""
 
-    def __init__(self, group=None):
-        import torch.distributed as dist
-        self._dist = dist
-        self._group = group
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-
-    def allreduce_sum(self, vec):
-        import torch
-        t = torch.tensor(np.asarray(vec, np.float64))
-        self._dist.all_reduce(t, group=self._group)
-        return t.numpy()
-
-    def gather_predictions(self, engine, local_block, n_rows, counts, out_dim):
-        import torch
-        block = local_block() if callable(local_block) else local_block
-        mine = torch.from_numpy(np.ascontiguousarray(block, np.float32))
-        if self.rank == 0:
-            parts = [torch.empty((n_rows, c * out_dim), dtype=torch.float32) for c in counts]
-            self._dist.gather(mine, parts, dst=0, group=self._group)
-            return np.hstack([p.numpy() for p in parts])
-        self._dist.gather(mine, None, dst=0, group=self._group)
-        return None
-
-    def barrier(self):
-        self._dist.barrier(group=self._group)
+def _job_tag():
+    """A name every rank of ONE job computes identically and no other job shares: the launcher's pid,
+    its start time (field 22 of /proc/<pid>/stat: a recycled pid gets another one) and MASTER_PORT."""
+    ppid = os.getppid()
+    born = "0"
+    try:
+        with open("/proc/%d/stat" % ppid) as f:
+            born = f.read().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        pass
+    return "%d_%s_%s" % (ppid, born, os.environ.get("MASTER_PORT", "0"))
 
 
 class RcclComm:
-    """RCCL over xGMI through libdimn (dimn_comm_*).  The 128-byte unique id is handed from
-    rank 0 to the others through a file in a directory named after the launcher's pid, so the
-    GPU processes never import torch."""
+    """RCCL over xGMI through libdimn (dimn_comm_*).  The 128-byte unique id is handed from rank 0 to
+    the others through a file in a 0700 directory named after the job (`_job_tag`) plus a per-process
+    sequence number, so that a second communicator of the same job (a second fit) never reads the
+    first one's id; the GPU processes never import torch."""
+    _seq = 0
+    device_gather = True        # predictions stay in HBM: predict_device + dimn_comm_gather_predictions
 
     def __init__(self, engine, rank, world, tag=None, timeout=300.0):
         self.rank, self.world, self._engine = rank, world, engine
-        tag = tag or "%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
-        self._dir = os.path.join("/tmp", "dimn_rdzv_" + tag)
-        os.makedirs(self._dir, exist_ok=True)
+        RcclComm._seq += 1
+        tag = tag or "%s_%d" % (_job_tag(), RcclComm._seq)
+        self._dir = os.path.join("/tmp", "dimn_rdzv_%d_%s" % (os.getuid(), tag))
+        os.makedirs(self._dir, mode=0o700, exist_ok=True)
         path = os.path.join(self._dir, "uid")
         if rank == 0:
             uid = engine.comm_unique_id()
@@ -100,6 +90,7 @@ class RcclComm:
             with open(path, "rb") as f:
                 uid = np.frombuffer(f.read(), np.uint8)
         engine.comm_init(uid, world, rank)
+        self._open = True
 
     def allreduce_sum(self, vec):
         return self._engine.comm_allreduce_sum(vec)
@@ -112,6 +103,11 @@ class RcclComm:
         self._engine.comm_allreduce_sum(np.zeros(1))
 
     def close(self):
+        """Collective: every rank has passed the barrier (hence read the id) before root removes it."""
+        if not self._open:
+            return
+        self._open = False
+        self.barrier()
         self._engine.comm_destroy()
         if self.rank == 0:
             import shutil
@@ -144,7 +140,7 @@ def fit_sharded(engine, comm, max_epochs, patience):
 
 def predict_sharded(engine, comm, counts, rows=None, n_rows=None):
     """model.predict over a sharded job: rank 0 gets np.hstack over ALL sub-nets, others None."""
-    if isinstance(comm, RcclComm):
+    if getattr(comm, "device_gather", False):
         engine.predict_device(rows, n_rows)
         n = len(rows) if rows is not None else (n_rows if n_rows is not None else engine.n_cells)
         return comm.gather_predictions(engine, None, n, counts, engine.O)

@@ -64,6 +64,9 @@ typedef struct dimn_config {
 const char* dimn_last_error(void);
 /* ABI version; bumped on any signature change. */
 int dimn_abi_version(void);
+/* Number of HIP devices visible to this process (0 when there is none: not an error).  Host code uses it
+ * to place one process per GPU; the reference has no analogue (multinet.py:222-223 sizes CPU threads). */
+int dimn_device_count(int32_t* n);
 
 /* build(inputdims) (multinet.py:126-148,226): D[k] = predictor count of sub-net k. */
 int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle* out);

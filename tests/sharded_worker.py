@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main(out_path):
     import torch.distributed as dist
     from deepimpute_amd.multinet import MultiNet
-    from deepimpute_amd.sharded import TorchComm
+    from torch_comm import TorchComm
     from oracle.dimo import OracleEngine
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -1,0 +1,92 @@
+"""GPU parity at the shapes of BASELINE.json configs[1] (5k x 5k, K = 10, D_k ~ 1935, H = 256, O = 512) and a
+long-horizon drift check of the fast-math pieces of the HIP path (1-ulp v_rcp/v_sqrt in Adam, hardware exp/log in
+the training softplus) against the fp64 build of the oracle.  Run on the MI355X box: pytest -m gpu."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    from deepimpute_amd.engine import HipEngine
+    return HipEngine
+
+
+def _oracle():
+    from oracle.dimo import OracleEngine
+    return OracleEngine
+
+
+def _cfg2_problem():
+    import bench
+    cfg = bench.CONFIGS["cfg2"]
+    n, g = cfg["n"], cfg["g"]
+    norm = bench.synth_counts(n, g, seed=0)
+    targets, preds = bench.synth_indices(g, cfg["O"], seed=0)
+    train, val = bench.split_rows(n, seed=0)
+    return cfg, norm, targets, preds, train, val
+
+
+@pytest.mark.parametrize("mid", ["1", "0"])      # fused second layer / two-kernel second layer (DIMN_MID)
+def test_cfg2_shapes_match_oracle(mid, monkeypatch):
+    """configs[1] at its real shapes: 4 optimiser steps (the last one partial), the validation pass over the 5 %
+    split and predict of 256 cells, HIP vs oracle, tolerances of test_two_epochs_match_oracle."""
+    monkeypatch.setenv("DIMN_MID", mid)
+    cfg, norm, targets, preds, train, val = _cfg2_problem()
+    K = targets.shape[0]
+    assert K == 10 and 1800 < min(map(len, preds)) and max(map(len, preds)) < 2100
+    engines = []
+    for cls in (_hip(), _oracle()):
+        e = cls([len(p) for p in preds], cfg["H"], cfg["O"], batch_size=cfg["B"], dropout_rate=0.2, learning_rate=1e-3, seed=1234)
+        e.set_matrix(norm)
+        for k in range(K):
+            e.set_indices(k, preds[k], targets[k])
+        e.gather(True)
+        e.set_split(train[:3 * 64 + 21], val)
+        e.init_weights()
+        engines.append(e)
+    a, b = engines
+    np.testing.assert_allclose(a.train_epoch(0), b.train_epoch(0), rtol=1e-4)
+    assert a.step_count() == b.step_count() == 4
+    np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
+    for k in (0, 4, 9):
+        for x, y, name in zip(a.get_weights(k), b.get_weights(k), ("W1", "b1", "W2", "b2")):
+            np.testing.assert_allclose(x, y, rtol=1e-3, atol=2e-5, err_msg="%s k=%d" % (name, k))
+    rows = np.arange(7, 7 + 256 * 19, 19, dtype=np.int32)
+    np.testing.assert_allclose(a.predict(rows), b.predict(rows), rtol=1e-4, atol=1e-6)      # north_star tolerance
+    a.close(); b.close()
+
+
+def test_long_horizon_drift_vs_fp64():
+    """>= 500 optimiser steps (K = 2, D = 300, H = 256, O = 512): the HIP path and the fp32 oracle are each compared
+    with the fp64 oracle on the same Philox streams; the HIP path's error must not exceed the plain-loop fp32
+    oracle's by more than 2x (plus an absolute floor of a few fp32 ulps of the quantities compared)."""
+    from helpers import make_problem, load_problem
+    prob = make_problem(n=1100, g=900, Ds=[300, 300], H=256, O=512, seed=23, val_frac=0.05)
+    kw = dict(batch_size=64, dropout_rate=0.2, learning_rate=1e-4, seed=77)
+    hip = load_problem(_hip(), prob, **kw)
+    o32 = load_problem(_oracle(), prob, **kw)
+    o64 = load_problem(_oracle(), prob, fp64=True, **kw)
+    for e in (hip, o32, o64):
+        e.init_weights()
+    steps = 0
+    epoch = 0
+    while steps < 500:
+        lh, l32, l64 = hip.train_epoch(epoch), o32.train_epoch(epoch), o64.train_epoch(epoch)
+        steps = o64.step_count()
+        epoch += 1
+        err_h, err_o = np.abs(lh - l64) / l64, np.abs(l32 - l64) / l64
+        assert (err_h <= 2 * err_o + 2e-6).all(), (epoch, err_h, err_o)
+    assert hip.step_count() == steps >= 500
+    vh, v32, v64 = hip.val_loss(), o32.val_loss(), o64.val_loss()
+    assert (np.abs(vh - v64) / v64 <= 2 * np.abs(v32 - v64) / v64 + 2e-6).all()
+    ph, p32, p64 = hip.predict(), o32.predict(), o64.predict()
+    eh, eo = np.abs(ph - p64), np.abs(p32 - p64)
+    assert eh.max() <= 2 * eo.max() + 1e-6, (eh.max(), eo.max())
+    assert np.sqrt((eh ** 2).mean()) <= 2 * np.sqrt((eo ** 2).mean()) + 1e-7
+    for k in range(2):
+        for x, y, z, name in zip(hip.get_weights(k), o32.get_weights(k), o64.get_weights(k), ("W1", "b1", "W2", "b2")):
+            dh, do = np.abs(x - z), np.abs(y - z)
+            assert np.sqrt((dh ** 2).mean()) <= 2 * np.sqrt((do ** 2).mean()) + 1e-8, (name, k)
+    for e in (hip, o32, o64):
+        e.close()
