@@ -15,6 +15,7 @@
 #include "../../include/dimn.h"
 #include "dimn_kernels.h"
 #include "dimn_corr.h"
+#include "dimn_resident.h"
 
 #define DIMN_ABI_VERSION 2
 
@@ -131,6 +132,11 @@ struct dimn_handle_s {
     float* d_loss_part = nullptr; int64_t loss_part_cap = 0;
     float *d_full = nullptr, *d_stage = nullptr; int64_t full_cap = 0;   // root's gathered predictions
     double* d_red = nullptr; int red_cap = 0;                            // all-reduce scratch
+    // register-resident epoch kernel (dimn_resident.h): chosen at create when the sub-nets of this handle fit the CUs
+    int res_G = 0, res_S1 = 0, res_T1 = 0;                                // 0: not eligible
+    float *d_res_P = nullptr, *d_res_D = nullptr, *d_res_b1 = nullptr, *d_res_alpha = nullptr;
+    unsigned* d_res_flags = nullptr; double* d_res_loss = nullptr; int64_t res_alpha_cap = 0;
+    double tm_res_ms = 0; int64_t tm_res_steps = 0;
     hipStream_t stream = nullptr;          // lane 0's stream; also used by every non-training call
     struct Lane { hipStream_t stream; int k0, k1, w0, w1; };   // sub-nets [k0,k1), work items [w0,w1)
     std::vector<Lane> lanes;               // independent sub-net groups trained on concurrent streams
@@ -242,6 +248,28 @@ static void build_mid(dimn_handle h) {
     h->mid_fused = 1;
 }
 
+static void build_resident(dimn_handle h) {
+    // Register-resident epoch kernel (dimn_resident.h): every sub-net gets G = 16*S1 co-resident workgroups (hidden tile x
+    // D-split), one per CU; eligible when all K*G fit the CUs, the W1 slice of a wave is at most 7 tiles (register
+    // budget), the output tiles fit the G workgroups, and the shapes are the ones the kernel is written for
+    // (H padded to 256, relu, H % 4 == 0).  DIMN_RESIDENT=0 disables it, =1 is the default (auto).
+    h->res_G = h->res_S1 = h->res_T1 = 0;
+    const Dims& dm = h->dm;
+    if (const char* e = getenv("DIMN_RESIDENT")) if (atoi(e) == 0) return;
+    if (dm.HT != 16 || (dm.H & 3) != 0 || h->B > DIMN_TB) return;
+    int S1 = std::min(8, h->ncu / std::max(1, h->K) / 16);
+    if (const char* e = getenv("DIMN_RES_S1")) S1 = std::min(S1, std::max(1, atoi(e)));      // tests: other decompositions
+    if (S1 < 1 || dm.OT > 16 * S1) return;
+    int maxchunk = 0, minchunk = 1 << 30;
+    for (auto& s : h->sn) { maxchunk = std::max(maxchunk, s.nchunk); minchunk = std::min(minchunk, s.nchunk); }
+    if (minchunk < S1) S1 = std::max(1, minchunk);
+    if (dm.OT > 16 * S1) return;
+    const int per_wg = ceil_div(maxchunk, S1);
+    const int T1 = ceil_div(per_wg + 1, 8);                  // +1: the integer split of nchunk may give one workgroup one more
+    if (T1 > 7) return;
+    h->res_G = 16 * S1; h->res_S1 = S1; h->res_T1 = T1 <= 2 ? 2 : (T1 <= 4 ? 4 : 7);
+}
+
 extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle* out) {
     if (!cfg || !D || !out) return fail(DIMN_ERR_ARG, "dimn_create: null argument");
     if (cfg->n_subnets < 1 || cfg->hidden < 1 || cfg->out_dim < 1)
@@ -312,6 +340,7 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     h->w1_total = w1;
     build_work(h);
     build_mid(h);
+    build_resident(h);
     // Sub-net lanes: independent sub-net groups on concurrent streams.  Default 1: with 2 lanes the
     // end-to-end rate is ~9 % higher on cfg3 (one lane's latency-bound kernels hide under the other's
     // weight update) but the two HBM-bound weight updates then share the bandwidth, which halves the
@@ -348,6 +377,13 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     TRY(dev_alloc(&h->d_loss_acc, (size_t)h->K * dm.LS));
     TRY(dev_alloc(&h->d_mask, (size_t)h->K * DIMN_TB * dm.Hp));
     TRY(dev_alloc(&h->d_rows_step, (size_t)DIMN_TB));
+    if (h->res_G) {
+        TRY(dev_alloc(&h->d_res_P, (size_t)2 * h->K * h->res_G * 1024));
+        TRY(dev_alloc(&h->d_res_D, (size_t)h->K * dm.OT * 16 * 1024));
+        TRY(dev_alloc(&h->d_res_b1, (size_t)2 * h->K * 256));
+        TRY(dev_alloc(&h->d_res_flags, (size_t)2 * h->K + 1));
+        TRY(dev_alloc(&h->d_res_loss, (size_t)h->K * dm.OT));
+    }
     if (h->mid_fused) {
         std::vector<int32_t> midk((size_t)2 * h->K);
         for (int k = 0; k < h->K; ++k) { midk[2 * k] = k * h->mid_slices; midk[2 * k + 1] = h->mid_slices; }
@@ -392,6 +428,7 @@ extern "C" int dimn_destroy(dimn_handle h) {
     DEV_FREE(h->d_midwork); DEV_FREE(h->d_midk); DEV_FREE(h->d_P2); DEV_FREE(h->d_G);
     DEV_FREE(h->d_epoch_rows); DEV_FREE(h->d_val_rows); DEV_FREE(h->d_pred_rows); DEV_FREE(h->d_out);
     DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage); DEV_FREE(h->d_red);
+    DEV_FREE(h->d_res_P); DEV_FREE(h->d_res_D); DEV_FREE(h->d_res_b1); DEV_FREE(h->d_res_alpha); DEV_FREE(h->d_res_flags); DEV_FREE(h->d_res_loss);
     for (auto& ln : h->lanes) (void)hipStreamDestroy(ln.stream);
     delete h;
     return DIMN_OK;
@@ -819,6 +856,74 @@ extern "C" int dimn_epoch_permutation(uint64_t seed, int32_t epoch, int64_t n, i
     return DIMN_OK;
 }
 
+// One epoch as ONE persistent launch with the optimiser state in registers (dimn_resident.h); d_epoch_rows is uploaded.
+static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss) {
+    const Dims& dm = h->dm;
+    const int steps = (int)((h->n_tr + h->B - 1) / h->B);
+    if (h->res_alpha_cap < steps) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        DEV_FREE(h->d_res_alpha);
+        CHK(dev_alloc(&h->d_res_alpha, (size_t)steps));
+        h->res_alpha_cap = steps;
+    }
+    std::vector<float> alpha((size_t)steps);
+    const double b1 = h->cfg.beta1, b2 = h->cfg.beta2;
+    for (int t = 0; t < steps; ++t) {
+        const double tt = (double)(h->t + 1 + t);
+        alpha[(size_t)t] = (float)((double)h->cfg.learning_rate * sqrt(1.0 - pow(b2, tt)) / (1.0 - pow(b1, tt)));
+    }
+    HIPCHK(hipMemcpyAsync(h->d_res_alpha, alpha.data(), alpha.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_res_flags, 0, ((size_t)2 * h->K + 1) * sizeof(unsigned), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_res_loss, 0, (size_t)h->K * dm.OT * sizeof(double), h->stream));
+    const size_t kh = (size_t)h->K * dm.Hp, ko = (size_t)h->K * dm.Op;
+    ResParams p;
+    p.sn = h->d_sn; p.X = h->d_X; p.Y = h->d_Y; p.n_cells = h->n;
+    p.W1 = h->d_W1; p.M1 = h->d_M1; p.V1 = h->d_V1; p.W2 = h->d_W2; p.M2 = h->d_M2; p.V2 = h->d_V2;
+    p.b1w = h->d_b1; p.b1m = h->d_b1 + kh; p.b1v = h->d_b1 + 2 * kh;
+    p.b2w = h->d_b2; p.b2m = h->d_b2 + ko; p.b2v = h->d_b2 + 2 * ko;
+    p.rows = h->d_epoch_rows; p.n_tr = (int32_t)h->n_tr; p.B = h->B; p.steps = steps;
+    p.alpha = h->d_res_alpha; p.Ppart = h->d_res_P; p.Dpart = h->d_res_D; p.b1pub = h->d_res_b1;
+    p.flags = h->d_res_flags; p.loss = h->d_res_loss; p.dm = dm;
+    p.omb1 = 1.0f - h->cfg.beta1; p.omb2 = 1.0f - h->cfg.beta2; p.eps = h->cfg.eps;
+    p.rate = h->cfg.dropout_rate; p.scale = 1.0f / (1.0f - h->cfg.dropout_rate);
+    p.seed = h->cfg.seed; p.epoch = (uint32_t)epoch; p.G = h->res_G; p.S1 = h->res_S1; p.loss_binary = h->cfg.loss_binary;
+    const size_t lds = (size_t)DIMN_RES_LDS_FLOATS * sizeof(float);
+    const dim3 grid((unsigned)(h->K * h->res_G));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profiling) { e0 = next_event(h); e1 = next_event(h); next_event(h); }
+    if (e0 && e1) (void)hipEventRecord(e0, h->stream);
+#define RES_LAUNCH(T)                                                                                                     \
+    do {                                                                                                                  \
+        (void)hipFuncSetAttribute((const void*)k_epoch_resident<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(k_epoch_resident<T>, grid, dim3(DIMN_RES_THREADS), lds, h->stream, p);                         \
+    } while (0)
+    if (h->res_T1 == 2) RES_LAUNCH(2); else if (h->res_T1 == 4) RES_LAUNCH(4); else RES_LAUNCH(7);
+#undef RES_LAUNCH
+    HIPCHK(hipGetLastError());
+    if (e0 && e1) (void)hipEventRecord(e1, h->stream);
+    std::vector<unsigned> flags((size_t)2 * h->K + 1);
+    std::vector<double> acc((size_t)h->K * dm.OT);
+    HIPCHK(hipMemcpyAsync(flags.data(), h->d_res_flags, flags.size() * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(acc.data(), h->d_res_loss, acc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (e0 && e1) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { h->tm_res_ms += ms; h->tm_res_steps += steps; }
+        h->ev_used = 0; h->ev_bytes.clear();
+    }
+    if (flags[(size_t)2 * h->K] != 0)
+        return fail(DIMN_ERR_HIP, "dimn_train_epoch: the register-resident epoch kernel timed out waiting for a workgroup "
+                                  "(another process on this GPU?); weights are undefined -- re-initialise, or set DIMN_RESIDENT=0");
+    h->t += steps;
+    if (train_loss)
+        for (int k = 0; k < h->K; ++k) {
+            double s = 0;
+            for (int o = 0; o < dm.OT; ++o) s += acc[(size_t)k * dm.OT + o];
+            train_loss[k] = s / ((double)h->O * (double)h->n_tr);
+        }
+    return DIMN_OK;
+}
+
 extern "C" int dimn_train_epoch(dimn_handle h, int32_t epoch, const int32_t* perm, double* train_loss) {
     if (!h) return fail(DIMN_ERR_ARG, "null handle");
     CHK(ready_for_training(h, "dimn_train_epoch"));
@@ -839,6 +944,7 @@ extern "C" int dimn_train_epoch(dimn_handle h, int32_t epoch, const int32_t* per
     }
     CHK(sync_lanes(h));
     HIPCHK(hipMemcpyAsync(h->d_epoch_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, h->stream));
+    if (h->res_G && h->act == DIMN_ACT_RELU) return train_epoch_resident(h, epoch, train_loss);
     HIPCHK(hipMemsetAsync(h->d_loss_acc, 0, (size_t)h->K * dm.LS * sizeof(double), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));     // every lane reads the row list and accumulates into d_loss_acc
     // d_loss_acc accumulates sum(w e^2) per step; the per-step means are weighted by b_act,
@@ -973,7 +1079,8 @@ extern "C" int dimn_get_timers(dimn_handle h, double* out4, int32_t reset) {
     if (!h || !out4) return fail(DIMN_ERR_ARG, "null argument");
     out4[0] = h->tm_step_ms; out4[1] = (double)h->tm_steps; out4[2] = h->tm_w1_ms; out4[3] = (double)h->tm_w1;
     out4[4] = h->tm_w1_bytes; out4[5] = (double)h->lanes.size();
-    if (reset) { h->tm_step_ms = h->tm_w1_ms = h->tm_w1_bytes = 0; h->tm_steps = h->tm_w1 = 0; }
+    out4[6] = h->tm_res_ms; out4[7] = (double)h->tm_res_steps;
+    if (reset) { h->tm_step_ms = h->tm_w1_ms = h->tm_w1_bytes = h->tm_res_ms = 0; h->tm_steps = h->tm_w1 = h->tm_res_steps = 0; }
     return DIMN_OK;
 }
 

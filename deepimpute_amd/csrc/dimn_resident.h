@@ -1,0 +1,464 @@
+// dimn_resident.h -- the REGISTER-RESIDENT epoch kernel of libdimn (gfx950).
+//
+// When a GPU owns only a few sub-networks (8-GPU sharding of BASELINE configs[3]: K_local = 5), the whole
+// optimiser state of the rank -- W, m, v of both layers, ~45 MB -- fits the chip's 128 MB of vector registers.
+// One persistent launch then runs a WHOLE EPOCH of model.fit (reference deepimpute/multinet.py:238-244):
+// every workgroup keeps its slice of W1/m/v (and of W2/m/v) in registers for all ~743 optimiser steps, so
+// no optimiser state moves through HBM at all; per step the workgroups of one sub-net exchange only small
+// activation tiles through L2/MALL (write-through stores + arrival counters, no grid-wide barrier: sub-nets
+// share nothing, multinet.py:132-146).  The four launches per step of the streaming path (RED, MF, MB, B1F1 --
+// each latency-bound at this size) disappear.
+//
+// Decomposition of sub-net k over G = 16*S1 workgroups (512 threads = 8 waves x 256 VGPRs, one per CU):
+//   role 1 (all G):      workgroup (ht, s) owns hidden tile ht (16 units) of the D-split s: the W1 tiles
+//                        [chunk c in split s][ht], T1 tiles per wave.  Per step: dA tile, W1 gradient + Adam in
+//                        registers, forward partial P[64][16] of the NEXT batch (k-slot trick, dimn_kernels.h).
+//   role 2 (first OT):   workgroup ot owns the W2 column block [all 16 hidden tiles][output tile ot], two tiles
+//                        per wave.  Per step: Dd = dropout(relu(sum_s P + b1)), Z tile, softplus, wMSE, dZ,
+//                        Adam(b2), W2 gradient + Adam in registers, dD partial [64][256] over its 16 outputs.
+// Exchange per step and sub-net (the only inter-workgroup traffic):
+//   P partials   G x [64][16]  (role 1 -> role 2, and to the S1 siblings of a hidden tile for the relu gate)
+//   dD partials  OT x 16 x [64][16]  (role 2 -> role 1: workgroup (ht, s) sums tile ht over the OT producers)
+// Both through 16-byte sc0 sc1 (write-through) stores, a vmcnt(0) drain, and ONE relaxed agent-scope counter
+// per sub-net and direction; consumers poll that counter with one lane and read with sc0 sc1 loads (L1 is
+// never refreshed by other CUs' stores, L2s of different XCDs are not coherent: MI355X guide, Guideline 16).
+// Counters are monotonic over the epoch (zeroed by the host before the launch); every spin is bounded and
+// a timeout raises an abort word that makes every workgroup leave, so a lost workgroup cannot hang the GPU.
+//
+// All arithmetic is the exact-fp32 path of the streaming kernels (v_mfma_f32_16x16x4_f32, adam4, the Philox
+// dropout streams, softplus_sigmoid_fast): only summation orders differ.
+#pragma once
+#include "dimn_kernels.h"
+
+#define DIMN_RES_THREADS 512
+#define DIMN_RES_LDD 260          // LDS row stride of Dd (as k_mid_fused)
+#define DIMN_RES_SPIN_LIMIT (1u << 22)
+#define DIMN_RES_AUX 17           // sc0 sc1 on every exchanged 16-byte access
+#define DIMN_RES_W2S 26976        // LDS float offset of the W2 state
+#define DIMN_RES_LDS_FLOATS (DIMN_RES_W2S + 3 * 16 * 256)
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct ResParams {
+    const SubnetDev* sn;
+    const float* X;                 // gathered predictors (arena)
+    const float* Y; int64_t n_cells;
+    float *W1, *M1, *V1, *W2, *M2, *V2;
+    float *b1w, *b1m, *b1v, *b2w, *b2m, *b2v;
+    const int32_t* rows;            // [n_tr] the epoch's row order (train_rows[perm])
+    int32_t n_tr, B, steps;
+    const float* alpha;             // [steps] lr*sqrt(1-b2^t)/(1-b1^t) of every step of the epoch
+    float* Ppart;                   // [2][K][G][64][16]   forward partials, double-buffered by step parity
+    float* Dpart;                   // [K][OT][16][64][16] dD partials
+    float* b1pub;                   // [2][K][256]         b1 as the forward of that parity saw it
+    unsigned* flags;                // [2K+1]: flagP[k], flagD[k], abort
+    double* loss;                   // [K][OT] sum over the epoch of sum(w e^2) per output tile
+    Dims dm;
+    float omb1, omb2, eps, rate, scale;
+    uint64_t seed; uint32_t epoch;
+    int32_t G, S1, loss_binary;
+};
+
+__device__ __forceinline__ f32x4 res_ld(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, DIMN_RES_AUX);
+    return __builtin_bit_cast(f32x4, v);
+}
+__device__ __forceinline__ void res_st(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, f32x4 x) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), r, byte_off, 0, DIMN_RES_AUX);
+}
+
+// One lane waits until *flag >= target (relaxed agent-scope polls, s_sleep between them); false on abort.
+__device__ __forceinline__ bool res_wait(unsigned* flag, unsigned target, unsigned* abort_w) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 255u) == 0u) {
+            if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > DIMN_RES_SPIN_LIMIT) {
+                __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
+template <int T1>   // W1 tiles per wave
+__global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int ldd = DIMN_RES_LDD;
+    // LDS map (floats).  Phase A and phase B regions alias (a workgroup runs them one after the other).
+    float* ddl = lds;                         // A: Dd [64][ldd]                       16640
+    float* zred = ddl + DIMN_TB * ldd;        // A: Z partials [8 waves][64][16]        8192
+    float* xst = lds;                         // B: X staging [8 waves][XT 1024 | XN 1024] 16384 (aliases ddl)
+    float* pred = lds + 16384;                // B: forward partials [8 waves][64][16]  8192 (aliases ddl/zred)
+    float* dzl = lds + 24832;                 // dZ tile [64][16]  / B: dA tile         1024
+    float* yl = dzl + 1024;                   // A: targets tile [64][16] / B: dD half sums 1024
+    float* b1l = yl + 1024;                   // b1 of own hidden tile [16]
+    float* smallf = b1l + 16;                 // [8] loss partials, [32..47] b2 tile     64
+    int* flagl = (int*)(smallf + 64);         // [4] broadcast of the poll result
+    float* w2s = lds + DIMN_RES_W2S;          // role 2 state: W2, m, v column block [3][16 hidden tiles][16 h][16 o]  12288
+    // (W1/m/v live in registers; the W2 column block lives in LDS -- its tiles are needed in two operand forms anyway,
+    //  and 24 more registers of state made the compiler spill)
+
+    const Dims dm = p.dm;
+    const int G = p.G, S1 = p.S1;
+    const int k = blockIdx.x / G, wi = blockIdx.x - k * G;
+    const int ht = wi & 15, sp = wi >> 4;
+    const bool is_o = wi < dm.OT;
+    const int ot = is_o ? wi : 0;
+    const SubnetDev s = p.sn[k];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    const int Hp = dm.Hp, Op = dm.Op, OT = dm.OT;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int K = dm.K;
+    unsigned* flagP = p.flags + k;
+    unsigned* flagD = p.flags + K + k;
+    unsigned* abort_w = p.flags + 2 * K;
+
+    // exchange buffers of this sub-net as buffer resources (wave-uniform descriptors)
+    const size_t pp_bytes = (size_t)G * 4096;                      // one parity of one sub-net
+    const __amdgpu_buffer_rsrc_t rP0 = __builtin_amdgcn_make_buffer_rsrc(p.Ppart + ((size_t)0 * K + k) * G * 1024, 0, (int)pp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP1 = __builtin_amdgcn_make_buffer_rsrc(p.Ppart + ((size_t)1 * K + k) * G * 1024, 0, (int)pp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(p.Dpart + (size_t)k * OT * 16 * 1024, 0, (int)((size_t)OT * 16 * 4096), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB0 = __builtin_amdgcn_make_buffer_rsrc(p.b1pub + ((size_t)0 * K + k) * 256, 0, 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc(p.b1pub + ((size_t)1 * K + k) * 256, 0, 1024, 0x00020000);
+
+    // ---- role 1 state: W1 tiles (chunk cb + wave + 8j, hidden tile ht) in registers ----
+    const int cb = (int)((int64_t)s.nchunk * sp / S1), ce = (int)((int64_t)s.nchunk * (sp + 1) / S1);
+    const int64_t cstride = (int64_t)Hp * 16;
+    const int64_t wbase = s.w1off + (int64_t)(16 * ht + li) * 16 + 4 * lj;
+    f32x4 w1[T1], m1[T1], v1[T1];
+    bool tv[T1];
+    int tc[T1];
+#pragma unroll
+    for (int j = 0; j < T1; ++j) {
+        const int c = cb + wave + 8 * j;
+        tv[j] = c < ce;
+        tc[j] = tv[j] ? c : cb;                                  // clamped: loads stay in bounds, results unused
+        const int64_t idx = wbase + tc[j] * cstride;
+        w1[j] = *(const f32x4*)(p.W1 + idx); m1[j] = *(const f32x4*)(p.M1 + idx); v1[j] = *(const f32x4*)(p.V1 + idx);
+    }
+    float b1w0 = 0.f, b1m0 = 0.f, b1v0 = 0.f;
+    const int64_t b1i = (int64_t)k * Hp + 16 * ht + (tid & 15);
+    if (tid < 16) { b1w0 = p.b1w[b1i]; b1m0 = p.b1m[b1i]; b1v0 = p.b1v[b1i]; b1l[tid] = b1w0; }
+    // ---- role 2 state: W2 tiles (hidden tiles 2*wave, 2*wave+1; output tile ot) ----
+    const int64_t t2base = (int64_t)k * Hp * Op + li * 16 + 4 * lj;
+    const int w2o = li * 16 + 4 * lj;                            // this lane's float4 of a [16 h][16 o] tile
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        const int tile = 2 * wave + h2;
+        const int64_t idx = t2base + ((int64_t)tile * OT + ot) * 256;
+        *(f32x4*)(w2s + tile * 256 + w2o) = *(const f32x4*)(p.W2 + idx);
+        *(f32x4*)(w2s + 4096 + tile * 256 + w2o) = *(const f32x4*)(p.M2 + idx);
+        *(f32x4*)(w2s + 8192 + tile * 256 + w2o) = *(const f32x4*)(p.V2 + idx);
+    }
+    float b2w0 = 0.f, b2m0 = 0.f, b2v0 = 0.f;
+    const int64_t b2i = (int64_t)k * Op + 16 * ot + (tid & 15);
+    if (is_o && tid < 16) { b2w0 = p.b2w[b2i]; b2m0 = p.b2m[b2i]; b2v0 = p.b2v[b2i]; smallf[32 + tid] = b2w0; }
+    double loss_total = 0.0;
+
+    const int B = p.B;
+
+    // Forward partial of batch `rows_n` with the CURRENT W1 registers (+ optional gradient/Adam of batch rows_t):
+    // the body of role 1.  do_grad: bfr = dA[b = 4kb+lj][h = li] is valid.
+    auto role1 = [&](const int tid, const int32_t* rows_t, int b_act, const int32_t* rows_n, int b_next, bool do_grad, bool do_fwd,
+                     const float (&bfr)[16], const AdamP ap, int par_out) {
+        const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lj = lane >> 4;
+        const float* xk = p.X + s.xoff + 4 * (lane & 3);         // staging: pass i moves row 16i + lane/4, quarter lane%4
+        float* xt = xst + wave * 2048;
+        float* xn = xt + 1024;
+        uint32_t xot[4], xon[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = 16 * i + (lane >> 2);
+            xot[i] = do_grad ? (uint32_t)rows_t[b < b_act ? b : 0] * (uint32_t)s.Dp : 0u;
+            xon[i] = do_fwd ? (uint32_t)rows_n[b < b_next ? b : 0] * (uint32_t)s.Dp : xot[i];
+        }
+        f32x4 pT[4] = {zero4, zero4, zero4, zero4};
+        f32x4 xa[4], xb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xa[i] = *(const f32x4*)(xk + xot[i] + 16 * tc[0]); xb[i] = *(const f32x4*)(xk + xon[i] + 16 * tc[0]); }
+#pragma unroll
+        for (int j = 0; j < T1; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                        // wave-private staging (in-order LDS, no barrier)
+                *(f32x4*)(xt + 256 * i + 4 * lane) = xa[i];
+                *(f32x4*)(xn + 256 * i + 4 * lane) = xb[i];
+            }
+            if (j + 1 < T1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { xa[i] = *(const f32x4*)(xk + xot[i] + 16 * tc[j + 1]); xb[i] = *(const f32x4*)(xk + xon[i] + 16 * tc[j + 1]); }
+            }
+            if (do_grad) {
+                f32x4 g = zero4;
+#pragma unroll
+                for (int kb = 0; kb < 16; ++kb) g = MFMA16(xt[64 * kb + lane], bfr[kb], g);     // A = X_t^T[d = li][b = 4kb+lj]
+                if (tv[j]) adam4(w1[j], m1[j], v1[j], g, ap);
+            }
+            if (do_fwd && tv[j]) {                               // wave-uniform
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const f32x4 x4 = *(const f32x4*)(xn + (16 * n + li) * 16 + 4 * lj);         // X_next[b = 16n+li][d = 4lj+r]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pT[n] = MFMA16(w1[j][r], x4[r], pT[n]);          // P^T[h][b] += W1^T X^T
+                }
+            }
+        }
+        if (do_fwd) {
+            __syncthreads();                                     // every wave is done with its staging buffers (pred aliases nothing of them, but dzl readers are done too)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) *(f32x4*)(pred + wave * 1024 + (16 * n + li) * 16 + 4 * lj) = pT[n];   // P[b = 16n+li][h = 4lj..]
+            __syncthreads();
+            if (tid < 256) {
+                f32x4 a = *(const f32x4*)(pred + 4 * tid);
+#pragma unroll
+                for (int wv = 1; wv < 8; ++wv) a += *(const f32x4*)(pred + wv * 1024 + 4 * tid);
+                res_st(par_out ? rP1 : rP0, (uint32_t)(wi * 4096 + 16 * tid), a);
+            }
+            if (sp == 0 && tid < 4) {                            // b1 as this forward's consumers must see it
+                const f32x4 bb = *(const f32x4*)(b1l + 4 * tid);
+                res_st(par_out ? rB1 : rB0, (uint32_t)(64 * ht + 16 * tid), bb);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every storing wave drains before the arrival
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(flagP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+
+    {   // prologue: forward partials of step 0
+        const float nob[16] = {0.f};
+        const int b0 = p.n_tr < B ? p.n_tr : B;
+        AdamP ap0; ap0.alpha = 0.f; ap0.omb1 = p.omb1; ap0.omb2 = p.omb2; ap0.eps = p.eps;
+        __syncthreads();                                         // b1l written
+        role1(tid, p.rows, 0, p.rows, b0, false, true, nob, ap0, 0);
+    }
+
+    for (int t = 0; t < p.steps; ++t) {
+        // Every per-thread index below derives from a copy of threadIdx.x the optimiser cannot see through: otherwise
+        // LICM hoists ~60 registers of address arithmetic out of the step loop and keeps them live next to the state
+        // (measured: 210 VGPRs at two state tiles per wave), which turns into scratch spills at seven tiles.
+        int tl = threadIdx.x;
+        asm volatile("" : "+v"(tl));
+        const int tid = tl, lane = tid & 63, wave = tid >> 6, li = lane & 15, lj = lane >> 4;
+        const int w2o = li * 16 + 4 * lj;
+        const int par = t & 1;
+        const int32_t* rows_t = p.rows + (int64_t)t * B;
+        const int b_act = (p.n_tr - t * B) < B ? (p.n_tr - t * B) : B;
+        const int rem = p.n_tr - (t + 1) * B;
+        const int b_next = rem <= 0 ? 0 : (rem < B ? rem : B);
+        const float inv_n = (float)(1.0 / ((double)b_act * dm.O));
+        AdamP ap; ap.alpha = p.alpha[t]; ap.omb1 = p.omb1; ap.omb2 = p.omb2; ap.eps = p.eps;
+        const __amdgpu_buffer_rsrc_t rP = par ? rP1 : rP0;
+        const __amdgpu_buffer_rsrc_t rB = par ? rB1 : rB0;
+
+        // =============================== phase A (role 2) ===============================
+        if (is_o) {
+            // work that depends on no other workgroup, done while the partials arrive: dropout keep bits of the whole
+            // [64][256] activation (unit q of this thread: hidden tile 2q + tid/256, row (tid%256)/4, quarter tid%4)
+            // and the targets tile
+            unsigned keep = 0u;
+            const int ub = (tid & 255) >> 2, uq = tid & 3;
+            if (p.rate > 0.f) {
+#pragma unroll 1
+                for (int q = 0; q < 8; ++q) {
+                    const int h = 16 * (2 * q + (tid >> 8)) + 4 * uq;
+                    const dimn_u32x4 rnd = dimn_dropout_block(p.seed, (uint32_t)s.kg, p.epoch, (uint32_t)t, (uint32_t)(ub * dm.H + h) >> 2);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) keep |= (dimn_u01(rnd.v[r]) >= p.rate ? 1u : 0u) << (4 * q + r);
+                }
+            } else {
+                keep = 0xffffffffu;
+            }
+            if (tid < 256) {
+                const int32_t row = rows_t[ub < b_act ? ub : 0];
+                *(f32x4*)(yl + 4 * tid) = *(const f32x4*)(p.Y + ((int64_t)k * p.n_cells + row) * Op + 16 * ot + 4 * uq);
+            }
+            if (tid == 0) flagl[0] = res_wait(flagP, (unsigned)(G * (t + 1)), abort_w) ? 1 : 0;
+            __syncthreads();
+            if (!flagl[0]) return;
+            // Dd = dropout(relu(b1 + sum_s P_s)) -> LDS
+#pragma unroll 2
+            for (int q = 0; q < 8; ++q) {
+                const int tile = 2 * q + (tid >> 8);
+                f32x4 a = res_ld(rB, (uint32_t)(64 * tile + 16 * uq));
+                for (int ss = 0; ss < S1; ++ss) a += res_ld(rP, (uint32_t)((ss * 16 + tile) * 4096 + 16 * (tid & 255)));
+                f32x4 dd;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool on = ((keep >> (4 * q + r)) & 1u) && ub < b_act;
+                    dd[r] = (on && a[r] > 0.f) ? a[r] * p.scale : 0.f;
+                }
+                *(f32x4*)(ddl + ub * ldd + 16 * tile + 4 * uq) = dd;
+            }
+            const float* ws = w2s + 2 * wave * 256;              // this wave's two W2 tiles [h][o]
+            __syncthreads();
+            {   // Z partial over this wave's 32 hidden units
+                f32x4 acc[4] = {zero4, zero4, zero4, zero4};
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    float bq[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bq[r] = ws[h2 * 256 + (4 * lj + r) * 16 + li];   // W2[h = 4lj+r][o = li]
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const f32x4 a4 = *(const f32x4*)(ddl + (16 * m + li) * ldd + 16 * (2 * wave + h2) + 4 * lj);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[m] = MFMA16(a4[r], bq[r], acc[m]);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zred[wave * 1024 + (16 * m + 4 * lj + r) * 16 + li] = acc[m][r];
+            }
+            __syncthreads();
+            {   // epilogue of the forward: two elements per thread of the [64][16] tile
+                float lsum = 0.f;
+                const bool col_ok = (16 * ot + (tid & 15)) < dm.O;
+                const float bias = smallf[32 + (tid & 15)];      // b2 tile (written at the end of the previous step / prologue)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int e = tid + 512 * half, b = e >> 4;
+                    float z = bias;
+#pragma unroll
+                    for (int wv = 0; wv < 8; ++wv) z += zred[wv * 1024 + e];
+                    float dz = 0.f;
+                    if (b < b_act && col_ok) {
+                        const float y = yl[e];
+                        const float w = p.loss_binary ? (y > 0.f ? 1.f : 0.f) : y;   // multinet.py:37-40
+                        float spv, sg;
+                        softplus_sigmoid_fast(z, spv, sg);
+                        const float er = y - spv;
+                        lsum += w * er * er;
+                        dz = -2.f * w * er * inv_n * sg;
+                    }
+                    dzl[e] = dz;
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
+                if (lane == 0) smallf[wave] = lsum;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                float tot = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 8; ++wv) tot += smallf[wv];
+                loss_total += (double)tot;
+            }
+            if (tid < 16) {                                      // gb2 = column sums of dZ -> Adam(b2)
+                float gb = 0.f;
+                for (int b = 0; b < DIMN_TB; ++b) gb += dzl[b * 16 + tid];
+                adam1(b2w0, b2m0, b2v0, gb, ap);
+            }
+            {   // W2 gradient, dD^T partial with the OLD W2, Adam in registers
+                f32x4 zf[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) zf[n] = *(const f32x4*)(dzl + (16 * n + li) * 16 + 4 * lj);      // dZ[b = 16n+li][o = 4lj+r]
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int tile = 2 * wave + h2;
+                    __builtin_amdgcn_sched_barrier(0);           // one hidden tile at a time: keeps the operand loads of the second out of the first's registers
+                    f32x4 g = zero4;
+#pragma unroll 8
+                    for (int kb = 0; kb < 16; ++kb)
+                        g = MFMA16(dzl[64 * kb + lane], ddl[(4 * kb + lj) * ldd + 16 * tile + li], g);          // dZ^T Dd
+                    f32x4 wq = *(const f32x4*)(w2s + tile * 256 + w2o);                                         // OLD W2 (h = li, o = 4lj..)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        f32x4 d = zero4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) d = MFMA16(wq[r], zf[n][r], d);                              // dD^T[h][b] = W2 dZ^T
+                        res_st(rD, (uint32_t)(((ot * 16 + tile) * 1024 + (16 * n + li) * 16 + 4 * lj) * 4), d);   // [b = 16n+li][h = 4lj..]
+                    }
+                    f32x4 mq = *(const f32x4*)(w2s + 4096 + tile * 256 + w2o), vq = *(const f32x4*)(w2s + 8192 + tile * 256 + w2o);
+                    adam4(wq, mq, vq, g, ap);
+                    *(f32x4*)(w2s + tile * 256 + w2o) = wq; *(f32x4*)(w2s + 4096 + tile * 256 + w2o) = mq; *(f32x4*)(w2s + 8192 + tile * 256 + w2o) = vq;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                     // also: everybody is done reading ddl/dzl/zred (phase B re-uses them)
+            if (tid < 16) smallf[32 + tid] = b2w0;
+            if (tid == 0) __hip_atomic_fetch_add(flagD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+
+        // =============================== phase B (role 1) ===============================
+        {
+            const int ub = (tid & 255) >> 2, uq = tid & 3, half = tid >> 8;
+            unsigned keep = 0xfu;
+            if (p.rate > 0.f) {
+                const dimn_u32x4 rnd = dimn_dropout_block(p.seed, (uint32_t)s.kg, p.epoch, (uint32_t)t, (uint32_t)(ub * dm.H + 16 * ht + 4 * uq) >> 2);
+                keep = 0u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) keep |= (dimn_u01(rnd.v[r]) >= p.rate ? 1u : 0u) << r;
+            }
+            if (tid == 0) flagl[1] = res_wait(flagD, (unsigned)(OT * (t + 1)), abort_w) ? 1 : 0;
+            __syncthreads();
+            if (!flagl[1]) return;
+            // dD tile = sum over the OT producers (two halves of the producers on the two thread halves)
+            f32x4 d = zero4;
+            {
+                const int o0 = half * (OT >> 1), o1 = half ? OT : (OT >> 1);
+                int o = o0;
+                for (; o + 4 <= o1; o += 4) {
+                    f32x4 tq[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tq[i] = res_ld(rD, (uint32_t)((((o + i) * 16 + ht) * 1024 + 4 * (tid & 255)) * 4));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d += tq[i];
+                }
+                for (; o < o1; ++o) d += res_ld(rD, (uint32_t)(((o * 16 + ht) * 1024 + 4 * (tid & 255)) * 4));
+            }
+            f32x4 a = zero4;
+            if (half == 0) {                                     // the relu gate: A of own tile from the S1 siblings' partials
+                a = *(const f32x4*)(b1l + 4 * uq);
+                for (int ss = 0; ss < S1; ++ss) a += res_ld(rP, (uint32_t)((ss * 16 + ht) * 4096 + 16 * tid));
+            } else {
+                *(f32x4*)(yl + 4 * (tid & 255)) = d;
+            }
+            __syncthreads();
+            if (half == 0) {
+                d += *(const f32x4*)(yl + 4 * tid);
+                f32x4 da;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) da[r] = (((keep >> r) & 1u) && ub < b_act && a[r] > 0.f) ? d[r] * p.scale : 0.f;
+                *(f32x4*)(dzl + 4 * tid) = da;                   // dA tile [64][16]
+            }
+            __syncthreads();
+            if (tid < 16) {                                      // gb1 = column sums of dA -> Adam(b1); identical on the S1 siblings
+                float gb = 0.f;
+                for (int b = 0; b < DIMN_TB; ++b) gb += dzl[b * 16 + tid];
+                adam1(b1w0, b1m0, b1v0, gb, ap);
+                b1l[tid] = b1w0;
+            }
+            float bfr[16];
+#pragma unroll
+            for (int kb = 0; kb < 16; ++kb) bfr[kb] = dzl[64 * kb + lane];                                        // dA[b = 4kb+lj][h = li]
+            __syncthreads();                                     // b1l updated, dzl read
+            role1(tid, rows_t, b_act, rows_t + B, b_next, true, b_next > 0, bfr, ap, par ^ 1);
+            if (b_next == 0) __syncthreads();
+        }
+    }
+
+    // ---- epilogue: the state goes back to its tile-native place in HBM ----
+#pragma unroll
+    for (int j = 0; j < T1; ++j)
+        if (tv[j]) {
+            const int64_t idx = wbase + tc[j] * cstride;
+            *(f32x4*)(p.W1 + idx) = w1[j]; *(f32x4*)(p.M1 + idx) = m1[j]; *(f32x4*)(p.V1 + idx) = v1[j];
+        }
+    if (sp == 0 && tid < 16) { p.b1w[b1i] = b1w0; p.b1m[b1i] = b1m0; p.b1v[b1i] = b1v0; }
+    if (is_o) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int tile = 2 * wave + h2;
+            const int64_t idx = t2base + ((int64_t)tile * OT + ot) * 256;
+            *(f32x4*)(p.W2 + idx) = *(const f32x4*)(w2s + tile * 256 + w2o);
+            *(f32x4*)(p.M2 + idx) = *(const f32x4*)(w2s + 4096 + tile * 256 + w2o);
+            *(f32x4*)(p.V2 + idx) = *(const f32x4*)(w2s + 8192 + tile * 256 + w2o);
+        }
+        if (tid < 16) { p.b2w[b2i] = b2w0; p.b2m[b2i] = b2m0; p.b2v[b2i] = b2v0; }
+        if (tid == 0) p.loss[(int64_t)k * OT + ot] = loss_total;
+    }
+}

@@ -193,7 +193,7 @@ class HipEngine(Engine):
         self._check(self._f["set_profiling"](self._h, int(bool(on))))
 
     def get_timers(self, reset=True):
-        out = np.zeros(6, np.float64)
+        out = np.zeros(8, np.float64)
         self._check(self._f["get_timers"](self._h, p_f64(out), int(bool(reset))))
         return out
 

@@ -161,10 +161,12 @@ int dimn_epoch_permutation(uint64_t seed, int32_t epoch, int64_t n, int32_t* per
 /* Wait for all queued GPU work of this handle. */
 int dimn_synchronize(dimn_handle h);
 /* Times (ms, HIP events on the stream each launch went to) accumulated since the last call
- * with reset != 0, over every sub-net lane: out6 = [0] sum of per-lane step times, [1] number of
+ * with reset != 0, over every sub-net lane: out8 = [0] sum of per-lane step times, [1] number of
  * (lane, step) pairs, [2] sum of W1-update kernel times, [3] W1-update launches, [4] sum of the
- * ALGORITHMIC bytes of those launches, [5] number of lanes.  bench.py's live roofline figure. */
-int dimn_get_timers(dimn_handle h, double* out6, int32_t reset);
+ * ALGORITHMIC bytes of those launches, [5] number of lanes, [6] sum of the durations of the
+ * register-resident epoch launches (few sub-nets per GPU), [7] optimiser steps they ran.
+ * bench.py's live roofline figure. */
+int dimn_get_timers(dimn_handle h, double* out8, int32_t reset);
 int dimn_set_profiling(dimn_handle h, int32_t on);
 
 /* ---- multi-GPU: sub-nets sharded over ranks, RCCL over xGMI (no reference analogue:

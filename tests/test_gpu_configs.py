@@ -57,11 +57,13 @@ def test_cfg2_shapes_match_oracle(mid, monkeypatch):
     a.close(); b.close()
 
 
-def test_long_horizon_drift_vs_fp64():
+@pytest.mark.parametrize("resident", ["0", "1"])     # streaming kernels / register-resident epoch kernel
+def test_long_horizon_drift_vs_fp64(resident, monkeypatch):
     """>= 500 optimiser steps (K = 2, D = 300, H = 256, O = 512): the HIP path and the fp32 oracle are each compared
     with the fp64 oracle on the same Philox streams; the HIP path's error must not exceed the plain-loop fp32
     oracle's by more than 2x (plus an absolute floor of a few fp32 ulps of the quantities compared)."""
     from helpers import make_problem, load_problem
+    monkeypatch.setenv("DIMN_RESIDENT", resident)
     prob = make_problem(n=1100, g=900, Ds=[300, 300], H=256, O=512, seed=23, val_frac=0.05)
     kw = dict(batch_size=64, dropout_rate=0.2, learning_rate=1e-4, seed=77)
     hip = load_problem(_hip(), prob, **kw)
@@ -90,3 +92,54 @@ def test_long_horizon_drift_vs_fp64():
             assert np.sqrt((dh ** 2).mean()) <= 2 * np.sqrt((do ** 2).mean()) + 1e-8, (name, k)
     for e in (hip, o32, o64):
         e.close()
+
+
+def test_resident_epoch_kernel_matches_streaming_at_8gpu_share():
+    """BASELINE configs[3], one rank's share (5 of the 40 sub-nets of the 50k x 20k job): the register-resident epoch
+    kernel against the streaming kernels on the same Philox streams -- 41 optimiser steps incl. a partial batch, then
+    validation and predict.  Also: two resident runs are bit-identical (a stale hand-off between workgroups would
+    show up as run-to-run differences)."""
+    import os
+    import bench
+    cfg = bench.CONFIGS["cfg3"]
+    n, g = cfg["n"], cfg["g"]
+    norm = bench.synth_counts(n, g, seed=0)
+    targets, preds = bench.synth_indices(g, cfg["O"], seed=0)
+    rng = np.random.default_rng(1)
+    train = np.sort(rng.choice(n, 64 * 40 + 17, replace=False)).astype(np.int32)
+    val = np.setdiff1d(np.arange(n, dtype=np.int32), train)[:1000].astype(np.int32)
+    rows = np.arange(0, n, 97, dtype=np.int32)
+
+    def run(resident, k0=10, k1=15):
+        old = os.environ.get("DIMN_RESIDENT")
+        os.environ["DIMN_RESIDENT"] = resident
+        try:
+            e = _hip()([len(preds[k]) for k in range(k0, k1)], cfg["H"], cfg["O"], batch_size=64, dropout_rate=0.2,
+                       learning_rate=1e-4, seed=1234, subnet_offset=k0)
+        finally:
+            if old is None:
+                del os.environ["DIMN_RESIDENT"]
+            else:
+                os.environ["DIMN_RESIDENT"] = old
+        e.set_matrix(norm)
+        for i, k in enumerate(range(k0, k1)):
+            e.set_indices(i, preds[k], targets[k])
+        e.gather(True)
+        e.set_split(train, val)
+        e.init_weights()
+        out = [e.train_epoch(0), e.train_epoch(1), e.val_loss(), e.predict(rows), e.get_weights(2), e.get_adam_state(2, 1)]
+        assert e.step_count() == 82
+        e.close()
+        return out
+
+    a, b, c = run("1"), run("1"), run("0")
+    for x, y in zip(a[:4], b[:4]):
+        assert np.array_equal(x, y)
+    for x, y in zip(a[4] + a[5], b[4] + b[5]):
+        assert np.array_equal(x, y)
+    np.testing.assert_allclose(a[0], c[0], rtol=1e-5)
+    np.testing.assert_allclose(a[1], c[1], rtol=1e-5)
+    np.testing.assert_allclose(a[2], c[2], rtol=1e-5)
+    np.testing.assert_allclose(a[3], c[3], rtol=1e-4, atol=1e-6)
+    for x, y, name in zip(a[4], c[4], ("W1", "b1", "W2", "b2")):
+        np.testing.assert_allclose(x, y, rtol=1e-3, atol=1e-6, err_msg=name)

@@ -70,7 +70,7 @@ def test_two_epochs_match_oracle(H, O, B, Ds, p):
     np.testing.assert_allclose(pa, pb, rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("mid", ["1", "0", "1:6", "1:4", "1:10"])     # fused (auto slices), two-kernel, fused with 6 / 4 / 10 slices
+@pytest.mark.parametrize("mid", ["1", "0", "1:6", "1:4", "1:10", "R", "R:1", "R:2"])     # fused (auto slices), two-kernel, fused with 6 / 4 / 10 slices; R: register-resident epoch kernel (auto / 1 / 2 D-splits)
 @pytest.mark.parametrize("O,B,Ds,p", [
     (512, 64, [300, 150, 77], 0.2),     # the default architecture: H = 256, O = 512
     (500, 37, [97, 260], 0.3),          # ragged output width and partial batches
@@ -79,9 +79,15 @@ def test_two_epochs_match_oracle(H, O, B, Ds, p):
 def test_h256_both_second_layer_paths_match_oracle(O, B, Ds, p, mid, monkeypatch):
     """H = 256 takes the ring B1F1 kernel and, by default only when the GPU is well filled, the fused
     second-layer kernel (k_mid_fused + k_reduce_dd); DIMN_MID forces either path (read at dimn_create)."""
-    monkeypatch.setenv("DIMN_MID", mid.split(":")[0])
-    if ":" in mid:                       # tiles per workgroup: 5-6 (units shared over SIMDs), 8, 3-4
-        monkeypatch.setenv("DIMN_MID_SLICES", mid.split(":")[1])
+    if mid[0] == "R":                    # whole epochs in one persistent launch, state in registers (dimn_resident.h)
+        monkeypatch.setenv("DIMN_RESIDENT", "1")
+        if ":" in mid:
+            monkeypatch.setenv("DIMN_RES_S1", mid.split(":")[1])
+    else:
+        monkeypatch.setenv("DIMN_RESIDENT", "0")
+        monkeypatch.setenv("DIMN_MID", mid.split(":")[0])
+        if ":" in mid:                   # tiles per workgroup: 5-6 (units shared over SIMDs), 8, 3-4
+            monkeypatch.setenv("DIMN_MID_SLICES", mid.split(":")[1])
     prob = make_problem(n=330, g=700, Ds=Ds, H=256, O=O, seed=17)
     kw = dict(batch_size=B, dropout_rate=p, learning_rate=1e-3, seed=99)
     a = load_problem(_hip(), prob, **kw)
