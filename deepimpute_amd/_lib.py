@@ -5,7 +5,8 @@ import os
 from . import _cabi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdimn.so")
+# DIMN_LIB_PATH: diagnostic builds of the same source (tools/ab_def.sh, tools/res_timeline.py); the product path is fixed
+LIB_PATH = os.environ.get("DIMN_LIB_PATH") or os.path.join(_HERE, "csrc", "libdimn.so")
 _fns = None
 _lib = None
 

@@ -380,7 +380,7 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     if (h->res_G) {
         TRY(dev_alloc(&h->d_res_P, (size_t)2 * h->K * h->res_G * 1024));
         TRY(dev_alloc(&h->d_res_D, (size_t)h->K * dm.OT * 16 * 1024));
-        TRY(dev_alloc(&h->d_res_b1, (size_t)2 * h->K * 256));
+        TRY(dev_alloc(&h->d_res_b1, (size_t)3 * h->K * 512));     // dropout keep words [3][K][512]
         TRY(dev_alloc(&h->d_res_flags, (size_t)2 * h->K + 1));
         TRY(dev_alloc(&h->d_res_loss, (size_t)h->K * dm.OT));
     }
@@ -882,7 +882,7 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
     p.b1w = h->d_b1; p.b1m = h->d_b1 + kh; p.b1v = h->d_b1 + 2 * kh;
     p.b2w = h->d_b2; p.b2m = h->d_b2 + ko; p.b2v = h->d_b2 + 2 * ko;
     p.rows = h->d_epoch_rows; p.n_tr = (int32_t)h->n_tr; p.B = h->B; p.steps = steps;
-    p.alpha = h->d_res_alpha; p.Ppart = h->d_res_P; p.Dpart = h->d_res_D; p.b1pub = h->d_res_b1;
+    p.alpha = h->d_res_alpha; p.Ppart = h->d_res_P; p.Dpart = h->d_res_D; p.maskw = (unsigned*)h->d_res_b1;
     p.flags = h->d_res_flags; p.loss = h->d_res_loss; p.dm = dm;
     p.omb1 = 1.0f - h->cfg.beta1; p.omb2 = 1.0f - h->cfg.beta2; p.eps = h->cfg.eps;
     p.rate = h->cfg.dropout_rate; p.scale = 1.0f / (1.0f - h->cfg.dropout_rate);
@@ -892,12 +892,16 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) { e0 = next_event(h); e1 = next_event(h); next_event(h); }
     if (e0 && e1) (void)hipEventRecord(e0, h->stream);
-#define RES_LAUNCH(T)                                                                                                     \
-    do {                                                                                                                  \
-        (void)hipFuncSetAttribute((const void*)k_epoch_resident<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(k_epoch_resident<T>, grid, dim3(DIMN_RES_THREADS), lds, h->stream, p);                         \
+#define RES_LAUNCH(T, S)                                                                                                       \
+    do {                                                                                                                     \
+        (void)hipFuncSetAttribute((const void*)k_epoch_resident<T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_epoch_resident<T, S>), grid, dim3(DIMN_RES_THREADS), lds, h->stream, p);                       \
     } while (0)
-    if (h->res_T1 == 2) RES_LAUNCH(2); else if (h->res_T1 == 4) RES_LAUNCH(4); else RES_LAUNCH(7);
+    // <7, 3>: one rank of the 8-GPU job (5 sub-nets of D ~ 2400 on 256 CUs); the others take the D-split count at run time
+    if (h->res_T1 == 7 && h->res_S1 == 3) RES_LAUNCH(7, 3);
+    else if (h->res_T1 == 2) RES_LAUNCH(2, 0);
+    else if (h->res_T1 == 4) RES_LAUNCH(4, 0);
+    else RES_LAUNCH(7, 0);
 #undef RES_LAUNCH
     HIPCHK(hipGetLastError());
     if (e0 && e1) (void)hipEventRecord(e1, h->stream);
@@ -1171,6 +1175,14 @@ extern "C" int dimn_comm_destroy(dimn_handle h) {
     if (h->comm) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
     return DIMN_OK;
 }
+
+#ifdef DIMN_RES_TL
+// diagnostic build only (tools/res_timeline.py): per-workgroup phase clocks of the last resident epoch launch
+extern "C" int dimn_debug_res_timeline(unsigned long long* out, int n_words) {
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_res_tl), (size_t)n_words * sizeof(unsigned long long)));
+    return DIMN_OK;
+}
+#endif
 
 // ---- get_distance_matrix on the GPU (reference multinet.py:20-34) -------------------
 extern "C" int dimn_abs_corrcoef(int32_t device_id, const double* X, int64_t n, int64_t g, double* out) {

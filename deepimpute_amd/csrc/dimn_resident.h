@@ -17,7 +17,8 @@
 //                        per wave.  Per step: Dd = dropout(relu(sum_s P + b1)), Z tile, softplus, wMSE, dZ,
 //                        Adam(b2), W2 gradient + Adam in registers, dD partial [64][256] over its 16 outputs.
 // Exchange per step and sub-net (the only inter-workgroup traffic):
-//   P partials   G x [64][16]  (role 1 -> role 2, and to the S1 siblings of a hidden tile for the relu gate)
+//   P partials   G x [64][16]  (role 1 -> role 2, and to the S1 siblings of a hidden tile for the relu gate);
+//                the split-0 workgroup of a hidden tile adds b1 to its partial, so A = sum_s P_s everywhere
 //   dD partials  OT x 16 x [64][16]  (role 2 -> role 1: workgroup (ht, s) sums tile ht over the OT producers)
 // Both through 16-byte sc0 sc1 (write-through) stores, a vmcnt(0) drain, and ONE relaxed agent-scope counter
 // per sub-net and direction; consumers poll that counter with one lane and read with sc0 sc1 loads (L1 is
@@ -39,6 +40,17 @@
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef DIMN_RES_TL   // tools/res_timeline.py: per-workgroup phase times (shader clock, thread 0), summed over the epoch
+__device__ unsigned long long g_res_tl[1024 * 12];
+#define RES_TL_DECL unsigned long long tl_acc[12] = {0}; unsigned long long tl_t = __builtin_amdgcn_s_memtime();
+#define RES_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl_acc[i] += t_ - tl_t; tl_t = t_; }
+#define RES_TL_FLUSH if (threadIdx.x == 0) for (int i_ = 0; i_ < 12; ++i_) g_res_tl[blockIdx.x * 12 + i_] = tl_acc[i_];
+#else
+#define RES_TL_DECL
+#define RES_STAMP(i)
+#define RES_TL_FLUSH
+#endif
+
 struct ResParams {
     const SubnetDev* sn;
     const float* X;                 // gathered predictors (arena)
@@ -50,7 +62,8 @@ struct ResParams {
     const float* alpha;             // [steps] lr*sqrt(1-b2^t)/(1-b1^t) of every step of the epoch
     float* Ppart;                   // [2][K][G][64][16]   forward partials, double-buffered by step parity
     float* Dpart;                   // [K][OT][16][64][16] dD partials
-    float* b1pub;                   // [2][K][256]         b1 as the forward of that parity saw it
+    unsigned* maskw;                // [3][K][64 rows][8 words] dropout keep bits of step t in buffer t % 3 (written one step
+                                    // ahead, before the writer has passed that step's flagD: two buffers would race with slow readers)
     unsigned* flags;                // [2K+1]: flagP[k], flagD[k], abort
     double* loss;                   // [K][OT] sum over the epoch of sum(w e^2) per output tile
     Dims dm;
@@ -83,7 +96,7 @@ __device__ __forceinline__ bool res_wait(unsigned* flag, unsigned target, unsign
     return true;
 }
 
-template <int T1>   // W1 tiles per wave
+template <int T1, int S1C>   // W1 tiles per wave; D-splits (0: run-time p.S1)
 __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int ldd = DIMN_RES_LDD;
@@ -102,7 +115,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
     //  and 24 more registers of state made the compiler spill)
 
     const Dims dm = p.dm;
-    const int G = p.G, S1 = p.S1;
+    const int G = p.G, S1 = S1C > 0 ? S1C : p.S1;
     const int k = blockIdx.x / G, wi = blockIdx.x - k * G;
     const int ht = wi & 15, sp = wi >> 4;
     const bool is_o = wi < dm.OT;
@@ -121,9 +134,9 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
     const size_t pp_bytes = (size_t)G * 4096;                      // one parity of one sub-net
     const __amdgpu_buffer_rsrc_t rP0 = __builtin_amdgcn_make_buffer_rsrc(p.Ppart + ((size_t)0 * K + k) * G * 1024, 0, (int)pp_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rP1 = __builtin_amdgcn_make_buffer_rsrc(p.Ppart + ((size_t)1 * K + k) * G * 1024, 0, (int)pp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(p.maskw, 0, (int)((size_t)3 * K * 2048), 0x00020000);
+    auto moff = [&](int t) -> uint32_t { return (uint32_t)(((t % 3) * K + k) * 2048); };     // byte offset of step t's words
     const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(p.Dpart + (size_t)k * OT * 16 * 1024, 0, (int)((size_t)OT * 16 * 4096), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB0 = __builtin_amdgcn_make_buffer_rsrc(p.b1pub + ((size_t)0 * K + k) * 256, 0, 1024, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc(p.b1pub + ((size_t)1 * K + k) * 256, 0, 1024, 0x00020000);
 
     // ---- role 1 state: W1 tiles (chunk cb + wave + 8j, hidden tile ht) in registers ----
     const int cb = (int)((int64_t)s.nchunk * sp / S1), ce = (int)((int64_t)s.nchunk * (sp + 1) / S1);
@@ -158,28 +171,41 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
     const int64_t b2i = (int64_t)k * Op + 16 * ot + (tid & 15);
     if (is_o && tid < 16) { b2w0 = p.b2w[b2i]; b2m0 = p.b2m[b2i]; b2v0 = p.b2v[b2i]; smallf[32 + tid] = b2w0; }
     double loss_total = 0.0;
+    RES_TL_DECL
 
     const int B = p.B;
 
     // Forward partial of batch `rows_n` with the CURRENT W1 registers (+ optional gradient/Adam of batch rows_t):
     // the body of role 1.  do_grad: bfr = dA[b = 4kb+lj][h = li] is valid.
-    auto role1 = [&](const int tid, const int32_t* rows_t, int b_act, const int32_t* rows_n, int b_next, bool do_grad, bool do_fwd,
-                     const float (&bfr)[16], const AdamP ap, int par_out) {
-        const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lj = lane >> 4;
-        const float* xk = p.X + s.xoff + 4 * (lane & 3);         // staging: pass i moves row 16i + lane/4, quarter lane%4
-        float* xt = xst + wave * 2048;
-        float* xn = xt + 1024;
-        uint32_t xot[4], xon[4];
+    // Per-lane addressing of the X tiles of a batch: pass i of a lane moves row 16i + lane/4, 16-byte quarter lane%4.
+    // Row indices of the batch that starts at position pos0 of the epoch's row order (b_cnt rows; lanes past the batch --
+    // and a batch past the epoch -- read a valid position: every load unconditional, no branch for hipcc to drain at).
+    auto xrows_raw = [&](const int tid, int pos0, int b_cnt, int32_t (&rr)[4]) {
+        const int lane = tid & 63;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int b = 16 * i + (lane >> 2);
-            xot[i] = do_grad ? (uint32_t)rows_t[b < b_act ? b : 0] * (uint32_t)s.Dp : 0u;
-            xon[i] = do_fwd ? (uint32_t)rows_n[b < b_next ? b : 0] * (uint32_t)s.Dp : xot[i];
+            int pos = pos0 + (b < b_cnt ? b : 0);
+            pos = pos < p.n_tr ? pos : p.n_tr - 1;
+            rr[i] = p.rows[pos];
         }
-        f32x4 pT[4] = {zero4, zero4, zero4, zero4};
-        f32x4 xa[4], xb[4];
+    };
+    auto xrows = [&](const int tid, int pos0, int b_cnt, uint32_t (&xo)[4]) {
+        int32_t rr[4];
+        xrows_raw(tid, pos0, b_cnt, rr);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { xa[i] = *(const f32x4*)(xk + xot[i] + 16 * tc[0]); xb[i] = *(const f32x4*)(xk + xon[i] + 16 * tc[0]); }
+        for (int i = 0; i < 4; ++i) xo[i] = (uint32_t)rr[i] * (uint32_t)s.Dp;
+    };
+    // The body of role 1: W1 gradient of batch t + Adam in registers (do_grad; bfr = dA[b = 4kb+lj][h = li]), then the
+    // forward partial of batch t+1 with the fresh W1 (do_fwd).  xa/xb: the X_t / X_{t+1} tiles of the wave's first
+    // chunk, requested by the caller (before its wait); xot/xon from xrows().
+    auto role1 = [&](const int tid, const uint32_t (&xot)[4], const uint32_t (&xon)[4], f32x4 (&xa)[4], f32x4 (&xb)[4], bool do_grad, bool do_fwd,
+                     const float (&bfr)[16], const AdamP ap, int par_out) {
+        const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lj = lane >> 4;
+        const float* xk = p.X + s.xoff + 4 * (lane & 3);
+        float* xt = xst + wave * 2048;
+        float* xn = xt + 1024;
+        f32x4 pT[4] = {zero4, zero4, zero4, zero4};
 #pragma unroll
         for (int j = 0; j < T1; ++j) {
 #pragma unroll
@@ -191,6 +217,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { xa[i] = *(const f32x4*)(xk + xot[i] + 16 * tc[j + 1]); xb[i] = *(const f32x4*)(xk + xon[i] + 16 * tc[j + 1]); }
             }
+            __builtin_amdgcn_sched_barrier(0);                   // the requests of the next tile leave before this tile's MFMAs
             if (do_grad) {
                 f32x4 g = zero4;
 #pragma unroll
@@ -206,8 +233,8 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 }
             }
         }
+        RES_STAMP(8)
         if (do_fwd) {
-            __syncthreads();                                     // every wave is done with its staging buffers (pred aliases nothing of them, but dzl readers are done too)
 #pragma unroll
             for (int n = 0; n < 4; ++n) *(f32x4*)(pred + wave * 1024 + (16 * n + li) * 16 + 4 * lj) = pT[n];   // P[b = 16n+li][h = 4lj..]
             __syncthreads();
@@ -215,24 +242,66 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 f32x4 a = *(const f32x4*)(pred + 4 * tid);
 #pragma unroll
                 for (int wv = 1; wv < 8; ++wv) a += *(const f32x4*)(pred + wv * 1024 + 4 * tid);
+                if (sp == 0) a += *(const f32x4*)(b1l + 4 * (tid & 3));     // split 0 carries the bias: A = sum_s P_s
                 res_st(par_out ? rP1 : rP0, (uint32_t)(wi * 4096 + 16 * tid), a);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every storing wave drains before the arrival
             }
-            if (sp == 0 && tid < 4) {                            // b1 as this forward's consumers must see it
-                const f32x4 bb = *(const f32x4*)(b1l + 4 * tid);
-                res_st(par_out ? rB1 : rB0, (uint32_t)(64 * ht + 16 * tid), bb);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every storing wave drains before the arrival
             __syncthreads();
             if (tid == 0) __hip_atomic_fetch_add(flagP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        RES_STAMP(9)
     };
 
+    // Dropout keep bits of the [64][256] activation of a step: 512 words (row b, word h/32; 4 bits per Philox block).  They
+    // depend on no data, so the workgroups that have no role 2 (idle while the second layer runs) -- or all of them when
+    // there are none -- compute them one step ahead, each its share of the words, and publish them with their partials.
+    const int nprod = G > OT ? G - OT : G, pidx = wi - (G - nprod);
+    const int mw0 = pidx >= 0 ? 512 * pidx / nprod : 0, mw1 = pidx >= 0 ? 512 * (pidx + 1) / nprod : 0;
+    unsigned* mscr = (unsigned*)(smallf + 48);                   // [<= 16] staging words of one pass (LDS)
+    auto publish_mask = [&](const int tid, int t) {
+        if (!(p.rate > 0.f)) return;                             // rate 0: consumers do not read the mask
+        for (int w0 = mw0; w0 < mw1; w0 += 16) {                 // 16 words = 128 blocks per pass, one block per thread
+            const int nw = (mw1 - w0) < 16 ? (mw1 - w0) : 16;
+            if (tid < 16) mscr[tid] = 0u;
+            __syncthreads();
+            if (tid < 8 * nw) {
+                const int ww = w0 + (tid >> 3), b = ww >> 3, hq = 8 * (ww & 7) + (tid & 7);
+                const dimn_u32x4 rnd = dimn_dropout_block(p.seed, (uint32_t)s.kg, p.epoch, (uint32_t)t, (uint32_t)((b * dm.H) >> 2) + (uint32_t)hq);
+                unsigned nib = 0u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nib |= (dimn_u01(rnd.v[r]) >= p.rate ? 1u : 0u) << r;
+                atomicOr(&mscr[tid >> 3], nib << (4 * (tid & 7)));
+            }
+            __syncthreads();
+            if (tid < nw) __builtin_amdgcn_raw_buffer_store_b32(mscr[tid], rM, moff(t) + (uint32_t)(4 * (w0 + tid)), 0, DIMN_RES_AUX);
+            __syncthreads();
+        }
+    };
+    auto batch_size_of = [&](int t) -> int { const int rem = p.n_tr - t * B; return rem <= 0 ? 0 : (rem < B ? rem : B); };
+    auto target_row = [&](const int tid, int t) -> int32_t {     // matrix row of this thread's piece of the targets tile of step t
+        const int ub = (tid & 255) >> 2, b_cnt = batch_size_of(t);
+        int pos = t * B + (ub < b_cnt ? ub : 0);
+        pos = pos < p.n_tr ? pos : p.n_tr - 1;
+        return p.rows[pos];
+    };
+    auto targets = [&](const int tid, int32_t row) -> f32x4 {
+        return *(const f32x4*)(p.Y + ((int64_t)k * p.n_cells + row) * Op + 16 * ot + 4 * (tid & 3));
+    };
+    f32x4 y_a = zero4;
+    uint32_t xo0[4];                                             // X row offsets of the CURRENT batch (kept from the step before)
     {   // prologue: forward partials of step 0
         const float nob[16] = {0.f};
         const int b0 = p.n_tr < B ? p.n_tr : B;
         AdamP ap0; ap0.alpha = 0.f; ap0.omb1 = p.omb1; ap0.omb2 = p.omb2; ap0.eps = p.eps;
+        xrows(tid, 0, b0, xo0);
+        f32x4 xa[4], xb[4];
+        const float* xk = p.X + s.xoff + 4 * (lane & 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xa[i] = *(const f32x4*)(xk + xo0[i] + 16 * tc[0]); xb[i] = xa[i]; }
         __syncthreads();                                         // b1l written
-        role1(tid, p.rows, 0, p.rows, b0, false, true, nob, ap0, 0);
+        publish_mask(tid, 0);
+        role1(tid, xo0, xo0, xa, xb, false, true, nob, ap0, 0);
+        y_a = targets(tid, target_row(tid, 0));
     }
 
     for (int t = 0; t < p.steps; ++t) {
@@ -251,49 +320,66 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
         const float inv_n = (float)(1.0 / ((double)b_act * dm.O));
         AdamP ap; ap.alpha = p.alpha[t]; ap.omb1 = p.omb1; ap.omb2 = p.omb2; ap.eps = p.eps;
         const __amdgpu_buffer_rsrc_t rP = par ? rP1 : rP0;
-        const __amdgpu_buffer_rsrc_t rB = par ? rB1 : rB0;
+        // row indices of the NEXT batch, requested a whole phase before their use (they head two dependent loads)
+        int32_t rn[4];
+        xrows_raw(tid, (t + 1) * B, b_next, rn);
+        const int32_t yrow_n = target_row(tid, t + 1);          // unconditional: a load under a divergent branch makes hipcc drain vmcnt at the join
 
         // =============================== phase A (role 2) ===============================
+        RES_STAMP(10)
         if (is_o) {
-            // work that depends on no other workgroup, done while the partials arrive: dropout keep bits of the whole
-            // [64][256] activation (unit q of this thread: hidden tile 2q + tid/256, row (tid%256)/4, quarter tid%4)
-            // and the targets tile
-            unsigned keep = 0u;
             const int ub = (tid & 255) >> 2, uq = tid & 3;
-            if (p.rate > 0.f) {
-#pragma unroll 1
-                for (int q = 0; q < 8; ++q) {
-                    const int h = 16 * (2 * q + (tid >> 8)) + 4 * uq;
-                    const dimn_u32x4 rnd = dimn_dropout_block(p.seed, (uint32_t)s.kg, p.epoch, (uint32_t)t, (uint32_t)(ub * dm.H + h) >> 2);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) keep |= (dimn_u01(rnd.v[r]) >= p.rate ? 1u : 0u) << (4 * q + r);
-                }
-            } else {
-                keep = 0xffffffffu;
-            }
-            if (tid < 256) {
-                const int32_t row = rows_t[ub < b_act ? ub : 0];
-                *(f32x4*)(yl + 4 * tid) = *(const f32x4*)(p.Y + ((int64_t)k * p.n_cells + row) * Op + 16 * ot + 4 * uq);
-            }
+            if (tid < 256) *(f32x4*)(yl + 4 * tid) = y_a;
+            RES_STAMP(0)
             if (tid == 0) flagl[0] = res_wait(flagP, (unsigned)(G * (t + 1)), abort_w) ? 1 : 0;
             __syncthreads();
             if (!flagl[0]) return;
-            // Dd = dropout(relu(b1 + sum_s P_s)) -> LDS
-#pragma unroll 2
-            for (int q = 0; q < 8; ++q) {
+            RES_STAMP(1)
+            u32x4 km0 = (u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, km1 = km0;
+            if (p.rate > 0.f) {                                  // keep bits of row ub: 8 words
+                km0 = __builtin_amdgcn_raw_buffer_load_b128(rM, moff(t) + (uint32_t)(32 * ub), 0, DIMN_RES_AUX);
+                km1 = __builtin_amdgcn_raw_buffer_load_b128(rM, moff(t) + (uint32_t)(32 * ub + 16), 0, DIMN_RES_AUX);
+            }
+            const int ksh = 16 * (tid >> 8) + 4 * uq;            // unit q: hidden units 32q + ksh .. +3 = word q, bits ksh..
+            const unsigned rowmask = ub < b_act ? 0xffffffffu : 0u;
+            // Dd = dropout(relu(sum_s P_s)) -> LDS (split 0 carries b1); every partial is requested before the first is used
+            auto put_dd = [&](int q, f32x4 a) {
                 const int tile = 2 * q + (tid >> 8);
-                f32x4 a = res_ld(rB, (uint32_t)(64 * tile + 16 * uq));
-                for (int ss = 0; ss < S1; ++ss) a += res_ld(rP, (uint32_t)((ss * 16 + tile) * 4096 + 16 * (tid & 255)));
                 f32x4 dd;
+                const unsigned kw = (q < 4 ? km0[q & 3] : km1[q & 3]) & rowmask;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool on = ((keep >> (4 * q + r)) & 1u) && ub < b_act;
-                    dd[r] = (on && a[r] > 0.f) ? a[r] * p.scale : 0.f;
-                }
+                for (int r = 0; r < 4; ++r) dd[r] = ((kw >> (ksh + r)) & 1u) ? fmaxf(a[r], 0.f) * p.scale : 0.f;      // one select, no branch
                 *(f32x4*)(ddl + ub * ldd + 16 * tile + 4 * uq) = dd;
+            };
+            if (S1C > 0) {
+#pragma unroll
+                for (int qh = 0; qh < 8; qh += 4) {              // two bursts of 4 x S1 loads
+                    f32x4 pv[4][S1C > 0 ? S1C : 1];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int ss = 0; ss < S1C; ++ss)
+                            pv[q][ss] = res_ld(rP, (uint32_t)((ss * 16 + 2 * (qh + q) + (tid >> 8)) * 4096 + 16 * (tid & 255)));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 a = pv[q][0];
+#pragma unroll
+                        for (int ss = 1; ss < S1C; ++ss) a += pv[q][ss];
+                        put_dd(qh + q, a);
+                    }
+                }
+            } else {
+#pragma unroll 2
+                for (int q = 0; q < 8; ++q) {
+                    const int tile = 2 * q + (tid >> 8);
+                    f32x4 a = res_ld(rP, (uint32_t)(tile * 4096 + 16 * (tid & 255)));
+                    for (int ss = 1; ss < S1; ++ss) a += res_ld(rP, (uint32_t)((ss * 16 + tile) * 4096 + 16 * (tid & 255)));
+                    put_dd(q, a);
+                }
             }
             const float* ws = w2s + 2 * wave * 256;              // this wave's two W2 tiles [h][o]
             __syncthreads();
+            RES_STAMP(2)
             {   // Z partial over this wave's 32 hidden units
                 f32x4 acc[4] = {zero4, zero4, zero4, zero4};
 #pragma unroll
@@ -347,24 +433,21 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 for (int wv = 0; wv < 8; ++wv) tot += smallf[wv];
                 loss_total += (double)tot;
             }
+            RES_STAMP(3)
             if (tid < 16) {                                      // gb2 = column sums of dZ -> Adam(b2)
                 float gb = 0.f;
                 for (int b = 0; b < DIMN_TB; ++b) gb += dzl[b * 16 + tid];
                 adam1(b2w0, b2m0, b2v0, gb, ap);
             }
-            {   // W2 gradient, dD^T partial with the OLD W2, Adam in registers
+            {   // dD^T partial with the OLD W2 first (its write-through stores travel while the rest computes), then the W2
+                // gradient + Adam on the LDS-resident state
                 f32x4 zf[4];
 #pragma unroll
                 for (int n = 0; n < 4; ++n) zf[n] = *(const f32x4*)(dzl + (16 * n + li) * 16 + 4 * lj);      // dZ[b = 16n+li][o = 4lj+r]
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     const int tile = 2 * wave + h2;
-                    __builtin_amdgcn_sched_barrier(0);           // one hidden tile at a time: keeps the operand loads of the second out of the first's registers
-                    f32x4 g = zero4;
-#pragma unroll 8
-                    for (int kb = 0; kb < 16; ++kb)
-                        g = MFMA16(dzl[64 * kb + lane], ddl[(4 * kb + lj) * ldd + 16 * tile + li], g);          // dZ^T Dd
-                    f32x4 wq = *(const f32x4*)(w2s + tile * 256 + w2o);                                         // OLD W2 (h = li, o = 4lj..)
+                    const f32x4 wq = *(const f32x4*)(w2s + tile * 256 + w2o);                                   // OLD W2 (h = li, o = 4lj..)
 #pragma unroll
                     for (int n = 0; n < 4; ++n) {
                         f32x4 d = zero4;
@@ -372,57 +455,101 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                         for (int r = 0; r < 4; ++r) d = MFMA16(wq[r], zf[n][r], d);                              // dD^T[h][b] = W2 dZ^T
                         res_st(rD, (uint32_t)(((ot * 16 + tile) * 1024 + (16 * n + li) * 16 + 4 * lj) * 4), d);   // [b = 16n+li][h = 4lj..]
                     }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int tile = 2 * wave + h2;
+                    f32x4 g = zero4;
+#pragma unroll
+                    for (int kb = 0; kb < 16; ++kb)
+                        g = MFMA16(dzl[64 * kb + lane], ddl[(4 * kb + lj) * ldd + 16 * tile + li], g);          // dZ^T Dd
+                    f32x4 wq = *(const f32x4*)(w2s + tile * 256 + w2o);
                     f32x4 mq = *(const f32x4*)(w2s + 4096 + tile * 256 + w2o), vq = *(const f32x4*)(w2s + 8192 + tile * 256 + w2o);
                     adam4(wq, mq, vq, g, ap);
                     *(f32x4*)(w2s + tile * 256 + w2o) = wq; *(f32x4*)(w2s + 4096 + tile * 256 + w2o) = mq; *(f32x4*)(w2s + 8192 + tile * 256 + w2o) = vq;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                     // also: everybody is done reading ddl/dzl/zred (phase B re-uses them)
             if (tid < 16) smallf[32 + tid] = b2w0;
             if (tid == 0) __hip_atomic_fetch_add(flagD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            RES_STAMP(4)
         }
 
         // =============================== phase B (role 1) ===============================
         {
             const int ub = (tid & 255) >> 2, uq = tid & 3, half = tid >> 8;
-            unsigned keep = 0xfu;
-            if (p.rate > 0.f) {
-                const dimn_u32x4 rnd = dimn_dropout_block(p.seed, (uint32_t)s.kg, p.epoch, (uint32_t)t, (uint32_t)(ub * dm.H + 16 * ht + 4 * uq) >> 2);
-                keep = 0u;
+            // Idle time before the dD partials arrive: keep bits of the own tile, the first X tiles of this step's tile
+            // loop, and (role 2) the mask and targets of the NEXT step
+            uint32_t xon[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) keep |= (dimn_u01(rnd.v[r]) >= p.rate ? 1u : 0u) << r;
+            for (int i = 0; i < 4; ++i) xon[i] = b_next > 0 ? (uint32_t)rn[i] * (uint32_t)s.Dp : xo0[i];
+            f32x4 xa[4], xb[4];
+            {   // first X tiles of the tile loop, requested before the wait
+                const float* xk = p.X + s.xoff + 4 * (lane & 3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { xa[i] = *(const f32x4*)(xk + xo0[i] + 16 * tc[0]); xb[i] = *(const f32x4*)(xk + xon[i] + 16 * tc[0]); }
             }
+            // (tried: touching the next batch's X rows here / before the flagP wait, by asm loads or LDS-DMA, to move
+            //  their HBM latency out of the tile loop: +3..5 us per step -- 16 hidden-tile workgroups fetch the same rows
+            //  and the extra requests queue in front of the hand-off traffic)
+            if (t + 1 < p.steps) {
+                publish_mask(tid, t + 1);                        // drained with the partials below, before the flagP arrival
+                y_a = targets(tid, yrow_n);                      // every thread (unconditional load); role 2 uses the first 256
+            }
+            RES_STAMP(5)
             if (tid == 0) flagl[1] = res_wait(flagD, (unsigned)(OT * (t + 1)), abort_w) ? 1 : 0;
             __syncthreads();
             if (!flagl[1]) return;
-            // dD tile = sum over the OT producers (two halves of the producers on the two thread halves)
+            RES_STAMP(6)
+            // requests first, in the order of need: the relu gate (A of the own tile from the S1 siblings' partials, its keep
+            // bits), then the dD partials of the OT producers (their two halves on the two thread halves)
+            unsigned keep = 0xfu;
+            if (p.rate > 0.f)
+                keep = __builtin_amdgcn_raw_buffer_load_b32(rM, moff(t) + (uint32_t)(32 * ub + 4 * (ht >> 1)), 0, DIMN_RES_AUX) >> (16 * (ht & 1) + 4 * uq);
+            f32x4 a;
+            if (S1C > 0) {
+                f32x4 gp[S1C > 0 ? S1C : 1];
+#pragma unroll
+                for (int ss = 0; ss < S1C; ++ss) gp[ss] = res_ld(rP, (uint32_t)((ss * 16 + ht) * 4096 + 16 * (tid & 255)));
+                a = gp[0];
+#pragma unroll
+                for (int ss = 1; ss < S1C; ++ss) a += gp[ss];
+            } else {
+                a = res_ld(rP, (uint32_t)(ht * 4096 + 16 * (tid & 255)));
+                for (int ss = 1; ss < S1; ++ss) a += res_ld(rP, (uint32_t)((ss * 16 + ht) * 4096 + 16 * (tid & 255)));
+            }
             f32x4 d = zero4;
             {
                 const int o0 = half * (OT >> 1), o1 = half ? OT : (OT >> 1);
+                const uint32_t base = (uint32_t)((ht * 1024 + 4 * (tid & 255)) * 4);
                 int o = o0;
+                for (; o + 8 <= o1; o += 8) {
+                    f32x4 tq[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) tq[i] = res_ld(rD, base + (uint32_t)((o + i) * 65536));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) d += tq[i];
+                }
                 for (; o + 4 <= o1; o += 4) {
                     f32x4 tq[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) tq[i] = res_ld(rD, (uint32_t)((((o + i) * 16 + ht) * 1024 + 4 * (tid & 255)) * 4));
+                    for (int i = 0; i < 4; ++i) tq[i] = res_ld(rD, base + (uint32_t)((o + i) * 65536));
 #pragma unroll
                     for (int i = 0; i < 4; ++i) d += tq[i];
                 }
-                for (; o < o1; ++o) d += res_ld(rD, (uint32_t)(((o * 16 + ht) * 1024 + 4 * (tid & 255)) * 4));
+                for (; o < o1; ++o) d += res_ld(rD, base + (uint32_t)(o * 65536));
             }
-            f32x4 a = zero4;
-            if (half == 0) {                                     // the relu gate: A of own tile from the S1 siblings' partials
-                a = *(const f32x4*)(b1l + 4 * uq);
-                for (int ss = 0; ss < S1; ++ss) a += res_ld(rP, (uint32_t)((ss * 16 + ht) * 4096 + 16 * tid));
-            } else {
-                *(f32x4*)(yl + 4 * (tid & 255)) = d;
-            }
+            if (half) *(f32x4*)(yl + 4 * (tid & 255)) = d;
             __syncthreads();
             if (half == 0) {
                 d += *(const f32x4*)(yl + 4 * tid);
+                if (ub >= b_act) keep = 0u;
                 f32x4 da;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) da[r] = (((keep >> r) & 1u) && ub < b_act && a[r] > 0.f) ? d[r] * p.scale : 0.f;
+                for (int r = 0; r < 4; ++r) da[r] = (((keep >> r) & 1u) & (a[r] > 0.f ? 1u : 0u)) ? d[r] * p.scale : 0.f;
                 *(f32x4*)(dzl + 4 * tid) = da;                   // dA tile [64][16]
             }
             __syncthreads();
@@ -435,12 +562,15 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             float bfr[16];
 #pragma unroll
             for (int kb = 0; kb < 16; ++kb) bfr[kb] = dzl[64 * kb + lane];                                        // dA[b = 4kb+lj][h = li]
-            __syncthreads();                                     // b1l updated, dzl read
-            role1(tid, rows_t, b_act, rows_t + B, b_next, true, b_next > 0, bfr, ap, par ^ 1);
+            RES_STAMP(7)
+            role1(tid, xo0, xon, xa, xb, true, b_next > 0, bfr, ap, par ^ 1);     // its first barrier orders b1l / dzl
             if (b_next == 0) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xo0[i] = xon[i];         // the next batch becomes the current one
         }
     }
 
+    RES_TL_FLUSH
     // ---- epilogue: the state goes back to its tile-native place in HBM ----
 #pragma unroll
     for (int j = 0; j < T1; ++j)

@@ -93,9 +93,17 @@ def test_h256_both_second_layer_paths_match_oracle(O, B, Ds, p, mid, monkeypatch
     a = load_problem(_hip(), prob, **kw)
     b = load_problem(_oracle(), prob, **kw)
     a.init_weights(); b.init_weights()
+    a.set_profiling(True)
     for epoch in range(2):
         np.testing.assert_allclose(a.train_epoch(epoch), b.train_epoch(epoch), rtol=1e-4)
         np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
+    # which path ran: [7] = optimiser steps executed by the register-resident epoch kernel
+    resident_steps = a.get_timers()[7]
+    if mid == "R" or (mid == "R:1" and O <= 256) or mid == "R:2":
+        assert resident_steps == a.step_count() > 0
+    else:
+        assert resident_steps == 0
+    a.set_profiling(False)
     for k in range(a.K):
         for x, y, name in zip(a.get_weights(k), b.get_weights(k), ("W1", "b1", "W2", "b2")):
             np.testing.assert_allclose(x, y, rtol=1e-3, atol=2e-5, err_msg="%s k=%d" % (name, k))
