@@ -10,11 +10,11 @@ def load_kat():
     return np.load(os.path.join(GOLDEN, "kat_steps.npz"))
 
 
-def kat_engine(cls, kat, **kw):
+def kat_engine(cls, kat, dropout_rate=None, **kw):
     """Build an engine of class `cls` loaded with the KAT problem (weights injected)."""
     Ds = [int(d) for d in kat["Ds"]]
     eng = cls(Ds, int(kat["H"]), int(kat["O"]), batch_size=int(kat["B"]),
-              dropout_rate=float(kat["p"]), learning_rate=float(kat["lr"]),
+              dropout_rate=float(kat["p"]) if dropout_rate is None else dropout_rate, learning_rate=float(kat["lr"]),
               beta1=float(kat["beta1"]), beta2=float(kat["beta2"]), eps=float(kat["eps"]),
               seed=7, **kw)
     eng.set_matrix(kat["norm"])
