@@ -1185,17 +1185,12 @@ extern "C" int dimn_debug_res_timeline(unsigned long long* out, int n_words) {
 #endif
 
 // ---- get_distance_matrix on the GPU (reference multinet.py:20-34) -------------------
-extern "C" int dimn_abs_corrcoef(int32_t device_id, const double* X, int64_t n, int64_t g, double* out) {
-    if (!X || !out || n < 2 || g < 1) return fail(DIMN_ERR_ARG, "dimn_abs_corrcoef: bad argument");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(DIMN_ERR_HIP, "dimn_abs_corrcoef: no HIP device visible");
-    if (device_id < 0 || device_id >= ndev) return fail(DIMN_ERR_ARG, "dimn_abs_corrcoef: device_id out of range");
-    HIPCHK(hipSetDevice(device_id));
+// |corr| of the columns of host X[n][g] (fp64) into a fresh device matrix *dOutp [g][g]; the caller frees it.
+static int corr_on_device(const double* X, int64_t n, int64_t g, hipStream_t st, double** dOutp) {
     const int64_t gp = (g + CORR_BT - 1) / CORR_BT * CORR_BT, np_ = (n + CORR_KC - 1) / CORR_KC * CORR_KC;
     const int nb = (int)(gp / CORR_BT);
     double *dZ = nullptr, *dC = nullptr, *dOut = nullptr, *dMean = nullptr, *dPart = nullptr;
     int2* dPairs = nullptr;
-    hipStream_t st = nullptr;
     int rc = DIMN_OK;
     std::vector<int2> pairs;
     for (int i = 0; i < nb; ++i)
@@ -1203,7 +1198,6 @@ extern "C" int dimn_abs_corrcoef(int32_t device_id, const double* X, int64_t n, 
     const int nparts = (int)std::min<int64_t>(64, (n + 255) / 256);
     const int64_t rows_per_block = (n + nparts - 1) / nparts;
 #define CORR_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
-    CORR_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     CORR_TRY(hipMalloc((void**)&dZ, (size_t)np_ * gp * 8));
     CORR_TRY(hipMalloc((void**)&dC, (size_t)gp * gp * 8));
     CORR_TRY(hipMalloc((void**)&dOut, (size_t)g * g * 8));
@@ -1219,16 +1213,86 @@ extern "C" int dimn_abs_corrcoef(int32_t device_id, const double* X, int64_t n, 
     hipLaunchKernelGGL(k_corr_gemm, dim3((unsigned)pairs.size()), dim3(256), 0, st, dZ, np_, gp, dPairs, dC);
     hipLaunchKernelGGL(k_corr_finish, dim3((unsigned)((g + 255) / 256), (unsigned)g), dim3(256), 0, st, dC, g, gp, 1.0 / (double)(n - 1), dOut);
     CORR_TRY(hipGetLastError());
-    CORR_TRY(hipMemcpyAsync(out, dOut, (size_t)g * g * 8, hipMemcpyDeviceToHost, st));
     CORR_TRY(hipStreamSynchronize(st));
 #undef CORR_TRY
 done:
     if (dZ) (void)hipFree(dZ);
     if (dC) (void)hipFree(dC);
-    if (dOut) (void)hipFree(dOut);
     if (dMean) (void)hipFree(dMean);
     if (dPart) (void)hipFree(dPart);
     if (dPairs) (void)hipFree(dPairs);
-    if (st) (void)hipStreamDestroy(st);
+    if (rc != DIMN_OK && dOut) { (void)hipFree(dOut); dOut = nullptr; }
+    *dOutp = dOut;
+    return rc;
+}
+static int corr_device_ok(const char* who, int32_t device_id) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(DIMN_ERR_HIP, "%s: no HIP device visible", who);
+    if (device_id < 0 || device_id >= ndev) return fail(DIMN_ERR_ARG, "%s: device_id out of range", who);
+    HIPCHK(hipSetDevice(device_id));
+    return DIMN_OK;
+}
+
+extern "C" int dimn_abs_corrcoef(int32_t device_id, const double* X, int64_t n, int64_t g, double* out) {
+    if (!X || !out || n < 2 || g < 1) return fail(DIMN_ERR_ARG, "dimn_abs_corrcoef: bad argument");
+    CHK(corr_device_ok("dimn_abs_corrcoef", device_id));
+    hipStream_t st = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    double* dOut = nullptr;
+    int rc = corr_on_device(X, n, g, st, &dOut);
+    if (rc == DIMN_OK && hipMemcpy(out, dOut, (size_t)g * g * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(DIMN_ERR_HIP, "dimn_abs_corrcoef: device-to-host copy failed");
+    if (dOut) (void)hipFree(dOut);
+    (void)hipStreamDestroy(st);
+    return rc;
+}
+
+// ---- next row: setPredictors on the device (multinet.py:344-365) ---------------------------
+extern "C" int dimn_select_predictors(int32_t device_id, const double* X, int64_t n, int64_t g, const int32_t* targ_pos, int32_t K, int32_t O,
+                                      const int32_t* col_rank, int32_t ntop, int32_t* out_idx) {
+    if (!X || !targ_pos || !col_rank || !out_idx || n < 2 || g < 1 || K < 1 || O < 1 || ntop < 1)
+        return fail(DIMN_ERR_ARG, "dimn_select_predictors: bad argument");
+    if (ntop > 16) return fail(DIMN_ERR_UNSUP, "dimn_select_predictors: ntop %d > 16 (use the host selection)", ntop);
+    for (int64_t i = 0; i < (int64_t)K * O; ++i)
+        if (targ_pos[i] < 0 || targ_pos[i] >= g) return fail(DIMN_ERR_ARG, "dimn_select_predictors: target position out of range");
+    CHK(corr_device_ok("dimn_select_predictors", device_id));
+    const int NT = ntop <= 5 ? 5 : (ntop <= 8 ? 8 : 16);
+    const size_t lds = ((((size_t)(g + 31) / 32) * 4 + 15) & ~(size_t)15) + (size_t)256 * NT * 16 + 64;
+    if (lds > 160 * 1024) return fail(DIMN_ERR_UNSUP, "dimn_select_predictors: %lld candidate genes exceed the LDS bitmap", (long long)g);
+    hipStream_t st = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    double* dOut = nullptr;
+    int32_t *dT = nullptr, *dR = nullptr, *dI = nullptr;
+    int rc = corr_on_device(X, n, g, st, &dOut);
+#define SEL_TRY(expr) do { hipError_t e_ = (expr); if (rc == DIMN_OK && e_ != hipSuccess) rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+    if (rc == DIMN_OK) {
+        SEL_TRY(hipMalloc((void**)&dT, (size_t)K * O * 4));
+        SEL_TRY(hipMalloc((void**)&dR, (size_t)g * 4));
+        SEL_TRY(hipMalloc((void**)&dI, (size_t)K * O * ntop * 4));
+    }
+    if (rc == DIMN_OK) {
+        SEL_TRY(hipMemcpyAsync(dT, targ_pos, (size_t)K * O * 4, hipMemcpyHostToDevice, st));
+        SEL_TRY(hipMemcpyAsync(dR, col_rank, (size_t)g * 4, hipMemcpyHostToDevice, st));
+        const dim3 grid((unsigned)O, (unsigned)K);
+        if (NT == 5) {
+            (void)hipFuncSetAttribute((const void*)k_corr_topk<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_corr_topk<5>, grid, dim3(256), lds, st, dOut, g, dT, O, dR, dI, ntop);
+        } else if (NT == 8) {
+            (void)hipFuncSetAttribute((const void*)k_corr_topk<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_corr_topk<8>, grid, dim3(256), lds, st, dOut, g, dT, O, dR, dI, ntop);
+        } else {
+            (void)hipFuncSetAttribute((const void*)k_corr_topk<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_corr_topk<16>, grid, dim3(256), lds, st, dOut, g, dT, O, dR, dI, ntop);
+        }
+        SEL_TRY(hipGetLastError());
+        SEL_TRY(hipMemcpyAsync(out_idx, dI, (size_t)K * O * ntop * 4, hipMemcpyDeviceToHost, st));
+        SEL_TRY(hipStreamSynchronize(st));
+    }
+#undef SEL_TRY
+    if (dOut) (void)hipFree(dOut);
+    if (dT) (void)hipFree(dT);
+    if (dR) (void)hipFree(dR);
+    if (dI) (void)hipFree(dI);
+    (void)hipStreamDestroy(st);
     return rc;
 }

@@ -133,3 +133,86 @@ __global__ __launch_bounds__(256) void k_corr_finish(const double* __restrict__ 
     c = fabs(c);
     out[i * g + j] = (c == c) ? c : 0.0;            // DataFrame.fillna(0)
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// setPredictors on the device (reference deepimpute/multinet.py:344-365): for every target gene of every sub-net the
+// NTOP most correlated pool genes outside the sub-net's own target set.  One workgroup per (target, sub-net) scans
+// the target's row of the resident |corr| matrix once (coalesced), each thread keeping a sorted private top-NTOP;
+// the 256 lists are merged through LDS in NTOP rounds of a block-wide arg-max.
+// Order: |corr| descending; ties by the column's position in label-sorted order (col_rank) -- the order in which the
+// reference's np.setdiff1d lists the candidate columns (its argsort is not stable, so on exact ties the reference
+// itself is arbitrary; the host implementation in multinet.py uses the same rule).  col_rank < 0: column not a
+// candidate (a repeated label).  out[k][t][i] = pool position of the i-th pick, -1 when fewer candidates exist.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NTOP>
+__global__ __launch_bounds__(256) void k_corr_topk(const double* __restrict__ corr, int64_t g, const int32_t* __restrict__ targ_pos, int O,
+                                                   const int32_t* __restrict__ col_rank, int32_t* __restrict__ out, int ntop) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char topk_lds[];
+    const int words = (int)((g + 31) >> 5);
+    unsigned* bitmap = (unsigned*)topk_lds;                                      // excluded columns (the sub-net's targets)
+    double* lval = (double*)(topk_lds + (((size_t)words * 4 + 15) & ~(size_t)15));   // [256][NTOP]
+    int32_t* lrank = (int32_t*)(lval + 256 * NTOP);
+    int32_t* lidx = lrank + 256 * NTOP;
+    double* wval = (double*)(lidx + 256 * NTOP);                                 // per-wave winners [4]
+    int32_t* wrank = (int32_t*)(wval + 4);
+    int32_t* wthr = wrank + 4;
+    const int t = blockIdx.x, k = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int w = tid; w < words; w += 256) bitmap[w] = 0u;
+    __syncthreads();
+    for (int i = tid; i < O; i += 256) {
+        const int c = targ_pos[(int64_t)k * O + i];
+        atomicOr(&bitmap[c >> 5], 1u << (c & 31));
+    }
+    __syncthreads();
+    const int64_t row = targ_pos[(int64_t)k * O + t];
+    const double* cr = corr + row * g;
+    double val[NTOP];
+    int32_t rk[NTOP], ix[NTOP];
+#pragma unroll
+    for (int i = 0; i < NTOP; ++i) { val[i] = -1.0; rk[i] = 0x7fffffff; ix[i] = -1; }
+    for (int64_t j = tid; j < g; j += 256) {
+        const int32_t r = col_rank[j];
+        const double v = cr[j];
+        const bool ok = r >= 0 && !((bitmap[j >> 5] >> (j & 31)) & 1u);
+        if (ok && (v > val[NTOP - 1] || (v == val[NTOP - 1] && r < rk[NTOP - 1]))) {
+            // insertion into the sorted private list (fully unrolled: the list stays in registers)
+            double cv = v; int32_t cr_ = r, ci = (int32_t)j;
+#pragma unroll
+            for (int i = 0; i < NTOP; ++i) {
+                const bool before = cv > val[i] || (cv == val[i] && cr_ < rk[i]);
+                const double tv = val[i]; const int32_t tr = rk[i], ti = ix[i];
+                val[i] = before ? cv : tv; rk[i] = before ? cr_ : tr; ix[i] = before ? ci : ti;
+                cv = before ? tv : cv; cr_ = before ? tr : cr_; ci = before ? ti : ci;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NTOP; ++i) { lval[tid * NTOP + i] = val[i]; lrank[tid * NTOP + i] = rk[i]; lidx[tid * NTOP + i] = ix[i]; }
+    __syncthreads();
+    int head = 0;
+    for (int round = 0; round < ntop; ++round) {
+        double bv = head < NTOP ? lval[tid * NTOP + head] : -1.0;
+        int32_t br = head < NTOP ? lrank[tid * NTOP + head] : 0x7fffffff;
+        int32_t bt = tid;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bv, off); const int32_t orr = __shfl_xor(br, off), ot = __shfl_xor(bt, off);
+            const bool take = ov > bv || (ov == bv && (orr < br || (orr == br && ot < bt)));
+            bv = take ? ov : bv; br = take ? orr : br; bt = take ? ot : bt;
+        }
+        if (lane == 0) { wval[wave] = bv; wrank[wave] = br; wthr[wave] = bt; }
+        __syncthreads();
+        double fv = wval[0]; int32_t fr = wrank[0], ft = wthr[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const bool take = wval[w] > fv || (wval[w] == fv && (wrank[w] < fr || (wrank[w] == fr && wthr[w] < ft)));
+            fv = take ? wval[w] : fv; fr = take ? wrank[w] : fr; ft = take ? wthr[w] : ft;
+        }
+        if (tid == ft) {
+            out[((int64_t)k * O + t) * ntop + round] = (fv >= 0.0 && head < NTOP) ? lidx[tid * NTOP + head] : -1;
+            ++head;
+        }
+        __syncthreads();
+    }
+}

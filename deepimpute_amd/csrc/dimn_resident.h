@@ -313,7 +313,6 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
         const int tid = tl, lane = tid & 63, wave = tid >> 6, li = lane & 15, lj = lane >> 4;
         const int w2o = li * 16 + 4 * lj;
         const int par = t & 1;
-        const int32_t* rows_t = p.rows + (int64_t)t * B;
         const int b_act = (p.n_tr - t * B) < B ? (p.n_tr - t * B) : B;
         const int rem = p.n_tr - (t + 1) * B;
         const int b_next = rem <= 0 ? 0 : (rem < B ? rem : B);

@@ -67,12 +67,9 @@ def _abs_corrcoef(values, backend="auto", device_id=0):
         return np.abs(np.corrcoef(values.T))
 
 
-def get_distance_matrix(raw, n_pred=None, backend="auto", device_id=0, _var_mean=None):
-    """Absolute Pearson correlation between candidate predictor genes (multinet.py:20-34).
-    Candidates: genes with std/mean > 0, or the `n_pred` genes with the largest ratio.  The g x g
-    float64 correlation itself runs on the GPU when one is visible (`backend`, see _abs_corrcoef).
-    `_var_mean`: (raw.var(), raw.mean()) when the caller already holds them (std = sqrt(var), as in
-    pandas)."""
+def _candidate_pool(raw, n_pred=None, _var_mean=None):
+    """(labels, values) of the candidate predictor genes of get_distance_matrix (multinet.py:20-30): genes with
+    std/mean > 0, or the `n_pred` genes with the largest ratio; values = their raw columns [cells, pool]."""
     var, mean = _var_mean if _var_mean is not None else _hostpar.column_var_mean(raw)
     ratio = np.sqrt(var) / mean
     ratio[np.isinf(ratio)] = 0
@@ -82,11 +79,28 @@ def get_distance_matrix(raw, n_pred=None, backend="auto", device_id=0, _var_mean
         print("Using {} predictors".format(n_pred))
         keep = ratio.sort_values(ascending=False).index[:n_pred]
     if keep.equals(raw.columns):
-        candidates = raw.values
-    else:
-        candidates = _hostpar.take_columns(raw.values, raw.columns.get_indexer(keep))
+        return keep, raw.values
+    return keep, _hostpar.take_columns(raw.values, raw.columns.get_indexer(keep))
+
+
+def get_distance_matrix(raw, n_pred=None, backend="auto", device_id=0, _var_mean=None):
+    """Absolute Pearson correlation between candidate predictor genes (multinet.py:20-34).
+    Candidates: genes with std/mean > 0, or the `n_pred` genes with the largest ratio.  The g x g
+    float64 correlation itself runs on the GPU when one is visible (`backend`, see _abs_corrcoef).
+    `_var_mean`: (raw.var(), raw.mean()) when the caller already holds them (std = sqrt(var), as in
+    pandas)."""
+    keep, candidates = _candidate_pool(raw, n_pred, _var_mean)
     corr = _abs_corrcoef(candidates, backend=backend, device_id=device_id)
     return pd.DataFrame(_hostpar.zero_nans_inplace(corr), index=keep, columns=keep, copy=False)   # .fillna(0)
+
+
+def _gpu_visible():
+    """True when libdimn loads and sees a HIP device (host planning may run without one; fit/predict may not)."""
+    try:
+        from . import _lib
+        return _lib.device_count() > 0
+    except (ImportError, OSError, AttributeError):
+        return False
 
 
 def wMSE(y_true, y_pred, binary=False):
@@ -275,11 +289,16 @@ class MultiNet:
         else:
             genes_to_impute = self._pad_gene_list(genes_to_impute, gene_metric)
 
-        correlations = get_distance_matrix(raw, n_pred=n_pred, device_id=self.device_id, _var_mean=(var, mean))
         # setTargets only looks at the column labels; the reference hands it raw.reindex(columns=...),
         # a full copy of the matrix (multinet.py:212) -- an empty frame has the same labels
         self.setTargets(pd.DataFrame(columns=pd.Index(genes_to_impute)), mode=mode)
-        self.setPredictors(correlations, ntop=ntop)
+        # get_distance_matrix + setPredictors (multinet.py:211-214; neither draws random numbers, so their order
+        # against setTargets is free): fused on the GPU -- the g x g correlation never comes back to the host --
+        # whenever a GPU is visible; otherwise, and for the shapes the kernel does not take, the two public
+        # functions below run as in the reference.
+        if not (_gpu_visible() and self._set_predictors_device(raw, n_pred, ntop, (var, mean))):
+            correlations = get_distance_matrix(raw, n_pred=n_pred, device_id=self.device_id, _var_mean=(var, mean))
+            self.setPredictors(correlations, ntop=ntop)
 
         print("Normalization")
         norm_data = _hostpar.log1p_float32(raw)
@@ -477,6 +496,44 @@ class MultiNet:
             self.targets = data.columns.values.reshape(shape)
         else:
             self.targets = np.random.choice(data.columns, shape, replace=False)
+
+    def _set_predictors_device(self, raw, n_pred, ntop, var_mean):
+        """get_distance_matrix + setPredictors as ONE device job (dimn_select_predictors: fp64-MFMA |corr| of the
+        candidate genes, then a top-`ntop` select per target over the resident matrix; multinet.py:20-34, 344-365).
+        Same predictor lists as setPredictors() -- |corr| descending, ties in label order, first-occurrence unique --
+        without the g x g host copy.  Returns False (nothing done) for what the kernel does not take: ntop > 16,
+        repeated pool labels, targets outside the pool (the host path raises the reference's KeyError), a sub-net
+        whose targets cover the whole pool (the reference's warning path)."""
+        if ntop > 16:
+            return False
+        pool, values = _candidate_pool(raw, n_pred, var_mean)
+        if not pool.is_unique or values.shape[0] < 2:
+            return False
+        targets = np.asarray(self.targets)
+        K, O = targets.shape
+        rows = pool.get_indexer(targets.reshape(-1))
+        if (rows < 0).any():
+            return False
+        rows = rows.reshape(K, O).astype(np.int32)
+        if any(len(np.unique(r)) >= len(pool) for r in rows):
+            return False
+        from . import _cabi, _lib
+        fns = _lib.load()
+        rank = np.empty(len(pool), np.int32)
+        rank[np.argsort(pool.values, kind="stable")] = np.arange(len(pool), dtype=np.int32)
+        x = np.ascontiguousarray(values, dtype=np.float64)
+        picks = np.empty((K, O, ntop), np.int32)
+        rc = fns["select_predictors"](int(self.device_id), _cabi.p_f64(x), x.shape[0], x.shape[1], _cabi.p_i32(rows), K, O,
+                                      _cabi.p_i32(rank), int(ntop), _cabi.p_i32(picks))
+        if rc != 0:
+            raise RuntimeError("dimn_select_predictors: " + fns["last_error"]().decode("utf-8", "replace"))
+        self.predictors = []
+        for net in range(K):
+            flat = picks[net].reshape(-1)
+            chosen = pool[pd.unique(flat[flat >= 0])]                  # first-occurrence order, multinet.py:362
+            self.predictors.append(chosen)
+            print("Net {}: {} predictors, {} targets".format(net, len(chosen), len(self.targets[net])))
+        return True
 
     def setPredictors(self, covariance_matrix, ntop=5):
         """Per sub-network: for each target the `ntop` most correlated genes outside the target

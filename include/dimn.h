@@ -191,6 +191,16 @@ int dimn_comm_destroy(dimn_handle h);
  * Needs no handle (fit() calls it before the network exists). */
 int dimn_abs_corrcoef(int32_t device_id, const double* X, int64_t n, int64_t g, double* out);
 
+/* ---- next row: setPredictors (multinet.py:344-365) fused behind the correlation ----------
+ * For every target gene of every sub-net: the `ntop` (<= 16) columns of X with the largest |Pearson r| to it,
+ * among the columns that are not targets of the same sub-net; the g x g matrix never leaves the GPU.
+ *   targ_pos  [K][O] column positions (into X) of the sub-nets' targets
+ *   col_rank  [g]    position of each column in label-sorted order (np.setdiff1d order: the tie rule), < 0 = not a candidate
+ *   out_idx   [K][O][ntop] picks, best first, -1 where fewer candidates exist
+ * The host turns each sub-net's O*ntop picks into its predictor list (first-occurrence unique, multinet.py:362). */
+int dimn_select_predictors(int32_t device_id, const double* X, int64_t n, int64_t g, const int32_t* targ_pos,
+                           int32_t K, int32_t O, const int32_t* col_rank, int32_t ntop, int32_t* out_idx);
+
 #ifdef __cplusplus
 }
 #endif
