@@ -255,6 +255,28 @@ def cpu_baseline(cfg, targets, preds, norm, train, val, epochs, lr, budget_s=20.
                       % (which, cnt, t_step, t_row, n_sample, epochs, steps_per_epoch, n, "; ".join(notes))}
 
 
+def dropin_run(norm, epochs):
+    """MultiNet(max_epochs=E).fit(raw) + predict(raw) on the counts the bench's log1p matrix came from."""
+    import contextlib
+    import io
+    import pandas as pd
+    from deepimpute_amd.multinet import MultiNet
+    n, g = norm.shape
+    raw = pd.DataFrame(np.rint(np.expm1(norm.astype(np.float64))), index=["c%d" % i for i in range(n)], columns=["g%d" % j for j in range(g)])
+    net = MultiNet(verbose=0, max_epochs=epochs, patience=10 ** 6)         # the bench fixes E epochs on every leg
+    with contextlib.redirect_stdout(io.StringIO()):
+        t0 = time.perf_counter()
+        net.fit(raw, NN_lim=g)
+        t1 = time.perf_counter()
+        out = net.predict(raw)
+        t2 = time.perf_counter()
+    assert out.shape == raw.shape and net.trained_epochs == epochs
+    net.close()
+    return {"fit_s": t1 - t0, "predict_s": t2 - t1, "cells_per_s": n / (t2 - t0), "subnets": len(net.predictors), "epochs": int(net.trained_epochs),
+            "note": "MultiNet.fit + predict on the same matrix as raw counts: host planning, host<->device copies of the counts and of the "
+                    "imputed frame included"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,6 +286,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=18, help="fixed epoch count E of every fit (see DESIGN.md)")
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in MultiNet.fit+predict run (config.dropin)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--limit-subnets", type=int, default=0, help="diagnostic: keep only the first N sub-nets (what one rank of an N-GPU job sees)")
     ap.add_argument("--hidden", type=int, default=0, help="diagnostic: hidden width (default: the config's 256; the reference CLI defaults to 300)")
@@ -411,6 +434,14 @@ def main():
         eng.comm_destroy()
         rdzv.cleanup()
     eng.close()
+    if rank == 0 and world == 1 and not args.no_dropin and not args.limit_subnets and not args.hidden:
+        # The drop-in surface on the SAME matrix, outside the timed region: deepimpute_amd.multinet.MultiNet.fit + predict,
+        # host planning included (gene selection, |corr| + predictor selection, split, save, held-out metrics, post-processing;
+        # raw counts and the returned frame live on the host, so this figure includes the PCIe copies `value` excludes)
+        try:
+            result["config"]["dropin"] = dropin_run(norm, args.epochs)
+        except Exception as e:
+            result["config"]["dropin"] = {"error": repr(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -80,6 +80,8 @@ GPU_ONLY = {
     "comm_gather_predictions": [_H, _i64, _pi, _i32, _pf],
     "comm_destroy": [_H],
     "abs_corrcoef": [_i32, _pd, _i64, _i64, _pd],
+    "val_metrics": [_H, _pd],
+    "impute_finish": [_H, _pd, _i64, _i64, _pi, _pi, _i32, C.c_double, _i32, _pd],
     "select_predictors": [_i32, _pd, _i64, _i64, _pi, _i32, _i32, _pi, _i32, _pi],
 }
 

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "../../include/dimn.h"
@@ -1067,6 +1068,122 @@ extern "C" int dimn_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, 
     return DIMN_OK;
 }
 
+// Held-out metrics of fit() (multinet.py:251-262) on the device: forward over the validation rows, then the seven sums
+// over the positive truth entries.  out7 = count, Sx, Sy, Sxx, Syy, Sxy, S(x-y)^2 (x = truth, y = prediction).
+extern "C" int dimn_val_metrics(dimn_handle h, double* out7) {
+    if (!h || !out7) return fail(DIMN_ERR_ARG, "dimn_val_metrics: null argument");
+    CHK(ready_for_training(h, "dimn_val_metrics"));
+    if (h->n_val < 1) return fail(DIMN_ERR_STATE, "dimn_val_metrics: no validation rows (dimn_set_split)");
+    CHK(dimn_predict_device(h, h->val_rows.data(), h->n_val, nullptr));
+    double* d = nullptr;
+    CHK(dev_alloc(&d, 8));
+    int rc = DIMN_OK;
+    if (hipMemsetAsync(d, 0, 8 * sizeof(double), h->stream) != hipSuccess) rc = fail(DIMN_ERR_HIP, "dimn_val_metrics: memset failed");
+    if (rc == DIMN_OK) {
+        hipLaunchKernelGGL(k_val_metrics, dim3((unsigned)std::min<int64_t>(h->n_val, 2048)), dim3(256), 0, h->stream, h->d_out, h->d_Y, h->d_pred_rows,
+                           h->n_val, h->n, h->dm, d);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out7, d, 7 * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess)
+            rc = fail(DIMN_ERR_HIP, "dimn_val_metrics: kernel or copy failed");
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+// memcpy of a large block on several host threads (one pageable <-> pinned copy per pipeline stage: a single thread
+// moves ~10 GB/s, the PCIe link five times that)
+static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(hw ? hw / 2 : 8, 24), bytes / (4u << 20)));
+    if (nt <= 1) { memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t chunk = ((bytes + nt - 1) / nt + 63) & ~(size_t)63;
+    for (size_t i = 0; i < nt; ++i) {
+        const size_t a = i * chunk, b = std::min(bytes, a + chunk);
+        if (a >= b) break;
+        th.emplace_back([=] { memcpy((char*)dst + a, (const char*)src + a, b - a); });
+    }
+    for (auto& t : th) t.join();
+}
+
+// ---- next row: predict() post-processing (multinet.py:282-305) as a device epilogue ----------
+// Row blocks of raw stream in, the finished float64 frame streams out, both through two pinned bounce buffers per
+// direction so that the PCIe copies of one block overlap the kernel and the host copies of its neighbours.
+extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_rows, int64_t g, const int32_t* gene_off,
+                                  const int32_t* gene_slot, int32_t policy, double ceiling, int32_t from_gathered, double* out) {
+    if (!h || !raw || !gene_off || !gene_slot || !out || n_rows < 0 || g < 1 || policy < 0 || policy > 2)
+        return fail(DIMN_ERR_ARG, "dimn_impute_finish: bad argument");
+    const int64_t S = gene_off[g];
+    const float* pred = from_gathered ? h->d_full : h->d_out;
+    if (!pred || h->out_rows != n_rows) return fail(DIMN_ERR_STATE, "dimn_impute_finish: run dimn_predict_device (and the gather) over the same %lld rows first", (long long)n_rows);
+    if (!from_gathered && S != (int64_t)h->K * h->O) return fail(DIMN_ERR_ARG, "dimn_impute_finish: %lld slots listed, the prediction has %lld", (long long)S, (long long)h->K * h->O);
+    for (int64_t j = 0; j < g; ++j) if (gene_off[j] > gene_off[j + 1]) return fail(DIMN_ERR_ARG, "dimn_impute_finish: gene_off not monotone");
+    for (int64_t s = 0; s < S; ++s) if (gene_slot[s] < 0 || gene_slot[s] >= S) return fail(DIMN_ERR_ARG, "dimn_impute_finish: slot out of range");
+    CHK(use_device(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (n_rows == 0) return DIMN_OK;
+    const int64_t blk = std::max<int64_t>(1, std::min<int64_t>(n_rows, (int64_t)(128u << 20) / (g * 8)));   // ~128 MB per block
+    int32_t *dOff = nullptr, *dSlot = nullptr;
+    double *dRaw[2] = {nullptr, nullptr}, *dRes[2] = {nullptr, nullptr}, *pIn[2] = {nullptr, nullptr}, *pOut[2] = {nullptr, nullptr};
+    hipStream_t st[2] = {nullptr, nullptr};
+    hipEvent_t evOut[2] = {nullptr, nullptr};
+    int rc = DIMN_OK;
+#define FIN_TRY(expr) do { hipError_t e_ = (expr); if (rc == DIMN_OK && e_ != hipSuccess) rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+    FIN_TRY(hipMalloc((void**)&dOff, (size_t)(g + 1) * 4));
+    FIN_TRY(hipMalloc((void**)&dSlot, (size_t)std::max<int64_t>(S, 1) * 4));
+    for (int b = 0; b < 2; ++b) {
+        FIN_TRY(hipMalloc((void**)&dRaw[b], (size_t)blk * g * 8));
+        FIN_TRY(hipMalloc((void**)&dRes[b], (size_t)blk * g * 8));
+        FIN_TRY(hipHostMalloc((void**)&pIn[b], (size_t)blk * g * 8, hipHostMallocDefault));
+        FIN_TRY(hipHostMalloc((void**)&pOut[b], (size_t)blk * g * 8, hipHostMallocDefault));
+        FIN_TRY(hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking));
+        FIN_TRY(hipEventCreateWithFlags(&evOut[b], hipEventDisableTiming));
+    }
+    if (rc == DIMN_OK) {
+        FIN_TRY(hipMemcpy(dOff, gene_off, (size_t)(g + 1) * 4, hipMemcpyHostToDevice));
+        if (S > 0) FIN_TRY(hipMemcpy(dSlot, gene_slot, (size_t)S * 4, hipMemcpyHostToDevice));
+    }
+    const int lds_stage = (size_t)S * 4 <= 150 * 1024 ? 1 : 0;
+    const size_t lds = lds_stage ? (size_t)S * 4 : 0;
+    if (rc == DIMN_OK && lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_impute_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int64_t nblk = (n_rows + blk - 1) / blk;
+    // software pipeline over blocks: [host copy in | H2D | kernel | D2H] of block i on stream i%2; the host copy out of
+    // block i-2 happens when its event has fired, right before its bounce buffer is re-used
+    for (int64_t bi = 0; bi < nblk + 2 && rc == DIMN_OK; ++bi) {
+        const int b = (int)(bi & 1);
+        std::thread retire;
+        if (bi >= 2) {                                   // retire block bi-2 (same buffers), beside the copy-in of block bi
+            const int64_t r0 = (bi - 2) * blk, nr = std::min(blk, n_rows - r0);
+            FIN_TRY(hipEventSynchronize(evOut[b]));
+            if (rc == DIMN_OK) retire = std::thread([=] { parallel_memcpy(out + r0 * g, pOut[b], (size_t)nr * g * 8); });
+        }
+        struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join_retire{retire};
+        if (bi < nblk && rc == DIMN_OK) {
+            const int64_t r0 = bi * blk, nr = std::min(blk, n_rows - r0);
+            parallel_memcpy(pIn[b], raw + r0 * g, (size_t)nr * g * 8);
+            if (retire.joinable()) retire.join();        // pOut[b] is free again before this block's D2H is queued
+            FIN_TRY(hipMemcpyAsync(dRaw[b], pIn[b], (size_t)nr * g * 8, hipMemcpyHostToDevice, st[b]));
+            hipLaunchKernelGGL(k_impute_finish, dim3((unsigned)std::min<int64_t>(nr, 4096)), dim3(512), lds, st[b], pred, S, r0, dRaw[b], nr, g,
+                               dOff, dSlot, ceiling, policy, lds_stage, dRes[b]);
+            FIN_TRY(hipGetLastError());
+            FIN_TRY(hipMemcpyAsync(pOut[b], dRes[b], (size_t)nr * g * 8, hipMemcpyDeviceToHost, st[b]));
+            FIN_TRY(hipEventRecord(evOut[b], st[b]));
+        }
+    }
+#undef FIN_TRY
+    for (int b = 0; b < 2; ++b) {
+        if (st[b]) { (void)hipStreamSynchronize(st[b]); (void)hipStreamDestroy(st[b]); }
+        if (evOut[b]) (void)hipEventDestroy(evOut[b]);
+        if (dRaw[b]) (void)hipFree(dRaw[b]);
+        if (dRes[b]) (void)hipFree(dRes[b]);
+        if (pIn[b]) (void)hipHostFree(pIn[b]);
+        if (pOut[b]) (void)hipHostFree(pOut[b]);
+    }
+    if (dOff) (void)hipFree(dOff);
+    if (dSlot) (void)hipFree(dSlot);
+    return rc;
+}
+
 extern "C" int dimn_synchronize(dimn_handle h) {
     if (!h) return fail(DIMN_ERR_ARG, "null handle");
     CHK(use_device(h));
@@ -1205,7 +1322,30 @@ static int corr_on_device(const double* X, int64_t n, int64_t g, hipStream_t st,
     CORR_TRY(hipMalloc((void**)&dPart, (size_t)nparts * gp * 8));
     CORR_TRY(hipMalloc((void**)&dPairs, pairs.size() * sizeof(int2)));
     CORR_TRY(hipMemsetAsync(dZ, 0, (size_t)np_ * gp * 8, st));
-    CORR_TRY(hipMemcpy2DAsync(dZ, (size_t)gp * 8, X, (size_t)g * 8, (size_t)g * 8, (size_t)n, hipMemcpyHostToDevice, st));
+    {   // X (pageable) -> pinned bounce buffers on several host threads -> device rows of pitch gp, double-buffered
+        const int64_t blk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(128u << 20) / (g * 8)));
+        double* pin[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        for (int b = 0; b < 2 && rc == DIMN_OK; ++b) {
+            if (hipHostMalloc((void**)&pin[b], (size_t)blk * g * 8, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&ev[b], hipEventDisableTiming) != hipSuccess)
+                rc = fail(DIMN_ERR_HIP, "corr: pinned staging allocation failed");
+        }
+        int64_t bi = 0;
+        for (int64_t r0 = 0; r0 < n && rc == DIMN_OK; r0 += blk, ++bi) {
+            const int b = (int)(bi & 1);
+            const int64_t nr = std::min(blk, n - r0);
+            if (bi >= 2 && hipEventSynchronize(ev[b]) != hipSuccess) rc = fail(DIMN_ERR_HIP, "corr: event wait failed");
+            if (rc != DIMN_OK) break;
+            parallel_memcpy(pin[b], X + r0 * g, (size_t)nr * g * 8);
+            if (hipMemcpy2DAsync(dZ + r0 * gp, (size_t)gp * 8, pin[b], (size_t)g * 8, (size_t)g * 8, (size_t)nr, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipEventRecord(ev[b], st) != hipSuccess)
+                rc = fail(DIMN_ERR_HIP, "corr: host-to-device copy failed");
+        }
+        (void)hipStreamSynchronize(st);
+        for (int b = 0; b < 2; ++b) { if (pin[b]) (void)hipHostFree(pin[b]); if (ev[b]) (void)hipEventDestroy(ev[b]); }
+        if (rc != DIMN_OK) goto done;
+    }
     CORR_TRY(hipMemcpyAsync(dPairs, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_corr_colsum, dim3((unsigned)((gp + 255) / 256), (unsigned)nparts), dim3(256), 0, st, dZ, n, gp, rows_per_block, dPart);
     hipLaunchKernelGGL(k_corr_mean, dim3((unsigned)((gp + 255) / 256)), dim3(256), 0, st, dPart, nparts, n, gp, dMean);

@@ -1624,3 +1624,80 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
         if (threadIdx.x == 0) loss_part[(int64_t)k * gridDim.x + blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
     }
 }
+
+
+// ---------------------------------------------------------------------------------------
+// predict() post-processing on the device (reference deepimpute/multinet.py:282-305), one workgroup per cell:
+//   predicted[gene] = mean over the gene's target slots of the network outputs (float32, slot order; the reference's
+//                     groupby(columns).mean()), genes no sub-net predicts keep log1p(raw);
+//   > ceiling (= 2 * max log1p(raw)) or NaN -> 0;  expm1 back to counts (float64);
+//   policy 1 "restore": observed counts win wherever raw > 0;  2 "max": max(raw, imputed);  0: none.
+// The prediction row [S] is staged once in LDS (coalesced) and gathered per gene from there; raw and the result are
+// streamed coalesced in float64.  goff[g+1] / gslot[S]: the slots of every output column (CSR, ascending slot order).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_impute_finish(const float* __restrict__ pred, int64_t S, int64_t pred_row0,
+                                                       const double* __restrict__ raw, int64_t n_rows, int64_t g,
+                                                       const int32_t* __restrict__ goff, const int32_t* __restrict__ gslot,
+                                                       double ceiling, int policy, int lds_stage, double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float prow[];
+    for (int64_t i = blockIdx.x; i < n_rows; i += gridDim.x) {
+        const float* pr = pred + (pred_row0 + i) * S;
+        if (lds_stage) {
+            __syncthreads();
+            for (int64_t c = threadIdx.x; c < S; c += 512) prow[c] = pr[c];
+            __syncthreads();
+        }
+        const float* src = lds_stage ? prow : pr;
+        const double* rr = raw + i * g;
+        double* orow = out + i * g;
+        for (int64_t j = threadIdx.x; j < g; j += 512) {
+            const double x = rr[j];
+            const int s0 = goff[j], s1 = goff[j + 1];
+            double v;
+            if (s1 > s0) {
+                float acc = src[gslot[s0]];
+                for (int s = s0 + 1; s < s1; ++s) acc += src[gslot[s]];
+                acc /= (float)(s1 - s0);
+                v = (double)acc;
+            } else {
+                v = log1p(x);
+            }
+            if (v > ceiling || v != v) v = 0.0;
+            v = expm1(v);
+            if (policy == 1) v = x > 0.0 ? x : v;
+            else if (policy == 2) v = x > v ? x : v;
+            orow[j] = v;
+        }
+    }
+}
+
+
+// Held-out metrics of fit() (reference deepimpute/multinet.py:251-262): over the validation cells and every target slot
+// with a positive observed value, the sums that give Pearson r and the MSE between truth (log1p counts) and prediction.
+// pred [n_rows][K*O] (dimn_predict_device over the validation rows), Y the gathered targets.  sums[7] (double,
+// zeroed by the caller): count, Sx, Sy, Sxx, Syy, Sxy, S(x-y)^2  with x = truth, y = prediction.
+__global__ __launch_bounds__(256) void k_val_metrics(const float* __restrict__ pred, const float* __restrict__ Y, const int32_t* __restrict__ rows,
+                                                     int64_t n_rows, int64_t n_cells, Dims dm, double* __restrict__ sums) {
+    __shared__ double red[4][7];
+    const int64_t S = (int64_t)dm.K * dm.O;
+    double a[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = blockIdx.x; i < n_rows; i += gridDim.x) {
+        const int64_t row = rows ? rows[i] : i;
+        for (int64_t c = threadIdx.x; c < S; c += 256) {
+            const int k = (int)(c / dm.O), o = (int)(c - (int64_t)k * dm.O);
+            const double x = Y[((int64_t)k * n_cells + row) * dm.Op + o], y = pred[i * S + c];
+            if (x > 0.0) { a[0] += 1.0; a[1] += x; a[2] += y; a[3] += x * x; a[4] += y * y; a[5] += x * y; a[6] += (x - y) * (x - y); }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[q] += __shfl_xor(a[q], off);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int q = 0; q < 7; ++q) red[wave][q] = a[q];
+    __syncthreads();
+    if (threadIdx.x < 7) atomicAdd(&sums[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}

@@ -186,6 +186,23 @@ class HipEngine(Engine):
         self._check(self._f["predict_device"](self._h, p_i32(rows), n_rows, C.byref(ptr)))
         return ptr.value
 
+    def val_metrics(self):
+        """(count, Sx, Sy, Sxx, Syy, Sxy, S(x-y)^2) over the positive validation targets (include/dimn.h)."""
+        out = np.zeros(7, np.float64)
+        self._check(self._f["val_metrics"](self._h, p_f64(out)))
+        return out
+
+    def impute_finish(self, raw, gene_off, gene_slot, policy, ceiling, from_gathered=False):
+        """predict()'s post-processing on the device over the last predict_device() result (include/dimn.h);
+        raw [cells, genes] float64 -> the finished [cells, genes] float64 matrix."""
+        raw = np.ascontiguousarray(raw, dtype=np.float64)
+        gene_off, gene_slot = i32(gene_off), i32(gene_slot)
+        out = np.empty(raw.shape, np.float64)
+        code = {None: 0, "restore": 1, "max": 2}.get(policy, 0)
+        self._check(self._f["impute_finish"](self._h, p_f64(raw), raw.shape[0], raw.shape[1], p_i32(gene_off), p_i32(gene_slot),
+                                             code, float(ceiling), int(bool(from_gathered)), p_f64(out)))
+        return out
+
     def synchronize(self):
         self._check(self._f["synchronize"](self._h))
 

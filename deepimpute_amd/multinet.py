@@ -408,6 +408,18 @@ class MultiNet:
 
     def _held_out_metrics(self, engine, norm_data, held_out, rows_val):
         """Pearson r and MSE on the positive entries of the validation targets (multinet.py:251-262)."""
+        comm = self._comm
+        if hasattr(engine, "val_metrics") and (comm is None or comm.world == 1 or hasattr(comm, "allreduce_sum")):
+            # the seven sums on the device (float64 accumulation over the resident predictions and targets; the
+            # reference's scipy.stats.pearsonr runs in float32 over the same ~n_val*K*O values), summed over the ranks
+            m = engine.val_metrics()
+            if comm is not None and comm.world > 1:
+                m = comm.allreduce_sum(m)
+                if comm.rank != 0:
+                    return None
+            cnt, sx, sy, sxx, syy, sxy, sse = (float(v) for v in m)
+            cov, vx, vy = sxy - sx * sy / cnt, sxx - sx * sx / cnt, syy - sy * sy / cnt
+            return {'correlation': np.float32(cov / np.sqrt(vx * vy)), 'MSE': np.float32(sse / cnt)}
         guess = self._predict_block(engine, rows_val)
         if guess is None:                     # sharded job: only rank 0 holds the gathered block
             return None
@@ -425,29 +437,59 @@ class MultiNet:
         engine.set_matrix(_hostpar.log1p_float32(raw).values)     # float32(log1p(raw)): what Keras is fed
         self._bind_columns(engine, raw.columns)
         engine.gather(False)
-        block = self._predict_block(engine)              # [cells, K*O], np.hstack of the K outputs
-        if block is None:
-            return None                                  # sharded job: rank 0 returns the frame
-
         # a gene may occupy several target slots: average them; the averaged columns are label-sorted,
         # like the reference's groupby(columns).mean() (multinet.py:282-284)
         slots = self.targets.flatten()
         genes, slot_gene = np.unique(slots, return_inverse=True)
-        per_gene = np.bincount(slot_gene, minlength=len(genes)).astype(np.float32)
-        first_slot = np.full(len(genes), -1, np.int64)
-        first_slot[slot_gene[::-1]] = np.arange(len(slots) - 1, -1, -1)     # lowest slot of each gene
-        later = np.flatnonzero(first_slot[slot_gene] != np.arange(len(slots)))   # the repeats, ascending
         where = pd.Index(raw.columns).get_indexer(genes)
         if policy == "restore":
             print("Filling zeros")
         elif policy == "max":
             print("Imputing data with 'max' policy")
+        observed = raw.values
+        ceiling = 2 * np.log1p(observed.max())           # overflow guard, multinet.py:292 (log1p is monotonic)
 
+        values = self._finish_on_device(engine, observed, where[slot_gene], policy, ceiling)
+        if values is False:
+            return None                                  # sharded job: rank 0 returns the frame
+        if values is None:                               # engines without the device epilogue (tests: oracle / fake engines)
+            block = self._predict_block(engine)          # [cells, K*O], np.hstack of the K outputs
+            if block is None:
+                return None
+            values = self._finish_on_host(block, observed, slot_gene, len(genes), where, policy, ceiling)
+        imputed = pd.DataFrame(values, index=raw.index, columns=raw.columns)
+        return imputed.loc[:, genes] if imputed_only else imputed
+
+    def _finish_on_device(self, engine, observed, slot_col, policy, ceiling):
+        """predict()'s post-processing as the device epilogue dimn_impute_finish (multinet.py:282-305): the K*O network
+        outputs never come to the host, only the finished [cells, genes] float64 frame does.  None: this engine has no
+        such epilogue (the host path runs); False: sharded job, this rank is not the root."""
+        if not hasattr(engine, "impute_finish") or policy not in (None, "restore", "max") or (slot_col < 0).any():
+            return None
+        order = np.lexsort((np.arange(len(slot_col)), slot_col))              # slots grouped by output column, ascending slot order
+        gene_off = np.zeros(observed.shape[1] + 1, np.int64)
+        np.cumsum(np.bincount(slot_col, minlength=observed.shape[1]), out=gene_off[1:])
+        comm = self._comm
+        sharded = comm is not None and comm.world > 1
+        if sharded and not getattr(comm, "device_gather", False):
+            return None
+        engine.predict_device()
+        if sharded:
+            engine.comm_gather_predictions(engine.n_cells, self._counts, root=0, is_root=False)   # stays in root's HBM
+            if comm.rank != 0:
+                return False
+        return engine.impute_finish(observed, gene_off, order, policy, ceiling, from_gathered=sharded)
+
+    def _finish_on_host(self, block, observed, slot_gene, n_genes, where, policy, ceiling):
+        """The same post-processing with numpy on row blocks from the host pool (engines without the device epilogue)."""
+        per_gene = np.bincount(slot_gene, minlength=n_genes).astype(np.float32)
+        n_slots = len(slot_gene)
+        first_slot = np.full(n_genes, -1, np.int64)
+        first_slot[slot_gene[::-1]] = np.arange(n_slots - 1, -1, -1)          # lowest slot of each gene
+        later = np.flatnonzero(first_slot[slot_gene] != np.arange(n_slots))   # the repeats, ascending
         # the reference concatenates predicted and untouched genes and re-orders them to raw's layout
         # (multinet.py:285-289); writing the averaged columns into a copy of log1p(raw) is the same
         # matrix.  Every step below is per cell, so it runs on row blocks from the host pool.
-        observed = raw.values
-        ceiling = 2 * np.log1p(observed.max())           # overflow guard, multinet.py:292 (log1p is monotonic)
         values = np.empty(observed.shape, dtype=np.float64)
         untouched = len(where) < observed.shape[1]       # genes no sub-network predicts keep log1p(raw)
 
@@ -471,9 +513,7 @@ class MultiNet:
                 keep_raw = seen > v
                 v[keep_raw] = seen[keep_raw]
         _hostpar.pmap(finish, _hostpar.spans(len(values), _POST_ROWS))
-
-        imputed = pd.DataFrame(values, index=raw.index, columns=raw.columns)
-        return imputed.loc[:, genes] if imputed_only else imputed
+        return values
 
     # -- planning helpers (public in the reference, so public here) --
     def filter_genes(self, gene_metric, threshold, NN_lim=None):

@@ -154,6 +154,25 @@ int dimn_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out)
 /* Same, result left in HBM; *dev_out stays valid until the next predict/destroy. */
 int dimn_predict_device(dimn_handle h, const int32_t* rows, int64_t n_rows, void** dev_out);
 
+/*
+ * predict()'s post-processing (multinet.py:282-305) as a device epilogue over the LAST dimn_predict_device result
+ * (from_gathered != 0: over root's gathered matrix of dimn_comm_gather_predictions): per output gene the mean of its
+ * target slots (float32, slot order), genes without a slot keep log1p(raw); values above `ceiling`
+ * (2 * max log1p(raw), multinet.py:292) or NaN -> 0; expm1; policy 1 "restore" / 2 "max" / 0 none against raw.
+ *   raw        host [n_rows][g] float64 (the observed counts, columns in output order), streamed in by row blocks
+ *   gene_off   [g+1], gene_slot [gene_off[g]]: the prediction slots (columns of np.hstack(predicted)) of every gene
+ *   out        host [n_rows][g] float64, streamed out by row blocks (pinned bounce buffers, copies overlap the kernel)
+ */
+int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_rows, int64_t g, const int32_t* gene_off,
+                       const int32_t* gene_slot, int32_t policy, double ceiling, int32_t from_gathered, double* out);
+
+/*
+ * The held-out metrics fit() reports (multinet.py:251-262: Pearson r and MSE between the validation cells' target
+ * values and their predictions, over the entries with a positive observed value) as seven sums computed on the device:
+ * out7 = count, Sx, Sy, Sxx, Syy, Sxy, S(x-y)^2 with x = truth (log1p counts), y = prediction.
+ */
+int dimn_val_metrics(dimn_handle h, double* out7);
+
 /* The epoch permutation the library uses when perm == NULL (host Fisher-Yates over a
  * Philox stream); exported so callers/tests can reproduce the batch order. */
 int dimn_epoch_permutation(uint64_t seed, int32_t epoch, int64_t n, int32_t* perm_out);

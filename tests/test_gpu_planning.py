@@ -50,3 +50,63 @@ def test_device_predictor_selection_matches_host_on_5k_genes(ntop, tmp_path):
     assert len(dev) == len(host) == 9
     for k, (a, b) in enumerate(zip(dev, host)):
         assert a == b, "sub-net %d: first difference at %d" % (k, next(i for i, (x, y) in enumerate(zip(a, b)) if x != y))
+
+
+@pytest.mark.parametrize("name", sorted(shell.CASES))
+def test_device_postprocessing_matches_host_path(name, tmp_path, monkeypatch):
+    """predict()'s post-processing as the device epilogue (dimn_impute_finish) against the host implementation (which the
+    reference-captured fixtures pin, tests/test_shell.py) on the five shell cases, both policies, no policy and
+    imputed_only: identical wherever the observed counts win; elsewhere expm1/log1p run in float64 on the device
+    (ocml) instead of glibc -- both within an ulp of the true value, so at most 2 ulp apart."""
+    meta = shell.CASES[name]
+    raw = shell._raw(name)
+    ctor = dict(meta["ctor"])
+    ctor.update(max_epochs=3, verbose=0)
+    net = MultiNet(output_prefix=str(tmp_path), **ctor)
+    net.fit(raw, **dict(meta["fit"]))
+    used = []
+    real = MultiNet._finish_on_device
+
+    def spy(self, *a):
+        used.append(real(self, *a))
+        return used[-1]
+    for policy in ("restore", "max", None):
+        monkeypatch.setattr(MultiNet, "_finish_on_device", spy)
+        dev = net.predict(raw, policy=policy)
+        assert used and used[-1] is not None and used[-1] is not False
+        monkeypatch.setattr(MultiNet, "_finish_on_device", lambda self, *a: None)
+        host = net.predict(raw, policy=policy)
+        assert list(dev.columns) == list(host.columns) and list(dev.index) == list(host.index)
+        a, b = dev.values, host.values
+        assert a.dtype == b.dtype == np.float64 and np.isfinite(a).all()
+        np.testing.assert_allclose(a, b, rtol=4.5e-16, atol=0)
+        if policy == "restore":
+            seen = raw.values > 0
+            assert np.array_equal(a[seen], raw.values[seen])
+        assert (a == b).mean() > 0.5        # the rest: 1-2 ulp (ocml vs glibc expm1)
+    monkeypatch.setattr(MultiNet, "_finish_on_device", spy)
+    only = net.predict(raw, imputed_only=True)
+    assert list(only.columns) == sorted(set(net.targets.flatten()))
+
+
+def test_device_held_out_metrics_match_scipy_path(tmp_path):
+    """fit()'s test_metrics from the seven device sums (dimn_val_metrics, float64) against the reference's own
+    scipy.stats.pearsonr / numpy MSE over the same predictions (multinet.py:251-262, float32 arithmetic)."""
+    raw = shell._raw("default64")
+    net = MultiNet(output_prefix=str(tmp_path), sub_outputdim=64, seed=11, verbose=0, max_epochs=4, learning_rate=1e-3,
+                   architecture=[{"type": "dense", "neurons": 48, "activation": "relu"}, {"type": "dropout", "rate": 0.2}])
+    net.fit(raw, NN_lim=128)
+    dev = net.test_metrics
+
+    class HostOnly:                                   # the same engine without the device metrics: the scipy path runs
+        def __init__(self, e):
+            self._e = e
+
+        def predict(self, rows=None):
+            return self._e.predict(rows)
+    np.random.seed(11)
+    norm = np.log1p(raw).astype(np.float32)
+    held = np.random.choice(norm.index, int(0.05 * norm.shape[0]), replace=False)
+    host = net._held_out_metrics(HostOnly(net._engine), norm, held, norm.index.get_indexer(held))
+    assert abs(float(dev["correlation"]) - float(host["correlation"])) < 2e-5
+    np.testing.assert_allclose(float(dev["MSE"]), float(host["MSE"]), rtol=2e-5)

@@ -35,10 +35,11 @@ def main():
     clock(multinet, "get_distance_matrix"); clock(multinet, "_abs_corrcoef"); clock(multinet, "inspect_data")
     for name in ("column_var_mean", "log1p_float32", "zero_nans_inplace", "take_columns"):
         clock(_hostpar, name)
-    for name in ("set_matrix", "gather", "fit", "predict", "get_weights", "init_weights"):
+    for name in ("set_matrix", "gather", "fit", "predict", "get_weights", "init_weights", "impute_finish", "val_metrics", "predict_device"):
         clock(eng_mod.HipEngine, name, "engine." + name)
     net = multinet.MultiNet(verbose=0, max_epochs=args.max_epochs)
-    clock(net, "setPredictors"); clock(net, "save"); clock(net, "_held_out_metrics")
+    clock(net, "setPredictors"); clock(net, "save"); clock(net, "_held_out_metrics"); clock(net, "_set_predictors_device")
+    clock(net, "filter_genes"); clock(net, "setTargets"); clock(net, "_bind_columns"); clock(multinet, "_candidate_pool")
     t0 = time.time()
     net.fit(raw, NN_lim=args.genes)
     t_fit = time.time() - t0
