@@ -82,3 +82,21 @@ def take_columns(values, positions):
         np.take(values[ab[0]:ab[1]], positions, axis=1, out=out[ab[0]:ab[1]])
     pmap(one, spans(values.shape[0], _block_for(out, 0)))
     return out
+
+
+def matrix_max(values):
+    """values.max() by row blocks (NaN propagates as in numpy)."""
+    parts = pmap(lambda ab: values[ab[0]:ab[1]].max(), spans(values.shape[0], _block_for(values, 0)))
+    return np.max(parts) if parts else values.max()
+
+
+def as_float64(values):
+    """np.ascontiguousarray(values, dtype=np.float64); the conversion (integer or float32 counts) by row blocks."""
+    if values.dtype == np.float64 and values.flags.c_contiguous:
+        return values
+    out = np.empty(values.shape, np.float64)
+
+    def one(ab):
+        out[ab[0]:ab[1]] = values[ab[0]:ab[1]]
+    pmap(one, spans(values.shape[0], _block_for(out, 0)))
+    return out

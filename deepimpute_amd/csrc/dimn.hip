@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -20,6 +21,17 @@
 
 #define DIMN_ABI_VERSION 2
 
+// DIMN_TRACE=1: stage times of the host-heavy entry points on stderr (diagnostic)
+struct Trace {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    bool on = getenv("DIMN_TRACE") && atoi(getenv("DIMN_TRACE")) != 0;
+    void lap(const char* what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[dimn] %-32s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 static thread_local char g_err[1024];
 static int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -138,6 +150,7 @@ struct dimn_handle_s {
     float *d_res_P = nullptr, *d_res_D = nullptr, *d_res_b1 = nullptr, *d_res_alpha = nullptr;
     unsigned* d_res_flags = nullptr; double* d_res_loss = nullptr; int64_t res_alpha_cap = 0;
     double tm_res_ms = 0; int64_t tm_res_steps = 0;
+    double* pin_buf[4] = {nullptr, nullptr, nullptr, nullptr}; size_t pin_cap = 0;   // pinned bounce buffers of dimn_impute_finish, kept across calls
     hipStream_t stream = nullptr;          // lane 0's stream; also used by every non-training call
     struct Lane { hipStream_t stream; int k0, k1, w0, w1; };   // sub-nets [k0,k1), work items [w0,w1)
     std::vector<Lane> lanes;               // independent sub-net groups trained on concurrent streams
@@ -429,6 +442,7 @@ extern "C" int dimn_destroy(dimn_handle h) {
     DEV_FREE(h->d_midwork); DEV_FREE(h->d_midk); DEV_FREE(h->d_P2); DEV_FREE(h->d_G);
     DEV_FREE(h->d_epoch_rows); DEV_FREE(h->d_val_rows); DEV_FREE(h->d_pred_rows); DEV_FREE(h->d_out);
     DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage); DEV_FREE(h->d_red);
+    for (auto& pb : h->pin_buf) if (pb) { (void)hipHostFree(pb); pb = nullptr; }
     DEV_FREE(h->d_res_P); DEV_FREE(h->d_res_D); DEV_FREE(h->d_res_b1); DEV_FREE(h->d_res_alpha); DEV_FREE(h->d_res_flags); DEV_FREE(h->d_res_loss);
     for (auto& ln : h->lanes) (void)hipStreamDestroy(ln.stream);
     delete h;
@@ -1123,6 +1137,7 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
     HIPCHK(hipStreamSynchronize(h->stream));
     if (n_rows == 0) return DIMN_OK;
     const int64_t blk = std::max<int64_t>(1, std::min<int64_t>(n_rows, (int64_t)(128u << 20) / (g * 8)));   // ~128 MB per block
+    Trace tr;
     int32_t *dOff = nullptr, *dSlot = nullptr;
     double *dRaw[2] = {nullptr, nullptr}, *dRes[2] = {nullptr, nullptr}, *pIn[2] = {nullptr, nullptr}, *pOut[2] = {nullptr, nullptr};
     hipStream_t st[2] = {nullptr, nullptr};
@@ -1134,8 +1149,13 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
     for (int b = 0; b < 2; ++b) {
         FIN_TRY(hipMalloc((void**)&dRaw[b], (size_t)blk * g * 8));
         FIN_TRY(hipMalloc((void**)&dRes[b], (size_t)blk * g * 8));
-        FIN_TRY(hipHostMalloc((void**)&pIn[b], (size_t)blk * g * 8, hipHostMallocDefault));
-        FIN_TRY(hipHostMalloc((void**)&pOut[b], (size_t)blk * g * 8, hipHostMallocDefault));
+        if (h->pin_cap < (size_t)blk * g * 8 && b == 0) {        // (re)allocate the four pinned buffers once per size
+            for (auto& pb : h->pin_buf) if (pb) { (void)hipHostFree(pb); pb = nullptr; }
+            h->pin_cap = 0;
+            for (auto& pb : h->pin_buf) FIN_TRY(hipHostMalloc((void**)&pb, (size_t)blk * g * 8, hipHostMallocDefault));
+            if (rc == DIMN_OK) h->pin_cap = (size_t)blk * g * 8;
+        }
+        pIn[b] = h->pin_buf[b]; pOut[b] = h->pin_buf[2 + b];
         FIN_TRY(hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking));
         FIN_TRY(hipEventCreateWithFlags(&evOut[b], hipEventDisableTiming));
     }
@@ -1143,6 +1163,7 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
         FIN_TRY(hipMemcpy(dOff, gene_off, (size_t)(g + 1) * 4, hipMemcpyHostToDevice));
         if (S > 0) FIN_TRY(hipMemcpy(dSlot, gene_slot, (size_t)S * 4, hipMemcpyHostToDevice));
     }
+    tr.lap("finish: allocations");
     const int lds_stage = (size_t)S * 4 <= 150 * 1024 ? 1 : 0;
     const size_t lds = lds_stage ? (size_t)S * 4 : 0;
     if (rc == DIMN_OK && lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_impute_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1171,16 +1192,16 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
         }
     }
 #undef FIN_TRY
+    tr.lap("finish: pipeline");
     for (int b = 0; b < 2; ++b) {
         if (st[b]) { (void)hipStreamSynchronize(st[b]); (void)hipStreamDestroy(st[b]); }
         if (evOut[b]) (void)hipEventDestroy(evOut[b]);
         if (dRaw[b]) (void)hipFree(dRaw[b]);
         if (dRes[b]) (void)hipFree(dRes[b]);
-        if (pIn[b]) (void)hipHostFree(pIn[b]);
-        if (pOut[b]) (void)hipHostFree(pOut[b]);
     }
     if (dOff) (void)hipFree(dOff);
     if (dSlot) (void)hipFree(dSlot);
+    tr.lap("finish: frees");
     return rc;
 }
 
@@ -1315,6 +1336,7 @@ static int corr_on_device(const double* X, int64_t n, int64_t g, hipStream_t st,
     const int nparts = (int)std::min<int64_t>(64, (n + 255) / 256);
     const int64_t rows_per_block = (n + nparts - 1) / nparts;
 #define CORR_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
+    Trace tr;
     CORR_TRY(hipMalloc((void**)&dZ, (size_t)np_ * gp * 8));
     CORR_TRY(hipMalloc((void**)&dC, (size_t)gp * gp * 8));
     CORR_TRY(hipMalloc((void**)&dOut, (size_t)g * g * 8));
@@ -1322,6 +1344,7 @@ static int corr_on_device(const double* X, int64_t n, int64_t g, hipStream_t st,
     CORR_TRY(hipMalloc((void**)&dPart, (size_t)nparts * gp * 8));
     CORR_TRY(hipMalloc((void**)&dPairs, pairs.size() * sizeof(int2)));
     CORR_TRY(hipMemsetAsync(dZ, 0, (size_t)np_ * gp * 8, st));
+    tr.lap("corr: device allocations");
     {   // X (pageable) -> pinned bounce buffers on several host threads -> device rows of pitch gp, double-buffered
         const int64_t blk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(128u << 20) / (g * 8)));
         double* pin[2] = {nullptr, nullptr};
@@ -1346,6 +1369,7 @@ static int corr_on_device(const double* X, int64_t n, int64_t g, hipStream_t st,
         for (int b = 0; b < 2; ++b) { if (pin[b]) (void)hipHostFree(pin[b]); if (ev[b]) (void)hipEventDestroy(ev[b]); }
         if (rc != DIMN_OK) goto done;
     }
+    tr.lap("corr: upload X");
     CORR_TRY(hipMemcpyAsync(dPairs, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_corr_colsum, dim3((unsigned)((gp + 255) / 256), (unsigned)nparts), dim3(256), 0, st, dZ, n, gp, rows_per_block, dPart);
     hipLaunchKernelGGL(k_corr_mean, dim3((unsigned)((gp + 255) / 256)), dim3(256), 0, st, dPart, nparts, n, gp, dMean);
@@ -1354,6 +1378,7 @@ static int corr_on_device(const double* X, int64_t n, int64_t g, hipStream_t st,
     hipLaunchKernelGGL(k_corr_finish, dim3((unsigned)((g + 255) / 256), (unsigned)g), dim3(256), 0, st, dC, g, gp, 1.0 / (double)(n - 1), dOut);
     CORR_TRY(hipGetLastError());
     CORR_TRY(hipStreamSynchronize(st));
+    tr.lap("corr: kernels");
 #undef CORR_TRY
 done:
     if (dZ) (void)hipFree(dZ);
@@ -1362,6 +1387,7 @@ done:
     if (dPart) (void)hipFree(dPart);
     if (dPairs) (void)hipFree(dPairs);
     if (rc != DIMN_OK && dOut) { (void)hipFree(dOut); dOut = nullptr; }
+    tr.lap("corr: free temporaries");
     *dOutp = dOut;
     return rc;
 }

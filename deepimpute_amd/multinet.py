@@ -50,7 +50,7 @@ def _abs_corrcoef(values, backend="auto", device_id=0):
         try:
             from . import _cabi, _lib
             fns = _lib.load()
-            x = np.ascontiguousarray(values, dtype=np.float64)
+            x = _hostpar.as_float64(values)
             out = np.empty((x.shape[1], x.shape[1]), np.float64)
             rc = fns["abs_corrcoef"](int(device_id), _cabi.p_f64(x), x.shape[0], x.shape[1], _cabi.p_f64(out))
             if rc == 0:
@@ -94,6 +94,14 @@ def get_distance_matrix(raw, n_pred=None, backend="auto", device_id=0, _var_mean
     return pd.DataFrame(_hostpar.zero_nans_inplace(corr), index=keep, columns=keep, copy=False)   # .fillna(0)
 
 
+class _ColumnsOnly:
+    """What setTargets() reads of its `data` argument: `.columns` and `.shape[1]`."""
+
+    def __init__(self, labels):
+        self.columns = pd.Index(labels)
+        self.shape = (0, len(self.columns))
+
+
 def _gpu_visible():
     """True when libdimn loads and sees a HIP device (host planning may run without one; fit/predict may not)."""
     try:
@@ -119,7 +127,7 @@ def inspect_data(data):
         if sum(labels.duplicated()):
             print("ERROR: duplicated {0} labels. Please provide unique {0} labels.".format(what))
             exit(1)
-    top = np.max(data.values)
+    top = _hostpar.matrix_max(data.values)
     if top < 10:
         print("ERROR: max value = {}. Is your data log-transformed? Please provide raw counts".format(top))
         exit(1)
@@ -290,8 +298,9 @@ class MultiNet:
             genes_to_impute = self._pad_gene_list(genes_to_impute, gene_metric)
 
         # setTargets only looks at the column labels; the reference hands it raw.reindex(columns=...),
-        # a full copy of the matrix (multinet.py:212) -- an empty frame has the same labels
-        self.setTargets(pd.DataFrame(columns=pd.Index(genes_to_impute)), mode=mode)
+        # a full copy of the matrix (multinet.py:212) -- `_ColumnsOnly` carries the same labels (even an empty
+        # DataFrame with 20k columns costs pandas half a second to build)
+        self.setTargets(_ColumnsOnly(genes_to_impute), mode=mode)
         # get_distance_matrix + setPredictors (multinet.py:211-214; neither draws random numbers, so their order
         # against setTargets is free): fused on the GPU -- the g x g correlation never comes back to the host --
         # whenever a GPU is visible; otherwise, and for the shapes the kernel does not take, the two public
@@ -309,8 +318,14 @@ class MultiNet:
         engine, comm, counts = self._build_shard([len(p) for p in self.predictors])
 
         held_out = np.random.choice(norm_data.index, int(_VALIDATION_FRACTION * norm_data.shape[0]), replace=False)
-        kept = np.setdiff1d(norm_data.index, held_out)          # label-sorted, multinet.py:229
-        rows_val, rows_train = norm_data.index.get_indexer(held_out), norm_data.index.get_indexer(kept)
+        # train_cells = np.setdiff1d(index, test_cells) (multinet.py:229) is label-sorted and unique; inspect_data()
+        # has made sure the labels are unique, so the same rows come out of one argsort of the labels
+        # (np.setdiff1d on 50k string labels takes 0.7 s)
+        rows_val = norm_data.index.get_indexer(held_out)
+        is_train = np.ones(norm_data.shape[0], bool)
+        is_train[rows_val] = False
+        by_label = np.argsort(norm_data.index.values, kind="stable")
+        rows_train = by_label[is_train[by_label]]
 
         engine.set_matrix(norm_data.values)
         self._bind_columns(engine, norm_data.columns)
@@ -447,7 +462,7 @@ class MultiNet:
         elif policy == "max":
             print("Imputing data with 'max' policy")
         observed = raw.values
-        ceiling = 2 * np.log1p(observed.max())           # overflow guard, multinet.py:292 (log1p is monotonic)
+        ceiling = 2 * np.log1p(_hostpar.matrix_max(observed))    # overflow guard, multinet.py:292 (log1p is monotonic)
 
         values = self._finish_on_device(engine, observed, where[slot_gene], policy, ceiling)
         if values is False:
@@ -478,7 +493,7 @@ class MultiNet:
             engine.comm_gather_predictions(engine.n_cells, self._counts, root=0, is_root=False)   # stays in root's HBM
             if comm.rank != 0:
                 return False
-        return engine.impute_finish(observed, gene_off, order, policy, ceiling, from_gathered=sharded)
+        return engine.impute_finish(_hostpar.as_float64(observed), gene_off, order, policy, ceiling, from_gathered=sharded)
 
     def _finish_on_host(self, block, observed, slot_gene, n_genes, where, policy, ceiling):
         """The same post-processing with numpy on row blocks from the host pool (engines without the device epilogue)."""
@@ -561,7 +576,7 @@ class MultiNet:
         fns = _lib.load()
         rank = np.empty(len(pool), np.int32)
         rank[np.argsort(pool.values, kind="stable")] = np.arange(len(pool), dtype=np.int32)
-        x = np.ascontiguousarray(values, dtype=np.float64)
+        x = _hostpar.as_float64(values)
         picks = np.empty((K, O, ntop), np.int32)
         rc = fns["select_predictors"](int(self.device_id), _cabi.p_f64(x), x.shape[0], x.shape[1], _cabi.p_i32(rows), K, O,
                                       _cabi.p_i32(rank), int(ntop), _cabi.p_i32(picks))

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--genes", type=int, default=5000)
     ap.add_argument("--max-epochs", type=int, default=500)
     args = ap.parse_args()
-    counts = np.expm1(bench.synth_counts(args.cells, args.genes, seed=0)).round()
+    counts = np.rint(np.expm1(bench.synth_counts(args.cells, args.genes, seed=0).astype(np.float64)))      # float64, as pd.read_csv gives
     raw = pd.DataFrame(counts, index=["c%d" % i for i in range(args.cells)], columns=["g%d" % j for j in range(args.genes)])
     marks = {}
 
