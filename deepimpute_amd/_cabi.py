@@ -36,6 +36,13 @@ class Config(C.Structure):
     ]
 
 
+class Layer(C.Structure):
+    """struct dimn_layer (include/dimn.h): one hidden Dense layer + the rate of the Dropout layer behind it."""
+    _fields_ = [("neurons", C.c_int32), ("activation", C.c_int32), ("dropout_rate", C.c_float)]
+
+
+LOSSES = {"wmse": 0, "wmse_binary": 1, "mean_squared_error": 2, "mse": 2, "mean_absolute_error": 3, "mae": 3}
+
 _H = C.c_void_p
 _i32 = C.c_int32
 _i64 = C.c_int64
@@ -66,6 +73,13 @@ SIGNATURES = {
     "predict": [_H, _pi, _i64, _pf],
     "epoch_permutation": [C.c_uint64, _i32, _i64, _pi],
 }
+# the general path (any architecture / batch size / loss): include/dimn.h dimn_create_general & co; the general
+# oracle (oracle/dimo_general.c) exports the same under dimog_
+GENERAL = {
+    "create_general": [C.POINTER(Config), _pi, C.POINTER(Layer), _i32, _i32, C.POINTER(_H)],
+    "set_layer_weights": [_H, _i32, _i32, _pf, _pf],
+    "get_layer_weights": [_H, _i32, _i32, _i32, _pf, _pf],
+}
 # entry points only the GPU library has
 GPU_ONLY = {
     "abi_version": [],
@@ -91,6 +105,7 @@ def bind(lib, prefix, gpu=False):
     table = dict(SIGNATURES)
     if gpu:
         table.update(GPU_ONLY)
+        table.update(GENERAL)
     fns = {}
     for name, argtypes in table.items():
         fn = getattr(lib, prefix + name)
@@ -126,3 +141,28 @@ def p_i32(a):
 
 def p_u8(a):
     return None if a is None else a.ctypes.data_as(_pu8)
+
+
+def bind_general_oracle(lib):
+    """Function table of the general CPU oracle (prefix dimog_; `create` there is the general constructor)."""
+    names = ["destroy", "set_matrix", "set_indices", "set_split", "init_weights", "get_step_count", "train_step_general",
+             "train_epoch", "val_loss", "fit", "predict", "epoch_permutation"]
+    fns = {}
+    for name in names:
+        real = "train_step" if name == "train_step_general" else name
+        fn = getattr(lib, "dimog_" + real)
+        fn.argtypes = [_H, _pi, _i32, _i32, _i32, _pf] if name == "train_step_general" else SIGNATURES[name]
+        fn.restype = C.c_int
+        fns[name] = fn
+    for name, args in (("create", GENERAL["create_general"]), ("set_layer_weights", GENERAL["set_layer_weights"]),
+                       ("get_layer_weights", GENERAL["get_layer_weights"])):
+        fn = getattr(lib, "dimog_" + name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+        fns["create_general" if name == "create" else name] = fn
+    fns["gather"] = lambda h, w: 0
+    le = lib.dimog_last_error
+    le.argtypes = []
+    le.restype = C.c_char_p
+    fns["last_error"] = le
+    return fns

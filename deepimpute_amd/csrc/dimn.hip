@@ -18,6 +18,7 @@
 #include "dimn_kernels.h"
 #include "dimn_corr.h"
 #include "dimn_resident.h"
+#include "dimn_general.h"
 
 #define DIMN_ABI_VERSION 2
 
@@ -139,6 +140,7 @@ struct dimn_handle_s {
     float* d_loss_step = nullptr; double* d_loss_acc = nullptr;
     uint8_t* d_mask = nullptr;
     int32_t *d_rows_step = nullptr, *d_epoch_rows = nullptr, *d_val_rows = nullptr, *d_pred_rows = nullptr;
+    int rows_step_cap = 0;
     int64_t pred_rows_cap = 0;
     std::vector<int32_t> train_rows, val_rows;
     float* d_out = nullptr; int64_t out_cap = 0; int64_t out_rows = 0;
@@ -163,6 +165,7 @@ struct dimn_handle_s {
     std::vector<double> ev_bytes;   // algorithmic bytes of the W1 launch bracketed by each event triple
     // comm
     ncclComm_t comm = nullptr; int n_ranks = 1, rank = 0;
+    struct GenNet* gen = nullptr;          // != NULL: the general path (dimn_general.h) owns the network of this handle
 };
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -184,6 +187,8 @@ static int dev_alloc(T** p, size_t count) {
         if (p) (void)hipFree(p); \
         p = nullptr;           \
     } while (0)
+
+#include "dimn_general_host.inc"
 
 static void build_work(dimn_handle h) {
     // Split every sub-net's chunk range into slices = workgroups of the W1 kernels.  The total is made
@@ -284,12 +289,12 @@ static void build_resident(dimn_handle h) {
     h->res_G = 16 * S1; h->res_S1 = S1; h->res_T1 = T1 <= 2 ? 2 : (T1 <= 4 ? 4 : 7);
 }
 
-extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle* out) {
+static int create_common(const dimn_config* cfg, const int32_t* D, bool general, dimn_handle* out) {
     if (!cfg || !D || !out) return fail(DIMN_ERR_ARG, "dimn_create: null argument");
     if (cfg->n_subnets < 1 || cfg->hidden < 1 || cfg->out_dim < 1)
         return fail(DIMN_ERR_ARG, "dimn_create: n_subnets/hidden/out_dim must be >= 1");
-    if (cfg->batch_size < 1 || cfg->batch_size > DIMN_MAX_BATCH)
-        return fail(DIMN_ERR_UNSUP, "dimn_create: batch_size %d not in 1..%d", cfg->batch_size, DIMN_MAX_BATCH);
+    if (cfg->batch_size < 1 || (!general && cfg->batch_size > DIMN_MAX_BATCH))
+        return fail(DIMN_ERR_UNSUP, "dimn_create: batch_size %d not in 1..%d (dimn_create_general takes any batch size)", cfg->batch_size, DIMN_MAX_BATCH);
     if (!(cfg->dropout_rate >= 0.f && cfg->dropout_rate < 1.f))
         return fail(DIMN_ERR_ARG, "dimn_create: dropout_rate must be in [0,1)");
     int ndev = 0;
@@ -317,11 +322,11 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     h->NT2 = ceil_div(dm.HT, 8);
     h->OTW = ceil_div(dm.OT, 4);   // output tiles per wave of the 4-wave middle-backward kernel
     h->HS = ceil_div(dm.HT, 2);
-    if (h->NT > 6) {
+    if (!general && h->NT > 6) {
         delete h;
-        return fail(DIMN_ERR_UNSUP, "dimn_create: hidden=%d > 384 not supported by the gfx950 kernels yet", cfg->hidden);
+        return fail(DIMN_ERR_UNSUP, "dimn_create: hidden=%d > 384 is outside the tuned kernels (use dimn_create_general)", cfg->hidden);
     }
-    if ((size_t)DIMN_TB * dm.ldd * sizeof(float) > 160 * 1024) {
+    if (!general && (size_t)DIMN_TB * dm.ldd * sizeof(float) > 160 * 1024) {
         delete h;
         return fail(DIMN_ERR_UNSUP, "dimn_create: hidden too large for LDS staging");
     }
@@ -353,8 +358,7 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     }
     h->w1_total = w1;
     build_work(h);
-    build_mid(h);
-    build_resident(h);
+    if (!general) { build_mid(h); build_resident(h); }
     // Sub-net lanes: independent sub-net groups on concurrent streams.  Default 1: with 2 lanes the
     // end-to-end rate is ~9 % higher on cfg3 (one lane's latency-bound kernels hide under the other's
     // weight update) but the two HBM-bound weight updates then share the bandwidth, which halves the
@@ -379,6 +383,14 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     }
     h->stream = h->lanes[0].stream;
     TRY(dev_alloc(&h->d_sn, (size_t)h->K));
+    if (general) {                                   // the general path allocates its own state (gen_setup)
+        if (hipMemcpy(h->d_sn, h->sn.data(), h->sn.size() * sizeof(SubnetDev), hipMemcpyHostToDevice) != hipSuccess) {
+            dimn_destroy(h);
+            return fail(DIMN_ERR_HIP, "dimn_create_general: descriptor upload failed");
+        }
+        *out = h;
+        return DIMN_OK;
+    }
     TRY(dev_alloc(&h->d_work, h->work.size()));
     TRY(dev_alloc(&h->d_W1, (size_t)w1)); TRY(dev_alloc(&h->d_M1, (size_t)w1)); TRY(dev_alloc(&h->d_V1, (size_t)w1));
     TRY(dev_alloc(&h->d_W2, w2n)); TRY(dev_alloc(&h->d_M2, w2n)); TRY(dev_alloc(&h->d_V2, w2n));
@@ -428,10 +440,45 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
     return DIMN_OK;
 }
 
+extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle* out) { return create_common(cfg, D, false, out); }
+
+// build(inputdims) for ANY architecture list (multinet.py:126-167): `layers` = the hidden Dense layers in order, each with the
+// rate of the Dropout layer that follows it (0: none); the softplus output layer of out_dim units is implied.
+extern "C" int dimn_create_general(const dimn_config* cfg, const int32_t* D, const dimn_layer* layers, int32_t n_layers, int32_t loss, dimn_handle* out) {
+    if (!cfg || !layers || n_layers < 1 || n_layers > 16) return fail(DIMN_ERR_ARG, "dimn_create_general: 1..16 hidden layers expected");
+    if (loss < DIMN_LOSS_WMSE || loss > DIMN_LOSS_MAE) return fail(DIMN_ERR_UNSUP, "dimn_create_general: unknown loss id %d", loss);
+    for (int l = 0; l < n_layers; ++l) {
+        if (layers[l].neurons < 1) return fail(DIMN_ERR_ARG, "dimn_create_general: layer %d has no neurons", l);
+        if (layers[l].activation < DIMN_ACT_RELU || layers[l].activation > DIMN_ACT_SOFTPLUS) return fail(DIMN_ERR_UNSUP, "dimn_create_general: unknown activation id in layer %d", l);
+        if (!(layers[l].dropout_rate >= 0.f && layers[l].dropout_rate < 1.f)) return fail(DIMN_ERR_ARG, "dimn_create_general: dropout rate of layer %d not in [0,1)", l);
+    }
+    dimn_config c = *cfg;
+    c.hidden = layers[0].neurons; c.dropout_rate = 0.f;
+    dimn_handle h = nullptr;
+    CHK(create_common(&c, D, true, &h));
+    h->cfg.loss_binary = loss == DIMN_LOSS_WMSE_BINARY;
+    const int rc = gen_setup(h, layers, n_layers, loss);
+    if (rc != DIMN_OK) { dimn_destroy(h); return rc; }
+    *out = h;
+    return DIMN_OK;
+}
+
+extern "C" int dimn_set_layer_weights(dimn_handle h, int32_t k, int32_t layer, const float* W, const float* b) {
+    if (!h || !h->gen || k < 0 || k >= h->K || !W || !b) return fail(DIMN_ERR_ARG, "dimn_set_layer_weights: bad argument (general handles only)");
+    CHK(use_device(h));
+    return gen_io_layer(h, k, layer, 0, (float*)W, (float*)b, true);
+}
+extern "C" int dimn_get_layer_weights(dimn_handle h, int32_t k, int32_t layer, int32_t which, float* W, float* b) {
+    if (!h || !h->gen || k < 0 || k >= h->K || which < 0 || which > 2 || !W || !b) return fail(DIMN_ERR_ARG, "dimn_get_layer_weights: bad argument (general handles only)");
+    CHK(use_device(h));
+    return gen_io_layer(h, k, layer, which, W, b, false);
+}
+
 extern "C" int dimn_destroy(dimn_handle h) {
     if (!h) return DIMN_OK;
     (void)hipSetDevice(h->cfg.device_id);
     for (auto& ln : h->lanes) (void)hipStreamSynchronize(ln.stream);
+    gen_free(h->gen); h->gen = nullptr;
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     DEV_FREE(h->d_sn); DEV_FREE(h->d_work); DEV_FREE(h->d_norm); DEV_FREE(h->d_X); DEV_FREE(h->d_Y);
@@ -565,6 +612,7 @@ static int zero_opt(dimn_handle h) {
 
 extern "C" int dimn_set_activation(dimn_handle h, int32_t activation) {
     if (!h) return fail(DIMN_ERR_ARG, "null handle");
+    if (h->gen) return fail(DIMN_ERR_ARG, "dimn_set_activation: a general handle takes its activations from dimn_create_general");
     if (activation < DIMN_ACT_RELU || activation > DIMN_ACT_SOFTPLUS) return fail(DIMN_ERR_UNSUP, "dimn_set_activation: unknown activation %d", activation);
     CHK(use_device(h));
     CHK(sync_lanes_fwd(h));
@@ -580,6 +628,12 @@ extern "C" int dimn_set_activation(dimn_handle h, int32_t activation) {
 extern "C" int dimn_reset_optimizer(dimn_handle h) {
     if (!h) return fail(DIMN_ERR_ARG, "null handle");
     CHK(use_device(h));
+    if (h->gen) {
+        HIPCHK(hipMemset(h->gen->d_M, 0, (size_t)h->gen->ptotal * 4));
+        HIPCHK(hipMemset(h->gen->d_V, 0, (size_t)h->gen->ptotal * 4));
+        h->t = 0;
+        return DIMN_OK;
+    }
     CHK(zero_opt(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     return DIMN_OK;
@@ -588,6 +642,7 @@ extern "C" int dimn_reset_optimizer(dimn_handle h) {
 extern "C" int dimn_init_weights(dimn_handle h, uint64_t seed) {
     if (!h) return fail(DIMN_ERR_ARG, "null handle");
     CHK(use_device(h));
+    if (h->gen) return gen_init_weights(h, seed);
     const Dims& dm = h->dm;
     HIPCHK(hipMemsetAsync(h->d_W1, 0, (size_t)h->w1_total * 4, h->stream));
     HIPCHK(hipMemsetAsync(h->d_W2, 0, (size_t)h->K * dm.Hp * dm.Op * 4, h->stream));
@@ -647,20 +702,39 @@ static int io_weights(dimn_handle h, int k, float* dW1, float* dB1, float* dW2, 
     return DIMN_OK;
 }
 
+static int gen_two_layer(dimn_handle h, const char* who) {
+    if (h->gen->L != 1) return fail(DIMN_ERR_ARG, "%s: the model has %d hidden layers -- use dimn_set/get_layer_weights", who, h->gen->L);
+    return DIMN_OK;
+}
 extern "C" int dimn_set_weights(dimn_handle h, int32_t k, const float* W1, const float* b1, const float* W2, const float* b2) {
     if (!h || k < 0 || k >= h->K || !W1 || !b1 || !W2 || !b2) return fail(DIMN_ERR_ARG, "dimn_set_weights: bad argument");
     CHK(use_device(h));
+    if (h->gen) {
+        CHK(gen_two_layer(h, "dimn_set_weights"));
+        CHK(gen_io_layer(h, k, 0, 0, (float*)W1, (float*)b1, true));
+        return gen_io_layer(h, k, 1, 0, (float*)W2, (float*)b2, true);
+    }
     return io_weights(h, k, h->d_W1, h->d_b1, h->d_W2, h->d_b2, 0, (float*)W1, (float*)b1, (float*)W2, (float*)b2, true);
 }
 extern "C" int dimn_get_weights(dimn_handle h, int32_t k, float* W1, float* b1, float* W2, float* b2) {
     if (!h || k < 0 || k >= h->K || !W1 || !b1 || !W2 || !b2) return fail(DIMN_ERR_ARG, "dimn_get_weights: bad argument");
     CHK(use_device(h));
+    if (h->gen) {
+        CHK(gen_two_layer(h, "dimn_get_weights"));
+        CHK(gen_io_layer(h, k, 0, 0, W1, b1, false));
+        return gen_io_layer(h, k, 1, 0, W2, b2, false);
+    }
     return io_weights(h, k, h->d_W1, h->d_b1, h->d_W2, h->d_b2, 0, W1, b1, W2, b2, false);
 }
 extern "C" int dimn_get_adam_state(dimn_handle h, int32_t k, int32_t which, float* W1, float* b1, float* W2, float* b2) {
     if (!h || k < 0 || k >= h->K || which < 0 || which > 1 || !W1 || !b1 || !W2 || !b2)
         return fail(DIMN_ERR_ARG, "dimn_get_adam_state: bad argument");
     CHK(use_device(h));
+    if (h->gen) {
+        CHK(gen_two_layer(h, "dimn_get_adam_state"));
+        CHK(gen_io_layer(h, k, 0, 1 + which, W1, b1, false));
+        return gen_io_layer(h, k, 1, 1 + which, W2, b2, false);
+    }
     return io_weights(h, k, which ? h->d_V1 : h->d_M1, h->d_b1, which ? h->d_V2 : h->d_M2, h->d_b2, 1 + which, W1, b1, W2, b2, false);
 }
 
@@ -835,6 +909,23 @@ extern "C" int dimn_train_step(dimn_handle h, const int32_t* rows, int32_t b_act
     for (int b = 0; b < b_act; ++b) if (rows[b] < 0 || rows[b] >= h->n) return fail(DIMN_ERR_ARG, "dimn_train_step: row %d out of range", rows[b]);
     CHK(use_device(h));
     const Dims& dm = h->dm;
+    if (h->gen) {
+        if (keep_mask) return fail(DIMN_ERR_UNSUP, "dimn_train_step: an injected keep mask is only defined for the one-hidden-layer kernels");
+        if (h->rows_step_cap < b_act) {
+            HIPCHK(hipStreamSynchronize(h->stream));
+            DEV_FREE(h->d_rows_step);
+            CHK(dev_alloc(&h->d_rows_step, (size_t)b_act));
+            h->rows_step_cap = b_act;
+        }
+        HIPCHK(hipMemcpyAsync(h->d_rows_step, rows, (size_t)b_act * 4, hipMemcpyHostToDevice, h->stream));
+        CHK(gen_zero_loss(h));
+        CHK(gen_train_step(h, h->d_rows_step, b_act, (uint32_t)epoch_key, (uint32_t)step_key, h->t + 1));
+        h->t += 1;
+        std::vector<double> ls;
+        CHK(gen_read_loss(h, ls));
+        if (loss_out) for (int k = 0; k < h->K; ++k) loss_out[k] = (float)(ls[(size_t)k] / ((double)b_act * h->O));
+        return DIMN_OK;
+    }
     HIPCHK(hipMemcpyAsync(h->d_rows_step, rows, (size_t)b_act * 4, hipMemcpyHostToDevice, h->stream));
     const uint8_t* dmask = nullptr;
     std::vector<uint8_t> padded;
@@ -963,6 +1054,19 @@ extern "C" int dimn_train_epoch(dimn_handle h, int32_t epoch, const int32_t* per
     }
     CHK(sync_lanes(h));
     HIPCHK(hipMemcpyAsync(h->d_epoch_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, h->stream));
+    if (h->gen) {
+        CHK(gen_zero_loss(h));
+        int step = 0;
+        for (int64_t i0 = 0; i0 < h->n_tr; i0 += h->B, ++step) {
+            const int b_act = (int)std::min<int64_t>(h->B, h->n_tr - i0);
+            CHK(gen_train_step(h, h->d_epoch_rows + i0, b_act, (uint32_t)epoch, (uint32_t)step, h->t + 1));
+            h->t += 1;
+        }
+        std::vector<double> ls;
+        CHK(gen_read_loss(h, ls));
+        if (train_loss) for (int k = 0; k < h->K; ++k) train_loss[k] = ls[(size_t)k] / ((double)h->O * (double)h->n_tr);
+        return DIMN_OK;
+    }
     if (h->res_G && h->act == DIMN_ACT_RELU) return train_epoch_resident(h, epoch, train_loss);
     HIPCHK(hipMemsetAsync(h->d_loss_acc, 0, (size_t)h->K * dm.LS * sizeof(double), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));     // every lane reads the row list and accumulates into d_loss_acc
@@ -1000,6 +1104,7 @@ extern "C" int dimn_val_loss(dimn_handle h, double* val_loss) {
     if (h->n_val < 1) return fail(DIMN_ERR_STATE, "dimn_val_loss: no validation rows (dimn_set_split)");
     for (int32_t r : h->val_rows) if (r < 0 || r >= h->n) return fail(DIMN_ERR_ARG, "dimn_val_loss: validation row %d outside the matrix", r);
     CHK(use_device(h));
+    if (h->gen) return gen_val_loss(h, val_loss);
     const int64_t tiles = (h->n_val + DIMN_TB - 1) / DIMN_TB;
     if (h->loss_part_cap < tiles * h->K) {
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -1065,7 +1170,9 @@ extern "C" int dimn_predict_device(dimn_handle h, const int32_t* rows, int64_t n
         HIPCHK(hipStreamSynchronize(h->stream));
         drows = h->d_pred_rows;
     }
-    if (n_rows > 0) {
+    if (n_rows > 0 && h->gen) {
+        CHK(gen_predict(h, drows, n_rows));
+    } else if (n_rows > 0) {
         DISPATCH_NT(launch_predict, h, drows, n_rows, h->d_out, (float*)nullptr);
         HIPCHK(hipGetLastError());
     }

@@ -1,0 +1,186 @@
+// dimn_general.h -- the GENERAL path of libdimn: every architecture MultiNet.build() accepts that the tuned kernels of
+// dimn_kernels.h do not take (reference deepimpute/multinet.py:135-143: any sequence of Dense / Dropout layers;
+// :150-162: other losses; parser.py:50-66: any batch size, any hidden width).  Same arithmetic definitions (Keras-form
+// Adam, Philox dropout streams, softplus output, wMSE), plain structure: per layer one batched fp32-MFMA GEMM over the
+// sub-nets (64 x 64 output tile per workgroup, operands staged through LDS, transposes resolved while staging) with the
+// layer's epilogue fused, an element-wise loss kernel, and one Adam pass over the flat parameter array.  Correct and
+// reasonably fast, not roofline-tuned: the default architecture (one hidden layer <= 384, batch <= 64) never comes here.
+#pragma once
+#include "dimn_kernels.h"
+
+// loss ids: DIMN_LOSS_* of include/dimn.h
+
+struct GDesc {                 // one GEMM of one sub-net:  C[M][N] = op(A)[M][K] * op(B)[K][N]
+    const float* A; const float* B; float* C;
+    const float* bias;         // epilogue 1, 2: [N]
+    float* G;                  // epilogue 1: gate out [M][N] (ldc); epilogue 3: gate in
+    int32_t N, K, lda, ldb, ldc, kg;
+};
+
+struct GEpi {
+    int32_t mode;              // 0 store; 1 hidden forward (bias, activation, dropout -> C = H, G = gate); 2 bias only; 3 C = acc * G
+    int32_t act, train;        // mode 1
+    float rate, scale;
+    uint64_t seed; uint32_t epoch, step;   // step already carries the dropout layer in its top byte
+};
+
+// dropout key of layer `dl` (0 = first Dropout layer, the stream of the tuned kernels): the layer ordinal rides in the
+// top byte of the step word, so dl = 0 reproduces dimn_dropout_block(seed, kg, epoch, step, ...) exactly
+__host__ __device__ static inline uint32_t gen_step_key(uint32_t step, int dl) { return (step & 0xFFFFFFu) | ((uint32_t)dl << 24); }
+
+// Mo >= 0: the row count of every sub-net (batch rows); Mo < 0: the descriptor's K field is the row count (weight
+// gradients: rows = inputs of the layer, which differ per sub-net) and Ko is the inner dimension (the batch).
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ descs, int Mo, int Ko, GEpi ep) {
+    __shared__ float As[16][68], Bs[16][68];                  // [k][m], [k][n]; 68: conflict-free column reads by 16-lane groups
+    GDesc d = descs[blockIdx.z];
+    const int M = Mo >= 0 ? Mo : d.K;
+    if (Ko >= 0) d.K = Ko;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    if (n0 >= d.N || m0 >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < d.K; k0 += 16) {
+        // stage 64 x 16 of A and 16 x 64 of B (zero outside the matrices); the fast index of the load follows memory
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q;
+            int m, k;
+            if (TA) { m = e & 63; k = e >> 6; } else { k = e & 15; m = e >> 4; }
+            const int gm = m0 + m, gk = k0 + k;
+            As[k][m] = (gm < M && gk < d.K) ? (TA ? d.A[(int64_t)gk * d.lda + gm] : d.A[(int64_t)gm * d.lda + gk]) : 0.f;
+            int n, kb;
+            if (TB) { kb = e & 15; n = e >> 4; } else { n = e & 63; kb = e >> 6; }
+            const int gn = n0 + n, gkb = k0 + kb;
+            Bs[kb][n] = (gn < d.N && gkb < d.K) ? (TB ? d.B[(int64_t)gn * d.ldb + gkb] : d.B[(int64_t)gkb * d.ldb + gn]) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 4) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { a[i] = As[kk + lj][wm + 16 * i + li]; b[i] = Bs[kk + lj][wn + 16 * i + li]; }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = MFMA16(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + 16 * j + li;
+            if (col >= d.N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm + 16 * i + 4 * lj + r;
+                if (row >= M) continue;
+                const int64_t o = (int64_t)row * d.ldc + col;
+                float v = acc[i][j][r];
+                if (ep.mode == 1) {
+                    v += d.bias[col];
+                    float f, df;
+                    hidden_act(ep.act, v, f, df);
+                    if (ep.train) {
+                        const bool keep = !(ep.rate > 0.f) || dimn_dropout_keep(ep.seed, (uint32_t)d.kg, ep.epoch, ep.step, (uint32_t)(row * d.N + col), ep.rate);
+                        d.C[o] = keep ? f * ep.scale : 0.f;
+                        d.G[o] = keep ? df * ep.scale : 0.f;
+                    } else {
+                        d.C[o] = f;
+                    }
+                } else if (ep.mode == 2) {
+                    d.C[o] = v + d.bias[col];
+                } else if (ep.mode == 3) {
+                    d.C[o] = v * d.G[o];
+                } else {
+                    d.C[o] = v;
+                }
+            }
+        }
+}
+
+// Xb[k][b][Dp_k] = X_k[rows[b]][:]  (the batch rows of every sub-net, dense, so that every GEMM operand is a plain matrix)
+__global__ __launch_bounds__(256) void k_gen_gather_batch(const SubnetDev* __restrict__ sn, const float* __restrict__ X, const int32_t* __restrict__ rows,
+                                                          int64_t row0, int b_cnt, float* __restrict__ Xb, int64_t xb_stride, int ldx) {
+    const int k = blockIdx.y;
+    const SubnetDev s = sn[k];
+    for (int b = blockIdx.x; b < b_cnt; b += gridDim.x) {
+        const int64_t row = rows ? rows[b] : row0 + b;
+        const float* src = X + s.xoff + row * s.Dp;
+        float* dst = Xb + (int64_t)k * xb_stride + (int64_t)b * ldx;
+        for (int d = threadIdx.x; d < s.Dp; d += 256) dst[d] = src[d];
+    }
+}
+
+// Output layer: yhat = softplus(Z); the loss of build()'s `loss` (multinet.py:150-162) and dZ = dL/dZ in place.
+// grid (K), block 256.  out != NULL (predict): out[(row0 + b)][k*O + o] = yhat, no loss.  loss_sum[k] += sum of the
+// per-element loss terms (the caller divides by the element count); train != 0 writes dZ over Z.
+__global__ __launch_bounds__(256) void k_gen_output(float* __restrict__ Z, int ldz, int64_t z_stride, const float* __restrict__ Y, int64_t n_cells,
+                                                    const int32_t* __restrict__ rows, int64_t row0, int b_cnt, Dims dm, int loss, int train,
+                                                    float inv_n, double* __restrict__ loss_sum, float* __restrict__ out, int64_t out_row0, int k_off) {
+    __shared__ double red[4];
+    const int k = blockIdx.x;
+    float* z = Z + (int64_t)k * z_stride;
+    double ls = 0.0;
+    for (int e = threadIdx.x; e < b_cnt * dm.O; e += 256) {
+        const int b = e / dm.O, o = e - b * dm.O;
+        const float zz = z[(int64_t)b * ldz + o];
+        if (out) {
+            out[((out_row0 + b) * dm.K + k) * dm.O + o] = softplus_f(zz);
+            continue;
+        }
+        const int64_t row = rows ? rows[b] : row0 + b;
+        const float y = Y[((int64_t)(k + k_off) * n_cells + row) * dm.Op + o];
+        float sp, sg;
+        if (train) softplus_sigmoid_fast(zz, sp, sg); else { sp = softplus_f(zz); sg = 0.f; }
+        const float er = y - sp;
+        float term, dy;                                          // loss term and dL/dyhat * N
+        if (loss == DIMN_LOSS_MAE) { term = fabsf(er); dy = er > 0.f ? -1.f : (er < 0.f ? 1.f : 0.f); }
+        else {
+            const float w = loss == DIMN_LOSS_WMSE ? y : (loss == DIMN_LOSS_WMSE_BINARY ? (y > 0.f ? 1.f : 0.f) : 1.f);
+            term = w * er * er; dy = -2.f * w * er;
+        }
+        ls += (double)term;
+        if (train) z[(int64_t)b * ldz + o] = dy * inv_n * sg;
+    }
+    if (out) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ls += __shfl_xor(ls, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ls;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_sum[k] += red[0] + red[1] + red[2] + red[3];
+}
+
+// bias gradients: gb[n] = sum_b dZ[b][n]   (one workgroup per (sub-net, layer) entry of `descs`: C = gb, A = dZ, N, lda)
+__global__ __launch_bounds__(256) void k_gen_colsum(const GDesc* __restrict__ descs, int M) {
+    const GDesc d = descs[blockIdx.x];
+    for (int n = threadIdx.x; n < d.N; n += 256) {
+        float s = 0.f;
+        for (int b = 0; b < M; ++b) s += d.A[(int64_t)b * d.lda + n];
+        d.C[n] = s;
+    }
+}
+
+// Keras-form Adam over the flat parameter array (every kernel and bias of every sub-net of the handle)
+__global__ __launch_bounds__(256) void k_gen_adam(float* __restrict__ P, float* __restrict__ Mo, float* __restrict__ Vo, const float* __restrict__ Gr,
+                                                  int64_t n, AdamP ap) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float w = P[i], m = Mo[i], v = Vo[i];
+        adam1(w, m, v, Gr[i], ap);
+        P[i] = w; Mo[i] = m; Vo[i] = v;
+    }
+}
+
+// Glorot-uniform kernels (Keras Dense default), Philox stream keyed (seed, global sub-net, layer, element) as k_init_weights
+__global__ __launch_bounds__(256) void k_gen_init(float* __restrict__ W, int64_t n, uint64_t seed, uint32_t kg, uint32_t layer, float limit) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
+        W[e] = dimn_init_value(seed, kg, layer, (uint32_t)e, limit);
+}

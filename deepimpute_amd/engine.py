@@ -168,6 +168,82 @@ class Engine:
         return perm
 
 
+class GeneralEngine(Engine):
+    """Engine for ANY architecture build() accepts (reference deepimpute/multinet.py:135-162): `layers` = the hidden Dense
+    layers as (neurons, activation name, dropout rate behind it); batch size and widths unrestricted; loss in
+    _cabi.LOSSES.  Same face as Engine; models with several hidden layers move weights per layer."""
+
+    def __init__(self, fns, D, layers, out_dim, batch_size=64, learning_rate=1e-4, beta1=0.9, beta2=0.999, eps=1e-7,
+                 loss="wmse", seed=1234, device_id=0, subnet_offset=0):
+        self._f = fns
+        self.D = [int(d) for d in D]
+        self.K = len(self.D)
+        self.layers = [(int(n), "linear" if a is None else str(a).lower(), float(p)) for n, a, p in layers]
+        self.L = len(self.layers)
+        self.H = self.layers[0][0]
+        self.O = int(out_dim)
+        self.B = int(batch_size)
+        self.subnet_offset = int(subnet_offset)
+        self.loss = str(loss).lower()
+        if self.loss not in _cabi.LOSSES:
+            raise NotImplementedError("loss %r: implemented are %s" % (loss, sorted(_cabi.LOSSES)))
+        for _, a, _p in self.layers:
+            if a not in _cabi.ACTIVATIONS:
+                raise NotImplementedError("hidden activation %r: implemented are %s" % (a, sorted(_cabi.ACTIVATIONS)))
+        self.cfg = Config(n_subnets=self.K, subnet_offset=int(subnet_offset), hidden=self.H, out_dim=self.O, batch_size=self.B,
+                          device_id=int(device_id), dropout_rate=0.0, learning_rate=float(learning_rate), beta1=float(beta1),
+                          beta2=float(beta2), eps=float(eps), loss_binary=int(self.loss == "wmse_binary"), seed=int(seed))
+        arr = (_cabi.Layer * self.L)(*[_cabi.Layer(n, _cabi.ACTIVATIONS[a], p) for n, a, p in self.layers])
+        self._h = C.c_void_p()
+        self.n_cells = self.n_train = self.n_val = 0
+        self._check(self._f["create_general"](C.byref(self.cfg), p_i32(i32(self.D)), arr, self.L, _cabi.LOSSES[self.loss], C.byref(self._h)))
+        self.activation = self.layers[0][1]
+
+    def layer_shape(self, k, layer):
+        widths = [n for n, _, _ in self.layers] + [self.O]
+        return (self.D[k] if layer == 0 else widths[layer - 1]), widths[layer]
+
+    def set_layer_weights(self, k, layer, W, b):
+        W, b = f32(W), f32(b)
+        assert W.shape == self.layer_shape(k, layer) and b.shape == (W.shape[1],)
+        self._check(self._f["set_layer_weights"](self._h, k, layer, p_f32(W), p_f32(b)))
+
+    def get_layer_weights(self, k, layer, which=0):
+        n_in, n_out = self.layer_shape(k, layer)
+        W, b = np.empty((n_in, n_out), np.float32), np.empty(n_out, np.float32)
+        self._check(self._f["get_layer_weights"](self._h, k, layer, int(which), p_f32(W), p_f32(b)))
+        return W, b
+
+    # the four-array face of the one-hidden-layer model, for code that treats every engine alike (save/load)
+    def get_weights(self, k):
+        out = []
+        for layer in range(self.L + 1):
+            out.extend(self.get_layer_weights(k, layer))
+        return tuple(out)
+
+    def set_weights(self, k, *arrays):
+        assert len(arrays) == 2 * (self.L + 1)
+        for layer in range(self.L + 1):
+            self.set_layer_weights(k, layer, arrays[2 * layer], arrays[2 * layer + 1])
+
+    def get_adam_state(self, k, which):
+        out = []
+        for layer in range(self.L + 1):
+            out.extend(self.get_layer_weights(k, layer, 1 + int(which)))
+        return tuple(out)
+
+    def train_step(self, rows, keep_mask=None, epoch_key=0, step_key=0, want_loss=True):
+        if keep_mask is not None:
+            raise NotImplementedError("injected keep masks exist only for the one-hidden-layer engine")
+        rows = i32(rows)
+        loss = np.empty(self.K, np.float32) if want_loss else None
+        if "train_step_general" in self._f:
+            self._check(self._f["train_step_general"](self._h, p_i32(rows), rows.size, int(epoch_key), int(step_key), p_f32(loss)))
+        else:
+            self._check(self._f["train_step"](self._h, p_i32(rows), rows.size, None, int(epoch_key), int(step_key), p_f32(loss)))
+        return loss
+
+
 class HipEngine(Engine):
     """Engine on libdimn.so (hand-written HIP kernels for gfx950).  Raises ImportError-like
     `DimnError` when the library is not built: the product never falls back to a CPU path."""
@@ -238,3 +314,11 @@ class HipEngine(Engine):
 
     def comm_destroy(self):
         self._check(self._f["comm_destroy"](self._h))
+
+
+class HipGeneralEngine(GeneralEngine, HipEngine):
+    """GeneralEngine on libdimn.so (dimn_create_general: batched fp32-MFMA GEMMs per layer, dimn_general.h)."""
+
+    def __init__(self, D, layers, out_dim, **kw):
+        from ._lib import load
+        GeneralEngine.__init__(self, load(), D, layers, out_dim, **kw)

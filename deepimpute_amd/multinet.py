@@ -136,30 +136,46 @@ def inspect_data(data):
     print(data.iloc[:3, :3])
 
 
-def _hidden_and_dropout(architecture):
-    """(H, p, activation) of an architecture list.  The kernels implement Dense(H, act) [-> Dropout(p)]
-    -> Dense(O, softplus) with act in relu / linear / sigmoid / tanh / elu / softplus: the form of
-    loadDefaultArchitecture (multinet.py:99-103) and of every caller in the reference tree
-    (deepImpute.py:24-26, tests/multinet_test.py:17-20), which all use relu."""
+def _parse_architecture(architecture):
+    """[(neurons, activation, dropout rate behind it)] of an architecture list (multinet.py:135-143: a sequence of
+    {"type": "dense", "neurons", "activation"} / {"type": "dropout", "rate"} entries; other types are skipped with the
+    reference's message).  Consecutive Dropout layers compose (keep probabilities multiply would change the stream
+    semantics, so they are rejected); a Dropout before the first Dense layer (dropout on the inputs) is not implemented."""
     from ._cabi import ACTIVATIONS
-    hidden, rate, dropped, act = None, 0.0, False, "relu"
+    layers = []
     for spec in architecture:
         kind = str(spec.get("type", "")).lower()
-        if kind == "dense" and hidden is None and not dropped:
-            name = spec.get("activation", "relu")
+        if kind == "dense":
+            name = spec.get("activation", None)
             act = "linear" if name is None else str(name).lower()
             if act not in ACTIVATIONS:
                 raise NotImplementedError("hidden activation %r: the gfx950 kernels implement %s" % (name, sorted(ACTIVATIONS)))
-            hidden = int(spec["neurons"])
-        elif kind == "dropout" and hidden is not None and not dropped:
-            rate, dropped = float(spec["rate"]), True
-        elif kind in ("dense", "dropout"):
-            raise NotImplementedError("only [dense, dropout] architectures are implemented, got %r" % (architecture,))
+            layers.append([int(spec["neurons"]), act, 0.0])
+        elif kind == "dropout":
+            if not layers or layers[-1][2] > 0.0:
+                raise NotImplementedError("a Dropout layer must follow a Dense layer (got %r)" % (architecture,))
+            layers[-1][2] = float(spec["rate"])
         else:
             print("Unknown layer type.")       # the reference skips such entries (multinet.py:142-143)
-    if hidden is None:
-        raise NotImplementedError("architecture needs a hidden dense layer")
-    return hidden, rate, act
+    if not layers:
+        raise NotImplementedError("architecture needs at least one dense layer")
+    return [tuple(l) for l in layers]
+
+
+def _loss_name(loss):
+    """The loss of NN_parameters['loss'] (multinet.py:150-162: the module's wMSE by name or callable, or a keras.losses
+    name) as an id of the engines: wmse / wmse_binary / mean_squared_error / mean_absolute_error."""
+    from ._cabi import LOSSES
+    if callable(loss):
+        binary = bool(getattr(loss, "keywords", {}) and loss.keywords.get("binary"))       # functools.partial(wMSE, binary=True)
+        loss = getattr(getattr(loss, "func", loss), "__name__", str(loss))
+        if binary and str(loss).lower() == "wmse":
+            loss = "wmse_binary"
+    name = str(loss).lower()
+    if name in LOSSES:
+        return name
+    print('Unknown loss: {}. Aborting.'.format(loss))       # multinet.py:160-161 (keras.losses names beyond mse / mae are not implemented)
+    exit(1)
 
 
 # ------------------------------------------------------------------------------- the estimator
@@ -203,20 +219,31 @@ class MultiNet:
         if self.NN_parameters['architecture'] is None:
             self.loadDefaultArchitecture()
         print(self.NN_parameters['architecture'])
-        hidden, rate, act = _hidden_and_dropout(self.NN_parameters['architecture'])
-        loss = self.NN_parameters['loss']
-        loss = getattr(loss, "__name__", loss)
-        if str(loss).lower() != "wmse":
-            print('Unknown loss: {}. Aborting.'.format(loss))
-            exit(1)
+        layers = _parse_architecture(self.NN_parameters['architecture'])
+        loss = _loss_name(self.NN_parameters['loss'])
+        batch = int(self.NN_parameters["batch_size"])
+        common = dict(batch_size=batch, learning_rate=self.NN_parameters["learning_rate"], seed=0 if self.seed is None else self.seed,
+                      device_id=self.device_id, subnet_offset=subnet_offset)
         make = self._engine_factory
+        # the tuned kernels take the reference's default shape family: one hidden layer of <= 384 units (+ dropout),
+        # batch <= 64, wMSE -- loadDefaultArchitecture(), the CLI defaults; everything else build() accepts runs on the
+        # general path (dimn_create_general)
+        tuned = len(layers) == 1 and layers[0][0] <= 384 and batch <= 64 and loss in ("wmse", "wmse_binary")
+        if tuned:
+            if make is None:
+                from .engine import HipEngine as make
+            hidden, act, rate = layers[0]
+            extra = {} if act == "relu" else {"activation": act}
+            if loss == "wmse_binary":
+                extra["loss_binary"] = True
+            return make(list(inputdims), hidden, self.sub_outputdim, dropout_rate=rate, **common, **extra)
         if make is None:
-            from .engine import HipEngine as make
-        return make(list(inputdims), hidden, self.sub_outputdim,
-                    batch_size=self.NN_parameters["batch_size"], dropout_rate=rate,
-                    learning_rate=self.NN_parameters["learning_rate"],
-                    seed=0 if self.seed is None else self.seed,
-                    device_id=self.device_id, subnet_offset=subnet_offset, **({} if act == "relu" else {"activation": act}))
+            from .engine import HipGeneralEngine as make
+        elif hasattr(make, "general"):
+            make = make.general                  # tests: an injected factory may offer a general constructor
+        else:
+            raise NotImplementedError("the injected engine factory has no general constructor for %r" % (self.NN_parameters['architecture'],))
+        return make(list(inputdims), layers, self.sub_outputdim, loss=loss, **common)
 
     # -- persistence (reference: model.json + model.h5, multinet.py:105-124) --
     def save(self, model):
@@ -224,19 +251,19 @@ class MultiNet:
         index: model.npz for a single process, model.rank<r>.npz per rank of a sharded job (one node, one
         file system), so a fresh MultiNet under any world size can load() them."""
         os.makedirs(self.outputdir, exist_ok=True)
-        hidden, rate, _ = _hidden_and_dropout(self.NN_parameters['architecture'])
         comm = self._comm
         rank, world = (comm.rank, comm.world) if comm is not None else (0, 1)
         if rank == 0:
             dims = [len(p) for p in self.predictors] if getattr(self, "predictors", None) is not None else list(model.D)
             with open(os.path.join(self.outputdir, "model.json"), "w") as fh:
-                json.dump({"format": "deepimpute_amd-1", "inputdims": dims, "hidden": hidden,
-                           "dropout_rate": rate, "sub_outputdim": self.sub_outputdim,
-                           "architecture": self.NN_parameters['architecture']}, fh)
+                json.dump({"format": "deepimpute_amd-2", "inputdims": dims, "sub_outputdim": self.sub_outputdim,
+                           "architecture": self.NN_parameters['architecture'], "loss": _loss_name(self.NN_parameters['loss']),
+                           "batch_size": int(self.NN_parameters["batch_size"])}, fh)
         blobs = {}
-        for k in range(model.K):
-            for name, arr in zip(("W1", "b1", "W2", "b2"), model.get_weights(k)):
-                blobs["%s_%d" % (name, self._first_subnet + k)] = arr
+        for k in range(model.K):                         # dense layer l (1-based, the last one is the output layer): Wl_<k>, bl_<k>
+            arrays = model.get_weights(k)
+            for i, arr in enumerate(arrays):
+                blobs["%s%d_%d" % ("Wb"[i % 2], i // 2 + 1, self._first_subnet + k)] = arr
         if world == 1:
             for stale in glob.glob(os.path.join(self.outputdir, "model.rank*.npz")):
                 os.remove(stale)
@@ -253,6 +280,10 @@ class MultiNet:
                 meta = json.load(fh)
             self.NN_parameters['architecture'] = meta["architecture"]
             self.sub_outputdim = meta["sub_outputdim"]
+            if "loss" in meta:
+                self.NN_parameters['loss'] = meta["loss"]
+            if "batch_size" in meta:
+                self.NN_parameters['batch_size'] = meta["batch_size"]
             engine, _, counts = self._build_shard(meta["inputdims"])
             files = sorted(glob.glob(os.path.join(self.outputdir, "model.rank*.npz"))) or [os.path.join(self.outputdir, "model.npz")]
             wanted = set(range(self._first_subnet, self._first_subnet + engine.K))
@@ -260,7 +291,9 @@ class MultiNet:
                 with np.load(path) as z:
                     for g in sorted(wanted):
                         if "W1_%d" % g in z.files:
-                            engine.set_weights(g - self._first_subnet, *(z["%s_%d" % (nm, g)] for nm in ("W1", "b1", "W2", "b2")))
+                            n_dense = sum(1 for f in z.files if f.startswith("W") and f.endswith("_%d" % g))
+                            arrays = [z["%s%d_%d" % (wb, l, g)] for l in range(1, n_dense + 1) for wb in "Wb"]
+                            engine.set_weights(g - self._first_subnet, *arrays)
                             wanted.discard(g)
             if wanted:
                 raise FileNotFoundError("weights of sub-networks %s not found in %s" % (sorted(wanted), self.outputdir))

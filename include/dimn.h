@@ -68,8 +68,33 @@ int dimn_abi_version(void);
  * to place one process per GPU; the reference has no analogue (multinet.py:222-223 sizes CPU threads). */
 int dimn_device_count(int32_t* n);
 
-/* build(inputdims) (multinet.py:126-148,226): D[k] = predictor count of sub-net k. */
+/* build(inputdims) (multinet.py:126-148,226): D[k] = predictor count of sub-net k.  The tuned kernels: one hidden
+ * Dense layer of at most 384 units (+ Dropout), batch <= DIMN_MAX_BATCH, wMSE -- loadDefaultArchitecture() and the CLI
+ * defaults.  Everything else build() accepts goes through dimn_create_general. */
 int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle* out);
+
+/* build(inputdims) for ANY architecture list and loss (multinet.py:135-143: a sequence of Dense / Dropout layers;
+ * :150-162: loss by name; parser.py:50-66: any batch size / hidden width): the hidden Dense layers in order, each with
+ * the rate of the Dropout layer behind it (0 = none); Dense(out_dim, softplus) is implied (multinet.py:145).
+ * cfg->hidden / dropout_rate / loss_binary are ignored here.  Every other entry point works on such a handle; weights of
+ * models with more than one hidden layer move through dimn_set/get_layer_weights.  Dropout layer j (j-th layer with a
+ * rate > 0) draws from the Philox stream keyed (seed, sub-net, epoch, step | j << 24, element): j = 0 is the stream
+ * of the tuned kernels, so both paths train the default architecture on identical masks. */
+typedef struct dimn_layer {
+    int32_t neurons;          /* units of the Dense layer                        */
+    int32_t activation;       /* DIMN_ACT_*                                      */
+    float dropout_rate;       /* rate of the Dropout layer that follows; 0: none */
+} dimn_layer;
+#define DIMN_LOSS_WMSE 0          /* multinet.py:36-41                                  */
+#define DIMN_LOSS_WMSE_BINARY 1   /* wMSE(binary=True)                                  */
+#define DIMN_LOSS_MSE 2           /* keras.losses.mean_squared_error                    */
+#define DIMN_LOSS_MAE 3           /* keras.losses.mean_absolute_error                   */
+int dimn_create_general(const dimn_config* cfg, const int32_t* D, const dimn_layer* layers, int32_t n_layers,
+                        int32_t loss, dimn_handle* out);
+/* Keras-layout kernel W[in][out] and bias[out] of dense layer `layer` (0 .. n_layers; the last one is the output layer);
+ * get: which = 0 weights, 1 Adam m, 2 Adam v. */
+int dimn_set_layer_weights(dimn_handle h, int32_t k, int32_t layer, const float* W, const float* b);
+int dimn_get_layer_weights(dimn_handle h, int32_t k, int32_t layer, int32_t which, float* W, float* b);
 int dimn_destroy(dimn_handle h);
 
 /*

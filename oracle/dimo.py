@@ -5,7 +5,7 @@ import os
 import subprocess
 
 from deepimpute_amd import _cabi
-from deepimpute_amd.engine import Engine
+from deepimpute_amd.engine import Engine, GeneralEngine
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _cache = {}
@@ -33,3 +33,23 @@ class OracleEngine(Engine):
 
     def __init__(self, D, hidden, out_dim, fp64=False, lib_path=None, **kw):
         super().__init__(_load(fp64, lib_path), D, hidden, out_dim, **kw)
+
+
+def _load_general(fp64=False):
+    name = os.path.join(_HERE, "libdimo_gen64.so" if fp64 else "libdimo_gen.so")
+    if name not in _cache:
+        if not os.path.exists(name):
+            build()
+        lib = C.CDLL(name)
+        lib.dimog_real_bytes.restype = C.c_int
+        assert lib.dimog_real_bytes() == (8 if fp64 else 4)
+        _cache[name] = _cabi.bind_general_oracle(lib)
+    return _cache[name]
+
+
+class GeneralOracleEngine(GeneralEngine):
+    """The general CPU oracle (oracle/dimo_general.c) behind the GeneralEngine face."""
+
+    def __init__(self, D, layers, out_dim, fp64=False, **kw):
+        kw.pop("device_id", None)
+        super().__init__(_load_general(fp64), D, layers, out_dim, **kw)

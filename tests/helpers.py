@@ -150,3 +150,38 @@ def check_activation_kat(cls, name, rtol, atol, **kw):
         np.testing.assert_allclose(got, z["%s/%s" % (name, nm)], rtol=rtol, atol=atol, err_msg="%s %s" % (name, nm))
     np.testing.assert_allclose(eng.predict(), z[name + "/predict"], rtol=rtol, atol=atol, err_msg=name + " predict")
     eng.close()
+
+
+def check_general_kat(cls, loss, rtol, atol, **kw):
+    """Two optimiser steps (batch 100 > 64, then a partial batch) + predict of the two-hidden-layer model of
+    tests/golden/kat_general.npz (torch-fp64 autograd, make_general.py) for one loss, on a GeneralEngine class."""
+    z = np.load(os.path.join(GOLDEN, "kat_general.npz"))
+    Ds = [int(d) for d in z["Ds"]]
+    layers = [(int(w), str(a), float(p)) for w, a, p in zip(z["widths"], z["acts"], z["rates"])]
+    eng = cls(Ds, layers, int(z["O"]), batch_size=int(z["B"]), learning_rate=float(z["lr"]), beta1=float(z["beta1"]), beta2=float(z["beta2"]),
+              eps=float(z["eps"]), loss=loss, seed=int(z["seed"]), subnet_offset=int(z["subnet_offset"]), **kw)
+    eng.set_matrix(z["norm"])
+    for k in range(len(Ds)):
+        eng.set_indices(k, z["pred%d" % k], z["targ%d" % k])
+    eng.gather(True)
+    n = z["norm"].shape[0]
+    eng.set_split(np.arange(n - 8, dtype=np.int32), np.arange(n - 8, n, dtype=np.int32))
+    for k in range(len(Ds)):
+        for l in range(3):
+            eng.set_layer_weights(k, l, z["init_W_%d_%d" % (k, l)], z["init_b_%d_%d" % (k, l)])
+    for t in range(2):
+        got = eng.train_step(z["rows_%d" % t], epoch_key=0, step_key=t)
+        for k in range(len(Ds)):
+            np.testing.assert_allclose(got[k], z["%s/loss_%d" % (loss, k)][t], rtol=rtol, err_msg="%s loss step %d k=%d" % (loss, t, k))
+    assert eng.step_count() == 2
+    pred = eng.predict()
+    O = int(z["O"])
+    for k in range(len(Ds)):
+        for l in range(3):
+            W, b = eng.get_layer_weights(k, l)
+            np.testing.assert_allclose(W, z["%s/W_%d_%d" % (loss, k, l)], rtol=rtol, atol=atol, err_msg="%s W k=%d l=%d" % (loss, k, l))
+            np.testing.assert_allclose(b, z["%s/b_%d_%d" % (loss, k, l)], rtol=rtol, atol=atol, err_msg="%s b k=%d l=%d" % (loss, k, l))
+            vW, _ = eng.get_layer_weights(k, l, which=2)
+            np.testing.assert_allclose(vW, z["%s/vW_%d_%d" % (loss, k, l)], rtol=10 * rtol, atol=atol * 1e-4, err_msg="%s v k=%d l=%d" % (loss, k, l))
+        np.testing.assert_allclose(pred[:, k * O:(k + 1) * O], z["%s/predict_%d" % (loss, k)], rtol=rtol, atol=atol, err_msg="%s predict k=%d" % (loss, k))
+    eng.close()

@@ -1,0 +1,77 @@
+"""GPU parity of the GENERAL path (dimn_create_general: any architecture / batch size / loss; reference
+deepimpute/multinet.py:135-162, parser.py:50-66) against torch-fp64 goldens and the general CPU oracle."""
+import numpy as np
+import pytest
+
+from helpers import check_general_kat, make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    from deepimpute_amd.engine import HipGeneralEngine
+    return HipGeneralEngine
+
+
+def _oracle():
+    from oracle.dimo import GeneralOracleEngine
+    return GeneralOracleEngine
+
+
+@pytest.mark.parametrize("loss", ["wmse", "wmse_binary", "mse", "mae"])
+def test_general_kat_matches_autograd_golden(loss):
+    check_general_kat(_hip(), loss, rtol=3e-4, atol=2e-6)
+
+
+def _pair(prob, layers, **kw):
+    out = []
+    for cls in (_hip(), _oracle()):
+        e = cls(prob["Ds"], layers, prob["O"], **kw)
+        e.set_matrix(prob["norm"])
+        for k in range(len(prob["Ds"])):
+            e.set_indices(k, prob["pred"][k], prob["targ"][k])
+        e.gather(True)
+        e.set_split(prob["train"], prob["val"])
+        e.init_weights()
+        out.append(e)
+    return out
+
+
+@pytest.mark.parametrize("layers,B,loss", [
+    ([(512, "relu", 0.2)], 128, "wmse"),                                  # hidden > 384, batch > 64 (deepImpute --batch-size 128)
+    ([(96, "relu", 0.3), (64, "tanh", 0.0), (48, "elu", 0.1)], 200, "wmse"),   # three hidden layers, one without dropout
+    ([(300, "relu", 0.2)], 333, "mse"),                                   # odd batch, keras loss by name
+    ([(40, "sigmoid", 0.0)], 16, "mae"),
+])
+def test_general_two_epochs_match_oracle(layers, B, loss):
+    prob = make_problem(n=700, g=600, Ds=[130, 77, 200], H=layers[0][0], O=100, seed=21)
+    a, b = _pair(prob, layers, batch_size=B, learning_rate=1e-3, seed=4242, loss=loss)
+    for k in range(a.K):                                                   # Glorot init per layer: bit-exact
+        for x, y in zip(a.get_weights(k), b.get_weights(k)):
+            assert np.array_equal(x, y)
+    for epoch in range(2):
+        np.testing.assert_allclose(a.train_epoch(epoch), b.train_epoch(epoch), rtol=1e-4)
+        np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
+    assert a.step_count() == b.step_count()
+    for k in range(a.K):
+        for x, y in zip(a.get_weights(k), b.get_weights(k)):
+            np.testing.assert_allclose(x, y, rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=1e-4, atol=1e-6)
+    rows = prob["train"][:50]
+    np.testing.assert_allclose(a.predict(rows), b.predict(rows), rtol=1e-4, atol=1e-6)
+    a.close(); b.close()
+
+
+def test_general_path_equals_tuned_kernels_on_default_architecture():
+    """Same Philox streams, same init: the general path trains the default architecture like the tuned kernels (fp32 rounding apart)."""
+    from deepimpute_amd.engine import HipEngine
+    from helpers import load_problem
+    prob = make_problem(n=400, g=500, Ds=[150, 90], H=256, O=128, seed=8)
+    kw = dict(batch_size=64, learning_rate=1e-3, seed=31)
+    a = load_problem(HipEngine, prob, dropout_rate=0.2, **kw)
+    b, _ = _pair(prob, [(256, "relu", 0.2)], **kw)
+    a.init_weights()
+    for e in range(2):
+        np.testing.assert_allclose(a.train_epoch(e), b.train_epoch(e), rtol=1e-4)
+    np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=1e-4, atol=1e-6)

@@ -117,3 +117,43 @@ def test_rccl_single_rank_comm_roundtrip():
     got = e.comm_gather_predictions(70, [2], root=0, is_root=True)
     assert np.array_equal(got, ref)
     e.comm_destroy()
+
+
+def test_general_architecture_through_the_shell_matches_oracle(tmp_path):
+    """What the tuned kernels do not take -- two hidden layers, batch 128, a keras loss by name -- through the whole
+    shell on the general path (build -> HipGeneralEngine -> fit -> save/load -> predict) against the general oracle."""
+    from deepimpute_amd.multinet import MultiNet
+    from oracle.dimo import GeneralOracleEngine, OracleEngine
+
+    class Oracles:
+        def __new__(cls, *a, **k):
+            return OracleEngine(*a, **k)
+        general = staticmethod(GeneralOracleEngine)
+    raw = _raw(n=400, g=300, seed=9)
+    kw = dict(sub_outputdim=64, seed=11, ncores=1, verbose=0, max_epochs=3, patience=3, learning_rate=1e-3, batch_size=128, loss="mean_squared_error",
+              architecture=[{"type": "dense", "neurons": 48, "activation": "relu"}, {"type": "dropout", "rate": 0.2},
+                            {"type": "dense", "neurons": 32, "activation": "tanh"}, {"type": "dropout", "rate": 0.1}])
+    a = MultiNet(output_prefix=str(tmp_path / "a"), **kw).fit(raw, NN_lim=128)
+    b = MultiNet(output_prefix=str(tmp_path / "b"), engine_factory=Oracles, **kw).fit(raw, NN_lim=128)
+    assert type(a._engine).__name__ == "HipGeneralEngine" and a.trained_epochs == b.trained_epochs == 3
+    np.testing.assert_allclose(a.history["val_loss"], b.history["val_loss"], rtol=1e-4)
+    np.testing.assert_allclose(a.predict(raw).values, b.predict(raw).values, rtol=1e-4, atol=1e-6)
+    fresh = MultiNet(output_prefix=str(tmp_path / "a"), sub_outputdim=64, seed=11, ncores=1, verbose=0)   # model.json carries architecture, loss, batch size
+    fresh.predictors, fresh.targets = a.predictors, a.targets
+    np.testing.assert_allclose(fresh.predict(raw).values, a.predict(raw).values, rtol=1e-6)
+    assert type(fresh._engine).__name__ == "HipGeneralEngine"
+
+
+def test_cli_with_batch_128_and_hidden_512(tmp_path):
+    """`deepImpute --batch-size 128 --hidden-neurons 512` (legal for the reference, parser.py:50-66) runs on the general path."""
+    from deepimpute_amd.deepImpute import deepImpute
+    raw = _raw(n=300, g=300, seed=9)
+    path = str(tmp_path / "in.csv")
+    raw.to_csv(path)
+    args = dict(inputFile=path, cell_axis="rows", cores=1, learning_rate=1e-3, batch_size=128, max_epochs=4, output_neurons=64, hidden_neurons=512,
+                dropout_rate=0.2, subset=1, limit=128, minVMR=0.5, n_pred=None, policy="restore", output=None)
+    with mock.patch("argparse.ArgumentParser.parse_args", return_value=argparse.Namespace(**args)):
+        out = deepImpute()
+    assert out.shape == raw.shape and np.isfinite(out.values).all()
+    pos = raw.values > 0
+    assert np.array_equal(out.values[pos], raw.values[pos])

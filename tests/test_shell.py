@@ -157,14 +157,41 @@ def test_unsupported_architecture_is_loud():
                    architecture=[{"type": "dense", "neurons": 8, "activation": "swish"}])
     with pytest.raises(NotImplementedError):
         net.build([10])
-    with pytest.raises(NotImplementedError):           # two hidden layers: not implemented
+    with pytest.raises(NotImplementedError):           # two hidden layers: the general path, which this injected factory lacks
         MultiNet(engine_factory=FakeEngine, ncores=1, architecture=[{"type": "dense", "neurons": 8, "activation": "relu"},
+                                                                    {"type": "dense", "neurons": 8, "activation": "relu"}]).build([10])
+    with pytest.raises(NotImplementedError):           # dropout on the inputs
+        MultiNet(engine_factory=FakeEngine, ncores=1, architecture=[{"type": "dropout", "rate": 0.1},
                                                                     {"type": "dense", "neurons": 8, "activation": "relu"}]).build([10])
     eng = MultiNet(engine_factory=FakeEngine, ncores=1,
                    architecture=[{"type": "dense", "neurons": 8, "activation": "tanh"}, {"type": "dropout", "rate": 0.1}]).build([10])
     assert eng.kw["activation"] == "tanh" and eng.H == 8 and abs(eng.kw["dropout_rate"] - 0.1) < 1e-12
-    with pytest.raises(SystemExit):
-        MultiNet(engine_factory=FakeEngine, ncores=1, loss="mse").build([10])
+    with pytest.raises(SystemExit):                    # the reference's "Unknown loss ... Aborting." (multinet.py:160-161)
+        MultiNet(engine_factory=FakeEngine, ncores=1, loss="not_a_loss").build([10])
+
+
+def test_general_architectures_reach_the_general_engine():
+    """build() routes what the tuned kernels do not take -- several hidden layers, hidden > 384, batch > 64, keras losses
+    by name -- to the general constructor with the parsed layer list (multinet.py:135-162, parser.py:50-66)."""
+    calls = []
+
+    class Factory(FakeEngine):
+        @staticmethod
+        def general(D, layers, out_dim, **kw):
+            calls.append((list(D), list(layers), out_dim, kw))
+            return "general"
+    arch = [{"type": "dense", "neurons": 600, "activation": "relu"}, {"type": "dropout", "rate": 0.3},
+            {"type": "dense", "neurons": 64, "activation": "tanh"}]
+    assert MultiNet(engine_factory=Factory, ncores=1, architecture=arch, batch_size=128, loss="mean_squared_error", seed=7).build([10, 12]) == "general"
+    D, layers, out_dim, kw = calls[-1]
+    assert D == [10, 12] and layers == [(600, "relu", 0.3), (64, "tanh", 0.0)] and out_dim == 512
+    assert kw["batch_size"] == 128 and kw["loss"] == "mean_squared_error" and kw["seed"] == 7
+    # each of the three limits of the tuned kernels alone is enough
+    for extra in (dict(batch_size=65), dict(architecture=[{"type": "dense", "neurons": 400, "activation": "relu"}]), dict(loss="mae")):
+        assert MultiNet(engine_factory=Factory, ncores=1, **extra).build([10]) == "general"
+    # and the default family stays on the tuned kernels
+    eng = MultiNet(engine_factory=Factory, ncores=1).build([10])
+    assert isinstance(eng, FakeEngine) and eng.H == 256
 
 
 def test_cli_parser_matches_reference_flags(monkeypatch):
