@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_BATCH = 64
 COMM_ID_BYTES = 128
 # hidden-layer activations the kernels implement (ids = DIMN_ACT_* of include/dimn.h; Keras names)
@@ -33,6 +33,7 @@ class Config(C.Structure):
         ("eps", C.c_float),
         ("loss_binary", C.c_int32),
         ("seed", C.c_uint64),
+        ("precision", C.c_int32),
     ]
 
 
@@ -41,6 +42,7 @@ class Layer(C.Structure):
     _fields_ = [("neurons", C.c_int32), ("activation", C.c_int32), ("dropout_rate", C.c_float)]
 
 
+PRECISIONS = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 LOSSES = {"wmse": 0, "wmse_binary": 1, "mean_squared_error": 2, "mse": 2, "mean_absolute_error": 3, "mae": 3}
 
 _H = C.c_void_p
@@ -84,6 +86,7 @@ GENERAL = {
 GPU_ONLY = {
     "abi_version": [],
     "device_count": [C.POINTER(C.c_int32)],
+    "set_matrix_streamed": [_H, _pf, _i64, _i64, _i32],
     "predict_device": [_H, _pi, _i64, C.POINTER(C.c_void_p)],
     "synchronize": [_H],
     "get_timers": [_H, _pd, _i32],

@@ -20,7 +20,7 @@
 #include "dimn_resident.h"
 #include "dimn_general.h"
 
-#define DIMN_ABI_VERSION 2
+#define DIMN_ABI_VERSION 3
 
 // DIMN_TRACE=1: stage times of the host-heavy entry points on stderr (diagnostic)
 struct Trace {
@@ -127,7 +127,7 @@ struct dimn_handle_s {
     int nslots = 0;
     int64_t w1_total = 0, x_total = 0, y_total = 0;
     int64_t n = 0, g = 0, n_tr = 0, n_val = 0;
-    bool gathered = false, gathered_targets = false, have_idx = false;
+    bool gathered = false, gathered_targets = false, have_idx = false, streamed = false;
     // device
     SubnetDev* d_sn = nullptr; Work* d_work = nullptr;
     float *d_norm = nullptr, *d_X = nullptr, *d_Y = nullptr;
@@ -165,10 +165,21 @@ struct dimn_handle_s {
     std::vector<double> ev_bytes;   // algorithmic bytes of the W1 launch bracketed by each event triple
     // comm
     ncclComm_t comm = nullptr; int n_ranks = 1, rank = 0;
+    int prec = 0;                          // DIMN_PREC_*: 1 = X arena in bfloat16, inference GEMMs on the bf16 matrix cores
     struct GenNet* gen = nullptr;          // != NULL: the general path (dimn_general.h) owns the network of this handle
 };
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// run a statement with XT = the element type of this handle's X arena
+#define WITH_XT(h_, ...)                                   \
+    do {                                                   \
+        if ((h_)->prec) { using XT = bf16_t; __VA_ARGS__; } \
+        else { using XT = float; __VA_ARGS__; }             \
+    } while (0)
+#define XBYTES(h_) ((h_)->prec ? 2 : 4)
+
+
 
 static int use_device(dimn_handle h) {
     HIPCHK(hipSetDevice(h->cfg.device_id));
@@ -275,7 +286,7 @@ static void build_resident(dimn_handle h) {
     h->res_G = h->res_S1 = h->res_T1 = 0;
     const Dims& dm = h->dm;
     if (const char* e = getenv("DIMN_RESIDENT")) if (atoi(e) == 0) return;
-    if (dm.HT != 16 || (dm.H & 3) != 0 || h->B > DIMN_TB) return;
+    if (dm.HT != 16 || (dm.H & 3) != 0 || h->B > DIMN_TB || h->prec) return;      // (the resident kernel reads an fp32 X arena)
     int S1 = std::min(8, h->ncu / std::max(1, h->K) / 16);
     if (const char* e = getenv("DIMN_RES_S1")) S1 = std::min(S1, std::max(1, atoi(e)));      // tests: other decompositions
     if (S1 < 1 || dm.OT > 16 * S1) return;
@@ -303,8 +314,11 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
     if (cfg->device_id < 0 || cfg->device_id >= ndev)
         return fail(DIMN_ERR_ARG, "dimn_create: device_id %d out of range (%d devices)", cfg->device_id, ndev);
 
+    if (cfg->precision != DIMN_PREC_F32 && cfg->precision != DIMN_PREC_BF16)
+        return fail(DIMN_ERR_ARG, "dimn_create: precision must be DIMN_PREC_F32 or DIMN_PREC_BF16");
     dimn_handle h = new dimn_handle_s();
     h->cfg = *cfg;
+    h->prec = cfg->precision;
     h->K = cfg->n_subnets; h->H = cfg->hidden; h->O = cfg->out_dim; h->B = cfg->batch_size;
     Dims& dm = h->dm;
     dm.K = h->K; dm.H = h->H; dm.O = h->O;
@@ -509,7 +523,7 @@ extern "C" int dimn_set_matrix(dimn_handle h, const float* norm, int64_t n, int6
     }
     HIPCHK(hipMemcpy(h->d_norm, norm, (size_t)n * g * sizeof(float), hipMemcpyHostToDevice));
     h->n = n; h->g = g;
-    h->gathered = false;
+    h->gathered = false; h->streamed = false;
     return DIMN_OK;
 }
 
@@ -522,9 +536,24 @@ extern "C" int dimn_set_indices(dimn_handle h, int32_t k, const int32_t* pred_id
     return DIMN_OK;
 }
 
-extern "C" int dimn_gather(dimn_handle h, int32_t with_targets) {
-    if (!h) return fail(DIMN_ERR_ARG, "dimn_gather: null handle");
-    if (!h->d_norm) return fail(DIMN_ERR_STATE, "dimn_gather: call dimn_set_matrix first");
+// memcpy of a large block on several host threads (one pageable <-> pinned copy per pipeline stage: a single thread
+// moves ~10 GB/s, the PCIe link five times that)
+static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(hw ? hw / 2 : 8, 24), bytes / (4u << 20)));
+    if (nt <= 1) { memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t chunk = ((bytes + nt - 1) / nt + 63) & ~(size_t)63;
+    for (size_t i = 0; i < nt; ++i) {
+        const size_t a = i * chunk, b = std::min(bytes, a + chunk);
+        if (a >= b) break;
+        th.emplace_back([=] { memcpy((char*)dst + a, (const char*)src + a, b - a); });
+    }
+    for (auto& t : th) t.join();
+}
+
+// Index lists and arenas of the device gather for a matrix of h->n cells (validated against h->g columns).
+static int gather_prepare(dimn_handle h, int32_t with_targets) {
     for (int k = 0; k < h->K; ++k) {
         if ((int)h->pred[k].size() != h->sn[k].D) return fail(DIMN_ERR_STATE, "dimn_gather: dimn_set_indices missing for sub-net %d", k);
         for (int32_t c : h->pred[k]) if (c < 0 || c >= h->g) return fail(DIMN_ERR_ARG, "dimn_gather: predictor column %d out of range", c);
@@ -532,7 +561,6 @@ extern "C" int dimn_gather(dimn_handle h, int32_t with_targets) {
     }
     CHK(use_device(h));
     HIPCHK(hipStreamSynchronize(h->stream));
-    // index lists
     std::vector<int32_t> pflat, tflat;
     std::vector<int64_t> poff(h->K);
     for (int k = 0; k < h->K; ++k) {
@@ -544,7 +572,6 @@ extern "C" int dimn_gather(dimn_handle h, int32_t with_targets) {
     HIPCHK(hipMemcpy(h->d_pred, pflat.data(), pflat.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_targ, tflat.data(), tflat.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_pred_off, poff.data(), poff.size() * 8, hipMemcpyHostToDevice));
-    // arenas
     int64_t x = 0;
     for (int k = 0; k < h->K; ++k) {
         if ((int64_t)h->n * h->sn[k].Dp > 0xffffffffLL) return fail(DIMN_ERR_UNSUP, "dimn_gather: n*Dp exceeds 32-bit row offsets");
@@ -554,7 +581,7 @@ extern "C" int dimn_gather(dimn_handle h, int32_t with_targets) {
     // the arenas are re-used across calls (19.5 GB at cfg3: a hipFree/hipMalloc pair costs up to a second)
     if (!h->d_X || h->x_total != x) {
         DEV_FREE(h->d_X);
-        CHK(dev_alloc(&h->d_X, (size_t)x));
+        HIPCHK(hipMalloc((void**)&h->d_X, std::max<size_t>(1, (size_t)x * XBYTES(h))));
         h->x_total = x;
     }
     const int64_t y_need = (int64_t)h->K * h->n * h->dm.Op;
@@ -564,16 +591,76 @@ extern "C" int dimn_gather(dimn_handle h, int32_t with_targets) {
         h->y_total = y_need;
     }
     HIPCHK(hipMemcpy(h->d_sn, h->sn.data(), h->sn.size() * sizeof(SubnetDev), hipMemcpyHostToDevice));
+    return DIMN_OK;
+}
+// X_k / Y_k rows [row0, row0 + nrows) from a device block of the matrix (the whole matrix, or one streamed block)
+static int gather_block(dimn_handle h, const float* d_block, int64_t nrows, int64_t row0, int32_t with_targets, hipStream_t st) {
     if ((size_t)h->g * sizeof(float) <= 150 * 1024) {      // the row fits in LDS: read `norm` once, serve all sub-nets from LDS
-        hipLaunchKernelGGL(k_gather_lds, dim3((unsigned)std::min<int64_t>(h->n, 2048)), dim3(512), (size_t)h->g * sizeof(float), h->stream,
-                           h->d_sn, h->d_norm, h->n, h->g, h->d_pred, h->d_pred_off, h->d_targ, h->d_X, h->d_Y, h->dm, with_targets ? 1 : 0);
+        const size_t lds = (size_t)h->g * sizeof(float);
+        WITH_XT(h, {
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_gather_lds<XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_gather_lds<XT>, dim3((unsigned)std::min<int64_t>(nrows, 2048)), dim3(512), lds, st, h->d_sn, d_block, nrows, h->g, h->d_pred,
+                               h->d_pred_off, h->d_targ, (XT*)h->d_X, h->d_Y, h->dm, with_targets ? 1 : 0, row0, h->n);
+        });
     } else {
-        dim3 grid((unsigned)h->K, (unsigned)std::min<int64_t>(h->n, 8192));
-        hipLaunchKernelGGL(k_gather, grid, dim3(256), 0, h->stream, h->d_sn, h->d_norm, h->n, h->g, h->d_pred, h->d_pred_off,
-                           h->d_targ, h->d_X, h->d_Y, h->dm, with_targets ? 1 : 0);
+        const dim3 grid((unsigned)h->K, (unsigned)std::min<int64_t>(nrows, 8192));
+        WITH_XT(h, hipLaunchKernelGGL(k_gather<XT>, grid, dim3(256), 0, st, h->d_sn, d_block, nrows, h->g, h->d_pred, h->d_pred_off, h->d_targ,
+                                      (XT*)h->d_X, h->d_Y, h->dm, with_targets ? 1 : 0, row0, h->n));
     }
     HIPCHK(hipGetLastError());
+    return DIMN_OK;
+}
+
+extern "C" int dimn_gather(dimn_handle h, int32_t with_targets) {
+    if (!h) return fail(DIMN_ERR_ARG, "dimn_gather: null handle");
+    if (!h->d_norm) return fail(DIMN_ERR_STATE, h->streamed ? "dimn_gather: the matrix was streamed (dimn_set_matrix_streamed gathers itself)" : "dimn_gather: call dimn_set_matrix first");
+    CHK(gather_prepare(h, with_targets));
+    CHK(gather_block(h, h->d_norm, h->n, 0, with_targets, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->gathered = true;
+    h->gathered_targets = with_targets != 0;
+    return DIMN_OK;
+}
+
+// BASELINE configs[4]: the log1p matrix streamed from host memory in row blocks (pinned bounce buffers, the copy of one
+// block overlapping the gather of the previous one); the device never holds the matrix itself, only the gathered X_k
+// (fp32 or bf16) and Y_k blocks.  Replaces dimn_set_matrix + dimn_gather; needs every dimn_set_indices first.
+extern "C" int dimn_set_matrix_streamed(dimn_handle h, const float* norm, int64_t n, int64_t g, int32_t with_targets) {
+    if (!h || !norm || n < 1 || g < 1) return fail(DIMN_ERR_ARG, "dimn_set_matrix_streamed: bad argument");
+    if (n > 0x7fffffffLL || g > 0x7fffffffLL) return fail(DIMN_ERR_UNSUP, "dimn_set_matrix_streamed: dimension exceeds int32");
+    CHK(use_device(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    DEV_FREE(h->d_norm);
+    if (n != h->n) { h->n_tr = 0; h->n_val = 0; h->train_rows.clear(); h->val_rows.clear(); }
+    h->n = n; h->g = g; h->gathered = false; h->streamed = true;
+    CHK(gather_prepare(h, with_targets));
+    const int64_t blk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(128u << 20) / (g * 4)));
+    float *pin[2] = {nullptr, nullptr}, *dev[2] = {nullptr, nullptr};
+    hipStream_t st[2] = {nullptr, nullptr};
+    int rc = DIMN_OK;
+#define STR_TRY(expr) do { hipError_t e_ = (expr); if (rc == DIMN_OK && e_ != hipSuccess) rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+    for (int b = 0; b < 2; ++b) {
+        STR_TRY(hipHostMalloc((void**)&pin[b], (size_t)blk * g * 4, hipHostMallocDefault));
+        STR_TRY(hipMalloc((void**)&dev[b], (size_t)blk * g * 4));
+        STR_TRY(hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking));
+    }
+    int64_t bi = 0;
+    for (int64_t r0 = 0; r0 < n && rc == DIMN_OK; r0 += blk, ++bi) {
+        const int b = (int)(bi & 1);
+        const int64_t nr = std::min(blk, n - r0);
+        STR_TRY(hipStreamSynchronize(st[b]));               // block bi-2 has left this pair of buffers
+        if (rc != DIMN_OK) break;
+        parallel_memcpy(pin[b], norm + r0 * g, (size_t)nr * g * 4);
+        STR_TRY(hipMemcpyAsync(dev[b], pin[b], (size_t)nr * g * 4, hipMemcpyHostToDevice, st[b]));
+        if (rc == DIMN_OK) rc = gather_block(h, dev[b], nr, r0, with_targets, st[b]);
+    }
+#undef STR_TRY
+    for (int b = 0; b < 2; ++b) {
+        if (st[b]) { (void)hipStreamSynchronize(st[b]); (void)hipStreamDestroy(st[b]); }
+        if (pin[b]) (void)hipHostFree(pin[b]);
+        if (dev[b]) (void)hipFree(dev[b]);
+    }
+    if (rc != DIMN_OK) return rc;
     h->gathered = true;
     h->gathered_targets = with_targets != 0;
     return DIMN_OK;
@@ -750,8 +837,8 @@ static hipEvent_t next_event(dimn_handle h) {
 
 template <int NT>
 static void launch_fwd1(dimn_handle h, const dimn_handle_s::Lane& ln, const int32_t* rows, int b_act) {
-    hipLaunchKernelGGL(k_fwd1<NT>, dim3((unsigned)(ln.w1 - ln.w0)), dim3(256), 0, ln.stream, h->d_work + ln.w0, h->d_sn, h->d_X, h->d_W1,
-                       rows, b_act, h->d_P, h->dm);
+    WITH_XT(h, hipLaunchKernelGGL((k_fwd1<NT, XT>), dim3((unsigned)(ln.w1 - ln.w0)), dim3(256), 0, ln.stream, h->d_work + ln.w0, h->d_sn, (const XT*)h->d_X, h->d_W1,
+                                  rows, b_act, h->d_P, h->dm));
 }
 template <int NT2>
 static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, const int32_t* rows, int b_act, const int32_t* rows_n, int b_next,
@@ -761,26 +848,28 @@ static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, const int32_
     // ev_begin/ev_end (timed launches only): hipExtLaunchKernelGGL stamps them with the kernel's own begin and end,
     // so the elapsed time is the launch's duration without the dispatch latency an event pair around it would add
 #define W1_LAUNCH(KERNEL, THREADS) hipExtLaunchKernelGGL((KERNEL), grid, dim3(THREADS), 0, ln.stream, ev_begin, ev_end, 0, wk, h->d_sn,      \
-                                                         (const float*)h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, \
+                                                         (const XT*)h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, \
                                                          (const float*)h->d_dA, h->d_P, h->dm, ap)
-    if (h->dm.HT == 20 && h->variant == 1)        // H = 300 (padded to 320): 10 waves x 2 hidden tiles, two-set shared-staging variant
-        W1_LAUNCH((k_w1_update_fwd_sh<10, 2, 1>), 640);
-    else if (h->dm.HT == 16 && h->variant == 1)   // H = 256: 16 waves x 1 hidden tile, X tiles staged once per workgroup, 3-set register ring
-        W1_LAUNCH((k_w1_update_fwd_ring<16, 1>), 1024);
-    else if (h->dm.HT == 16 && h->variant == 2)
-        W1_LAUNCH((k_w1_update_fwd_sh<16, 1>), 1024);
-    else if (h->dm.HT == 8 * NT2)
-        W1_LAUNCH((k_w1_update_fwd<NT2, true>), 512);
-    else
-        W1_LAUNCH((k_w1_update_fwd<NT2, false>), 512);
+    WITH_XT(h, {
+        if (h->dm.HT == 20 && h->variant == 1)        // H = 300 (padded to 320): 10 waves x 2 hidden tiles, two-set shared-staging variant
+            W1_LAUNCH((k_w1_update_fwd_sh<10, 2, 1, XT>), 640);
+        else if (h->dm.HT == 16 && h->variant == 1)   // H = 256: 16 waves x 1 hidden tile, X tiles staged once per workgroup, 3-set register ring
+            W1_LAUNCH((k_w1_update_fwd_ring<16, 1, 3, 1, XT>), 1024);
+        else if (h->dm.HT == 16 && h->variant == 2)
+            W1_LAUNCH((k_w1_update_fwd_sh<16, 1, 1, XT>), 1024);
+        else if (h->dm.HT == 8 * NT2)
+            W1_LAUNCH((k_w1_update_fwd<NT2, true, XT>), 512);
+        else
+            W1_LAUNCH((k_w1_update_fwd<NT2, false, XT>), 512);
+    });
 #undef W1_LAUNCH
 }
 template <int NT>
 static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out, float* loss_part) {
     const unsigned tiles = (unsigned)((n_rows + DIMN_TB - 1) / DIMN_TB);
     const size_t lds = (size_t)DIMN_TB * h->dm.ldd * sizeof(float);
-    hipLaunchKernelGGL(k_predict<NT>, dim3(tiles, (unsigned)h->K), dim3(256), lds, h->stream, h->d_sn, h->d_X, h->d_W1, h->d_b1,
-                       h->d_W2, h->d_b2, rows, n_rows, out, h->d_Y, h->n, loss_part, h->dm, h->cfg.loss_binary, h->act);
+    WITH_XT(h, hipLaunchKernelGGL((k_predict<NT, XT>), dim3(tiles, (unsigned)h->K), dim3(256), lds, h->stream, h->d_sn, (const XT*)h->d_X, h->d_W1, h->d_b1,
+                                  h->d_W2, h->d_b2, rows, n_rows, out, h->d_Y, h->n, loss_part, h->dm, h->cfg.loss_binary, h->act));
 }
 #define DISPATCH_NT(fn, ...)                          \
     switch (h->NT) {                                  \
@@ -1209,22 +1298,6 @@ extern "C" int dimn_val_metrics(dimn_handle h, double* out7) {
     }
     (void)hipFree(d);
     return rc;
-}
-
-// memcpy of a large block on several host threads (one pageable <-> pinned copy per pipeline stage: a single thread
-// moves ~10 GB/s, the PCIe link five times that)
-static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
-    const unsigned hw = std::thread::hardware_concurrency();
-    const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(hw ? hw / 2 : 8, 24), bytes / (4u << 20)));
-    if (nt <= 1) { memcpy(dst, src, bytes); return; }
-    std::vector<std::thread> th;
-    const size_t chunk = ((bytes + nt - 1) / nt + 63) & ~(size_t)63;
-    for (size_t i = 0; i < nt; ++i) {
-        const size_t a = i * chunk, b = std::min(bytes, a + chunk);
-        if (a >= b) break;
-        th.emplace_back([=] { memcpy((char*)dst + a, (const char*)src + a, b - a); });
-    }
-    for (auto& t : th) t.join();
 }
 
 // ---- next row: predict() post-processing (multinet.py:282-305) as a device epilogue ----------

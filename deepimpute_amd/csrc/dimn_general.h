@@ -108,15 +108,16 @@ __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ desc
 }
 
 // Xb[k][b][Dp_k] = X_k[rows[b]][:]  (the batch rows of every sub-net, dense, so that every GEMM operand is a plain matrix)
-__global__ __launch_bounds__(256) void k_gen_gather_batch(const SubnetDev* __restrict__ sn, const float* __restrict__ X, const int32_t* __restrict__ rows,
+template <typename XT>
+__global__ __launch_bounds__(256) void k_gen_gather_batch(const SubnetDev* __restrict__ sn, const XT* __restrict__ X, const int32_t* __restrict__ rows,
                                                           int64_t row0, int b_cnt, float* __restrict__ Xb, int64_t xb_stride, int ldx) {
     const int k = blockIdx.y;
     const SubnetDev s = sn[k];
     for (int b = blockIdx.x; b < b_cnt; b += gridDim.x) {
         const int64_t row = rows ? rows[b] : row0 + b;
-        const float* src = X + s.xoff + row * s.Dp;
+        const XT* src = X + s.xoff + row * s.Dp;
         float* dst = Xb + (int64_t)k * xb_stride + (int64_t)b * ldx;
-        for (int d = threadIdx.x; d < s.Dp; d += 256) dst[d] = src[d];
+        for (int d = threadIdx.x; d < s.Dp; d += 256) dst[d] = sizeof(XT) == 2 ? bf16_to_f32((bf16_t)src[d]) : (float)src[d];
     }
 }
 

@@ -44,6 +44,35 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// ---- bf16 X arena (precision DIMN_PREC_BF16: BASELINE configs[4]) -------------------------------------------------
+// The gathered predictor blocks X_k may be stored in bfloat16 (half the arena and half the X traffic; the weights, the
+// Adam state and every accumulation stay fp32).  A kernel templated on the element type XT keeps a tile piece in its
+// RAW form (what the load instruction returns: 16 bytes of fp32 or 8 bytes of bf16) across the software pipeline and
+// expands it to four floats only where the fp32 path would use the registers -- so the load stays asynchronous.
+typedef unsigned short bf16_t;
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+template <typename XT> struct XRaw;
+template <> struct XRaw<float> {
+    f32x4 v;
+    __device__ __forceinline__ void load(const float* p) { v = *(const f32x4*)p; }
+    __device__ __forceinline__ f32x4 get() const { return v; }
+};
+template <> struct XRaw<bf16_t> {
+    uint2 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *(const uint2*)p; }
+    __device__ __forceinline__ f32x4 get() const {
+        return (f32x4){__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+    }
+};
+__host__ __device__ static inline bf16_t f32_to_bf16(float f) {       // round to nearest even (finite inputs)
+    union { float f; uint32_t u; } c; c.f = f;
+    return (bf16_t)((c.u + 0x7fffu + ((c.u >> 16) & 1u)) >> 16);
+}
+__host__ __device__ static inline float bf16_to_f32(bf16_t b) { union { float f; uint32_t u; } c; c.u = (uint32_t)b << 16; return c.f; }
+template <typename XT> __device__ __forceinline__ XT x_store(float f);
+template <> __device__ __forceinline__ float x_store<float>(float f) { return f; }
+template <> __device__ __forceinline__ bf16_t x_store<bf16_t>(float f) { return f32_to_bf16(f); }
+
 // Streamed optimiser state (read once, written once per step).  DIMN_NT bit 0 marks all of B1F1's state loads, bit 4
 // only its m and v loads, bit 1 the state stores non-temporal; bit 2 the split-K partial stores of B1F1, bit 3 the dD
 // partial stores of MFB.  Measured (tools/ab_nt.sh / ab_def.sh, one box, cfg3): non-temporal STATE STORES keep the X
@@ -171,19 +200,22 @@ __device__ __forceinline__ void softplus_sigmoid_fast(float x, float& sp, float&
 // gather: X_k[i][d] = norm[i][pred_k[d]], Y_k[i][o] = norm[i][targ_k[o]]
 // (replaces the K pandas .loc gathers, multinet.py:231-235 / 273-274).  grid (K, rows)
 // ---------------------------------------------------------------------------------------
+// `norm` holds rows [row0, row0 + n) of the matrix of n_all cells (row0 = 0, n = n_all: the whole matrix resident;
+// otherwise one streamed row block, dimn_set_matrix_streamed).
+template <typename XT>
 __global__ __launch_bounds__(256) void k_gather(const SubnetDev* __restrict__ sn, const float* __restrict__ norm,
                                                 int64_t n, int64_t g, const int32_t* __restrict__ pred,
                                                 const int64_t* __restrict__ pred_off, const int32_t* __restrict__ targ,
-                                                float* __restrict__ X, float* __restrict__ Y, Dims dm, int with_targets) {
+                                                XT* __restrict__ X, float* __restrict__ Y, Dims dm, int with_targets, int64_t row0, int64_t n_all) {
     const int k = blockIdx.x;
     const SubnetDev s = sn[k];
     const int32_t* pk = pred + pred_off[k];
     for (int64_t i = blockIdx.y; i < n; i += gridDim.y) {
         const float* row = norm + i * g;
-        float* xr = X + s.xoff + i * s.Dp;
-        for (int d = threadIdx.x; d < s.Dp; d += 256) xr[d] = d < s.D ? row[pk[d]] : 0.f;
+        XT* xr = X + s.xoff + (row0 + i) * s.Dp;
+        for (int d = threadIdx.x; d < s.Dp; d += 256) xr[d] = x_store<XT>(d < s.D ? row[pk[d]] : 0.f);
         if (with_targets) {
-            float* yr = Y + ((int64_t)k * n + i) * dm.Op;
+            float* yr = Y + ((int64_t)k * n_all + row0 + i) * dm.Op;
             const int32_t* tk = targ + (int64_t)k * dm.O;
             for (int o = threadIdx.x; o < dm.Op; o += 256) yr[o] = o < dm.O ? row[tk[o]] : 0.f;
         }
@@ -193,10 +225,11 @@ __global__ __launch_bounds__(256) void k_gather(const SubnetDev* __restrict__ sn
 // Same gather with the matrix row staged ONCE in LDS (g floats <= 160 KB): every sub-net of the
 // workgroup's row is served from LDS, so `norm` is read from HBM once instead of once per sub-net
 // (measured on cfg3: 174 GB fetched by k_gather vs 4 GB needed).  grid = rows (grid-stride).
+template <typename XT>
 __global__ __launch_bounds__(512) void k_gather_lds(const SubnetDev* __restrict__ sn, const float* __restrict__ norm,
                                                     int64_t n, int64_t g, const int32_t* __restrict__ pred,
                                                     const int64_t* __restrict__ pred_off, const int32_t* __restrict__ targ,
-                                                    float* __restrict__ X, float* __restrict__ Y, Dims dm, int with_targets) {
+                                                    XT* __restrict__ X, float* __restrict__ Y, Dims dm, int with_targets, int64_t row0, int64_t n_all) {
     extern __shared__ __attribute__((aligned(16))) float rowbuf[];
     for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
         const float* row = norm + i * g;
@@ -206,10 +239,10 @@ __global__ __launch_bounds__(512) void k_gather_lds(const SubnetDev* __restrict_
         for (int k = 0; k < dm.K; ++k) {
             const SubnetDev s = sn[k];
             const int32_t* pk = pred + pred_off[k];
-            float* xr = X + s.xoff + i * s.Dp;
-            for (int d = threadIdx.x; d < s.Dp; d += 512) __builtin_nontemporal_store(d < s.D ? rowbuf[pk[d]] : 0.f, &xr[d]);   // written once, read much later
+            XT* xr = X + s.xoff + (row0 + i) * s.Dp;
+            for (int d = threadIdx.x; d < s.Dp; d += 512) __builtin_nontemporal_store(x_store<XT>(d < s.D ? rowbuf[pk[d]] : 0.f), &xr[d]);   // written once, read much later
             if (with_targets) {
-                float* yr = Y + ((int64_t)k * n + i) * dm.Op;
+                float* yr = Y + ((int64_t)k * n_all + row0 + i) * dm.Op;
                 const int32_t* tk = targ + (int64_t)k * dm.O;
                 for (int o = threadIdx.x; o < dm.Op; o += 512) __builtin_nontemporal_store(o < dm.O ? rowbuf[tk[o]] : 0.f, &yr[o]);
             }
@@ -241,9 +274,9 @@ __global__ __launch_bounds__(256) void k_init_weights(const SubnetDev* __restric
 // F1: split-K first layer.  Workgroup = (sub-net k, chunk range [c0,c1)); 4 waves, wave w
 // owns hidden tiles [w*NT, w*NT+NT).  P[slot][b][h] = sum_{d in chunks} X[rows[b]][d] W1[d][h]
 // ---------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, typename XT>
 __global__ __launch_bounds__(256) void k_fwd1(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
-                                              const float* __restrict__ X, const float* __restrict__ W1,
+                                              const XT* __restrict__ X, const float* __restrict__ W1,
                                               const int32_t* __restrict__ rows, int b_act,
                                               float* __restrict__ P, Dims dm) {
     const Work wk = work[blockIdx.x];
@@ -258,7 +291,7 @@ __global__ __launch_bounds__(256) void k_fwd1(const Work* __restrict__ work, con
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float* xk = X + s.xoff;
+    const XT* xk = X + s.xoff;
     uint32_t xo[4];
     bool valid[4];
 #pragma unroll
@@ -274,7 +307,7 @@ __global__ __launch_bounds__(256) void k_fwd1(const Work* __restrict__ work, con
         f32x4 a[4], b[NT];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
-            a[mt] = valid[mt] ? *(const f32x4*)(xk + xo[mt] + 16 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            { XRaw<XT> xr_; xr_.load(xk + xo[mt] + 16 * c); a[mt] = valid[mt] ? xr_.get() : (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
             b[nt] = (nt0 + nt < dm.HT) ? *(const f32x4*)(wb + c * cstride + nt * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1012,15 +1045,15 @@ __global__ __launch_bounds__(1024) void k_reduce_dd(const int32_t* __restrict__ 
 // cost ~2x).  State and X tiles of chunk c+1 are prefetched into registers while chunk c
 // computes.
 // ---------------------------------------------------------------------------------------
-template <int NT2, bool FULL>   // FULL: every wave's NT2 tiles exist (HT == 8*NT2) -> no predicated memory ops in the loop
+template <int NT2, bool FULL, typename XT>   // FULL: every wave's NT2 tiles exist (HT == 8*NT2) -> no predicated memory ops in the loop
 __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
-                                                       const float* __restrict__ X, float* __restrict__ W1,
+                                                       const XT* __restrict__ X, float* __restrict__ W1,
                                                        float* __restrict__ M1, float* __restrict__ V1,
                                                        const int32_t* __restrict__ rows_t, int b_act,
                                                        const int32_t* __restrict__ rows_n, int b_next,
                                                        const float* __restrict__ dA, float* __restrict__ P, Dims dm, AdamP ap) {
-    constexpr int XT = DIMN_TB * 16, XN = DIMN_TB * 20;          // floats per staged tile
-    constexpr int WSZ = 2 * (XT + XN);                           // floats of LDS per wave
+    constexpr int XTS = DIMN_TB * 16, XN = DIMN_TB * 20;         // floats per staged tile
+    constexpr int WSZ = 2 * (XTS + XN);                          // floats of LDS per wave
     __shared__ __attribute__((aligned(16))) float sm_all[8 * WSZ];
     const Work wk = work[blockIdx.x];
     const SubnetDev s = sn[wk.k];
@@ -1046,7 +1079,7 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
         for (int nt = 0; nt < NT2; ++nt) bfr[kb][nt] = dak[(4 * kb + lj) * Hp + 16 * tcl[nt] + li];
 
     // staging: pass i (0..3) of this lane moves row 16i + lane/4, 16-byte quarter lane%4
-    const float* xk = X + s.xoff + 4 * (lane & 3);
+    const XT* xk = X + s.xoff + 4 * (lane & 3);
     uint32_t xot[4], xon[4];
     bool vt[4], vn[4];
     const bool have_next = b_next > 0;
@@ -1078,10 +1111,11 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        f32x4 a = *(const f32x4*)(xk + xot[i] + 16 * wk.c0);
-        f32x4 b = *(const f32x4*)(xk + xon[i] + 16 * wk.c0);
-        *(f32x4*)(sm + 256 * i + 4 * lane) = vt[i] ? a : zero4;
-        *(f32x4*)(sm + 2 * XT + (16 * i + (lane >> 2)) * 20 + 4 * (lane & 3)) = vn[i] ? b : zero4;
+        XRaw<XT> a, b;
+        a.load(xk + xot[i] + 16 * wk.c0);
+        b.load(xk + xon[i] + 16 * wk.c0);
+        *(f32x4*)(sm + 256 * i + 4 * lane) = vt[i] ? a.get() : zero4;
+        *(f32x4*)(sm + 2 * XTS + (16 * i + (lane >> 2)) * 20 + 4 * (lane & 3)) = vn[i] ? b.get() : zero4;
     }
     // Retire every prologue load before the loop: otherwise the waitcnt pass, merging the
     // pre-header state into the loop header, drains the in-loop prefetch with vmcnt(0).
@@ -1096,11 +1130,11 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
     for (int c = wk.c0; c < wk.c1; ++c) {
         const int cur = (c - wk.c0) & 1;
         const int cn = c < clast ? c + 1 : clast;            // clamped prefetch (the last one is a harmless re-read)
-        f32x4 xa[4], xb[4];
+        XRaw<XT> xa[4], xb[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            xa[i] = *(const f32x4*)(xk + xot[i] + 16 * cn);
-            xb[i] = *(const f32x4*)(xk + xon[i] + 16 * cn);
+            xa[i].load(xk + xot[i] + 16 * cn);
+            xb[i].load(xk + xon[i] + 16 * cn);
         }
         f32x4 w1[NT2], m1[NT2], v1[NT2];
 #pragma unroll
@@ -1111,7 +1145,7 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
         __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch at the top of the iteration
 
         // gW1 tile: A = X_t^T[d=li][b=4kb+lj] straight out of this wave's linear LDS tile
-        const float* xt = sm + cur * XT;
+        const float* xt = sm + cur * XTS;
         f32x4 g[NT2];
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) g[nt] = zero4;
@@ -1131,7 +1165,7 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
             }
         }
         if (have_next) {
-            const float* xn = sm + 2 * XT + cur * XN;
+            const float* xn = sm + 2 * XTS + cur * XN;
             f32x4 af[4];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) af[mt] = *(const f32x4*)(xn + (16 * mt + li) * 20 + 4 * lj);
@@ -1146,8 +1180,8 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
         // execute in order, no barrier needed)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *(f32x4*)(sm + (cur ^ 1) * XT + 256 * i + 4 * lane) = vt[i] ? xa[i] : zero4;
-            *(f32x4*)(sm + 2 * XT + (cur ^ 1) * XN + (16 * i + (lane >> 2)) * 20 + 4 * (lane & 3)) = vn[i] ? xb[i] : zero4;
+            *(f32x4*)(sm + (cur ^ 1) * XTS + 256 * i + 4 * lane) = vt[i] ? xa[i].get() : zero4;
+            *(f32x4*)(sm + 2 * XTS + (cur ^ 1) * XN + (16 * i + (lane >> 2)) * 20 + 4 * (lane & 3)) = vn[i] ? xb[i].get() : zero4;
         }
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) { w[nt] = w1[nt]; m[nt] = m1[nt]; v[nt] = v1[nt]; }
@@ -1174,15 +1208,15 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
 // grid.y (e.g. <8,1> x 2 for H = 256): two such workgroups fit on one CU, so the prologue/epilogue
 // of one overlaps the streaming of the other.
 // ---------------------------------------------------------------------------------------
-template <int WAVES, int NT2, int MINW = 1>
+template <int WAVES, int NT2, int MINW = 1, typename XT = float>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
-                                                                const float* __restrict__ X, float* __restrict__ W1,
+                                                                const XT* __restrict__ X, float* __restrict__ W1,
                                                                 float* __restrict__ M1, float* __restrict__ V1,
                                                                 const int32_t* __restrict__ rows_t, int b_act,
                                                                 const int32_t* __restrict__ rows_n, int b_next,
                                                                 const float* __restrict__ dA, float* __restrict__ P, Dims dm, AdamP ap) {
-    constexpr int XT = DIMN_TB * 16, XN = DIMN_TB * 20;
-    __shared__ __attribute__((aligned(16))) float sm[2 * (XT + XN)];
+    constexpr int XTS = DIMN_TB * 16, XN = DIMN_TB * 20;
+    __shared__ __attribute__((aligned(16))) float sm[2 * (XTS + XN)];
     const Work wk = work[blockIdx.x];
     const SubnetDev s = sn[wk.k];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1205,9 +1239,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
     const int sb = (tid & 255) >> 2, sq = tid & 3;
     const bool svalid = stager && (stage_next ? (sb < b_next) : (sb < b_act));
     const int32_t* srows = (stage_next && have_next) ? rows_n : rows_t;
-    const float* xsrc = X + s.xoff + (int64_t)srows[svalid ? sb : 0] * s.Dp + 4 * sq;
-    const int sdst = stage_next ? (2 * XT + sb * 20 + 4 * sq) : (sb * 16 + 4 * sq);
-    const int sbuf = stage_next ? XN : XT;
+    const XT* xsrc = X + s.xoff + (int64_t)srows[svalid ? sb : 0] * s.Dp + 4 * sq;
+    const int sdst = stage_next ? (2 * XTS + sb * 20 + 4 * sq) : (sb * 16 + 4 * sq);
+    const int sbuf = stage_next ? XN : XTS;
 
     const int64_t cstride = (int64_t)Hp * 16;
     int64_t wb[NT2];
@@ -1227,11 +1261,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
         const int64_t i0 = wb[nt] + wk.c0 * cstride;
         w[nt] = *(const f32x4*)(W1 + i0); m[nt] = DIMN_LD_STATE_MV(M1 + i0); v[nt] = DIMN_LD_STATE_MV(V1 + i0);
     }
-    f32x4 xa = zero4;
+    XRaw<XT> xa;
+    xa.load(xsrc + 16 * (wk.c0 < clast ? wk.c0 + 1 : clast));
     if (stager) {
-        f32x4 x0 = *(const f32x4*)(xsrc + 16 * wk.c0);
-        xa = *(const f32x4*)(xsrc + 16 * (wk.c0 < clast ? wk.c0 + 1 : clast));
-        *(f32x4*)(sm + sdst) = svalid ? x0 : zero4;
+        XRaw<XT> x0;
+        x0.load(xsrc + 16 * wk.c0);
+        *(f32x4*)(sm + sdst) = svalid ? x0.get() : zero4;
     }
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb)
@@ -1239,15 +1274,15 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
         for (int nt = 0; nt < NT2; ++nt) asm volatile("" : "+v"(bfr[kb][nt]));
 #pragma unroll
     for (int nt = 0; nt < NT2; ++nt) asm volatile("" : "+v"(w[nt]), "+v"(m[nt]), "+v"(v[nt]));
-    asm volatile("" : "+v"(xa));
+    asm volatile("" : "+v"(xa.v));
     __syncthreads();
 
     for (int c = wk.c0; c < wk.c1; ++c) {
         const int cur = (c - wk.c0) & 1;
         const int c1n = c < clast ? c + 1 : clast;
         const int c2n = c + 2 < wk.c1 ? c + 2 : clast;
-        f32x4 xb = xa;
-        if (stager) xb = *(const f32x4*)(xsrc + 16 * c2n);          // X tile of chunk c+2
+        XRaw<XT> xb = xa;
+        if (stager) xb.load(xsrc + 16 * c2n);                       // X tile of chunk c+2
         f32x4 w1[NT2], m1[NT2], v1[NT2];
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
@@ -1256,7 +1291,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
         }
         __builtin_amdgcn_sched_barrier(0);
 
-        const float* xt = sm + cur * XT;
+        const float* xt = sm + cur * XTS;
         f32x4 g[NT2];
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) g[nt] = zero4;
@@ -1268,14 +1303,14 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
         }
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) adam4(w[nt], m[nt], v[nt], g[nt], ap);
-        if (stager) *(f32x4*)(sm + sdst + (cur ^ 1) * sbuf) = svalid ? xa : zero4;      // tile of chunk c+1
+        if (stager) *(f32x4*)(sm + sdst + (cur ^ 1) * sbuf) = svalid ? xa.get() : zero4;      // tile of chunk c+1
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
             const int64_t idx = wb[nt] + c * cstride;
             DIMN_ST_STATE(W1 + idx, w[nt]); DIMN_ST_STATE(M1 + idx, m[nt]); DIMN_ST_STATE(V1 + idx, v[nt]);
         }
         if (have_next) {
-            const float* xn = sm + 2 * XT + cur * XN;
+            const float* xn = sm + 2 * XTS + cur * XN;
             f32x4 af[4];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) af[mt] = *(const f32x4*)(xn + (16 * mt + li) * 20 + 4 * lj);
@@ -1309,19 +1344,19 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
 // state of chunk c+2 and the X tile of chunk c+2 are requested while chunk c computes: two
 // chunks (~13 KB per wave) stay in flight.
 // ---------------------------------------------------------------------------------------
-template <int NT2>
-struct W1Set { f32x4 w[NT2], m[NT2], v[NT2]; f32x4 x; };
+template <int NT2, typename XT>
+struct W1Set { f32x4 w[NT2], m[NT2], v[NT2]; XRaw<XT> x; };
 
-template <int WAVES, int NT2, int DEPTH = 3, int WPS = 1>   // DEPTH named register sets = DEPTH-1 chunks in flight; WPS: waves per SIMD to fit (co-resident workgroups)
+template <int WAVES, int NT2, int DEPTH = 3, int WPS = 1, typename XT = float>   // DEPTH named register sets = DEPTH-1 chunks in flight; WPS: waves per SIMD to fit (co-resident workgroups)
 __global__ __launch_bounds__(WAVES * 64, WPS) void k_w1_update_fwd_ring(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
-                                                                  const float* __restrict__ X, float* __restrict__ W1,
+                                                                  const XT* __restrict__ X, float* __restrict__ W1,
                                                                   float* __restrict__ M1, float* __restrict__ V1,
                                                                   const int32_t* __restrict__ rows_t, int b_act,
                                                                   const int32_t* __restrict__ rows_n, int b_next,
                                                                   const float* __restrict__ dA, float* __restrict__ P, Dims dm, AdamP ap) {
-    constexpr int XT = DIMN_TB * 16, XN = DIMN_TB * 20;
-    constexpr int DUMMY = 2 * (XT + XN);                       // LDS words nobody reads: target of non-staging threads
-    __shared__ __attribute__((aligned(16))) float sm[2 * (XT + XN) + 4 * WAVES * 64];
+    constexpr int XTS = DIMN_TB * 16, XN = DIMN_TB * 20;
+    constexpr int DUMMY = 2 * (XTS + XN);                       // LDS words nobody reads: target of non-staging threads
+    __shared__ __attribute__((aligned(16))) float sm[2 * (XTS + XN) + 4 * WAVES * 64];
     const Work wk = work[blockIdx.x];
     const SubnetDev s = sn[wk.k];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1346,9 +1381,9 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void k_w1_update_fwd_ring(const Wo
     const int sb = (tid & 255) >> 2, sq = tid & 3;
     const bool svalid = stage_next ? (sb < b_next) : (sb < b_act);
     const int32_t* srows = (stage_next && have_next) ? rows_n : rows_t;
-    const float* xsrc = X + s.xoff + (int64_t)srows[svalid ? sb : 0] * s.Dp + 4 * sq;
-    const int sdst0 = stage_next ? (2 * XT + sb * 20 + 4 * sq) : (sb * 16 + 4 * sq);
-    const int sbuf = stager ? (stage_next ? XN : XT) : 0;
+    const XT* xsrc = X + s.xoff + (int64_t)srows[svalid ? sb : 0] * s.Dp + 4 * sq;
+    const int sdst0 = stage_next ? (2 * XTS + sb * 20 + 4 * sq) : (sb * 16 + 4 * sq);
+    const int sbuf = stager ? (stage_next ? XN : XTS) : 0;
     const int sdst = stager ? sdst0 : DUMMY + 4 * tid;
 
     const int64_t cstride = (int64_t)Hp * 16;
@@ -1363,11 +1398,11 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void k_w1_update_fwd_ring(const Wo
         for (int nt = 0; nt < NT2; ++nt) pacc[mt][nt] = zero4;
 
     const int clast = wk.c1 - 1;
-    auto fetch = [&](W1Set<NT2>& st, int c) {               // issue the loads of chunk c (clamped)
+    auto fetch = [&](W1Set<NT2, XT>& st, int c) {           // issue the loads of chunk c (clamped)
         const int cc = c < clast ? c : clast;
         // X tile first: one iteration later it is the oldest request of this wave, so waiting for it
         // (in-order vmcnt) leaves the three state loads issued after it in flight
-        st.x = *(const f32x4*)(xsrc + 16 * cc);
+        st.x.load(xsrc + 16 * cc);
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
             const int64_t idx = wb[nt] + cc * cstride;
@@ -1376,11 +1411,11 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void k_w1_update_fwd_ring(const Wo
     };
     // one chunk: `cur` holds chunk c, `nx1` chunk c+1 (its X tile is staged into LDS here),
     // `nx2` receives the loads of chunk c+2
-    auto step = [&](W1Set<NT2>& cur, W1Set<NT2>& nx1, W1Set<NT2>& nx2, int c) {
+    auto step = [&](W1Set<NT2, XT>& cur, W1Set<NT2, XT>& nx1, W1Set<NT2, XT>& nx2, int c) {
         const int par = (c - wk.c0) & 1;
         fetch(nx2, c + DEPTH - 1);                            // nx2 = the set that is free again (chunk c-1's)
         __builtin_amdgcn_sched_barrier(0);
-        const float* xt = sm + par * XT;
+        const float* xt = sm + par * XTS;
         f32x4 g[NT2];
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) g[nt] = zero4;
@@ -1392,14 +1427,14 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void k_w1_update_fwd_ring(const Wo
         }
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) adam4(cur.w[nt], cur.m[nt], cur.v[nt], g[nt], ap);
-        *(f32x4*)(sm + sdst + (par ^ 1) * sbuf) = svalid ? nx1.x : zero4;
+        *(f32x4*)(sm + sdst + (par ^ 1) * sbuf) = svalid ? nx1.x.get() : zero4;
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
             const int64_t idx = wb[nt] + c * cstride;
             DIMN_ST_STATE(W1 + idx, cur.w[nt]); DIMN_ST_STATE(M1 + idx, cur.m[nt]); DIMN_ST_STATE(V1 + idx, cur.v[nt]);
         }
         if (have_next) {
-            const float* xn = sm + 2 * XT + par * XN;
+            const float* xn = sm + 2 * XTS + par * XN;
             f32x4 af[4];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) af[mt] = *(const f32x4*)(xn + (16 * mt + li) * 20 + 4 * lj);
@@ -1413,11 +1448,11 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void k_w1_update_fwd_ring(const Wo
         __syncthreads();
     };
 
-    W1Set<NT2> A, B, C, D4;
+    W1Set<NT2, XT> A, B, C, D4;
     fetch(A, wk.c0);
     fetch(B, wk.c0 + 1);
     if (DEPTH == 4) fetch(C, wk.c0 + 2);
-    *(f32x4*)(sm + sdst) = svalid ? A.x : zero4;
+    *(f32x4*)(sm + sdst) = svalid ? A.x.get() : zero4;
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
@@ -1445,15 +1480,15 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void k_w1_update_fwd_ring(const Wo
         asm volatile("" : "+v"(A.w[nt]), "+v"(A.m[nt]), "+v"(A.v[nt]));
         asm volatile("" : "+v"(B.w[nt]), "+v"(B.m[nt]), "+v"(B.v[nt]));
     }
-    asm volatile("" : "+v"(A.x), "+v"(B.x));
+    asm volatile("" : "+v"(A.x.v), "+v"(B.x.v));
 #else
-    asm volatile("" : "+v"(B.x));
+    asm volatile("" : "+v"(B.x.v));
     __syncthreads();
 
     int c = wk.c0;
 #endif
     if (DEPTH == 4) {
-        asm volatile("" : "+v"(C.x));
+        asm volatile("" : "+v"(C.x.v));
         for (; c + 4 <= wk.c1; c += 4) {                   // full groups: no conditional memory op inside
             step(A, B, D4, c);
             step(B, C, A, c + 1);
@@ -1492,8 +1527,8 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void k_w1_update_fwd_ring(const Wo
 // grid (row tiles, K).  out != NULL: out[i][k*O + o] = softplus(z).  loss_part != NULL:
 // loss_part[k*gridDim.x + tile] = sum w*(y-yhat)^2 over the tile (S9).
 // ---------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ sn, const float* __restrict__ X,
+template <int NT, typename XT>
+__global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ sn, const XT* __restrict__ X,
                                                  const float* __restrict__ W1, const float* __restrict__ b1,
                                                  const float* __restrict__ W2, const float* __restrict__ b2,
                                                  const int32_t* __restrict__ rows, int64_t n_rows,
@@ -1513,7 +1548,7 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* xk = X + s.xoff;
+    const XT* xk = X + s.xoff;
     int64_t xo[4];
     bool valid[4];
 #pragma unroll
@@ -1532,21 +1567,24 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
     }
     // Two named operand sets, loop unrolled x2: the loads of chunk c+1 are in flight while chunk c feeds the
     // MFMAs (rows past n_rows read row 0 and are dropped at the end, so every load is unconditional).
-    struct Ops { f32x4 a[4], b[NT]; };
+    struct Ops { XRaw<XT> a[4]; f32x4 b[NT]; };
     auto fetch = [&](Ops& o, int c) {
         const int cc = c < s.nchunk ? c : s.nchunk - 1;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) o.a[mt] = *(const f32x4*)(xk + xo[mt] + 16 * cc);
+        for (int mt = 0; mt < 4; ++mt) o.a[mt].load(xk + xo[mt] + 16 * cc);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) o.b[nt] = *(const f32x4*)(wbt[nt] + cc * cstride);
     };
     auto mma = [&](const Ops& o) {
+        f32x4 a4[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a4[mt] = o.a[mt].get();
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA16(o.a[mt][r], o.b[nt][r], acc[mt][nt]);
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA16(a4[mt][r], o.b[nt][r], acc[mt][nt]);
     };
     Ops P0, P1;
     fetch(P0, 0);

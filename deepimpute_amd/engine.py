@@ -23,7 +23,7 @@ class Engine:
 
     def __init__(self, fns, D, hidden, out_dim, batch_size=64, dropout_rate=0.2,
                  learning_rate=1e-4, beta1=0.9, beta2=0.999, eps=1e-7, loss_binary=False,
-                 seed=1234, device_id=0, subnet_offset=0, activation="relu"):
+                 seed=1234, device_id=0, subnet_offset=0, activation="relu", precision="fp32"):
         self._f = fns
         self.D = [int(d) for d in D]
         self.K = len(self.D)
@@ -35,7 +35,8 @@ class Engine:
             n_subnets=self.K, subnet_offset=int(subnet_offset), hidden=self.H, out_dim=self.O,
             batch_size=self.B, device_id=int(device_id), dropout_rate=float(dropout_rate),
             learning_rate=float(learning_rate), beta1=float(beta1), beta2=float(beta2),
-            eps=float(eps), loss_binary=int(bool(loss_binary)), seed=int(seed))
+            eps=float(eps), loss_binary=int(bool(loss_binary)), seed=int(seed), precision=_cabi.PRECISIONS[str(precision).lower()])
+        self.precision = "bf16" if self.cfg.precision else "fp32"
         self._h = C.c_void_p()
         self.n_cells = 0
         self.n_train = 0
@@ -66,12 +67,19 @@ class Engine:
             pass
 
     # -- data -------------------------------------------------------------
-    def set_matrix(self, norm):
+    def set_matrix(self, norm, streamed=False, with_targets=True):
+        """Hand over the log1p matrix.  streamed=True (HIP engines): the matrix is streamed through pinned buffers in row
+        blocks and gathered on the fly -- it never resides on the device, and gather() must not be called afterwards
+        (every set_indices() first)."""
         norm = f32(norm)
         if norm.ndim != 2:
             raise ValueError("norm must be 2-D [cells, genes]")
         self.n_cells, self.n_genes = norm.shape
-        self._check(self._f["set_matrix"](self._h, p_f32(norm), norm.shape[0], norm.shape[1]))
+        self._streamed = bool(streamed)
+        if streamed:
+            self._check(self._f["set_matrix_streamed"](self._h, p_f32(norm), norm.shape[0], norm.shape[1], int(bool(with_targets))))
+        else:
+            self._check(self._f["set_matrix"](self._h, p_f32(norm), norm.shape[0], norm.shape[1]))
 
     def set_indices(self, k, pred_idx, targ_idx):
         pred_idx, targ_idx = i32(pred_idx), i32(targ_idx)
@@ -80,6 +88,8 @@ class Engine:
         self._check(self._f["set_indices"](self._h, k, p_i32(pred_idx), pred_idx.size, p_i32(targ_idx)))
 
     def gather(self, with_targets=True):
+        if getattr(self, "_streamed", False):
+            return                                   # set_matrix(streamed=True) has gathered already
         self._check(self._f["gather"](self._h, int(bool(with_targets))))
 
     def set_split(self, train_rows, val_rows):
@@ -174,7 +184,7 @@ class GeneralEngine(Engine):
     _cabi.LOSSES.  Same face as Engine; models with several hidden layers move weights per layer."""
 
     def __init__(self, fns, D, layers, out_dim, batch_size=64, learning_rate=1e-4, beta1=0.9, beta2=0.999, eps=1e-7,
-                 loss="wmse", seed=1234, device_id=0, subnet_offset=0):
+                 loss="wmse", seed=1234, device_id=0, subnet_offset=0, precision="fp32"):
         self._f = fns
         self.D = [int(d) for d in D]
         self.K = len(self.D)
@@ -192,7 +202,9 @@ class GeneralEngine(Engine):
                 raise NotImplementedError("hidden activation %r: implemented are %s" % (a, sorted(_cabi.ACTIVATIONS)))
         self.cfg = Config(n_subnets=self.K, subnet_offset=int(subnet_offset), hidden=self.H, out_dim=self.O, batch_size=self.B,
                           device_id=int(device_id), dropout_rate=0.0, learning_rate=float(learning_rate), beta1=float(beta1),
-                          beta2=float(beta2), eps=float(eps), loss_binary=int(self.loss == "wmse_binary"), seed=int(seed))
+                          beta2=float(beta2), eps=float(eps), loss_binary=int(self.loss == "wmse_binary"), seed=int(seed),
+                          precision=_cabi.PRECISIONS[str(precision).lower()])
+        self.precision = "bf16" if self.cfg.precision else "fp32"
         arr = (_cabi.Layer * self.L)(*[_cabi.Layer(n, _cabi.ACTIVATIONS[a], p) for n, a, p in self.layers])
         self._h = C.c_void_p()
         self.n_cells = self.n_train = self.n_val = 0

@@ -59,7 +59,13 @@ typedef struct dimn_config {
     float beta1, beta2, eps;  /* Keras Adam                                             */
     int32_t loss_binary;      /* wMSE(binary=True) weights 1[y>0] (multinet.py:37-38)   */
     uint64_t seed;            /* multinet.py:77; keys the Philox streams                */
+    int32_t precision;        /* DIMN_PREC_F32 (reference: float32 everywhere) or DIMN_PREC_BF16: the gathered predictor
+                                 blocks X_k are stored in bfloat16 (round to nearest even) and the inference / validation
+                                 GEMMs run on the bf16 matrix cores with fp32 accumulation; weights, Adam state, targets
+                                 and the training GEMMs stay fp32 (BASELINE configs[4]) */
 } dimn_config;
+#define DIMN_PREC_F32 0
+#define DIMN_PREC_BF16 1
 
 const char* dimn_last_error(void);
 /* ABI version; bumped on any signature change. */
@@ -103,6 +109,11 @@ int dimn_destroy(dimn_handle h);
  * `.loc[cells, genes].values` host copies (multinet.py:231-235, 273-274).
  */
 int dimn_set_matrix(dimn_handle h, const float* norm, int64_t n_cells, int64_t n_genes);
+/* The same matrix STREAMED from host memory in row blocks (pinned bounce buffers, copy of one block overlapping the
+ * gather of the previous one): the device holds only the gathered X_k / Y_k blocks, never the matrix -- for matrices
+ * that do not fit beside their own gathered copy (BASELINE configs[4], 1M x 30k).  Replaces dimn_set_matrix +
+ * dimn_gather; every dimn_set_indices must have been made. */
+int dimn_set_matrix_streamed(dimn_handle h, const float* norm, int64_t n_cells, int64_t n_genes, int32_t with_targets);
 /* Column lists of sub-net k: predictors (multinet.py:362) and targets (:338-342),
  * as column indices into the matrix. */
 int dimn_set_indices(dimn_handle h, int32_t k, const int32_t* pred_idx, int32_t D_k,

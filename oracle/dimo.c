@@ -267,9 +267,17 @@ static void forward_row(const struct dimo_handle_s* h, const subnet* s, const re
     for (int o = 0; o < O; ++o) z[o] += s->b2[o];
 }
 
+/* bfloat16 rounding (nearest even) of an fp32 value, as a float */
+static inline float bf16_round(float f) {
+    union { float f; uint32_t u; } c; c.f = f;
+    c.u = (c.u + 0x7fffu + ((c.u >> 16) & 1u)) & 0xffff0000u;
+    return c.f;
+}
+/* cfg.precision == DIMN_PREC_BF16: the predictor blocks are STORED in bfloat16 (targets are not) */
 static inline void load_x(const struct dimo_handle_s* h, const subnet* s, int64_t row, real* x) {
     const float* r = h->norm + (size_t)row * h->g;
-    for (int d = 0; d < s->D; ++d) x[d] = (real)r[s->pred[d]];
+    if (h->cfg.precision == DIMN_PREC_BF16) for (int d = 0; d < s->D; ++d) x[d] = (real)bf16_round(r[s->pred[d]]);
+    else for (int d = 0; d < s->D; ++d) x[d] = (real)r[s->pred[d]];
 }
 
 /* S7: Keras-form Adam (TF ResourceApplyAdam): alpha = lr*sqrt(1-b2^t)/(1-b1^t);

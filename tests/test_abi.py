@@ -35,9 +35,9 @@ def test_abi_version_and_struct_layout():
     lib = _lib.library()
     lib.dimn_abi_version.restype = C.c_int
     assert lib.dimn_abi_version() == _cabi.ABI_VERSION
-    # 6 int32, 5 float, 1 int32, (pad), uint64  -> 56 bytes, seed at offset 48
-    assert C.sizeof(_cabi.Config) == 56
-    assert _cabi.Config.seed.offset == 48
+    # 6 int32, 5 float, 1 int32, uint64, int32 (+ pad) -> 64 bytes, seed at offset 48, precision at 56
+    assert C.sizeof(_cabi.Config) == 64
+    assert _cabi.Config.seed.offset == 48 and _cabi.Config.precision.offset == 56
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

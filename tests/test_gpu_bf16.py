@@ -1,0 +1,105 @@
+"""BASELINE configs[4] pieces on one GPU: the bfloat16 X arena (precision="bf16") and the host-streamed matrix
+(set_matrix(streamed=True): row blocks through pinned buffers, the matrix never resident).  Parity definition of the
+bf16 arena: fp32 arithmetic on predictor values rounded to bfloat16 (nearest even) when they are stored; targets,
+weights, Adam state and accumulation are fp32 -- so the oracle in the same mode must agree at the fp32 tolerances."""
+import numpy as np
+import pytest
+
+from helpers import load_problem, make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    from deepimpute_amd.engine import HipEngine
+    return HipEngine
+
+
+def _oracle():
+    from oracle.dimo import OracleEngine
+    return OracleEngine
+
+
+@pytest.mark.parametrize("H,O,B,Ds,p", [
+    (256, 512, 64, [300, 150, 77], 0.2),    # ring B1F1 + fused second layer
+    (300, 512, 64, [260], 0.35),            # CLI default hidden = 300 (shared-staging B1F1)
+    (150, 100, 37, [97, 64, 33], 0.2),      # generic B1F1, ragged everything, partial batches
+])
+def test_bf16_x_arena_matches_oracle_on_rounded_inputs(H, O, B, Ds, p, monkeypatch):
+    monkeypatch.setenv("DIMN_PREDICT_BF16", "0")      # this test pins the arena alone: inference GEMMs in fp32 too
+    prob = make_problem(n=330, g=700, Ds=Ds, H=H, O=O, seed=11)
+    kw = dict(batch_size=B, dropout_rate=p, learning_rate=1e-3, seed=4242, precision="bf16")
+    a = load_problem(_hip(), prob, **kw)
+    b = load_problem(_oracle(), prob, **kw)
+    c = load_problem(_oracle(), prob, **dict(kw, precision="fp32"))
+    for e in (a, b, c):
+        e.init_weights()
+    for epoch in range(2):
+        la, lb, lc = a.train_epoch(epoch), b.train_epoch(epoch), c.train_epoch(epoch)
+        np.testing.assert_allclose(la, lb, rtol=1e-4)
+        np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
+    assert not np.allclose(lb, lc, rtol=1e-5)         # the rounding of the inputs is visible (and small)
+    np.testing.assert_allclose(lb, lc, rtol=2e-2)
+    for k in range(a.K):
+        for x, y, name in zip(a.get_weights(k), b.get_weights(k), ("W1", "b1", "W2", "b2")):
+            np.testing.assert_allclose(x, y, rtol=1e-3, atol=2e-5, err_msg="%s k=%d" % (name, k))
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=1e-4, atol=1e-6)
+    for e in (a, b, c):
+        e.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_streamed_matrix_equals_resident_matrix(precision):
+    """The streamed hand-over (many row blocks: the block size is ~128 MB, so a wide matrix is used) gathers the same
+    X_k / Y_k as the resident one: identical training and prediction, bit for bit."""
+    rng = np.random.default_rng(3)
+    n, g = 5000, 16000                                 # 320 MB matrix -> 3 streamed blocks
+    norm = np.log1p(rng.poisson(1.5, size=(n, g))).astype(np.float32)
+    Ds = [200, 120]
+    pred = [rng.choice(g, D, replace=False).astype(np.int32) for D in Ds]
+    targ = [rng.choice(g, 64, replace=False).astype(np.int32) for _ in Ds]
+    train, val = np.arange(0, 1000, dtype=np.int32), np.arange(4000, 4200, dtype=np.int32)
+    outs = []
+    for streamed in (False, True):
+        e = _hip()(Ds, 64, 64, batch_size=64, dropout_rate=0.2, learning_rate=1e-3, seed=5, precision=precision)
+        for k in range(2):
+            e.set_indices(k, pred[k], targ[k])
+        e.set_matrix(norm, streamed=streamed)
+        e.gather(True)
+        e.set_split(train, val)
+        e.init_weights()
+        outs.append((e.train_epoch(0), e.val_loss(), e.predict(np.arange(0, n, 7, dtype=np.int32))))
+        e.close()
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+
+
+def test_general_path_on_bf16_arena_matches_general_oracle_rounded():
+    from deepimpute_amd.engine import HipGeneralEngine
+    from oracle.dimo import GeneralOracleEngine
+    prob = make_problem(n=400, g=500, Ds=[130, 77], H=96, O=100, seed=21)
+    layers = [(96, "relu", 0.2), (48, "tanh", 0.0)]
+    rounded = prob["norm"].view(np.uint32)
+    rounded = (((rounded + 0x7FFF + ((rounded >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+    engines = []
+    for cls, matrix, prec in ((HipGeneralEngine, prob["norm"], "bf16"),):
+        e = cls(prob["Ds"], layers, prob["O"], batch_size=128, learning_rate=1e-3, seed=7, precision=prec)
+        e.set_matrix(matrix)
+        engines.append(e)
+    # the general oracle has no precision switch: it gets pre-rounded predictors and unrounded targets through two matrices
+    o = GeneralOracleEngine(prob["Ds"], layers, prob["O"], batch_size=128, learning_rate=1e-3, seed=7)
+    g = prob["norm"].shape[1]
+    both = np.hstack([rounded, prob["norm"]])          # columns [0, g): rounded (predictors); [g, 2g): exact (targets)
+    o.set_matrix(both)
+    a = engines[0]
+    for k in range(2):
+        a.set_indices(k, prob["pred"][k], prob["targ"][k])
+        o.set_indices(k, prob["pred"][k], prob["targ"][k] + g)
+    a.gather(True)
+    for e in (a, o):
+        e.set_split(prob["train"], prob["val"])
+        e.init_weights()
+    for epoch in range(2):
+        np.testing.assert_allclose(a.train_epoch(epoch), o.train_epoch(epoch), rtol=1e-4)
+    np.testing.assert_allclose(a.val_loss(), o.val_loss(), rtol=1e-4)
+    np.testing.assert_allclose(a.predict(), o.predict(), rtol=1e-4, atol=1e-6)
