@@ -35,6 +35,8 @@ if ROOT not in sys.path:
 CONFIGS = {
     # name: (cells, genes, hidden, out, batch)
     "cfg3": dict(n=50000, g=20000, H=256, O=512, B=64, label="50k cells x 20k genes, K=40 sub-nets, H=256, O=512, batch 64"),
+    # BASELINE configs[4]: one rank's share with --limit-subnets 8 (K = 59 sub-nets over 8 GPUs), --precision bf16 --stream
+    "cfg5": dict(n=1000000, g=30000, H=256, O=512, B=64, label="1M cells x 30k genes (streamed from host), K=59 sub-nets, H=256, O=512, batch 64"),
     "cfg2": dict(n=5000, g=5000, H=256, O=512, B=64, label="5k cells x 5k genes, K=10 sub-nets, H=256, O=512, batch 64"),
     "tiny": dict(n=2000, g=1500, H=256, O=512, B=64, label="2k cells x 1.5k genes (plumbing check)"),
 }
@@ -130,20 +132,31 @@ class FileRendezvous:
             shutil.rmtree(self.dir, ignore_errors=True)
 
 
-def make_engine(cls, cfg, targets, preds, norm, train, val, counts, offs, rank, device_id, lr, **kw):
+def make_engine(cls, cfg, targets, preds, norm, train, val, counts, offs, rank, device_id, lr, stream=False, **kw):
     ks = range(offs[rank], offs[rank] + counts[rank])
     eng = cls([len(preds[k]) for k in ks], cfg["H"], cfg["O"], batch_size=cfg["B"], dropout_rate=0.2,
               learning_rate=lr, seed=1234, device_id=device_id, subnet_offset=offs[rank], **kw)
-    eng.set_matrix(norm)
     for i, k in enumerate(ks):
         eng.set_indices(i, preds[k], targets[k])
-    eng.set_split(train, val)
+    if stream:
+        eng._bench_norm = norm                       # streamed hand-over: the matrix stays on the host, every impute re-streams it
+    else:
+        eng.set_matrix(norm)
+    eng.n_cells = norm.shape[0]
+    eng.set_split_later = (train, val)
+    if not stream:
+        eng.set_split(train, val)
     return eng
 
 
 def impute_once(eng, epochs, comm=None, counts=None, n=None):
-    """The timed unit: gather -> init -> E x (train epoch + validation) -> predict (-> gather)."""
-    eng.gather(True)
+    """The timed unit: gather -> init -> E x (train epoch + validation) -> predict (-> gather).  With a streamed matrix
+    (--stream) the hand-over IS the gather: the matrix crosses PCIe in row blocks inside the timed region."""
+    if getattr(eng, "_bench_norm", None) is not None:
+        eng.set_matrix(eng._bench_norm, streamed=True, with_targets=True)
+        eng.set_split(*eng.set_split_later)
+    else:
+        eng.gather(True)
     eng.init_weights()
     vsum = 0.0
     ident = np.arange(eng.n_train, dtype=np.int32) if os.environ.get("DIMN_BENCH_IDENTITY_PERM") else None   # diagnostic only
@@ -153,7 +166,10 @@ def impute_once(eng, epochs, comm=None, counts=None, n=None):
         if comm is not None:                       # global early-stopping quantity (multinet.py:242-243)
             v = eng.comm_allreduce_sum(np.array([v.sum()]))
         vsum = float(np.sum(v))
+    t_p = time.perf_counter()
     eng.predict_device()
+    eng.synchronize()
+    eng._bench_predict_s = time.perf_counter() - t_p
     if comm is not None:
         eng.comm_gather_predictions(n, counts, root=0, is_root=False)   # result stays in root's HBM
     eng.synchronize()
@@ -290,6 +306,9 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--limit-subnets", type=int, default=0, help="diagnostic: keep only the first N sub-nets (what one rank of an N-GPU job sees)")
     ap.add_argument("--hidden", type=int, default=0, help="diagnostic: hidden width (default: the config's 256; the reference CLI defaults to 300)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="bf16: X arena in bfloat16, inference / validation on the bf16 matrix cores")
+    ap.add_argument("--stream", action="store_true", help="stream the matrix from host memory in row blocks (it never resides on the GPU)")
+    ap.add_argument("--cells", type=int, default=0, help="diagnostic: override the config's cell count")
     ap.add_argument("--early-stop-probe", action="store_true", help="also run the early-stopped fit once and report its epoch count")
     args = ap.parse_args()
 
@@ -309,6 +328,9 @@ def main():
     if args.hidden:
         cfg["H"] = args.hidden
         cfg["label"] += " [hidden=%d]" % args.hidden
+    if args.cells:
+        cfg["n"] = args.cells
+        cfg["label"] += " [cells=%d]" % args.cells
     n, g = cfg["n"], cfg["g"]
     t_gen = time.time()
     norm = synth_counts(n, g, seed=0)
@@ -320,7 +342,8 @@ def main():
     counts, offs = shard(K, world)
     t_gen = time.time() - t_gen
 
-    eng = make_engine(HipEngine, cfg, targets, preds, norm, train, val, counts, offs, rank, local_rank, args.lr)
+    eng = make_engine(HipEngine, cfg, targets, preds, norm, train, val, counts, offs, rank, local_rank, args.lr, stream=args.stream,
+                      **({"precision": "bf16"} if args.precision == "bf16" else {}))
     comm = None
     if world > 1:
         rdzv = FileRendezvous(rank, world)
@@ -415,14 +438,23 @@ def main():
         result = {
             "metric": "cells/sec end-to-end impute (fit+predict)", "value": value, "unit": "cells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "bf16 (X arena, inference GEMMs; fp32 accumulate) + f32 (weights, Adam, training GEMMs)",
             "data": "synthetic (seeded Poisson-Gamma counts, BASELINE.md generator; random-init Glorot weights)",
             "config": {"workload": cfg["label"], "cells": n, "genes": g, "subnets": K, "epochs_per_fit": args.epochs,
                        "train_steps_per_epoch": steps_per_epoch, "parallelism": "subnets sharded x%d" % world,
-                       "final_val_loss": vsum, "subnet_lanes": int(timers[5]),
+                       "final_val_loss": vsum, "subnet_lanes": int(timers[5]), "matrix": "streamed from host (pinned row blocks)" if args.stream else "resident",
                        "lane_step_ms": lane_step_ms},
             "roofline": roofline,
         }
+        # the forward over all cells (model.predict), the MFMA-bound kernel of the path: fp32 matrix cores, or bf16 ones with --precision bf16
+        pred_s = getattr(eng, "_bench_predict_s", None)
+        if pred_s:
+            mine = preds[offs[0]:offs[0] + counts[0]]
+            pf = n * sum(2.0 * len(p) * H_ + 2.0 * H_ * O_ for p in mine)
+            peak = 2500.0 if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
+            result["roofline"]["predict"] = {"kernel": "k_predict_bf16" if args.precision == "bf16" else "k_predict", "ms": 1e3 * pred_s, "achieved": pf / pred_s / 1e12,
+                                             "peak": peak, "unit": "TFLOP/s", "frac": pf / pred_s / 1e12 / peak}
         if args.early_stop_probe:
             eng.gather(True); eng.init_weights()
             t1 = time.perf_counter()

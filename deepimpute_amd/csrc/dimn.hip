@@ -165,6 +165,7 @@ struct dimn_handle_s {
     std::vector<double> ev_bytes;   // algorithmic bytes of the W1 launch bracketed by each event triple
     // comm
     ncclComm_t comm = nullptr; int n_ranks = 1, rank = 0;
+    bf16_t *d_W1b = nullptr, *d_W2t = nullptr; bool predict_bf16 = false;   // bf16 images of the weights for k_predict_bf16
     int prec = 0;                          // DIMN_PREC_*: 1 = X arena in bfloat16, inference GEMMs on the bf16 matrix cores
     struct GenNet* gen = nullptr;          // != NULL: the general path (dimn_general.h) owns the network of this handle
 };
@@ -417,6 +418,11 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
     TRY(dev_alloc(&h->d_loss_acc, (size_t)h->K * dm.LS));
     TRY(dev_alloc(&h->d_mask, (size_t)h->K * DIMN_TB * dm.Hp));
     TRY(dev_alloc(&h->d_rows_step, (size_t)DIMN_TB));
+    if (h->prec == DIMN_PREC_BF16) {
+        // inference / validation on the bf16 matrix cores unless DIMN_PREDICT_BF16=0 (then only the arena is bf16)
+        h->predict_bf16 = !(getenv("DIMN_PREDICT_BF16") && atoi(getenv("DIMN_PREDICT_BF16")) == 0);
+        if (h->predict_bf16) { TRY(dev_alloc(&h->d_W1b, (size_t)w1)); TRY(dev_alloc(&h->d_W2t, w2n)); }
+    }
     if (h->res_G) {
         TRY(dev_alloc(&h->d_res_P, (size_t)2 * h->K * h->res_G * 1024));
         TRY(dev_alloc(&h->d_res_D, (size_t)h->K * dm.OT * 16 * 1024));
@@ -504,6 +510,7 @@ extern "C" int dimn_destroy(dimn_handle h) {
     DEV_FREE(h->d_epoch_rows); DEV_FREE(h->d_val_rows); DEV_FREE(h->d_pred_rows); DEV_FREE(h->d_out);
     DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage); DEV_FREE(h->d_red);
     for (auto& pb : h->pin_buf) if (pb) { (void)hipHostFree(pb); pb = nullptr; }
+    DEV_FREE(h->d_W1b); DEV_FREE(h->d_W2t);
     DEV_FREE(h->d_res_P); DEV_FREE(h->d_res_D); DEV_FREE(h->d_res_b1); DEV_FREE(h->d_res_alpha); DEV_FREE(h->d_res_flags); DEV_FREE(h->d_res_loss);
     for (auto& ln : h->lanes) (void)hipStreamDestroy(ln.stream);
     delete h;
@@ -867,6 +874,15 @@ static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, const int32_
 template <int NT>
 static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out, float* loss_part) {
     const unsigned tiles = (unsigned)((n_rows + DIMN_TB - 1) / DIMN_TB);
+    if (h->predict_bf16) {                         // bf16 matrix cores (precision bf16): fresh bf16 images of the weights, then the forward
+        hipLaunchKernelGGL(k_prep_bf16, dim3(256, (unsigned)h->K), dim3(256), 0, h->stream, h->d_sn, (const float*)h->d_W1, (const float*)h->d_W2,
+                           h->d_W1b, h->d_W2t, h->dm);
+        const size_t ldsb = (size_t)DIMN_TB * (h->dm.Hp + 4) * 2 + 16;
+        hipLaunchKernelGGL(k_predict_bf16<NT>, dim3(tiles, (unsigned)h->K), dim3(256), ldsb, h->stream, h->d_sn, (const bf16_t*)h->d_X, (const bf16_t*)h->d_W1b,
+                           (const float*)h->d_b1, (const bf16_t*)h->d_W2t, (const float*)h->d_b2, rows, n_rows, out, (const float*)h->d_Y, h->n, loss_part, h->dm,
+                           h->cfg.loss_binary, h->act);
+        return;
+    }
     const size_t lds = (size_t)DIMN_TB * h->dm.ldd * sizeof(float);
     WITH_XT(h, hipLaunchKernelGGL((k_predict<NT, XT>), dim3(tiles, (unsigned)h->K), dim3(256), lds, h->stream, h->d_sn, (const XT*)h->d_X, h->d_W1, h->d_b1,
                                   h->d_W2, h->d_b2, rows, n_rows, out, h->d_Y, h->n, loss_part, h->dm, h->cfg.loss_binary, h->act));

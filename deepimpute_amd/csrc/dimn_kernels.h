@@ -1739,3 +1739,158 @@ __global__ __launch_bounds__(256) void k_val_metrics(const float* __restrict__ p
     __syncthreads();
     if (threadIdx.x < 7) atomicAdd(&sums[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+
+
+// ---------------------------------------------------------------------------------------
+// Inference on the bf16 matrix cores (precision DIMN_PREC_BF16; BASELINE configs[4]): model.predict / the validation
+// pass with v_mfma_f32_16x16x16_bf16 -- operands bfloat16, accumulation fp32.  Operand maps of that instruction (lane l,
+// li = l&15, lj = l>>4): A[i = li][k = 4lj..4lj+3], B[k = 4lj..4lj+3][j = li], C/D as the fp32 one (col = li, row =
+// 4lj + reg): the four k's of a lane are exactly what the k-slot trick loads as ONE 8-byte piece, so every operand of
+// this kernel is a single 8-byte load and one MFMA covers a whole 16-deep chunk (4x fewer matrix instructions than fp32,
+// each ~4x faster).  X is the bf16 arena; W1b / W2t are bf16 images of the fp32 master weights made by k_prep_bf16
+// before the launch (W1b: chunk-blocked like W1; W2t: [o][h], so a lane's four h's are contiguous); the hidden
+// activations are rounded to bf16 when they are staged in LDS.  Biases, softplus, the loss: fp32.
+// ---------------------------------------------------------------------------------------
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
+
+__global__ __launch_bounds__(256) void k_prep_bf16(const SubnetDev* __restrict__ sn, const float* __restrict__ W1, const float* __restrict__ W2,
+                                                   bf16_t* __restrict__ W1b, bf16_t* __restrict__ W2t, Dims dm) {
+    const int k = blockIdx.y;
+    const SubnetDev s = sn[k];
+    const int64_t n1 = (int64_t)s.Dp * dm.Hp, n2 = (int64_t)dm.Hp * dm.Op;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n1 + n2; e += (int64_t)gridDim.x * 256) {
+        if (e < n1) {
+            W1b[s.w1off + e] = f32_to_bf16(W1[s.w1off + e]);
+        } else {
+            const int64_t e2 = e - n1;                           // output index: [o][h]
+            const int o = (int)(e2 / dm.Hp), h = (int)(e2 - (int64_t)o * dm.Hp);
+            W2t[(int64_t)k * n2 + e2] = f32_to_bf16(W2[(int64_t)k * n2 + ((int64_t)(h >> 4) * dm.OT + (o >> 4)) * 256 + (h & 15) * 16 + (o & 15)]);
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_predict_bf16(const SubnetDev* __restrict__ sn, const bf16_t* __restrict__ X,
+                                                      const bf16_t* __restrict__ W1b, const float* __restrict__ b1,
+                                                      const bf16_t* __restrict__ W2t, const float* __restrict__ b2,
+                                                      const int32_t* __restrict__ rows, int64_t n_rows,
+                                                      float* __restrict__ out, const float* __restrict__ Y, int64_t n_cells,
+                                                      float* __restrict__ loss_part, Dims dm, int loss_binary, int act) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pl_lds[];
+    bf16_t* ddl = (bf16_t*)pl_lds;                               // Dd [64][ldb] bf16
+    const int ldb = dm.Hp + 4;                                   // 8 bytes of padding per row
+    float* redl = (float*)(pl_lds + (size_t)DIMN_TB * ldb * 2);  // [4] loss partials
+    const int k = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * DIMN_TB;
+    const SubnetDev s = sn[k];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    const int nt0 = wave * NT;
+    const int Hp = dm.Hp;
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16_t* xk = X + s.xoff;
+    int64_t xo[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int64_t i = r0 + 16 * mt + li;
+        const int64_t row = i < n_rows ? (rows ? (int64_t)rows[i] : i) : 0;      // rows past the end read row 0 and are dropped
+        xo[mt] = row * s.Dp + 4 * lj;
+    }
+    const int64_t cstride = (int64_t)Hp * 16;
+    const bf16_t* wbt[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int t = (nt0 + nt) < dm.HT ? (nt0 + nt) : (dm.HT - 1);
+        wbt[nt] = W1b + s.w1off + (int64_t)(16 * t + li) * 16 + 4 * lj;
+    }
+    struct Ops { bf16x4 a[4], b[NT]; };
+    auto fetch = [&](Ops& o, int c) {
+        const int cc = c < s.nchunk ? c : s.nchunk - 1;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) o.a[mt] = *(const bf16x4*)(xk + xo[mt] + 16 * cc);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) o.b[nt] = *(const bf16x4*)(wbt[nt] + cc * cstride);
+    };
+    auto mma = [&](const Ops& o) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA_BF16(o.a[mt], o.b[nt], acc[mt][nt]);
+    };
+    Ops P0, P1;
+    fetch(P0, 0);
+    int c = 0;
+    for (; c + 2 <= s.nchunk; c += 2) {
+        fetch(P1, c + 1);
+        mma(P0);
+        fetch(P0, c + 2);
+        mma(P1);
+    }
+    if (c < s.nchunk) mma(P0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+        if (nt0 + nt < dm.HT) {
+            const int h = 16 * (nt0 + nt) + li;
+            const float bias = b1[(int64_t)k * Hp + h];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[mt][nt][r] + bias;
+                    float f = v > 0.f ? v : 0.f, df;
+                    if (act != 0) { hidden_act(act, v, f, df); if (h >= dm.H) f = 0.f; }
+                    ddl[(16 * mt + 4 * lj + r) * ldb + h] = f32_to_bf16(f);
+                }
+        }
+    __syncthreads();
+
+    float lsum = 0.f;
+    const bf16_t* w2k = W2t + (int64_t)k * Hp * dm.Op;
+    for (int ot = wave; ot < dm.OT; ot += 4) {
+        f32x4 z[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) z[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bf16_t* wrow = w2k + (int64_t)(16 * ot + li) * Hp + 4 * lj;         // W2[h = 16ht + 4lj..][o = 16ot + li]
+        for (int ht = 0; ht < dm.HT; ++ht) {
+            const bf16x4 bq = *(const bf16x4*)(wrow + 16 * ht);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const bf16x4 aq = *(const bf16x4*)(ddl + (16 * mt + li) * ldb + 16 * ht + 4 * lj);
+                z[mt] = MFMA_BF16(aq, bq, z[mt]);
+            }
+        }
+        const int o = 16 * ot + li;
+        if (o < dm.O) {
+            const float bias = b2[(int64_t)k * dm.Op + o];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t i = r0 + 16 * mt + 4 * lj + r;
+                    if (i < n_rows) {
+                        const float yh = softplus_f(z[mt][r] + bias);
+                        if (out) __builtin_nontemporal_store(yh, &out[(i * dm.K + k) * dm.O + o]);
+                        if (loss_part) {
+                            const int64_t row = rows ? (int64_t)rows[i] : i;
+                            const float y = Y[((int64_t)k * n_cells + row) * dm.Op + o];
+                            const float w = loss_binary ? (y > 0.f ? 1.f : 0.f) : y;
+                            const float e = y - yh;
+                            lsum += w * e * e;
+                        }
+                    }
+                }
+        }
+    }
+    if (loss_part) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
+        if (lane == 0) redl[wave] = lsum;
+        __syncthreads();
+        if (threadIdx.x == 0) loss_part[(int64_t)k * gridDim.x + blockIdx.x] = redl[0] + redl[1] + redl[2] + redl[3];
+    }
+}

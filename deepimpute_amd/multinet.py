@@ -182,7 +182,7 @@ def _loss_name(loss):
 class MultiNet:
     def __init__(self, learning_rate=1e-4, batch_size=64, max_epochs=500, patience=5, ncores=-1,
                  loss="wMSE", output_prefix=_SCRATCH, sub_outputdim=512, verbose=1, seed=1234,
-                 architecture=None, device_id=0, engine_factory=None, comm=None):
+                 architecture=None, device_id=0, engine_factory=None, comm=None, precision="fp32", stream_matrix=None):
         self.NN_parameters = dict(learning_rate=learning_rate, batch_size=batch_size, loss=loss,
                                   architecture=architecture, max_epochs=max_epochs, patience=patience)
         self.sub_outputdim = sub_outputdim
@@ -190,6 +190,12 @@ class MultiNet:
         self.verbose = verbose
         self.seed = seed
         self.device_id = device_id                 # extension: which GPU
+        # extensions (BASELINE configs[4]): "bf16" stores the gathered predictor blocks in bfloat16 and runs inference /
+        # validation on the bf16 matrix cores (weights, Adam state, targets, training GEMMs stay fp32); stream_matrix
+        # hands the log1p matrix over in row blocks through pinned buffers so that it never resides on the GPU
+        # (None: automatically, for matrices above 32 GB)
+        self.precision = precision
+        self.stream_matrix = stream_matrix
         self._engine_factory = engine_factory      # extension (tests): None -> HipEngine, no fallback
         self._engine = None
         # extension: a deepimpute_amd.sharded Comm (one process per GPU); the string "rccl" builds
@@ -224,6 +230,8 @@ class MultiNet:
         batch = int(self.NN_parameters["batch_size"])
         common = dict(batch_size=batch, learning_rate=self.NN_parameters["learning_rate"], seed=0 if self.seed is None else self.seed,
                       device_id=self.device_id, subnet_offset=subnet_offset)
+        if str(self.precision).lower() not in ("fp32", "f32", "float32"):
+            common["precision"] = self.precision
         make = self._engine_factory
         # the tuned kernels take the reference's default shape family: one hidden layer of <= 384 units (+ dropout),
         # batch <= 64, wMSE -- loadDefaultArchitecture(), the CLI defaults; everything else build() accepts runs on the
@@ -301,6 +309,18 @@ class MultiNet:
             self._counts = counts
         return self._engine
 
+    def _hand_over(self, engine, norm, with_targets):
+        """The log1p matrix to the engine + the device gather of every sub-net's blocks; streamed in row blocks when asked
+        for (or automatically above 32 GB) on engines that can."""
+        stream = self.stream_matrix
+        if stream is None:
+            stream = norm.size * 4 > (32 << 30)
+        if stream and hasattr(engine, "predict_device"):          # HIP engines
+            engine.set_matrix(norm, streamed=True, with_targets=with_targets)
+        else:
+            engine.set_matrix(norm)
+            engine.gather(with_targets)
+
     def _bind_columns(self, engine, columns):
         """Translate gene labels of predictors/targets into column positions of the matrix."""
         where = pd.Index(columns)
@@ -360,9 +380,8 @@ class MultiNet:
         by_label = np.argsort(norm_data.index.values, kind="stable")
         rows_train = by_label[is_train[by_label]]
 
-        engine.set_matrix(norm_data.values)
         self._bind_columns(engine, norm_data.columns)
-        engine.gather(True)
+        self._hand_over(engine, norm_data.values, True)
         engine.set_split(rows_train, rows_val)
         engine.init_weights(0 if self.seed is None else self.seed)
 
@@ -482,9 +501,8 @@ class MultiNet:
     # -- predict: forward on the GPU, post-processing as multinet.py:282-310 --
     def predict(self, raw, imputed_only=False, policy="restore"):
         engine = self.load()
-        engine.set_matrix(_hostpar.log1p_float32(raw).values)     # float32(log1p(raw)): what Keras is fed
         self._bind_columns(engine, raw.columns)
-        engine.gather(False)
+        self._hand_over(engine, _hostpar.log1p_float32(raw).values, False)     # float32(log1p(raw)): what Keras is fed
         # a gene may occupy several target slots: average them; the averaged columns are label-sorted,
         # like the reference's groupby(columns).mean() (multinet.py:282-284)
         slots = self.targets.flatten()

@@ -69,6 +69,7 @@ struct dimo_handle_s {
     int32_t *train_rows, *val_rows; int64_t n_tr, n_val;
     int64_t t;                        /* Adam step counter */
     int act;                          /* hidden activation, DIMN_ACT_* (multinet.py:137) */
+    int infer_bf16;                   /* precision bf16: inference/validation GEMM operands rounded to bfloat16 (fp32 accumulate) */
 };
 typedef struct dimo_handle_s* dimo_handle;
 
@@ -240,17 +241,27 @@ int dimo_set_activation(dimo_handle h, int32_t activation) {
     return DIMN_OK;
 }
 
+/* bfloat16 rounding (nearest even) of an fp32 value, as a float */
+static inline float bf16_round(float f) {
+    union { float f; uint32_t u; } c; c.f = f;
+    c.u = (c.u + 0x7fffu + ((c.u >> 16) & 1u)) & 0xffff0000u;
+    return c.f;
+}
+int dimo_set_inference_bf16(struct dimo_handle_s* h, int32_t on) { h->infer_bf16 = on != 0; return DIMN_OK; }
+
 /* Forward of one row of one sub-net.  x[D] in; a[H] pre-activation, dd[H] hidden output
  * after relu(+dropout when keep != NULL), z[O] pre-softplus out. */
 static void forward_row(const struct dimo_handle_s* h, const subnet* s, const real* x,
                         const uint8_t* keep, real* a, real* dd, real* z) {
     const int H = h->H, O = h->O, D = s->D;
     const real scale = keep ? (real)(1.0f / (1.0f - h->cfg.dropout_rate)) : (real)1;
+    const int q = !keep && h->infer_bf16;               /* inference on the bf16 matrix cores: operands rounded, fp32 accumulate */
     for (int j = 0; j < H; ++j) a[j] = 0;
     for (int d = 0; d < D; ++d) {                       /* S1: a = x W1 + b1 */
         const real xv = x[d];
         const real* w = s->W1 + (size_t)d * H;
-        for (int j = 0; j < H; ++j) a[j] += xv * w[j];
+        if (q) for (int j = 0; j < H; ++j) a[j] += xv * (real)bf16_round((float)w[j]);
+        else for (int j = 0; j < H; ++j) a[j] += xv * w[j];
     }
     for (int j = 0; j < H; ++j) {
         a[j] += s->b1[j];
@@ -260,19 +271,14 @@ static void forward_row(const struct dimo_handle_s* h, const subnet* s, const re
     }
     for (int o = 0; o < O; ++o) z[o] = 0;
     for (int j = 0; j < H; ++j) {
-        const real dv = dd[j];
+        const real dv = q ? (real)bf16_round((float)dd[j]) : dd[j];
         const real* w = s->W2 + (size_t)j * O;
-        for (int o = 0; o < O; ++o) z[o] += dv * w[o];
+        if (q) for (int o = 0; o < O; ++o) z[o] += dv * (real)bf16_round((float)w[o]);
+        else for (int o = 0; o < O; ++o) z[o] += dv * w[o];
     }
     for (int o = 0; o < O; ++o) z[o] += s->b2[o];
 }
 
-/* bfloat16 rounding (nearest even) of an fp32 value, as a float */
-static inline float bf16_round(float f) {
-    union { float f; uint32_t u; } c; c.f = f;
-    c.u = (c.u + 0x7fffu + ((c.u >> 16) & 1u)) & 0xffff0000u;
-    return c.f;
-}
 /* cfg.precision == DIMN_PREC_BF16: the predictor blocks are STORED in bfloat16 (targets are not) */
 static inline void load_x(const struct dimo_handle_s* h, const subnet* s, int64_t row, real* x) {
     const float* r = h->norm + (size_t)row * h->g;

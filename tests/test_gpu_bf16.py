@@ -103,3 +103,57 @@ def test_general_path_on_bf16_arena_matches_general_oracle_rounded():
         np.testing.assert_allclose(a.train_epoch(epoch), o.train_epoch(epoch), rtol=1e-4)
     np.testing.assert_allclose(a.val_loss(), o.val_loss(), rtol=1e-4)
     np.testing.assert_allclose(a.predict(), o.predict(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("H,O,B,Ds", [(256, 512, 64, [300, 150, 77]), (300, 512, 64, [260]), (150, 100, 37, [97, 64, 33])])
+def test_bf16_matrix_core_inference_matches_oracle_rounding(H, O, B, Ds):
+    """precision="bf16" in full: the arena in bf16 and model.predict / the validation pass on v_mfma_f32_16x16x16_bf16
+    (k_predict_bf16: X, W1, the hidden activations and W2 as bfloat16 operands, fp32 accumulation).  The oracle restates
+    exactly that rounding (infer_bf16); products of two bf16 values are exact in fp32, so what is left is the summation
+    order -- and, rarely, a hidden activation that rounds to the neighbouring bf16 value (a 0.4 % step of one of the H
+    terms of an output).  Stated tolerance: validation loss 5e-4 relative, imputed values 2e-3 relative + 2e-4 absolute;
+    against the all-fp32 path the predictions move by < 2 % (the price of the format, not of the kernel)."""
+    prob = make_problem(n=330, g=700, Ds=Ds, H=H, O=O, seed=11)
+    kw = dict(batch_size=B, dropout_rate=0.2, learning_rate=1e-3, seed=4242)
+    a = load_problem(_hip(), prob, precision="bf16", **kw)
+    b = load_problem(_oracle(), prob, precision="bf16", infer_bf16=True, **kw)
+    c = load_problem(_hip(), prob, precision="fp32", **kw)
+    for e in (a, b, c):
+        e.init_weights()
+    for epoch in range(2):
+        np.testing.assert_allclose(a.train_epoch(epoch), b.train_epoch(epoch), rtol=1e-4)      # training GEMMs: fp32 matrix cores
+        np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=5e-4)
+        c.train_epoch(epoch)
+    pa, pb, pc = a.predict(), b.predict(), c.predict()
+    np.testing.assert_allclose(pa, pb, rtol=2e-3, atol=2e-4)
+    rows = prob["val"]
+    np.testing.assert_allclose(a.predict(rows), pa[rows], rtol=0, atol=0)
+    assert np.abs(pa - pc).max() / np.abs(pc).max() < 2e-2
+    for e in (a, b, c):
+        e.close()
+
+
+def test_multinet_streamed_and_bf16_through_the_shell(tmp_path):
+    """MultiNet(stream_matrix=True) imputes exactly what the resident hand-over does; MultiNet(precision="bf16") stays close
+    to fp32 (same early-stopping epoch on this problem, held-out correlation within 1e-2)."""
+    import pandas as pd
+    from deepimpute_amd.multinet import MultiNet
+    rng = np.random.default_rng(0)
+    n, g = 300, 700
+    u, v = rng.normal(size=(n, 6)), rng.normal(size=(g, 6))
+    counts = rng.poisson(np.exp(0.6 * (u @ v.T) / np.sqrt(6) + rng.normal(0.3, 0.8, size=g))).astype(np.float64)
+    counts[:, :5] += rng.poisson(20, size=(n, 5))
+    raw = pd.DataFrame(counts, index=["c%d" % i for i in range(n)], columns=["g%d" % j for j in range(g)])
+    kw = dict(sub_outputdim=128, seed=123, ncores=2, verbose=0, max_epochs=12, learning_rate=1e-3)
+    res = MultiNet(output_prefix=str(tmp_path / "a"), **kw).fit(raw)
+    stm = MultiNet(output_prefix=str(tmp_path / "b"), stream_matrix=True, **kw).fit(raw)
+    assert res.history == stm.history
+    assert np.array_equal(res.predict(raw).values, stm.predict(raw).values)
+    b16 = MultiNet(output_prefix=str(tmp_path / "c"), precision="bf16", stream_matrix=True, **kw).fit(raw)
+    assert b16._engine.precision == "bf16" and b16.trained_epochs == res.trained_epochs
+    assert abs(float(b16.test_metrics["correlation"]) - float(res.test_metrics["correlation"])) < 1e-2
+    out = b16.predict(raw)
+    assert np.isfinite(out.values).all() and np.array_equal(out.values[counts > 0], counts[counts > 0])
+    fresh = MultiNet(output_prefix=str(tmp_path / "c"), precision="bf16", **kw)            # reload on a bf16 engine
+    fresh.predictors, fresh.targets = b16.predictors, b16.targets
+    np.testing.assert_allclose(fresh.predict(raw).values, out.values, rtol=1e-6)
