@@ -105,10 +105,11 @@ class FileRendezvous:
     agent -> the parent pid + MASTER_PORT name a directory nobody else uses)."""
 
     def __init__(self, rank, world):
-        tag = "%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
-        self.dir = os.path.join("/tmp", "dimn_rdzv_" + tag)
+        from deepimpute_amd.sharded import _job_tag
+        # launcher pid + its start time + MASTER_PORT: a name no earlier job can have left a stale id under
+        self.dir = os.path.join("/tmp", "dimn_rdzv_%d_bench_%s" % (os.getuid(), _job_tag()))
         self.rank, self.world = rank, world
-        os.makedirs(self.dir, exist_ok=True)
+        os.makedirs(self.dir, mode=0o700, exist_ok=True)
 
     def broadcast_bytes(self, name, payload=None, timeout=300.0):
         path = os.path.join(self.dir, name)
