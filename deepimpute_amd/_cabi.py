@@ -99,6 +99,9 @@ GPU_ONLY = {
     "abs_corrcoef": [_i32, _pd, _i64, _i64, _pd],
     "val_metrics": [_H, _pd],
     "impute_finish": [_H, _pd, _i64, _i64, _pi, _pi, _i32, C.c_double, _i32, _pd],
+    "csv_scan": [C.c_char_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
+    "csv_read": [C.c_char_p, _i64, _i64, C.POINTER(_i64), C.c_char_p, _i64],
+    "csv_write": [C.c_char_p, _pd, _i64, _i64, C.c_char_p, C.c_char_p, C.c_char_p],
     "select_predictors": [_i32, _pd, _i64, _i64, _pi, _i32, _i32, _pi, _i32, _pi],
 }
 

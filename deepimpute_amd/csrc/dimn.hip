@@ -19,6 +19,7 @@
 #include "dimn_corr.h"
 #include "dimn_resident.h"
 #include "dimn_general.h"
+#include "dimn_csv.h"
 
 #define DIMN_ABI_VERSION 3
 
@@ -1508,6 +1509,27 @@ extern "C" int dimn_comm_destroy(dimn_handle h) {
     if (!h) return fail(DIMN_ERR_ARG, "null handle");
     if (h->comm) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
     return DIMN_OK;
+}
+
+// ---- next row: the CSV edges of the CLI (deepImpute.py:13, :35), host code, no GPU needed ----------
+extern "C" int dimn_csv_scan(const char* path, int64_t* n_rows, int64_t* n_cols, int64_t* label_bytes) {
+    if (!path || !n_rows || !n_cols || !label_bytes) return fail(DIMN_ERR_ARG, "dimn_csv_scan: null argument");
+    std::string err;
+    const int rc = csv_scan(path, n_rows, n_cols, label_bytes, err);
+    return rc ? fail(rc == -4 ? DIMN_ERR_UNSUP : DIMN_ERR_ARG, "dimn_csv_scan(%s): %s", path, err.c_str()) : DIMN_OK;
+}
+extern "C" int dimn_csv_read(const char* path, int64_t n_rows, int64_t n_cols, int64_t* values, char* labels, int64_t label_bytes) {
+    if (!path || !values || !labels || n_rows < 1 || n_cols < 1) return fail(DIMN_ERR_ARG, "dimn_csv_read: bad argument");
+    std::string err;
+    const int rc = csv_read(path, n_rows, n_cols, values, labels, label_bytes, err);
+    return rc ? fail(rc == -4 ? DIMN_ERR_UNSUP : DIMN_ERR_ARG, "dimn_csv_read(%s): %s", path, err.c_str()) : DIMN_OK;
+}
+extern "C" int dimn_csv_write(const char* path, const double* values, int64_t n_rows, int64_t n_cols, const char* index_name, const char* col_labels,
+                              const char* row_labels) {
+    if (!path || !values || !col_labels || !row_labels || n_rows < 0 || n_cols < 0) return fail(DIMN_ERR_ARG, "dimn_csv_write: bad argument");
+    std::string err;
+    const int rc = csv_write(path, values, n_rows, n_cols, index_name, col_labels, row_labels, err);
+    return rc ? fail(DIMN_ERR_ARG, "dimn_csv_write(%s): %s", path, err.c_str()) : DIMN_OK;
 }
 
 #ifdef DIMN_RES_TL

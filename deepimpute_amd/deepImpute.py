@@ -1,8 +1,7 @@
 """`deepImpute` entry point (function + console script), same call shape as the reference's
 deepimpute/deepImpute.py:6-40: parse flags, let keyword arguments override them, read the CSV,
 fit a MultiNet on the GPU, impute, write or return the result."""
-import pandas as pd
-
+from . import csvio
 from .multinet import MultiNet
 from .parser import parse_args
 
@@ -12,7 +11,7 @@ def deepImpute(**kwargs):
     for name, value in kwargs.items():
         setattr(args, name, value)
 
-    counts = pd.read_csv(args.inputFile, index_col=0)
+    counts = csvio.read_csv(args.inputFile)             # pd.read_csv(inputFile, index_col=0), multi-threaded for count matrices
     if args.cell_axis == "columns":
         counts = counts.T
 
@@ -28,7 +27,7 @@ def deepImpute(**kwargs):
 
     if args.output is None:
         return imputed
-    imputed.to_csv(args.output)
+    csvio.to_csv(imputed, args.output)                  # imputed.to_csv(output), multi-threaded
 
 
 if __name__ == "__main__":

@@ -256,6 +256,19 @@ int dimn_abs_corrcoef(int32_t device_id, const double* X, int64_t n, int64_t g, 
 int dimn_select_predictors(int32_t device_id, const double* X, int64_t n, int64_t g, const int32_t* targ_pos,
                            int32_t K, int32_t O, const int32_t* col_rank, int32_t ntop, int32_t* out_idx);
 
+/* ---- next row: the CSV edges of the CLI, multi-threaded host code (no GPU needed) -------------
+ * deepImpute.py:13 pd.read_csv(inputFile, index_col=0) for the input the tool is specified for -- a rectangular matrix of
+ * raw integer counts with unquoted labels.  Two passes: dimn_csv_scan gives the shape and the size of the label buffer,
+ * dimn_csv_read fills values[n_rows][n_cols] (int64) and `labels` = index name, column labels, row labels, each
+ * NUL-terminated.  Returns DIMN_ERR_UNSUP for anything else (decimal / empty / quoted fields, ragged rows): the caller
+ * then uses pandas itself, whose float parser this code does not imitate. */
+int dimn_csv_scan(const char* path, int64_t* n_rows, int64_t* n_cols, int64_t* label_bytes);
+int dimn_csv_read(const char* path, int64_t n_rows, int64_t n_cols, int64_t* values, char* labels, int64_t label_bytes);
+/* deepImpute.py:35 imputed.to_csv(output): float64 in Python's repr() form (shortest round trip; scientific iff the decimal
+ * exponent is < -4 or >= 16), NaN -> "", labels NUL-separated; byte-identical to DataFrame.to_csv for unquoted labels. */
+int dimn_csv_write(const char* path, const double* values, int64_t n_rows, int64_t n_cols, const char* index_name,
+                   const char* col_labels, const char* row_labels);
+
 #ifdef __cplusplus
 }
 #endif
