@@ -133,6 +133,67 @@ class FileRendezvous:
             shutil.rmtree(self.dir, ignore_errors=True)
 
 
+class RcclBenchComm:
+    """The job's collectives on RCCL over xGMI (libdimn's dimn_comm_*)."""
+    kind = "rccl"
+
+    def __init__(self, eng):
+        self.eng = eng
+
+    def allreduce_sum(self, vec):
+        return self.eng.comm_allreduce_sum(vec)
+
+    def gather(self, n, counts):
+        self.eng.comm_gather_predictions(n, counts, root=0, is_root=False)       # result stays in root's HBM
+
+    def close(self):
+        self.eng.comm_destroy()
+
+
+class FileBenchComm:
+    """ONLY when RCCL cannot be brought up on this node (the line then says so in config.collectives): the two scalars per
+    epoch and the timing reductions go through files of the rendezvous directory and the gather of the prediction blocks is
+    SKIPPED -- the sub-nets still train and predict on their own GPUs, so the line remains a measurement of the sharded
+    compute, not of the complete job."""
+    kind = "files (RCCL unavailable: no gather)"
+
+    def __init__(self, rdzv):
+        self.rdzv, self.seq = rdzv, 0
+
+    def allreduce_sum(self, vec):
+        self.seq += 1
+        vec = np.asarray(vec, np.float64)
+        path = os.path.join(self.rdzv.dir, "ar%d_%d" % (self.seq, self.rdzv.rank))
+        with open(path + ".tmp", "wb") as f:
+            f.write(vec.tobytes())
+        os.replace(path + ".tmp", path)
+        total = np.zeros_like(vec)
+        for r in range(self.rdzv.world):
+            q = os.path.join(self.rdzv.dir, "ar%d_%d" % (self.seq, r))
+            t0 = time.time()
+            while not os.path.exists(q):
+                if time.time() - t0 > 600:
+                    raise TimeoutError("file all-reduce: rank %d never arrived" % r)
+                time.sleep(0.0005)
+            with open(q, "rb") as f:
+                total += np.frombuffer(f.read(), np.float64)
+        return total
+
+    def gather(self, n, counts):
+        pass
+
+    def close(self):
+        # rank 0 removes the directory afterwards: it must not do so before every rank has read the last files
+        if self.rdzv.rank != 0:
+            open(os.path.join(self.rdzv.dir, "done_%d" % self.rdzv.rank), "w").close()
+            return
+        t0 = time.time()
+        while not all(os.path.exists(os.path.join(self.rdzv.dir, "done_%d" % r)) for r in range(1, self.rdzv.world)):
+            if time.time() - t0 > 60:
+                break
+            time.sleep(0.001)
+
+
 def make_engine(cls, cfg, targets, preds, norm, train, val, counts, offs, rank, device_id, lr, stream=False, **kw):
     ks = range(offs[rank], offs[rank] + counts[rank])
     eng = cls([len(preds[k]) for k in ks], cfg["H"], cfg["O"], batch_size=cfg["B"], dropout_rate=0.2,
@@ -165,14 +226,14 @@ def impute_once(eng, epochs, comm=None, counts=None, n=None):
         eng.train_epoch(e, ident)
         v = eng.val_loss()
         if comm is not None:                       # global early-stopping quantity (multinet.py:242-243)
-            v = eng.comm_allreduce_sum(np.array([v.sum()]))
+            v = comm.allreduce_sum(np.array([v.sum()]))
         vsum = float(np.sum(v))
     t_p = time.perf_counter()
     eng.predict_device()
     eng.synchronize()
     eng._bench_predict_s = time.perf_counter() - t_p
     if comm is not None:
-        eng.comm_gather_predictions(n, counts, root=0, is_root=False)   # result stays in root's HBM
+        comm.gather(n, counts)
     eng.synchronize()
     return vsum
 
@@ -348,31 +409,35 @@ def main():
     comm = None
     if world > 1:
         rdzv = FileRendezvous(rank, world)
-        sys.stdout.flush()
-        saved0 = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            uid = eng.comm_unique_id().tobytes() if rank == 0 else None
-        finally:
-            os.dup2(saved0, 1)
-            os.close(saved0)
-        uid = rdzv.broadcast_bytes("uid", uid)
+        rccl_error = None
         # RCCL prints a version banner on stdout at init; stdout must carry exactly one JSON line
         sys.stdout.flush()
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
+            uid = rdzv.broadcast_bytes("uid", eng.comm_unique_id().tobytes() if rank == 0 else None)
             eng.comm_init(np.frombuffer(uid, np.uint8), world, rank)
+            eng.comm_allreduce_sum(np.zeros(1))
+        except Exception as e:                      # reported in the line; the job continues without the gather
+            rccl_error = repr(e)
         finally:
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
-        comm = True
+        # every rank must take the same road: one vote through the files
+        votes = FileBenchComm(rdzv).allreduce_sum(np.array([0.0 if rccl_error is None else 1.0]))
+        if votes[0] == 0:
+            comm = RcclBenchComm(eng)
+        else:
+            comm = FileBenchComm(rdzv)
+            comm.seq = 1
+            comm.error = rccl_error or "RCCL failed on another rank"
+            sys.stderr.write("bench.py rank %d: RCCL unavailable (%s); collectives through files, gather skipped\n" % (rank, comm.error))
 
     def barrier():
         eng.synchronize()
         if comm:
-            eng.comm_allreduce_sum(np.zeros(1))
+            comm.allreduce_sum(np.zeros(1))
 
     for _ in range(args.warmup):
         impute_once(eng, args.epochs, comm, counts, n)
@@ -387,7 +452,7 @@ def main():
     eng.set_profiling(False)
     if comm:
         times = np.zeros(world); times[rank] = dt
-        dt = float(eng.comm_allreduce_sum(times).max())
+        dt = float(comm.allreduce_sum(times).max())
     timers = eng.get_timers(reset=True)
 
     result = None
@@ -464,7 +529,10 @@ def main():
             result["config"]["early_stopped"] = {"epochs": int(ne), "seconds": time.perf_counter() - t1,
                                                  "val_loss": [float(x) for x in vh[-6:]]}
     if comm:
-        eng.comm_destroy()
+        if rank == 0 and result is not None:
+            result["config"]["collectives"] = comm.kind if comm.kind == "rccl" else {"kind": comm.kind, "rccl_error": getattr(comm, "error", None)}
+        comm.allreduce_sum(np.zeros(1))
+        comm.close()
         rdzv.cleanup()
     eng.close()
     if rank == 0 and world == 1 and not args.no_dropin and not args.limit_subnets and not args.hidden:

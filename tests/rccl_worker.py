@@ -49,7 +49,7 @@ def main(out_path):
     rdzv = bench.FileRendezvous(rank, world)
     uid = rdzv.broadcast_bytes("uid", eng.comm_unique_id().tobytes() if rank == 0 else None)
     eng.comm_init(np.frombuffer(uid, np.uint8), world, rank)
-    vsum = bench.impute_once(eng, 2, True, counts, cfg["n"])
+    vsum = bench.impute_once(eng, 2, bench.RcclBenchComm(eng), counts, cfg["n"])
     eng.predict_device()
     full = eng.comm_gather_predictions(cfg["n"], counts, root=0, is_root=rank == 0)
     eng.comm_allreduce_sum(np.zeros(1))
