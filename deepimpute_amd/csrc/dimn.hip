@@ -1541,9 +1541,85 @@ extern "C" int dimn_debug_res_timeline(unsigned long long* out, int n_words) {
 #endif
 
 // ---- get_distance_matrix on the GPU (reference multinet.py:20-34) -------------------
+// The same for a matrix that does not fit the GPU beside its g x g result (BASELINE configs[4]: 1M x 30k = 240 GB of float64):
+// two streamed passes over row blocks of X through pinned bounce buffers -- column sums, then centre each block and
+// accumulate C += Zb^T Zb on the fp64 matrix cores (2 GB per block: 0.2 s of GEMM behind 50 ms of copy).
+static int corr_on_device_streamed(const double* X, int64_t n, int64_t g, hipStream_t st, double** dOutp) {
+    const int64_t gp = (g + CORR_BT - 1) / CORR_BT * CORR_BT;
+    const int nb = (int)(gp / CORR_BT);
+    int64_t blk = std::max<int64_t>(CORR_KC, (int64_t)(2048ll << 20) / (gp * 8) / CORR_KC * CORR_KC);      // rows per block, a multiple of 16
+    if (const char* e = getenv("DIMN_CORR_BLOCK_ROWS")) blk = std::max<int64_t>(CORR_KC, atoll(e) / CORR_KC * CORR_KC);   // tests
+    double *dZ[2] = {nullptr, nullptr}, *pin[2] = {nullptr, nullptr}, *dC = nullptr, *dOut = nullptr, *dMean = nullptr;
+    int2* dPairs = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int rc = DIMN_OK;
+    std::vector<int2> pairs;
+    for (int i = 0; i < nb; ++i)
+        for (int j = i; j < nb; ++j) pairs.push_back(make_int2(i, j));
+#define CORR_TRY(expr) do { hipError_t e_ = (expr); if (rc == DIMN_OK && e_ != hipSuccess) rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+    for (int b = 0; b < 2; ++b) {
+        CORR_TRY(hipMalloc((void**)&dZ[b], (size_t)blk * gp * 8));
+        CORR_TRY(hipHostMalloc((void**)&pin[b], (size_t)blk * g * 8, hipHostMallocDefault));
+        CORR_TRY(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
+    }
+    CORR_TRY(hipMalloc((void**)&dC, (size_t)gp * gp * 8));
+    CORR_TRY(hipMalloc((void**)&dOut, (size_t)g * g * 8));
+    CORR_TRY(hipMalloc((void**)&dMean, (size_t)gp * 8));
+    CORR_TRY(hipMalloc((void**)&dPairs, pairs.size() * sizeof(int2)));
+    if (rc == DIMN_OK) {
+        CORR_TRY(hipMemsetAsync(dMean, 0, (size_t)gp * 8, st));
+        CORR_TRY(hipMemcpyAsync(dPairs, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+    }
+    bool recorded[2] = {false, false};
+    for (int pass = 0; pass < 2 && rc == DIMN_OK; ++pass) {
+        int64_t bi = 0;
+        for (int64_t r0 = 0; r0 < n && rc == DIMN_OK; r0 += blk, ++bi) {
+            const int b = (int)(bi & 1);
+            const int64_t nr = std::min(blk, n - r0), nrp = (nr + CORR_KC - 1) / CORR_KC * CORR_KC;
+            if (recorded[b]) CORR_TRY(hipEventSynchronize(ev[b]));      // the previous user of this buffer pair (also across the two passes)
+            if (rc != DIMN_OK) break;
+            parallel_memcpy(pin[b], X + r0 * g, (size_t)nr * g * 8);
+            if (nrp > nr || gp > g) CORR_TRY(hipMemsetAsync(dZ[b], 0, (size_t)nrp * gp * 8, st));      // zero padding rows / columns
+            CORR_TRY(hipMemcpy2DAsync(dZ[b], (size_t)gp * 8, pin[b], (size_t)g * 8, (size_t)g * 8, (size_t)nr, hipMemcpyHostToDevice, st));
+            if (pass == 0) {
+                hipLaunchKernelGGL(k_corr_colsum_acc, dim3((unsigned)((gp + 255) / 256)), dim3(256), 0, st, dZ[b], nr, gp, dMean);
+            } else {
+                hipLaunchKernelGGL(k_corr_center, dim3((unsigned)((g + 255) / 256), (unsigned)std::min<int64_t>(nr, 1024)), dim3(256), 0, st, dZ[b], nr, g, gp, dMean);
+                hipLaunchKernelGGL(k_corr_gemm, dim3((unsigned)pairs.size()), dim3(256), 0, st, dZ[b], nrp, gp, dPairs, dC, bi > 0 ? 1 : 0);
+            }
+            CORR_TRY(hipGetLastError());
+            CORR_TRY(hipEventRecord(ev[b], st));
+            recorded[b] = true;
+        }
+        if (pass == 0 && rc == DIMN_OK) hipLaunchKernelGGL(k_corr_scale, dim3((unsigned)((gp + 255) / 256)), dim3(256), 0, st, dMean, gp, 1.0 / (double)n);
+    }
+    if (rc == DIMN_OK) {
+        hipLaunchKernelGGL(k_corr_finish, dim3((unsigned)((g + 255) / 256), (unsigned)g), dim3(256), 0, st, dC, g, gp, 1.0 / (double)(n - 1), dOut);
+        CORR_TRY(hipGetLastError());
+    }
+    CORR_TRY(hipStreamSynchronize(st));
+#undef CORR_TRY
+    for (int b = 0; b < 2; ++b) {
+        if (dZ[b]) (void)hipFree(dZ[b]);
+        if (pin[b]) (void)hipHostFree(pin[b]);
+        if (ev[b]) (void)hipEventDestroy(ev[b]);
+    }
+    if (dC) (void)hipFree(dC);
+    if (dMean) (void)hipFree(dMean);
+    if (dPairs) (void)hipFree(dPairs);
+    if (rc != DIMN_OK && dOut) { (void)hipFree(dOut); dOut = nullptr; }
+    *dOutp = dOut;
+    return rc;
+}
+
 // |corr| of the columns of host X[n][g] (fp64) into a fresh device matrix *dOutp [g][g]; the caller frees it.
 static int corr_on_device(const double* X, int64_t n, int64_t g, hipStream_t st, double** dOutp) {
     const int64_t gp = (g + CORR_BT - 1) / CORR_BT * CORR_BT, np_ = (n + CORR_KC - 1) / CORR_KC * CORR_KC;
+    {   // the resident form needs np*gp + 2 g^2 doubles; above the budget (default 64 GB) the matrix is streamed in row blocks
+        double budget = 64.0;
+        if (const char* e = getenv("DIMN_CORR_BUDGET_GB")) budget = atof(e);
+        if (((double)np_ * gp + 2.0 * gp * gp) * 8.0 > budget * 1073741824.0) return corr_on_device_streamed(X, n, g, st, dOutp);
+    }
     const int nb = (int)(gp / CORR_BT);
     double *dZ = nullptr, *dC = nullptr, *dOut = nullptr, *dMean = nullptr, *dPart = nullptr;
     int2* dPairs = nullptr;
@@ -1592,7 +1668,7 @@ static int corr_on_device(const double* X, int64_t n, int64_t g, hipStream_t st,
     hipLaunchKernelGGL(k_corr_colsum, dim3((unsigned)((gp + 255) / 256), (unsigned)nparts), dim3(256), 0, st, dZ, n, gp, rows_per_block, dPart);
     hipLaunchKernelGGL(k_corr_mean, dim3((unsigned)((gp + 255) / 256)), dim3(256), 0, st, dPart, nparts, n, gp, dMean);
     hipLaunchKernelGGL(k_corr_center, dim3((unsigned)((g + 255) / 256), (unsigned)std::min<int64_t>(n, 1024)), dim3(256), 0, st, dZ, n, g, gp, dMean);
-    hipLaunchKernelGGL(k_corr_gemm, dim3((unsigned)pairs.size()), dim3(256), 0, st, dZ, np_, gp, dPairs, dC);
+    hipLaunchKernelGGL(k_corr_gemm, dim3((unsigned)pairs.size()), dim3(256), 0, st, dZ, np_, gp, dPairs, dC, 0);
     hipLaunchKernelGGL(k_corr_finish, dim3((unsigned)((g + 255) / 256), (unsigned)g), dim3(256), 0, st, dC, g, gp, 1.0 / (double)(n - 1), dOut);
     CORR_TRY(hipGetLastError());
     CORR_TRY(hipStreamSynchronize(st));

@@ -39,6 +39,18 @@ __global__ __launch_bounds__(256) void k_corr_mean(const double* __restrict__ pa
     for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * gp + j];
     mean[j] = s / (double)n;
 }
+// partial += column sums of one row block (streamed matrix): one thread per column, sequential over the block's rows
+__global__ __launch_bounds__(256) void k_corr_colsum_acc(const double* __restrict__ X, int64_t n, int64_t gp, double* __restrict__ acc) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= gp) return;
+    double s = 0;
+    for (int64_t i = 0; i < n; ++i) s += X[i * gp + j];
+    acc[j] += s;
+}
+__global__ __launch_bounds__(256) void k_corr_scale(double* __restrict__ v, int64_t gp, double f) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < gp) v[j] *= f;
+}
 // X -= mean (rows < n, columns < g); padding rows/columns are zero and stay zero
 __global__ __launch_bounds__(256) void k_corr_center(double* __restrict__ X, int64_t n, int64_t g, int64_t gp, const double* __restrict__ mean) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -49,8 +61,9 @@ __global__ __launch_bounds__(256) void k_corr_center(double* __restrict__ X, int
 
 // C[I-block][J-block] = Z[:, I]^T Z[:, J] for the upper-triangular block pairs (pairs[] lists them);
 // 4 waves as 2 x 2, each wave a 64 x 64 sub-tile = 4 x 4 MFMA tiles.  Z is [np][gp], np % 16 == 0.
+// accumulate != 0: C += (the matrix is streamed in row blocks, corr_on_device_streamed).
 __global__ __launch_bounds__(256) void k_corr_gemm(const double* __restrict__ Z, int64_t np_, int64_t gp, const int2* __restrict__ pairs,
-                                                   double* __restrict__ C) {
+                                                   double* __restrict__ C, int accumulate) {
     __shared__ __attribute__((aligned(16))) double sm[2][2][CORR_KC * CORR_LD];   // [buffer][A|B][k][col]
     const int2 pr = pairs[blockIdx.x];
     const int64_t I0 = (int64_t)pr.x * CORR_BT, J0 = (int64_t)pr.y * CORR_BT;
@@ -114,8 +127,9 @@ __global__ __launch_bounds__(256) void k_corr_gemm(const double* __restrict__ Z,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t i = I0 + wi + 16 * a + lj + 4 * r, j = J0 + wj + 16 * b + li;
-                C[i * gp + j] = acc[a][b][r];
-                if (pr.x != pr.y) C[j * gp + i] = acc[a][b][r];
+                const double v = accumulate ? C[i * gp + j] + acc[a][b][r] : acc[a][b][r];
+                C[i * gp + j] = v;
+                if (pr.x != pr.y) C[j * gp + i] = v;
             }
 }
 

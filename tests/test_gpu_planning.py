@@ -110,3 +110,21 @@ def test_device_held_out_metrics_match_scipy_path(tmp_path):
     host = net._held_out_metrics(HostOnly(net._engine), norm, held, norm.index.get_indexer(held))
     assert abs(float(dev["correlation"]) - float(host["correlation"])) < 2e-5
     np.testing.assert_allclose(float(dev["MSE"]), float(host["MSE"]), rtol=2e-5)
+
+
+def test_streamed_correlation_matches_resident(monkeypatch):
+    """|corr| with the counts streamed in row blocks (two passes: column sums, then centre + accumulate on the fp64 matrix
+    cores) -- what a matrix too large for the GPU takes (configs[4]) -- against the resident single pass and numpy."""
+    from deepimpute_amd.multinet import _abs_corrcoef
+    rng = np.random.default_rng(2)
+    x = rng.poisson(rng.gamma(0.8, 3.0, size=700), size=(1111, 700)).astype(np.float64)
+    x[:, 17] = 3.0                                                     # a constant gene: NaN -> 0
+    resident = _abs_corrcoef(x, backend="hip")
+    monkeypatch.setenv("DIMN_CORR_BUDGET_GB", "0")                     # force the streamed form ...
+    monkeypatch.setenv("DIMN_CORR_BLOCK_ROWS", "208")                  # ... in six row blocks, the last one partial
+    streamed = _abs_corrcoef(x, backend="hip")
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ref = np.nan_to_num(np.abs(np.corrcoef(x.T)), nan=0.0)
+    np.testing.assert_allclose(streamed, resident, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(streamed, ref, rtol=0, atol=1e-12)
+    assert streamed[17].max() == 0.0
