@@ -1,0 +1,100 @@
+"""Edge cases of the hot path on the GPU, each against the oracle: degenerate sizes (one predictor, one cell per split,
+fewer training cells than a batch, one sub-net), empty requests, and the same through the register-resident, general and
+bf16 paths."""
+import numpy as np
+import pytest
+
+from helpers import load_problem, make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    from deepimpute_amd.engine import HipEngine
+    return HipEngine
+
+
+def _oracle():
+    from oracle.dimo import OracleEngine
+    return OracleEngine
+
+
+def _compare(prob, epochs=2, rtol=1e-4, **kw):
+    a, b = load_problem(_hip(), prob, **kw), load_problem(_oracle(), prob, **kw)
+    a.init_weights(); b.init_weights()
+    for e in range(epochs):
+        np.testing.assert_allclose(a.train_epoch(e), b.train_epoch(e), rtol=rtol)
+        np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=rtol)
+    assert a.step_count() == b.step_count()
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=rtol, atol=1e-6)
+    return a, b
+
+
+@pytest.mark.parametrize("resident", ["0", "1"])
+@pytest.mark.parametrize("n_train,n_val,B", [(5, 1, 64), (64, 3, 64), (65, 70, 64), (1, 1, 1), (130, 9, 7)])
+def test_tiny_splits_and_partial_batches(n_train, n_val, B, resident, monkeypatch):
+    """Fewer training cells than a batch, exactly one batch, one cell over, a single cell, an odd small batch size --
+    on the streaming kernels and (H = 256) on the register-resident epoch kernel."""
+    monkeypatch.setenv("DIMN_RESIDENT", resident)
+    prob = make_problem(n=n_train + n_val + 5, g=120, Ds=[40, 17], H=256, O=32, seed=2)
+    prob["train"] = np.arange(n_train, dtype=np.int32)
+    prob["val"] = np.arange(n_train, n_train + n_val, dtype=np.int32)
+    a, b = _compare(prob, batch_size=B, dropout_rate=0.25, learning_rate=1e-3, seed=9)
+    a.close(); b.close()
+
+
+def test_single_predictor_single_subnet_and_ragged_widths():
+    prob = make_problem(n=150, g=60, Ds=[1], H=24, O=5, seed=4)              # D = 1, O = 5, H = 24: everything padded
+    a, b = _compare(prob, batch_size=32, dropout_rate=0.0, learning_rate=2e-3, seed=1)
+    a.close(); b.close()
+    prob = make_problem(n=150, g=400, Ds=[16, 17, 15, 300], H=384, O=17, seed=5)     # the widest tuned hidden layer, D around a chunk edge
+    a, b = _compare(prob, batch_size=64, dropout_rate=0.5, learning_rate=1e-3, seed=2)
+    a.close(); b.close()
+
+
+def test_empty_and_repeated_requests():
+    prob = make_problem(n=90, g=80, Ds=[20], H=32, O=16, seed=6)
+    a = load_problem(_hip(), prob, batch_size=16, learning_rate=1e-3, seed=3)
+    a.init_weights()
+    assert a.predict(np.zeros(0, np.int32)).shape == (0, 16)
+    rows = np.array([5, 5, 5, 0, 89], np.int32)                           # repeated rows
+    out = a.predict(rows)
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[1], out[2])
+    full = a.predict()
+    assert np.array_equal(out[3], full[0]) and np.array_equal(out[4], full[89])
+    first = a.train_epoch(0)
+    a.init_weights()                                                      # re-initialising replays the run exactly
+    assert np.array_equal(a.train_epoch(0), first)
+    a.close()
+
+
+def test_general_and_bf16_paths_on_degenerate_sizes():
+    from deepimpute_amd.engine import HipGeneralEngine
+    from oracle.dimo import GeneralOracleEngine
+    prob = make_problem(n=40, g=50, Ds=[3, 1], H=8, O=2, seed=7)
+    prob["train"], prob["val"] = np.arange(0, 33, dtype=np.int32), np.arange(33, 34, dtype=np.int32)
+    engines = []
+    for cls in (HipGeneralEngine, GeneralOracleEngine):
+        e = cls(prob["Ds"], [(8, "tanh", 0.5), (3, "relu", 0.0)], 2, batch_size=100, learning_rate=1e-3, seed=5, loss="mae")
+        e.set_matrix(prob["norm"])
+        for k in range(2):
+            e.set_indices(k, prob["pred"][k], prob["targ"][k])
+        e.gather(True)
+        e.set_split(prob["train"], prob["val"])
+        e.init_weights()
+        engines.append(e)
+    a, b = engines
+    for epoch in range(3):
+        np.testing.assert_allclose(a.train_epoch(epoch), b.train_epoch(epoch), rtol=1e-4)
+    np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=1e-4, atol=1e-6)
+    a.close(); b.close()
+    prob = make_problem(n=70, g=90, Ds=[5, 33], H=256, O=20, seed=8)
+    prob["train"], prob["val"] = np.arange(0, 3, dtype=np.int32), np.arange(3, 70, dtype=np.int32)
+    a = load_problem(_hip(), prob, batch_size=64, dropout_rate=0.2, learning_rate=1e-3, seed=5, precision="bf16")
+    b = load_problem(_oracle(), prob, batch_size=64, dropout_rate=0.2, learning_rate=1e-3, seed=5, precision="bf16", infer_bf16=True)
+    a.init_weights(); b.init_weights()
+    np.testing.assert_allclose(a.train_epoch(0), b.train_epoch(0), rtol=1e-4)
+    np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=5e-4)
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=2e-3, atol=2e-4)
+    a.close(); b.close()
