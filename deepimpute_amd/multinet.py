@@ -254,38 +254,82 @@ class MultiNet:
         return make(list(inputdims), layers, self.sub_outputdim, loss=loss, **common)
 
     # -- persistence (reference: model.json + model.h5, multinet.py:105-124) --
+    def _model_format(self):
+        """"h5" (the reference's pair: Keras model.json + Keras-layout model.h5) when the machine has an HDF5 library, else
+        "npz" (model.json + model.npz).  DIMN_MODEL_FORMAT=npz|h5|both overrides."""
+        from . import keras_io
+        want = os.environ.get("DIMN_MODEL_FORMAT", "").lower()
+        if want in ("h5", "both") and not keras_io.available():
+            raise OSError("DIMN_MODEL_FORMAT=%s but no HDF5 library was found (set DIMN_LIBHDF5)" % want)
+        return want if want in ("npz", "h5", "both") else ("h5" if keras_io.available() else "npz")
+
     def save(self, model):
-        """model.json (rank 0) + the weights of this rank's sub-nets in Keras layout, keyed by GLOBAL sub-net
-        index: model.npz for a single process, model.rank<r>.npz per rank of a sharded job (one node, one
-        file system), so a fresh MultiNet under any world size can load() them."""
+        """model.json (rank 0; the Keras functional-model JSON of build()'s network, our own metadata under the extra key
+        "deepimpute_amd") + the weights in Keras layout: model.h5 as Keras save_weights writes it (keras_io.py) or, without
+        an HDF5 library, model.npz keyed by GLOBAL sub-net index.  A sharded job writes model.rank<r>.npz per rank (one
+        node, one file system), from which rank 0 assembles model.h5; a fresh MultiNet under any world size can load() either."""
+        from . import keras_io
         os.makedirs(self.outputdir, exist_ok=True)
         comm = self._comm
         rank, world = (comm.rank, comm.world) if comm is not None else (0, 1)
+        fmt = self._model_format()
+        layers = _parse_architecture(self.NN_parameters['architecture'])
+        dims = [len(p) for p in self.predictors] if getattr(self, "predictors", None) is not None else list(model.D)
         if rank == 0:
-            dims = [len(p) for p in self.predictors] if getattr(self, "predictors", None) is not None else list(model.D)
+            meta = {"format": "deepimpute_amd-3", "inputdims": dims, "sub_outputdim": self.sub_outputdim,
+                    "architecture": self.NN_parameters['architecture'], "loss": _loss_name(self.NN_parameters['loss']),
+                    "batch_size": int(self.NN_parameters["batch_size"]), "weights": fmt}
             with open(os.path.join(self.outputdir, "model.json"), "w") as fh:
-                json.dump({"format": "deepimpute_amd-2", "inputdims": dims, "sub_outputdim": self.sub_outputdim,
-                           "architecture": self.NN_parameters['architecture'], "loss": _loss_name(self.NN_parameters['loss']),
-                           "batch_size": int(self.NN_parameters["batch_size"])}, fh)
+                json.dump(keras_io.model_json(dims, layers, self.sub_outputdim, self.seed, meta), fh)
         blobs = {}
         for k in range(model.K):                         # dense layer l (1-based, the last one is the output layer): Wl_<k>, bl_<k>
             arrays = model.get_weights(k)
             for i, arr in enumerate(arrays):
                 blobs["%s%d_%d" % ("Wb"[i % 2], i // 2 + 1, self._first_subnet + k)] = arr
-        if world == 1:
-            for stale in glob.glob(os.path.join(self.outputdir, "model.rank*.npz")):
-                os.remove(stale)
-        np.savez(os.path.join(self.outputdir, "model.npz" if world == 1 else "model.rank%d.npz" % rank), **blobs)
+        for stale in (glob.glob(os.path.join(self.outputdir, "model.rank*.npz")) if world == 1 else []) + \
+                ([os.path.join(self.outputdir, "model.npz" if fmt == "h5" else "model.h5")] if rank == 0 and fmt != "both" else []):
+            if os.path.exists(stale):
+                os.remove(stale)                         # never leave weights of an older fit beside the new ones
+        if world > 1:
+            np.savez(os.path.join(self.outputdir, "model.rank%d.npz" % rank), **blobs)
+            comm.barrier()                               # every shard is on disk
+            if rank == 0 and fmt != "npz":
+                blobs = {}
+                for path in sorted(glob.glob(os.path.join(self.outputdir, "model.rank*.npz"))):
+                    with np.load(path) as z:
+                        blobs.update({f: z[f] for f in z.files})
+        elif fmt != "h5":
+            np.savez(os.path.join(self.outputdir, "model.npz"), **blobs)
+        if rank == 0 and fmt != "npz":
+            K = len(dims)
+            inputs, hidden, drops, outputs = keras_io.layer_names(K, layers)
+            order = list(inputs)
+            for l in range(len(layers)):
+                order += hidden[l] + (drops[l] or [])
+            order += outputs
+            weights = {}
+            for k in range(K):
+                for l, name in enumerate([h[k] for h in hidden] + [outputs[k]], start=1):
+                    weights[name] = (blobs["W%d_%d" % (l, k)], blobs["b%d_%d" % (l, k)])
+            keras_io.write_weights_h5(os.path.join(self.outputdir, "model.h5"), order, weights)
         if comm is not None:
-            comm.barrier()                               # every shard is on disk when any rank returns
+            comm.barrier()                               # every file is on disk when any rank returns
         print("Saved model to disk in {}".format(self.outputdir))
 
     def load(self):
-        """The engine holding the fitted weights: the live one if this object trained it, else
-        rebuilt from outputdir (weights only, like Keras load_weights: no optimizer state)."""
+        """The engine holding the fitted weights: the live one if this object trained it, else rebuilt from outputdir
+        (weights only, like Keras load_weights: no optimizer state).  Reads what save() writes and the reference's own
+        pair (a Keras model.json without our metadata + model.h5; loss and batch size then stay as constructed)."""
         if self._engine is None:
+            from . import keras_io
             with open(os.path.join(self.outputdir, "model.json")) as fh:
-                meta = json.load(fh)
+                doc = json.load(fh)
+            dense_names = None
+            if "config" in doc:                          # a Keras functional-model JSON
+                inputdims, arch, out_dim, dense_names = keras_io.parse_model_json(doc)
+                meta = doc.get("deepimpute_amd") or {"inputdims": inputdims, "architecture": arch, "sub_outputdim": out_dim}
+            else:
+                meta = doc                               # format deepimpute_amd-2
             self.NN_parameters['architecture'] = meta["architecture"]
             self.sub_outputdim = meta["sub_outputdim"]
             if "loss" in meta:
@@ -293,16 +337,24 @@ class MultiNet:
             if "batch_size" in meta:
                 self.NN_parameters['batch_size'] = meta["batch_size"]
             engine, _, counts = self._build_shard(meta["inputdims"])
-            files = sorted(glob.glob(os.path.join(self.outputdir, "model.rank*.npz"))) or [os.path.join(self.outputdir, "model.npz")]
             wanted = set(range(self._first_subnet, self._first_subnet + engine.K))
-            for path in files:
-                with np.load(path) as z:
-                    for g in sorted(wanted):
-                        if "W1_%d" % g in z.files:
-                            n_dense = sum(1 for f in z.files if f.startswith("W") and f.endswith("_%d" % g))
-                            arrays = [z["%s%d_%d" % (wb, l, g)] for l in range(1, n_dense + 1) for wb in "Wb"]
-                            engine.set_weights(g - self._first_subnet, *arrays)
-                            wanted.discard(g)
+            h5_path = os.path.join(self.outputdir, "model.h5")
+            if dense_names is not None and os.path.exists(h5_path) and meta.get("weights", "h5") != "npz":
+                by_layer = keras_io.read_weights_h5(h5_path, only={name for g in wanted for name in dense_names[g]})
+                for g in sorted(wanted):
+                    arrays = [a for name in dense_names[g] for a in by_layer[name]]
+                    engine.set_weights(g - self._first_subnet, *arrays)
+                wanted.clear()
+            else:
+                files = sorted(glob.glob(os.path.join(self.outputdir, "model.rank*.npz"))) or [os.path.join(self.outputdir, "model.npz")]
+                for path in files:
+                    with np.load(path) as z:
+                        for g in sorted(wanted):
+                            if "W1_%d" % g in z.files:
+                                n_dense = sum(1 for f in z.files if f.startswith("W") and f.endswith("_%d" % g))
+                                arrays = [z["%s%d_%d" % (wb, l, g)] for l in range(1, n_dense + 1) for wb in "Wb"]
+                                engine.set_weights(g - self._first_subnet, *arrays)
+                                wanted.discard(g)
             if wanted:
                 raise FileNotFoundError("weights of sub-networks %s not found in %s" % (sorted(wanted), self.outputdir))
             self._engine = engine
