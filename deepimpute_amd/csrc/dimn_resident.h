@@ -34,17 +34,25 @@
 #define DIMN_RES_THREADS 512
 #define DIMN_RES_LDD 260          // LDS row stride of Dd (as k_mid_fused)
 #define DIMN_RES_SPIN_LIMIT (1u << 22)
+#ifndef DIMN_RES_AUX
 #define DIMN_RES_AUX 17           // sc0 sc1 on every exchanged 16-byte access
+#endif
 #define DIMN_RES_W2S 26976        // LDS float offset of the W2 state
 #define DIMN_RES_LDS_FLOATS (DIMN_RES_W2S + 3 * 16 * 256)
+#ifndef DIMN_RES_ROLL
+#define DIMN_RES_ROLL 1           // partial sums over rolling request windows (0: whole bursts, as first built)
+#endif
+#ifndef DIMN_RES_GW2_LATE
+#define DIMN_RES_GW2_LATE 1       // role 2 publishes its dD partials before the W2 gradient (0: after, as first built)
+#endif
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef DIMN_RES_TL   // tools/res_timeline.py: per-workgroup phase times (shader clock, thread 0), summed over the epoch
-__device__ unsigned long long g_res_tl[1024 * 12];
-#define RES_TL_DECL unsigned long long tl_acc[12] = {0}; unsigned long long tl_t = __builtin_amdgcn_s_memtime();
+__device__ unsigned long long g_res_tl[1024 * 16];
+#define RES_TL_DECL unsigned long long tl_acc[16] = {0}; unsigned long long tl_t = __builtin_amdgcn_s_memtime();
 #define RES_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl_acc[i] += t_ - tl_t; tl_t = t_; }
-#define RES_TL_FLUSH if (threadIdx.x == 0) for (int i_ = 0; i_ < 12; ++i_) g_res_tl[blockIdx.x * 12 + i_] = tl_acc[i_];
+#define RES_TL_FLUSH if (threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) g_res_tl[blockIdx.x * 16 + i_] = tl_acc[i_];
 #else
 #define RES_TL_DECL
 #define RES_STAMP(i)
@@ -351,14 +359,33 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 *(f32x4*)(ddl + ub * ldd + 16 * tile + 4 * uq) = dd;
             };
             if (S1C > 0) {
+                auto ldp = [&](int q, int ss) { return res_ld(rP, (uint32_t)((ss * 16 + 2 * q + (tid >> 8)) * 4096 + 16 * (tid & 255))); };
+                f32x4 pv[4][S1C > 0 ? S1C : 1];
+#if DIMN_RES_ROLL
+                // a rolling window of 4 x S1 requests: the slot a tile pair has just left takes the requests of the pair four
+                // places on, so the second half of the partials travels while the first is summed (one round trip, not two)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int ss = 0; ss < S1C; ++ss) pv[q][ss] = ldp(q, ss);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    f32x4 a = pv[q & 3][0];
+#pragma unroll
+                    for (int ss = 1; ss < S1C; ++ss) a += pv[q & 3][ss];
+                    if (q < 4) {
+#pragma unroll
+                        for (int ss = 0; ss < S1C; ++ss) pv[q][ss] = ldp(q + 4, ss);
+                    }
+                    put_dd(q, a);
+                }
+#else
 #pragma unroll
                 for (int qh = 0; qh < 8; qh += 4) {              // two bursts of 4 x S1 loads
-                    f32x4 pv[4][S1C > 0 ? S1C : 1];
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
-                        for (int ss = 0; ss < S1C; ++ss)
-                            pv[q][ss] = res_ld(rP, (uint32_t)((ss * 16 + 2 * (qh + q) + (tid >> 8)) * 4096 + 16 * (tid & 255)));
+                        for (int ss = 0; ss < S1C; ++ss) pv[q][ss] = ldp(qh + q, ss);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         f32x4 a = pv[q][0];
@@ -367,6 +394,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                         put_dd(qh + q, a);
                     }
                 }
+#endif
             } else {
 #pragma unroll 2
                 for (int q = 0; q < 8; ++q) {
@@ -438,8 +466,8 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 for (int b = 0; b < DIMN_TB; ++b) gb += dzl[b * 16 + tid];
                 adam1(b2w0, b2m0, b2v0, gb, ap);
             }
-            {   // dD^T partial with the OLD W2 first (its write-through stores travel while the rest computes), then the W2
-                // gradient + Adam on the LDS-resident state
+            {   // dD^T partial with the OLD W2: published (write-through stores, drain, arrival) BEFORE the W2 gradient, which
+                // then runs while the role-1 workgroups already pick the partials up
                 f32x4 zf[4];
 #pragma unroll
                 for (int n = 0; n < 4; ++n) zf[n] = *(const f32x4*)(dzl + (16 * n + li) * 16 + 4 * lj);      // dZ[b = 16n+li][o = 4lj+r]
@@ -455,6 +483,14 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                         res_st(rD, (uint32_t)(((ot * 16 + tile) * 1024 + (16 * n + li) * 16 + 4 * lj) * 4), d);   // [b = 16n+li][h = 4lj..]
                     }
                 }
+            }
+#if DIMN_RES_GW2_LATE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(flagD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            RES_STAMP(4)
+#endif
+            {   // W2 gradient + Adam on the LDS-resident state
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
@@ -470,11 +506,17 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#if DIMN_RES_GW2_LATE
+            __syncthreads();                                     // everybody is done reading ddl/dzl/zred (phase B re-uses them)
+            if (tid < 16) smallf[32 + tid] = b2w0;
+            RES_STAMP(11)
+#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                     // also: everybody is done reading ddl/dzl/zred (phase B re-uses them)
             if (tid < 16) smallf[32 + tid] = b2w0;
             if (tid == 0) __hip_atomic_fetch_add(flagD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             RES_STAMP(4)
+#endif
         }
 
         // =============================== phase B (role 1) ===============================
@@ -494,6 +536,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             // (tried: touching the next batch's X rows here / before the flagP wait, by asm loads or LDS-DMA, to move
             //  their HBM latency out of the tile loop: +3..5 us per step -- 16 hidden-tile workgroups fetch the same rows
             //  and the extra requests queue in front of the hand-off traffic)
+            RES_STAMP(12)
             if (t + 1 < p.steps) {
                 publish_mask(tid, t + 1);                        // drained with the partials below, before the flagP arrival
                 y_a = targets(tid, yrow_n);                      // every thread (unconditional load); role 2 uses the first 256
@@ -525,6 +568,18 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 const int o0 = half * (OT >> 1), o1 = half ? OT : (OT >> 1);
                 const uint32_t base = (uint32_t)((ht * 1024 + 4 * (tid & 255)) * 4);
                 int o = o0;
+#if DIMN_RES_ROLL
+                if (o + 16 <= o1) {                              // rolling window of 8 requests over 16 producers
+                    f32x4 tq[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) tq[i] = res_ld(rD, base + (uint32_t)((o + i) * 65536));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { d += tq[i]; tq[i] = res_ld(rD, base + (uint32_t)((o + 8 + i) * 65536)); }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) d += tq[i];
+                    o += 16;
+                }
+#endif
                 for (; o + 8 <= o1; o += 8) {
                     f32x4 tq[8];
 #pragma unroll

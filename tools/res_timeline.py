@@ -36,17 +36,17 @@ steps = -(-train.size // cfg["B"])
 print("resident steps %d, %.2f us per step (HIP events)" % (tm[7], 1e3 * tm[6] / max(1, tm[7])))
 G = 256 // K // 16 * 16
 n = K * G
-buf = (C.c_ulonglong * (n * 12))()
+buf = (C.c_ulonglong * (n * 16))()
 fn = _lib.library().dimn_debug_res_timeline
 fn.argtypes = [C.c_void_p, C.c_int]
-assert fn(buf, n * 12) == 0
-tl = np.frombuffer(buf, np.uint64).reshape(n, 12).astype(np.float64) / steps
+assert fn(buf, n * 16) == 0
+tl = np.frombuffer(buf, np.uint64).reshape(n, 16).astype(np.float64) / steps
 names = ["A pre-wait", "A wait P", "A Dd build", "A Z+loss", "A gW2+dD+publish", "B pre-wait", "B wait D", "B dD sum+dA", "B tile loop",
-         "B P reduce+publish", "loop top", "-"]
+         "B P reduce+publish", "loop top", "A gW2 after publish", "B X requests", "-", "-", "-"]
 wi = np.arange(n) % G
 for label, sel in (("role 1+2 workgroups (wi < 32)", wi < 32), ("role 1 only workgroups", wi >= 32)):
     print(label)
-    for i, nm in enumerate(names[:11]):
+    for i, nm in enumerate(names[:13]):
         v = tl[sel, i]
         print("  %-20s mean %8.0f clk  min %8.0f  max %8.0f" % (nm, v.mean(), v.min(), v.max()))
-    print("  total %.0f clk per step" % tl[sel, :11].sum(axis=1).mean())
+    print("  total %.0f clk per step" % tl[sel, :13].sum(axis=1).mean())
