@@ -425,9 +425,9 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
         if (h->predict_bf16) { TRY(dev_alloc(&h->d_W1b, (size_t)w1)); TRY(dev_alloc(&h->d_W2t, w2n)); }
     }
     if (h->res_G) {
-        TRY(dev_alloc(&h->d_res_P, (size_t)2 * h->K * h->res_G * 1024));
-        TRY(dev_alloc(&h->d_res_D, (size_t)h->K * dm.OT * 16 * 1024));
-        TRY(dev_alloc(&h->d_res_b1, (size_t)3 * h->K * 512));     // dropout keep words [3][K][512]
+        TRY(dev_alloc(&h->d_res_P, (size_t)DIMN_RES_PSLOTS * h->K * h->res_G * 1024));
+        TRY(dev_alloc(&h->d_res_D, (size_t)DIMN_RES_DSLOTS * h->K * dm.OT * 16 * 1024));
+        if (!DIMN_RES_SENT) TRY(dev_alloc(&h->d_res_b1, (size_t)3 * h->K * 512));     // dropout keep words [3][K][512] (sentinel protocol: per epoch, below)
         TRY(dev_alloc(&h->d_res_flags, (size_t)2 * h->K + 1));
         TRY(dev_alloc(&h->d_res_loss, (size_t)h->K * dm.OT));
     }
@@ -1076,6 +1076,10 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
         HIPCHK(hipStreamSynchronize(h->stream));
         DEV_FREE(h->d_res_alpha);
         CHK(dev_alloc(&h->d_res_alpha, (size_t)steps));
+        if (DIMN_RES_SENT) {                                     // the keep words of a whole epoch: [steps][K][512]
+            DEV_FREE(h->d_res_b1);
+            CHK(dev_alloc(&h->d_res_b1, (size_t)steps * h->K * 512));
+        }
         h->res_alpha_cap = steps;
     }
     std::vector<float> alpha((size_t)steps);
@@ -1104,6 +1108,14 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) { e0 = next_event(h); e1 = next_event(h); next_event(h); }
     if (e0 && e1) (void)hipEventRecord(e0, h->stream);
+#if DIMN_RES_SENT
+    // sentinel protocol: every exchange slot starts "not written" (all-ones words); the keep words of the epoch come from their own kernel
+    HIPCHK(hipMemsetAsync(h->d_res_P, 0xff, (size_t)DIMN_RES_PSLOTS * h->K * h->res_G * 4096, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_res_D, 0xff, (size_t)DIMN_RES_DSLOTS * h->K * dm.OT * 65536, h->stream));
+    if (h->cfg.dropout_rate > 0.f)
+        hipLaunchKernelGGL(k_res_masks, dim3((unsigned)(steps * h->K)), dim3(512), 0, h->stream, h->d_sn, (unsigned*)h->d_res_b1, h->K, h->H,
+                           (uint64_t)h->cfg.seed, (uint32_t)epoch, h->cfg.dropout_rate);
+#endif
 #define RES_LAUNCH(T, S)                                                                                                       \
     do {                                                                                                                     \
         (void)hipFuncSetAttribute((const void*)k_epoch_resident<T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -1173,7 +1185,8 @@ extern "C" int dimn_train_epoch(dimn_handle h, int32_t epoch, const int32_t* per
         if (train_loss) for (int k = 0; k < h->K; ++k) train_loss[k] = ls[(size_t)k] / ((double)h->O * (double)h->n_tr);
         return DIMN_OK;
     }
-    if (h->res_G && h->act == DIMN_ACT_RELU) return train_epoch_resident(h, epoch, train_loss);
+    if (h->res_G && h->act == DIMN_ACT_RELU && ((h->n_tr + h->B - 1) / h->B) * h->K * 2048 < (1ll << 31))      // (keep words of the epoch: 32-bit offsets)
+        return train_epoch_resident(h, epoch, train_loss);
     HIPCHK(hipMemsetAsync(h->d_loss_acc, 0, (size_t)h->K * dm.LS * sizeof(double), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));     // every lane reads the row list and accumulates into d_loss_acc
     // d_loss_acc accumulates sum(w e^2) per step; the per-step means are weighted by b_act,

@@ -39,12 +39,11 @@
 #endif
 #define DIMN_RES_W2S 26976        // LDS float offset of the W2 state
 #define DIMN_RES_LDS_FLOATS (DIMN_RES_W2S + 3 * 16 * 256)
-#ifndef DIMN_RES_ROLL
-#define DIMN_RES_ROLL 1           // partial sums over rolling request windows (0: whole bursts, as first built)
+#ifndef DIMN_RES_SENT
+#define DIMN_RES_SENT 1           // hand-offs validated by a sentinel in the data (no drain, no arrival counter); 0: counters, as first built
 #endif
-#ifndef DIMN_RES_GW2_LATE
-#define DIMN_RES_GW2_LATE 1       // role 2 publishes its dD partials before the W2 gradient (0: after, as first built)
-#endif
+#define DIMN_RES_PSLOTS (DIMN_RES_SENT ? 3 : 2)
+#define DIMN_RES_DSLOTS (DIMN_RES_SENT ? 2 : 1)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -68,11 +67,17 @@ struct ResParams {
     const int32_t* rows;            // [n_tr] the epoch's row order (train_rows[perm])
     int32_t n_tr, B, steps;
     const float* alpha;             // [steps] lr*sqrt(1-b2^t)/(1-b1^t) of every step of the epoch
-    float* Ppart;                   // [2][K][G][64][16]   forward partials, double-buffered by step parity
+#if DIMN_RES_SENT
+    float* Ppart;                   // [K][3][G][64][16]   forward partials of step t in slot t % 3 (all-ones = "not written yet")
+    float* Dpart;                   // [K][2][OT][16][64][16] dD partials of step t in slot t % 2
+    unsigned* maskw;                // [steps][K][64 rows][8 words] dropout keep bits of the whole epoch (k_res_masks, before the launch)
+#else
+    float* Ppart;                   // [K][2][G][64][16]   forward partials, double-buffered by step parity
     float* Dpart;                   // [K][OT][16][64][16] dD partials
     unsigned* maskw;                // [3][K][64 rows][8 words] dropout keep bits of step t in buffer t % 3 (written one step
                                     // ahead, before the writer has passed that step's flagD: two buffers would race with slow readers)
-    unsigned* flags;                // [2K+1]: flagP[k], flagD[k], abort
+#endif
+    unsigned* flags;                // [2K+1]: flagP[k], flagD[k] (counter protocol only), abort
     double* loss;                   // [K][OT] sum over the epoch of sum(w e^2) per output tile
     Dims dm;
     float omb1, omb2, eps, rate, scale;
@@ -103,6 +108,59 @@ __device__ __forceinline__ bool res_wait(unsigned* flag, unsigned target, unsign
     }
     return true;
 }
+
+#if DIMN_RES_SENT
+// The sentinel protocol.  An exchange slot is filled with all-ones words before its producer writes it (a NaN pattern no
+// arithmetic produces), so a consumer sees in the DATA whether a 16-byte piece has arrived: no store drain, no barrier, no
+// arrival counter on the producer side -- the hand-off costs one store latency plus one load latency.
+#define DIMN_RES_SENTW 0xffffffffu
+__device__ __forceinline__ bool res_unwritten(f32x4 x) {
+    const u32x4 v = __builtin_bit_cast(u32x4, x);
+    return (v[0] == DIMN_RES_SENTW) | (v[1] == DIMN_RES_SENTW) | (v[2] == DIMN_RES_SENTW) | (v[3] == DIMN_RES_SENTW);
+}
+// One whole wave waits until piece 0 of each of `n` tiles (base + i * stride bytes) is written; false on abort / timeout.
+// The bulk loads that follow validate every piece again (res_fix): the canary only keeps the polling traffic small.
+__device__ __forceinline__ bool res_poll(__amdgpu_buffer_rsrc_t r, uint32_t base, int n, uint32_t stride, unsigned* abort_w) {
+    const int lane = threadIdx.x & 63;
+    unsigned spins = 0;
+    for (;;) {
+        bool missing = false;
+        for (int i = lane; i < n; i += 64) missing |= res_unwritten(res_ld(r, base + (uint32_t)i * stride));
+        if (__builtin_amdgcn_ballot_w64(missing) == 0) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 63u) == 0u) {
+            if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > DIMN_RES_SPIN_LIMIT) {
+                __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+}
+// A piece requested before it was written (rare: its tile's canary was) is requested again; wave-uniform loop, bounded.
+__device__ __forceinline__ void res_fix(f32x4& x, __amdgpu_buffer_rsrc_t r, uint32_t off, unsigned* abort_w) {
+    unsigned spins = 0;
+    while (__builtin_amdgcn_ballot_w64(res_unwritten(x)) != 0) {
+        x = res_ld(r, off);
+        if (++spins > DIMN_RES_SPIN_LIMIT) { __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+}
+// The dropout keep words of a whole epoch (they depend on no data): maskw[t][k][row b][word h/32], bit h%32 = keep(b, h);
+// Philox block (b*H)/4 + h/4 of step t gives four units.  grid (steps * K), 512 threads: one word per thread.
+__global__ __launch_bounds__(512) void k_res_masks(const SubnetDev* __restrict__ sn, unsigned* __restrict__ maskw, int K, int H,
+                                                   uint64_t seed, uint32_t epoch, float rate) {
+    const int t = blockIdx.x / K, k = blockIdx.x - t * K;
+    const int ww = threadIdx.x, b = ww >> 3, q = ww & 7;
+    unsigned word = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const dimn_u32x4 rnd = dimn_dropout_block(seed, (uint32_t)sn[k].kg, epoch, (uint32_t)t, (uint32_t)((b * H) >> 2) + (uint32_t)(8 * q + i));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) word |= (dimn_u01(rnd.v[r]) >= rate ? 1u : 0u) << (4 * i + r);
+    }
+    maskw[(size_t)blockIdx.x * 512 + ww] = word;
+}
+#endif
 
 template <int T1, int S1C>   // W1 tiles per wave; D-splits (0: run-time p.S1)
 __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParams p) {
@@ -137,14 +195,22 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
     unsigned* flagP = p.flags + k;
     unsigned* flagD = p.flags + K + k;
     unsigned* abort_w = p.flags + 2 * K;
+    (void)flagP; (void)flagD;
 
-    // exchange buffers of this sub-net as buffer resources (wave-uniform descriptors)
-    const size_t pp_bytes = (size_t)G * 4096;                      // one parity of one sub-net
-    const __amdgpu_buffer_rsrc_t rP0 = __builtin_amdgcn_make_buffer_rsrc(p.Ppart + ((size_t)0 * K + k) * G * 1024, 0, (int)pp_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rP1 = __builtin_amdgcn_make_buffer_rsrc(p.Ppart + ((size_t)1 * K + k) * G * 1024, 0, (int)pp_bytes, 0x00020000);
+    // exchange buffers of this sub-net as buffer resources (wave-uniform descriptors); slots are byte offsets inside them
+    const uint32_t pslot = (uint32_t)G * 4096u, dslot = (uint32_t)OT * 65536u;
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(p.Ppart + (size_t)k * DIMN_RES_PSLOTS * G * 1024, 0, (int)(DIMN_RES_PSLOTS * pslot), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(p.Dpart + (size_t)k * DIMN_RES_DSLOTS * OT * 16 * 1024, 0, (int)(DIMN_RES_DSLOTS * dslot), 0x00020000);
+#if DIMN_RES_SENT
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(p.maskw, 0, (int)((size_t)p.steps * K * 2048), 0x00020000);
+    auto moff = [&](int t) -> uint32_t { return (uint32_t)((t * K + k) * 2048); };             // byte offset of step t's words
+    const int maux = 0;                                                                         // written by an earlier kernel: plain loads
+    const f32x4 sent4 = __builtin_bit_cast(f32x4, (u32x4){DIMN_RES_SENTW, DIMN_RES_SENTW, DIMN_RES_SENTW, DIMN_RES_SENTW});
+#else
     const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(p.maskw, 0, (int)((size_t)3 * K * 2048), 0x00020000);
     auto moff = [&](int t) -> uint32_t { return (uint32_t)(((t % 3) * K + k) * 2048); };     // byte offset of step t's words
-    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(p.Dpart + (size_t)k * OT * 16 * 1024, 0, (int)((size_t)OT * 16 * 4096), 0x00020000);
+    const int maux = DIMN_RES_AUX;
+#endif
 
     // ---- role 1 state: W1 tiles (chunk cb + wave + 8j, hidden tile ht) in registers ----
     const int cb = (int)((int64_t)s.nchunk * sp / S1), ce = (int)((int64_t)s.nchunk * (sp + 1) / S1);
@@ -208,7 +274,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
     // forward partial of batch t+1 with the fresh W1 (do_fwd).  xa/xb: the X_t / X_{t+1} tiles of the wave's first
     // chunk, requested by the caller (before its wait); xot/xon from xrows().
     auto role1 = [&](const int tid, const uint32_t (&xot)[4], const uint32_t (&xon)[4], f32x4 (&xa)[4], f32x4 (&xb)[4], bool do_grad, bool do_fwd,
-                     const float (&bfr)[16], const AdamP ap, int par_out) {
+                     const float (&bfr)[16], const AdamP ap, uint32_t slot_out) {
         const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lj = lane >> 4;
         const float* xk = p.X + s.xoff + 4 * (lane & 3);
         float* xt = xst + wave * 2048;
@@ -251,11 +317,17 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
 #pragma unroll
                 for (int wv = 1; wv < 8; ++wv) a += *(const f32x4*)(pred + wv * 1024 + 4 * tid);
                 if (sp == 0) a += *(const f32x4*)(b1l + 4 * (tid & 3));     // split 0 carries the bias: A = sum_s P_s
-                res_st(par_out ? rP1 : rP0, (uint32_t)(wi * 4096 + 16 * tid), a);
+#if DIMN_RES_SENT
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the reset of the slot after this one (issued a phase ago) is in place
+                res_st(rP, slot_out + (uint32_t)(wi * 4096 + 16 * tid), a);
+            }
+#else
+                res_st(rP, slot_out + (uint32_t)(wi * 4096 + 16 * tid), a);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every storing wave drains before the arrival
             }
             __syncthreads();
             if (tid == 0) __hip_atomic_fetch_add(flagP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         }
         RES_STAMP(9)
     };
@@ -267,7 +339,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
     const int mw0 = pidx >= 0 ? 512 * pidx / nprod : 0, mw1 = pidx >= 0 ? 512 * (pidx + 1) / nprod : 0;
     unsigned* mscr = (unsigned*)(smallf + 48);                   // [<= 16] staging words of one pass (LDS)
     auto publish_mask = [&](const int tid, int t) {
-        if (!(p.rate > 0.f)) return;                             // rate 0: consumers do not read the mask
+        if (DIMN_RES_SENT || !(p.rate > 0.f)) return;            // sentinel protocol: k_res_masks made them; rate 0: consumers do not read the mask
         for (int w0 = mw0; w0 < mw1; w0 += 16) {                 // 16 words = 128 blocks per pass, one block per thread
             const int nw = (mw1 - w0) < 16 ? (mw1 - w0) : 16;
             if (tid < 16) mscr[tid] = 0u;
@@ -308,7 +380,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
         for (int i = 0; i < 4; ++i) { xa[i] = *(const f32x4*)(xk + xo0[i] + 16 * tc[0]); xb[i] = xa[i]; }
         __syncthreads();                                         // b1l written
         publish_mask(tid, 0);
-        role1(tid, xo0, xo0, xa, xb, false, true, nob, ap0, 0);
+        role1(tid, xo0, xo0, xa, xb, false, true, nob, ap0, 0u);
         y_a = targets(tid, target_row(tid, 0));
     }
 
@@ -326,7 +398,12 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
         const int b_next = rem <= 0 ? 0 : (rem < B ? rem : B);
         const float inv_n = (float)(1.0 / ((double)b_act * dm.O));
         AdamP ap; ap.alpha = p.alpha[t]; ap.omb1 = p.omb1; ap.omb2 = p.omb2; ap.eps = p.eps;
-        const __amdgpu_buffer_rsrc_t rP = par ? rP1 : rP0;
+#if DIMN_RES_SENT
+        const uint32_t pcur = (uint32_t)(t % 3) * pslot, pnext = (uint32_t)((t + 1) % 3) * pslot, pfree = (uint32_t)((t + 2) % 3) * pslot;
+        const uint32_t dcur = (uint32_t)par * dslot, dfree = (uint32_t)(par ^ 1) * dslot;
+#else
+        const uint32_t pcur = (uint32_t)par * pslot, pnext = (uint32_t)(par ^ 1) * pslot, dcur = 0u;
+#endif
         // row indices of the NEXT batch, requested a whole phase before their use (they head two dependent loads)
         int32_t rn[4];
         xrows_raw(tid, (t + 1) * B, b_next, rn);
@@ -338,14 +415,20 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             const int ub = (tid & 255) >> 2, uq = tid & 3;
             if (tid < 256) *(f32x4*)(yl + 4 * tid) = y_a;
             RES_STAMP(0)
+#if DIMN_RES_SENT
+            if (wave == 0) { const bool ok = res_poll(rP, pcur, G, 4096u, abort_w); if (lane == 0) flagl[0] = ok ? 1 : 0; }
+            __syncthreads();
+            if (!flagl[0]) return;
+#else
             if (tid == 0) flagl[0] = res_wait(flagP, (unsigned)(G * (t + 1)), abort_w) ? 1 : 0;
             __syncthreads();
             if (!flagl[0]) return;
+#endif
             RES_STAMP(1)
             u32x4 km0 = (u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, km1 = km0;
             if (p.rate > 0.f) {                                  // keep bits of row ub: 8 words
-                km0 = __builtin_amdgcn_raw_buffer_load_b128(rM, moff(t) + (uint32_t)(32 * ub), 0, DIMN_RES_AUX);
-                km1 = __builtin_amdgcn_raw_buffer_load_b128(rM, moff(t) + (uint32_t)(32 * ub + 16), 0, DIMN_RES_AUX);
+                km0 = __builtin_amdgcn_raw_buffer_load_b128(rM, moff(t) + (uint32_t)(32 * ub), 0, maux);
+                km1 = __builtin_amdgcn_raw_buffer_load_b128(rM, moff(t) + (uint32_t)(32 * ub + 16), 0, maux);
             }
             const int ksh = 16 * (tid >> 8) + 4 * uq;            // unit q: hidden units 32q + ksh .. +3 = word q, bits ksh..
             const unsigned rowmask = ub < b_act ? 0xffffffffu : 0u;
@@ -358,53 +441,54 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 for (int r = 0; r < 4; ++r) dd[r] = ((kw >> (ksh + r)) & 1u) ? fmaxf(a[r], 0.f) * p.scale : 0.f;      // one select, no branch
                 *(f32x4*)(ddl + ub * ldd + 16 * tile + 4 * uq) = dd;
             };
+            auto poff = [&](int q, int ss) -> uint32_t { return pcur + (uint32_t)((ss * 16 + 2 * q + (tid >> 8)) * 4096 + 16 * (tid & 255)); };
+#if DIMN_RES_SENT
+#define RES_FIX(x, r, off) res_fix((x), (r), (off), abort_w)
+#else
+#define RES_FIX(x, r, off)
+#endif
             if (S1C > 0) {
-                auto ldp = [&](int q, int ss) { return res_ld(rP, (uint32_t)((ss * 16 + 2 * q + (tid >> 8)) * 4096 + 16 * (tid & 255))); };
-                f32x4 pv[4][S1C > 0 ? S1C : 1];
-#if DIMN_RES_ROLL
                 // a rolling window of 4 x S1 requests: the slot a tile pair has just left takes the requests of the pair four
                 // places on, so the second half of the partials travels while the first is summed (one round trip, not two)
+                f32x4 pv[4][S1C > 0 ? S1C : 1];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int ss = 0; ss < S1C; ++ss) pv[q][ss] = ldp(q, ss);
+                    for (int ss = 0; ss < S1C; ++ss) pv[q][ss] = res_ld(rP, poff(q, ss));
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                    for (int ss = 0; ss < S1C; ++ss) RES_FIX(pv[q & 3][ss], rP, poff(q, ss));
                     f32x4 a = pv[q & 3][0];
 #pragma unroll
                     for (int ss = 1; ss < S1C; ++ss) a += pv[q & 3][ss];
                     if (q < 4) {
 #pragma unroll
-                        for (int ss = 0; ss < S1C; ++ss) pv[q][ss] = ldp(q + 4, ss);
+                        for (int ss = 0; ss < S1C; ++ss) pv[q][ss] = res_ld(rP, poff(q + 4, ss));
                     }
                     put_dd(q, a);
                 }
-#else
-#pragma unroll
-                for (int qh = 0; qh < 8; qh += 4) {              // two bursts of 4 x S1 loads
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int ss = 0; ss < S1C; ++ss) pv[q][ss] = ldp(qh + q, ss);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        f32x4 a = pv[q][0];
-#pragma unroll
-                        for (int ss = 1; ss < S1C; ++ss) a += pv[q][ss];
-                        put_dd(qh + q, a);
-                    }
-                }
-#endif
             } else {
 #pragma unroll 2
                 for (int q = 0; q < 8; ++q) {
-                    const int tile = 2 * q + (tid >> 8);
-                    f32x4 a = res_ld(rP, (uint32_t)(tile * 4096 + 16 * (tid & 255)));
-                    for (int ss = 1; ss < S1; ++ss) a += res_ld(rP, (uint32_t)((ss * 16 + tile) * 4096 + 16 * (tid & 255)));
+                    f32x4 a = res_ld(rP, poff(q, 0));
+                    RES_FIX(a, rP, poff(q, 0));
+                    for (int ss = 1; ss < S1; ++ss) {
+                        f32x4 a2 = res_ld(rP, poff(q, ss));
+                        RES_FIX(a2, rP, poff(q, ss));
+                        a += a2;
+                    }
                     put_dd(q, a);
                 }
             }
             const float* ws = w2s + 2 * wave * 256;              // this wave's two W2 tiles [h][o]
+#if DIMN_RES_SENT
+            // every partial of this step was out, so every workgroup has finished the step before: the dD slot of that step is
+            // free -- mark it "not written" for the step after this one.  Behind the partial requests (in front of them the
+            // 64 KB of stores delayed the loads), and acknowledged before this step's dD stores leave (vmcnt(0) there).
+#pragma unroll
+            for (int i = 0; i < 8; ++i) res_st(rD, dfree + (uint32_t)(ot * 65536 + (i * 512 + tid) * 16), sent4);
+#endif
             __syncthreads();
             RES_STAMP(2)
             {   // Z partial over this wave's 32 hidden units
@@ -466,11 +550,14 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 for (int b = 0; b < DIMN_TB; ++b) gb += dzl[b * 16 + tid];
                 adam1(b2w0, b2m0, b2v0, gb, ap);
             }
-            {   // dD^T partial with the OLD W2: published (write-through stores, drain, arrival) BEFORE the W2 gradient, which
-                // then runs while the role-1 workgroups already pick the partials up
+            {   // dD^T partial with the OLD W2: published BEFORE the W2 gradient, which then runs while the role-1 workgroups
+                // already pick the partials up
                 f32x4 zf[4];
 #pragma unroll
                 for (int n = 0; n < 4; ++n) zf[n] = *(const f32x4*)(dzl + (16 * n + li) * 16 + 4 * lj);      // dZ[b = 16n+li][o = 4lj+r]
+#if DIMN_RES_SENT
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the reset of the other dD slot (issued before the Dd build) is in place
+#endif
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     const int tile = 2 * wave + h2;
@@ -480,16 +567,16 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                         f32x4 d = zero4;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) d = MFMA16(wq[r], zf[n][r], d);                              // dD^T[h][b] = W2 dZ^T
-                        res_st(rD, (uint32_t)(((ot * 16 + tile) * 1024 + (16 * n + li) * 16 + 4 * lj) * 4), d);   // [b = 16n+li][h = 4lj..]
+                        res_st(rD, dcur + (uint32_t)(((ot * 16 + tile) * 1024 + (16 * n + li) * 16 + 4 * lj) * 4), d);   // [b = 16n+li][h = 4lj..]
                     }
                 }
             }
-#if DIMN_RES_GW2_LATE
+#if !DIMN_RES_SENT
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) __hip_atomic_fetch_add(flagD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            RES_STAMP(4)
 #endif
+            RES_STAMP(4)
             {   // W2 gradient + Adam on the LDS-resident state
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -506,17 +593,9 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-#if DIMN_RES_GW2_LATE
             __syncthreads();                                     // everybody is done reading ddl/dzl/zred (phase B re-uses them)
             if (tid < 16) smallf[32 + tid] = b2w0;
             RES_STAMP(11)
-#else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                     // also: everybody is done reading ddl/dzl/zred (phase B re-uses them)
-            if (tid < 16) smallf[32 + tid] = b2w0;
-            if (tid == 0) __hip_atomic_fetch_add(flagD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            RES_STAMP(4)
-#endif
         }
 
         // =============================== phase B (role 1) ===============================
@@ -542,7 +621,11 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 y_a = targets(tid, yrow_n);                      // every thread (unconditional load); role 2 uses the first 256
             }
             RES_STAMP(5)
+#if DIMN_RES_SENT
+            if (wave == 0) { const bool ok = res_poll(rD, dcur + (uint32_t)(ht * 4096), OT, 65536u, abort_w); if (lane == 0) flagl[1] = ok ? 1 : 0; }
+#else
             if (tid == 0) flagl[1] = res_wait(flagD, (unsigned)(OT * (t + 1)), abort_w) ? 1 : 0;
+#endif
             __syncthreads();
             if (!flagl[1]) return;
             RES_STAMP(6)
@@ -550,52 +633,56 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             // bits), then the dD partials of the OT producers (their two halves on the two thread halves)
             unsigned keep = 0xfu;
             if (p.rate > 0.f)
-                keep = __builtin_amdgcn_raw_buffer_load_b32(rM, moff(t) + (uint32_t)(32 * ub + 4 * (ht >> 1)), 0, DIMN_RES_AUX) >> (16 * (ht & 1) + 4 * uq);
+                keep = __builtin_amdgcn_raw_buffer_load_b32(rM, moff(t) + (uint32_t)(32 * ub + 4 * (ht >> 1)), 0, maux) >> (16 * (ht & 1) + 4 * uq);
+            auto goff = [&](int ss) -> uint32_t { return pcur + (uint32_t)((ss * 16 + ht) * 4096 + 16 * (tid & 255)); };
             f32x4 a;
             if (S1C > 0) {
                 f32x4 gp[S1C > 0 ? S1C : 1];
 #pragma unroll
-                for (int ss = 0; ss < S1C; ++ss) gp[ss] = res_ld(rP, (uint32_t)((ss * 16 + ht) * 4096 + 16 * (tid & 255)));
+                for (int ss = 0; ss < S1C; ++ss) gp[ss] = res_ld(rP, goff(ss));
+#pragma unroll
+                for (int ss = 0; ss < S1C; ++ss) RES_FIX(gp[ss], rP, goff(ss));
                 a = gp[0];
 #pragma unroll
                 for (int ss = 1; ss < S1C; ++ss) a += gp[ss];
             } else {
-                a = res_ld(rP, (uint32_t)(ht * 4096 + 16 * (tid & 255)));
-                for (int ss = 1; ss < S1; ++ss) a += res_ld(rP, (uint32_t)((ss * 16 + ht) * 4096 + 16 * (tid & 255)));
+                a = res_ld(rP, goff(0));
+                RES_FIX(a, rP, goff(0));
+                for (int ss = 1; ss < S1; ++ss) { f32x4 a2 = res_ld(rP, goff(ss)); RES_FIX(a2, rP, goff(ss)); a += a2; }
             }
             f32x4 d = zero4;
             {
                 const int o0 = half * (OT >> 1), o1 = half ? OT : (OT >> 1);
-                const uint32_t base = (uint32_t)((ht * 1024 + 4 * (tid & 255)) * 4);
+                const uint32_t base = dcur + (uint32_t)((ht * 1024 + 4 * (tid & 255)) * 4);
                 int o = o0;
-#if DIMN_RES_ROLL
                 if (o + 16 <= o1) {                              // rolling window of 8 requests over 16 producers
                     f32x4 tq[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) tq[i] = res_ld(rD, base + (uint32_t)((o + i) * 65536));
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { d += tq[i]; tq[i] = res_ld(rD, base + (uint32_t)((o + 8 + i) * 65536)); }
+                    for (int i = 0; i < 8; ++i) {
+                        RES_FIX(tq[i], rD, base + (uint32_t)((o + i) * 65536));
+                        d += tq[i];
+                        tq[i] = res_ld(rD, base + (uint32_t)((o + 8 + i) * 65536));
+                    }
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) d += tq[i];
+                    for (int i = 0; i < 8; ++i) { RES_FIX(tq[i], rD, base + (uint32_t)((o + 8 + i) * 65536)); d += tq[i]; }
                     o += 16;
-                }
-#endif
-                for (; o + 8 <= o1; o += 8) {
-                    f32x4 tq[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) tq[i] = res_ld(rD, base + (uint32_t)((o + i) * 65536));
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) d += tq[i];
                 }
                 for (; o + 4 <= o1; o += 4) {
                     f32x4 tq[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) tq[i] = res_ld(rD, base + (uint32_t)((o + i) * 65536));
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) d += tq[i];
+                    for (int i = 0; i < 4; ++i) { RES_FIX(tq[i], rD, base + (uint32_t)((o + i) * 65536)); d += tq[i]; }
                 }
-                for (; o < o1; ++o) d += res_ld(rD, base + (uint32_t)(o * 65536));
+                for (; o < o1; ++o) { f32x4 t1 = res_ld(rD, base + (uint32_t)(o * 65536)); RES_FIX(t1, rD, base + (uint32_t)(o * 65536)); d += t1; }
             }
+#if DIMN_RES_SENT
+            // every dD partial of this step was out, so every workgroup has read the partials of the step before: that slot is
+            // free -- mark it "not written" for the step after the next (acknowledged before P of the next step leaves: vmcnt(0) there)
+            if (tid < 256) res_st(rP, pfree + (uint32_t)(wi * 4096 + 16 * tid), sent4);
+#endif
             if (half) *(f32x4*)(yl + 4 * (tid & 255)) = d;
             __syncthreads();
             if (half == 0) {
@@ -617,7 +704,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
 #pragma unroll
             for (int kb = 0; kb < 16; ++kb) bfr[kb] = dzl[64 * kb + lane];                                        // dA[b = 4kb+lj][h = li]
             RES_STAMP(7)
-            role1(tid, xo0, xon, xa, xb, true, b_next > 0, bfr, ap, par ^ 1);     // its first barrier orders b1l / dzl
+            role1(tid, xo0, xon, xa, xb, true, b_next > 0, bfr, ap, pnext);     // its first barrier orders b1l / dzl
             if (b_next == 0) __syncthreads();
 #pragma unroll
             for (int i = 0; i < 4; ++i) xo0[i] = xon[i];         // the next batch becomes the current one
