@@ -167,6 +167,7 @@ struct dimn_handle_s {
     // comm
     ncclComm_t comm = nullptr; int n_ranks = 1, rank = 0;
     bf16_t *d_W1b = nullptr, *d_W2t = nullptr; bool predict_bf16 = false;   // bf16 images of the weights for k_predict_bf16
+    float* d_W2tf = nullptr;                                                // W2 in the operand form of k_predict's second layer (k_prep_w2t)
     int prec = 0;                          // DIMN_PREC_*: 1 = X arena in bfloat16, inference GEMMs on the bf16 matrix cores
     struct GenNet* gen = nullptr;          // != NULL: the general path (dimn_general.h) owns the network of this handle
 };
@@ -299,7 +300,14 @@ static void build_resident(dimn_handle h) {
     const int per_wg = ceil_div(maxchunk, S1);
     const int T1 = ceil_div(per_wg + 1, 8);                  // +1: the integer split of nchunk may give one workgroup one more
     if (T1 > 7) return;
-    h->res_G = 16 * S1; h->res_S1 = S1; h->res_T1 = T1 <= 2 ? 2 : (T1 <= 4 ? 4 : 7);
+    const int T1c = T1 <= 2 ? 2 : (T1 <= 4 ? 4 : 7);         // the kernel instance; res_chunk_range() never gives a split more than 8 * T1c chunks
+    for (auto& s : h->sn)
+        for (int sp = 0; sp < S1; ++sp) {
+            int cb, ce;
+            res_chunk_range(s.nchunk, S1, (dm.OT + 15) >> 4, 8 * T1c, sp, cb, ce);
+            if (ce - cb > 8 * T1c || ce - cb < 1 || cb < 0 || ce > s.nchunk) return;
+        }
+    h->res_G = 16 * S1; h->res_S1 = S1; h->res_T1 = T1c;
 }
 
 static int create_common(const dimn_config* cfg, const int32_t* D, bool general, dimn_handle* out) {
@@ -332,6 +340,7 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
     if (dm.HT == 19 && !(getenv("DIMN_HT20") && atoi(getenv("DIMN_HT20")) == 0)) { dm.Hp = 320; dm.HT = 20; }
     dm.Op = ceil_div(h->O, 16) * 16; dm.OT = dm.Op / 16;
     dm.ldd = dm.Hp + ((dm.Hp % 32 == 0) ? 2 : 18);   // LDS row stride = 2 (mod 32) words: conflict-free b32 column reads
+    dm.ldp = dm.Hp + ((dm.Hp % 32 == 0) ? 4 : 20);   // k_predict: 4 (mod 32) words, rows 16-byte aligned: conflict-free b128 row reads
     dm.OS = ceil_div(dm.OT, 4);
     dm.LS = dm.OS;
     h->NT = ceil_div(dm.HT, 4);
@@ -342,7 +351,7 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
         delete h;
         return fail(DIMN_ERR_UNSUP, "dimn_create: hidden=%d > 384 is outside the tuned kernels (use dimn_create_general)", cfg->hidden);
     }
-    if (!general && (size_t)DIMN_TB * dm.ldd * sizeof(float) > 160 * 1024) {
+    if (!general && (size_t)DIMN_TB * dm.ldp * sizeof(float) > 160 * 1024) {
         delete h;
         return fail(DIMN_ERR_UNSUP, "dimn_create: hidden too large for LDS staging");
     }
@@ -424,6 +433,7 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
         h->predict_bf16 = !(getenv("DIMN_PREDICT_BF16") && atoi(getenv("DIMN_PREDICT_BF16")) == 0);
         if (h->predict_bf16) { TRY(dev_alloc(&h->d_W1b, (size_t)w1)); TRY(dev_alloc(&h->d_W2t, w2n)); }
     }
+    if (!h->predict_bf16) TRY(dev_alloc(&h->d_W2tf, w2n));
     if (h->res_G) {
         TRY(dev_alloc(&h->d_res_P, (size_t)DIMN_RES_PSLOTS * h->K * h->res_G * 1024));
         TRY(dev_alloc(&h->d_res_D, (size_t)DIMN_RES_DSLOTS * h->K * dm.OT * 16 * 1024));
@@ -511,7 +521,7 @@ extern "C" int dimn_destroy(dimn_handle h) {
     DEV_FREE(h->d_epoch_rows); DEV_FREE(h->d_val_rows); DEV_FREE(h->d_pred_rows); DEV_FREE(h->d_out);
     DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage); DEV_FREE(h->d_red);
     for (auto& pb : h->pin_buf) if (pb) { (void)hipHostFree(pb); pb = nullptr; }
-    DEV_FREE(h->d_W1b); DEV_FREE(h->d_W2t);
+    DEV_FREE(h->d_W1b); DEV_FREE(h->d_W2t); DEV_FREE(h->d_W2tf);
     DEV_FREE(h->d_res_P); DEV_FREE(h->d_res_D); DEV_FREE(h->d_res_b1); DEV_FREE(h->d_res_alpha); DEV_FREE(h->d_res_flags); DEV_FREE(h->d_res_loss);
     for (auto& ln : h->lanes) (void)hipStreamDestroy(ln.stream);
     delete h;
@@ -884,9 +894,11 @@ static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, f
                            h->cfg.loss_binary, h->act);
         return;
     }
-    const size_t lds = (size_t)DIMN_TB * h->dm.ldd * sizeof(float);
+    // the second-layer operand form of k_predict: a fresh W2T image (21 MB at 40 sub-nets: ~10 us per call)
+    hipLaunchKernelGGL(k_prep_w2t, dim3(128, (unsigned)h->K), dim3(256), 0, h->stream, (const float*)h->d_W2, h->d_W2tf, h->dm);
+    const size_t lds = (size_t)DIMN_TB * h->dm.ldp * sizeof(float);
     WITH_XT(h, hipLaunchKernelGGL((k_predict<NT, XT>), dim3(tiles, (unsigned)h->K), dim3(256), lds, h->stream, h->d_sn, (const XT*)h->d_X, h->d_W1, h->d_b1,
-                                  h->d_W2, h->d_b2, rows, n_rows, out, h->d_Y, h->n, loss_part, h->dm, h->cfg.loss_binary, h->act));
+                                  h->d_W2tf, h->d_b2, rows, n_rows, out, h->d_Y, h->n, loss_part, h->dm, h->cfg.loss_binary, h->act));
 }
 #define DISPATCH_NT(fn, ...)                          \
     switch (h->NT) {                                  \

@@ -136,8 +136,9 @@ struct Work {               // one workgroup of the split-K / weight-update kern
 };
 
 struct Dims {
-    int32_t K, H, O, Hp, Op, HT, OT, ldd, OS, LS;
-    // Hp = ceil16(H), HT = Hp/16, Op = ceil16(O), OT = Op/16, ldd = LDS row stride of Dd,
+    int32_t K, H, O, Hp, Op, HT, OT, ldd, OS, LS, ldp;
+    // Hp = ceil16(H), HT = Hp/16, Op = ceil16(O), OT = Op/16, ldd = LDS row stride of Dd (2 mod 32 words: b32 column reads),
+    // ldp = LDS row stride of k_predict's activations (4 mod 32 words, 16-byte aligned rows: b128 row reads),
     // OS = ceil(OT/4) output slices of 64 columns; LS = loss slots per sub-net (>= OS, >= slices of the fused kernel)
 };
 
@@ -1526,7 +1527,29 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void k_w1_update_fwd_ring(const Wo
 // Fused forward for 64 rows: model.predict (multinet.py:253,278) and the validation pass.
 // grid (row tiles, K).  out != NULL: out[i][k*O + o] = softplus(z).  loss_part != NULL:
 // loss_part[k*gridDim.x + tile] = sum w*(y-yhat)^2 over the tile (S9).
+// Second layer in the k-slot form: one 16-byte LDS read of an activation row feeds four MFMAs, and the W2 operand comes
+// from W2T (k_prep_w2t), where the float4 of a lane is W2[h = 16ht + 4lj .. +3][o = 16ot + li] -- one coalesced 1 KB wave
+// request per (hidden tile, output tile), prefetched one tile ahead.
 // ---------------------------------------------------------------------------------------
+// W2T[k][ot][ht][lane][r] = W2 tile (ht, ot) [h = 4*(lane>>4) + r][o = lane & 15]   (the tile-native W2 is [h][o])
+__global__ __launch_bounds__(256) void k_prep_w2t(const float* __restrict__ W2, float* __restrict__ W2T, Dims dm) {
+    const int k = blockIdx.y;
+    const int64_t n2 = (int64_t)dm.Hp * dm.Op;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n2 / 4; e += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(e & 63);
+        const int64_t tile = e >> 6;                             // = ot * HT + ht
+        const int ot = (int)(tile / dm.HT), ht = (int)(tile - (int64_t)ot * dm.HT);
+        const float* src = W2 + (int64_t)k * n2 + ((int64_t)ht * dm.OT + ot) * 256 + (4 * (lane >> 4)) * 16 + (lane & 15);
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = src[16 * r];
+        *(f32x4*)(W2T + (int64_t)k * n2 + e * 4) = v;
+    }
+}
+
+#ifndef DIMN_PREDICT_DEPTH
+#define DIMN_PREDICT_DEPTH 3
+#endif
 template <int NT, typename XT>
 __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ sn, const XT* __restrict__ X,
                                                  const float* __restrict__ W1, const float* __restrict__ b1,
@@ -1541,7 +1564,7 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lj = lane >> 4;
     const int nt0 = wave * NT;
-    const int Hp = dm.Hp, ldd = dm.ldd;
+    const int Hp = dm.Hp;
 
     f32x4 acc[4][NT];
 #pragma unroll
@@ -1586,6 +1609,28 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA16(a4[mt][r], o.b[nt][r], acc[mt][nt]);
     };
+#if DIMN_PREDICT_DEPTH == 3
+    Ops P0, P1, P2;                                          // three named sets: two chunks in flight (the X rows come from HBM)
+    fetch(P0, 0);
+    fetch(P1, 1);
+    int c = 0;
+    for (; c + 3 <= s.nchunk; c += 3) {                      // (sched_barrier: hipcc sinks the requests below the MFMAs and drains vmcnt(0) mid-loop otherwise)
+        fetch(P2, c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(P0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(P0, c + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(P1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(P1, c + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(P2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (c < s.nchunk) mma(P0);
+    if (c + 1 < s.nchunk) mma(P1);
+#else
     Ops P0, P1;
     fetch(P0, 0);
     int c = 0;
@@ -1596,7 +1641,9 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
         mma(P1);
     }
     if (c < s.nchunk) mma(P0);
+#endif
     // bias + relu -> LDS (dropout is identity at inference, S3/S12)
+    const int ldp = dm.ldp;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
         if (nt0 + nt < dm.HT) {
@@ -1609,28 +1656,42 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
                     const float v = acc[mt][nt][r] + bias;
                     float f = v > 0.f ? v : 0.f, df;
                     if (act != 0) { hidden_act(act, v, f, df); if (h >= dm.H) f = 0.f; }
-                    lds[(16 * mt + 4 * lj + r) * ldd + h] = f;
+                    lds[(16 * mt + 4 * lj + r) * ldp + h] = f;
                 }
         }
     __syncthreads();
 
     float lsum = 0.f;
+    const int HT = dm.HT;
+    const float* arow = lds + li * ldp + 4 * lj;                 // activations [b = 16mt + li][h = 16ht + 4lj ..]
     for (int ot = wave; ot < dm.OT; ot += 4) {
         f32x4 z[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) z[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* w2 = W2 + (int64_t)k * Hp * dm.Op + (int64_t)ot * 256 + lj * 16 + li;
-        for (int ht = 0; ht < dm.HT; ++ht) {
-            const float* wt = w2 + (int64_t)ht * dm.OT * 256;
-            float bv[4];
+        const float* wt = W2 + ((int64_t)k * dm.OT + ot) * HT * 256 + lane * 4;      // W2T: the tiles (ht, ot), ht = 0.., contiguous
+        auto tile = [&](const f32x4 bq, int ht) {
+            f32x4 a4[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bv[q] = wt[q * 64];
+            for (int mt = 0; mt < 4; ++mt) a4[mt] = *(const f32x4*)(arow + 16 * mt * ldp + 16 * ht);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    z[mt] = MFMA16(lds[(16 * mt + li) * ldd + 16 * ht + 4 * q + lj], bv[q], z[mt]);
+                for (int mt = 0; mt < 4; ++mt) z[mt] = MFMA16(a4[mt][r], bq[r], z[mt]);
+        };
+        // two named operand registers, loop unrolled x2: the request of tile ht+1 leaves before tile ht feeds the MFMAs
+        f32x4 q0 = *(const f32x4*)wt, q1;
+        int ht = 0;
+        for (; ht + 2 <= HT; ht += 2) {
+            q1 = *(const f32x4*)(wt + (ht + 1) * 256);
+            __builtin_amdgcn_sched_barrier(0);
+            tile(q0, ht);
+            __builtin_amdgcn_sched_barrier(0);
+            q0 = *(const f32x4*)(wt + (ht + 2 < HT ? ht + 2 : ht + 1) * 256);
+            __builtin_amdgcn_sched_barrier(0);
+            tile(q1, ht + 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (ht < HT) tile(q0, ht);
         const int o = 16 * ot + li;
         if (o < dm.O) {
             const float bias = b2[(int64_t)k * dm.Op + o];

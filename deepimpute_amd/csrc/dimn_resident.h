@@ -58,6 +58,23 @@ __device__ unsigned long long g_res_tl[1024 * 16];
 #define RES_TL_FLUSH
 #endif
 
+// The D-chunks [cb, ce) of sub-net chunks 0..nchunk-1 that D-split `sp` of S1 owns.  Splits whose workgroups also carry role 2
+// (the first n2 = ceil(OT/16)) are on the critical path of a step for the whole second layer, the others idle meanwhile: the
+// role-1-only splits take what the others give up (at most cap = 8 * T1 chunks each: what the registers of a workgroup hold).
+__host__ __device__ static inline void res_chunk_range(int nchunk, int S1, int n2, int cap, int sp, int& cb, int& ce) {
+    const int n1 = S1 - n2;
+    if (n1 <= 0 || n2 <= 0 || nchunk < 8 * S1) {             // one role everywhere, or a tile loop too short to matter: the even split
+        cb = (int)((int64_t)nchunk * sp / S1); ce = (int)((int64_t)nchunk * (sp + 1) / S1);
+        return;
+    }
+    const int lo_t = nchunk * 15 / (16 * S1);                // a role-2 split gives up ~6 % of the even share ...
+    int hi = (nchunk - n2 * lo_t + n1 - 1) / n1;             // ... which the role-1-only splits take,
+    hi = hi < cap ? hi : cap;                                // as far as their registers go
+    const int rest = nchunk - n1 * hi;
+    if (sp < n2) { cb = (int)((int64_t)rest * sp / n2); ce = (int)((int64_t)rest * (sp + 1) / n2); }
+    else { cb = rest + (sp - n2) * hi; ce = cb + hi; }
+}
+
 struct ResParams {
     const SubnetDev* sn;
     const float* X;                 // gathered predictors (arena)
@@ -213,7 +230,8 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
 #endif
 
     // ---- role 1 state: W1 tiles (chunk cb + wave + 8j, hidden tile ht) in registers ----
-    const int cb = (int)((int64_t)s.nchunk * sp / S1), ce = (int)((int64_t)s.nchunk * (sp + 1) / S1);
+    int cb, ce;
+    res_chunk_range(s.nchunk, S1, (OT + 15) >> 4, 8 * T1, sp, cb, ce);
     const int64_t cstride = (int64_t)Hp * 16;
     const int64_t wbase = s.w1off + (int64_t)(16 * ht + li) * 16 + 4 * lj;
     f32x4 w1[T1], m1[T1], v1[T1];
@@ -282,6 +300,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
         f32x4 pT[4] = {zero4, zero4, zero4, zero4};
 #pragma unroll
         for (int j = 0; j < T1; ++j) {
+            if (j > 0 && !tv[j]) break;                          // wave-uniform: a wave's tiles are its first ones (tile 0 always runs: it may be a clamped one)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                        // wave-private staging (in-order LDS, no barrier)
                 *(f32x4*)(xt + 256 * i + 4 * lane) = xa[i];
