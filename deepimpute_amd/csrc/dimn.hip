@@ -351,7 +351,7 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
         delete h;
         return fail(DIMN_ERR_UNSUP, "dimn_create: hidden=%d > 384 is outside the tuned kernels (use dimn_create_general)", cfg->hidden);
     }
-    if (!general && (size_t)DIMN_TB * dm.ldp * sizeof(float) > 160 * 1024) {
+    if (!general && ((size_t)DIMN_TB * dm.ldp + DIMN_PRED_XS) * sizeof(float) > 160 * 1024) {
         delete h;
         return fail(DIMN_ERR_UNSUP, "dimn_create: hidden too large for LDS staging");
     }
@@ -896,9 +896,12 @@ static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, f
     }
     // the second-layer operand form of k_predict: a fresh W2T image (21 MB at 40 sub-nets: ~10 us per call)
     hipLaunchKernelGGL(k_prep_w2t, dim3(128, (unsigned)h->K), dim3(256), 0, h->stream, (const float*)h->d_W2, h->d_W2tf, h->dm);
-    const size_t lds = (size_t)DIMN_TB * h->dm.ldp * sizeof(float);
-    WITH_XT(h, hipLaunchKernelGGL((k_predict<NT, XT>), dim3(tiles, (unsigned)h->K), dim3(256), lds, h->stream, h->d_sn, (const XT*)h->d_X, h->d_W1, h->d_b1,
-                                  h->d_W2tf, h->d_b2, rows, n_rows, out, h->d_Y, h->n, loss_part, h->dm, h->cfg.loss_binary, h->act));
+    const size_t lds = ((size_t)DIMN_TB * h->dm.ldp + DIMN_PRED_XS) * sizeof(float);      // activations + the X staging ring
+    WITH_XT(h, {
+        (void)hipFuncSetAttribute((const void*)k_predict<NT, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_predict<NT, XT>), dim3(tiles, (unsigned)h->K), dim3(256), lds, h->stream, h->d_sn, (const XT*)h->d_X, h->d_W1, h->d_b1,
+                           h->d_W2tf, h->d_b2, rows, n_rows, out, h->d_Y, h->n, loss_part, h->dm, h->cfg.loss_binary, h->act);
+    });
 }
 #define DISPATCH_NT(fn, ...)                          \
     switch (h->NT) {                                  \
@@ -1557,6 +1560,15 @@ extern "C" int dimn_csv_write(const char* path, const double* values, int64_t n_
     return rc ? fail(DIMN_ERR_ARG, "dimn_csv_write(%s): %s", path, err.c_str()) : DIMN_OK;
 }
 
+#ifdef DIMN_PRED_TL
+// diagnostic build only (tools/predict_timeline.py): phase clocks of k_predict, summed over waves since the last call
+extern "C" int dimn_debug_pred_timeline(unsigned long long* out) {
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pred_tl), 8 * sizeof(unsigned long long)));
+    unsigned long long z[8] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_pred_tl), z, sizeof(z)));
+    return DIMN_OK;
+}
+#endif
 #ifdef DIMN_RES_TL
 // diagnostic build only (tools/res_timeline.py): per-workgroup phase clocks of the last resident epoch launch
 extern "C" int dimn_debug_res_timeline(unsigned long long* out, int n_words) {

@@ -171,6 +171,25 @@ __device__ __forceinline__ float softplus_f(float x) {
     return log1pf(expf(x));
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+// The output layer of the inference kernels: the same function within ~3 ulp of libm's (log1pf(expf(x)) is ~100 VALU
+// instructions per element -- 40 % of k_predict's wave time went there), no branch:  t = exp(-|x|) on v_exp_f32 with the
+// exponent product x*log2(e) carried in two pieces;  log1p(t) = log(u) * t / (u - 1), u = 1 + t, on v_log_f32 / v_rcp_f32
+// (the classic correction; its series t - t^2/2 + t^3/3 below 2^-12);  TensorFlow's thresholds as selects.
+__device__ __forceinline__ float softplus_out(float x) {
+    const float thr = 13.942385f;
+    const float ax = fabsf(x);
+    const float p = -ax * 1.44269502f;
+    float pe = fmaf(-ax, 1.44269502f, -p);
+    pe = fmaf(-ax, 1.92596299e-8f, pe);
+    float t = __builtin_amdgcn_exp2f(p);
+    t = fmaf(t, pe * 0.693147182f, t);                       // exp(-|x|)
+    const float u = 1.0f + t, d = u - 1.0f;
+    const float lg = __builtin_amdgcn_logf(u) * 0.693147182f;
+    const float l = t < 2.44140625e-4f ? t * fmaf(t, fmaf(t, 0.333333343f, -0.5f), 1.0f)      // series below 2^-12: no cancellation in u - 1
+                                       : lg * (t * __builtin_amdgcn_rcpf(d));
+    const float sp = fmaxf(x, 0.f) + l;
+    return x > thr ? x : (x < -thr ? t : sp);
+}
 
 // Hidden activation f and derivative f' at pre-activation a (multinet.py:137; ids = DIMN_ACT_* of dimn.h, elu alpha = 1).
 // relu is handled inline by the kernels (bit-identical to the path that has no activation switch).
@@ -1547,9 +1566,22 @@ __global__ __launch_bounds__(256) void k_prep_w2t(const float* __restrict__ W2, 
     }
 }
 
-#ifndef DIMN_PREDICT_DEPTH
-#define DIMN_PREDICT_DEPTH 3
+#ifdef DIMN_PRED_TL   // tools/predict_timeline.py: phase clocks of every wave, summed over the workgroups of a launch
+__device__ unsigned long long g_pred_tl[8];
+#define PRED_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&g_pred_tl[i], t_ - tl_t); tl_t = t_; }
+#define PRED_TL_DECL unsigned long long tl_t = __builtin_amdgcn_s_memtime();
+#else
+#define PRED_STAMP(i)
+#define PRED_TL_DECL
 #endif
+#define DIMN_PRED_XS (3 * DIMN_TB * 16)   // floats of the X staging ring behind the activations in LDS
+// 64 rows per workgroup, 4 waves of NT hidden tiles each.  First layer: per 16-deep chunk a wave requests ITS 16 rows of the
+// X tile (one 16-byte load per lane) and its NT W1 tiles; the X tile goes through a three-stage LDS ring (one barrier per chunk)
+// and every wave reads all four row tiles from there.  Measured on the way here (50k cells x 40 sub-nets): every wave loading
+// the whole X tile itself -- 8 vector loads per 64 MFMAs -- ran at 0.69 of the matrix pipe with two or three chunks in flight,
+// and just the same with every load an L1 hit: bound by the vector-memory instruction rate of the CU, not by latency or bytes
+// (8 waves x 2 hidden tiles, at 64 or 128 rows: 12 loads per 64 MFMAs, 1.6x slower).  With the ring: 0.72; the same loop with
+// its loads removed 0.81, without its barrier 0.83 -- the rest is the second layer and the output epilogue (tools/predict_timeline.py).
 template <int NT, typename XT>
 __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ sn, const XT* __restrict__ X,
                                                  const float* __restrict__ W1, const float* __restrict__ b1,
@@ -1557,6 +1589,7 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
                                                  const int32_t* __restrict__ rows, int64_t n_rows,
                                                  float* __restrict__ out, const float* __restrict__ Y, int64_t n_cells,
                                                  float* __restrict__ loss_part, Dims dm, int loss_binary, int act) {
+    constexpr int MT = 4, NW = 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int k = blockIdx.y;
     const int64_t r0 = (int64_t)blockIdx.x * DIMN_TB;
@@ -1564,23 +1597,19 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lj = lane >> 4;
     const int nt0 = wave * NT;
-    const int Hp = dm.Hp;
+    const int Hp = dm.Hp, ldp = dm.ldp;
+    float* xs = lds + DIMN_TB * ldp;                         // X staging ring [3][64 rows][16]
+    PRED_TL_DECL
 
-    f32x4 acc[4][NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const XT* xk = X + s.xoff;
-    int64_t xo[4];
-    bool valid[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int64_t i = r0 + 16 * mt + li;
-        valid[mt] = i < n_rows;
-        const int64_t row = valid[mt] ? (rows ? (int64_t)rows[i] : i) : 0;
-        xo[mt] = row * s.Dp + 4 * lj;
-    }
+    // this wave's rows of the X tile (rows past n_rows read row 0 and are dropped at the end: every load unconditional)
+    const int64_t irow = r0 + 16 * wave + li;
+    const int64_t xrow = irow < n_rows ? (rows ? (int64_t)rows[irow] : irow) : 0;
+    const XT* xk = X + s.xoff + xrow * s.Dp + 4 * lj;
     const int64_t cstride = (int64_t)Hp * 16;
     const float* wbt[NT];                                    // tiles past HT are clamped: loaded, never used
 #pragma unroll
@@ -1588,69 +1617,57 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
         const int t = (nt0 + nt) < dm.HT ? (nt0 + nt) : (dm.HT - 1);
         wbt[nt] = W1 + s.w1off + (int64_t)(16 * t + li) * 16 + 4 * lj;
     }
-    // Two named operand sets, loop unrolled x2: the loads of chunk c+1 are in flight while chunk c feeds the
-    // MFMAs (rows past n_rows read row 0 and are dropped at the end, so every load is unconditional).
-    struct Ops { XRaw<XT> a[4]; f32x4 b[NT]; };
-    auto fetch = [&](Ops& o, int c) {
-        const int cc = c < s.nchunk ? c : s.nchunk - 1;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) o.a[mt].load(xk + xo[mt] + 16 * cc);
+    struct WSet { f32x4 b[NT]; };
+    auto clampc = [&](int c) { return c < s.nchunk ? c : s.nchunk - 1; };
+    auto fetch_w = [&](WSet& o, int c) {
+        const int cc = clampc(c);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) o.b[nt] = *(const f32x4*)(wbt[nt] + cc * cstride);
     };
-    auto mma = [&](const Ops& o) {
-        f32x4 a4[4];
+    XRaw<XT> xr;                                             // the X piece in flight (chunk c + 1 at the top of iteration c)
+    float* xw = xs + (16 * wave + li) * 16 + 4 * lj;         // where this lane's piece goes in a stage
+    const float* xrd = xs + li * 16 + 4 * lj;                // row tile mt of a stage: + 256 * mt
+    // iteration c (stage st = c % 3):  X(c+1) -> stage st+1;  request X(c+2), W(c+2);  barrier;  MFMAs of chunk c from stage st, W(c)
+    auto step = [&](WSet& wcur, WSet& wnew, int c, int st) {
+        *(f32x4*)(xw + ((st + 1) % 3) * (DIMN_TB * 16)) = xr.get();
+        xr.load(xk + 16 * clampc(c + 2));
+        fetch_w(wnew, c + 2);
+        __builtin_amdgcn_sched_barrier(0);                   // the requests leave before this chunk's MFMAs (hipcc sinks them otherwise)
+        __syncthreads();
+        f32x4 a4[MT];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) a4[mt] = o.a[mt].get();
+        for (int mt = 0; mt < MT; ++mt) a4[mt] = *(const f32x4*)(xrd + st * (DIMN_TB * 16) + 256 * mt);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA16(a4[mt][r], o.b[nt][r], acc[mt][nt]);
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA16(a4[mt][r], wcur.b[nt][r], acc[mt][nt]);
+        __builtin_amdgcn_sched_barrier(0);
     };
-#if DIMN_PREDICT_DEPTH == 3
-    Ops P0, P1, P2;                                          // three named sets: two chunks in flight (the X rows come from HBM)
-    fetch(P0, 0);
-    fetch(P1, 1);
+    WSet W0, W1s, W2s;                                       // three named sets: the W1 tiles of two chunks in flight
+    xr.load(xk);
+    fetch_w(W0, 0);
+    *(f32x4*)xw = xr.get();                                  // chunk 0 -> stage 0
+    xr.load(xk + 16 * clampc(1));
+    fetch_w(W1s, 1);
     int c = 0;
-    for (; c + 3 <= s.nchunk; c += 3) {                      // (sched_barrier: hipcc sinks the requests below the MFMAs and drains vmcnt(0) mid-loop otherwise)
-        fetch(P2, c + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(P0);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(P0, c + 3);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(P1);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(P1, c + 4);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(P2);
-        __builtin_amdgcn_sched_barrier(0);
+    for (; c + 3 <= s.nchunk; c += 3) {
+        step(W0, W2s, c, 0);
+        step(W1s, W0, c + 1, 1);
+        step(W2s, W1s, c + 2, 2);
     }
-    if (c < s.nchunk) mma(P0);
-    if (c + 1 < s.nchunk) mma(P1);
-#else
-    Ops P0, P1;
-    fetch(P0, 0);
-    int c = 0;
-    for (; c + 2 <= s.nchunk; c += 2) {
-        fetch(P1, c + 1);
-        mma(P0);
-        fetch(P0, c + 2);
-        mma(P1);
-    }
-    if (c < s.nchunk) mma(P0);
-#endif
+    if (c < s.nchunk) step(W0, W2s, c, 0);
+    if (c + 1 < s.nchunk) step(W1s, W0, c + 1, 1);
+    PRED_STAMP(0)
     // bias + relu -> LDS (dropout is identity at inference, S3/S12)
-    const int ldp = dm.ldp;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
         if (nt0 + nt < dm.HT) {
             const int h = 16 * (nt0 + nt) + li;
             const float bias = b1[(int64_t)k * Hp + h];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = acc[mt][nt][r] + bias;
@@ -1659,24 +1676,26 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
                     lds[(16 * mt + 4 * lj + r) * ldp + h] = f;
                 }
         }
+    PRED_STAMP(1)
     __syncthreads();
+    PRED_STAMP(2)
 
     float lsum = 0.f;
     const int HT = dm.HT;
     const float* arow = lds + li * ldp + 4 * lj;                 // activations [b = 16mt + li][h = 16ht + 4lj ..]
-    for (int ot = wave; ot < dm.OT; ot += 4) {
-        f32x4 z[4];
+    for (int ot = wave; ot < dm.OT; ot += NW) {
+        f32x4 z[MT];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) z[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; ++mt) z[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* wt = W2 + ((int64_t)k * dm.OT + ot) * HT * 256 + lane * 4;      // W2T: the tiles (ht, ot), ht = 0.., contiguous
         auto tile = [&](const f32x4 bq, int ht) {
-            f32x4 a4[4];
+            f32x4 a4[MT];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) a4[mt] = *(const f32x4*)(arow + 16 * mt * ldp + 16 * ht);
+            for (int mt = 0; mt < MT; ++mt) a4[mt] = *(const f32x4*)(arow + 16 * mt * ldp + 16 * ht);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) z[mt] = MFMA16(a4[mt][r], bq[r], z[mt]);
+                for (int mt = 0; mt < MT; ++mt) z[mt] = MFMA16(a4[mt][r], bq[r], z[mt]);
         };
         // two named operand registers, loop unrolled x2: the request of tile ht+1 leaves before tile ht feeds the MFMAs
         f32x4 q0 = *(const f32x4*)wt, q1;
@@ -1692,16 +1711,17 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
             __builtin_amdgcn_sched_barrier(0);
         }
         if (ht < HT) tile(q0, ht);
+        PRED_STAMP(3)
         const int o = 16 * ot + li;
         if (o < dm.O) {
             const float bias = b2[(int64_t)k * dm.Op + o];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t i = r0 + 16 * mt + 4 * lj + r;
                     if (i < n_rows) {
-                        const float yh = softplus_f(z[mt][r] + bias);
+                        const float yh = softplus_out(z[mt][r] + bias);
                         if (out) __builtin_nontemporal_store(yh, &out[(i * dm.K + k) * dm.O + o]);
                         if (loss_part) {
                             const int64_t row = rows ? (int64_t)rows[i] : i;
@@ -1713,14 +1733,21 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
                     }
                 }
         }
+        PRED_STAMP(4)
     }
+    PRED_STAMP(5)
     if (loss_part) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
         __syncthreads();
         if (lane == 0) lds[wave] = lsum;
         __syncthreads();
-        if (threadIdx.x == 0) loss_part[(int64_t)k * gridDim.x + blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+        if (threadIdx.x == 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) tot += lds[wv];
+            loss_part[(int64_t)k * gridDim.x + blockIdx.x] = tot;
+        }
     }
 }
 
@@ -1934,7 +1961,7 @@ __global__ __launch_bounds__(256) void k_predict_bf16(const SubnetDev* __restric
                 for (int r = 0; r < 4; ++r) {
                     const int64_t i = r0 + 16 * mt + 4 * lj + r;
                     if (i < n_rows) {
-                        const float yh = softplus_f(z[mt][r] + bias);
+                        const float yh = softplus_out(z[mt][r] + bias);
                         if (out) __builtin_nontemporal_store(yh, &out[(i * dm.K + k) * dm.O + o]);
                         if (loss_part) {
                             const int64_t row = rows ? (int64_t)rows[i] : i;

@@ -153,6 +153,22 @@ def test_single_forward_tight():
     assert a.predict(np.zeros(0, np.int32)).shape == (0, 2 * 512)   # empty input
 
 
+@pytest.mark.parametrize("H,O,Ds", [(256, 512, [300, 150]), (200, 100, [77, 40, 130]), (64, 48, [33]), (300, 512, [19, 7])])
+def test_forward_kernel_shapes(H, O, Ds):
+    """k_predict (X tile through the LDS ring, second layer from the W2T image): predictions, arbitrary row lists, a ragged
+    last tile, sub-nets of one or two chunks, and the validation loss."""
+    prob = make_problem(n=333, g=500, Ds=Ds, H=H, O=O, seed=5)
+    kw = dict(batch_size=64, dropout_rate=0.2, learning_rate=1e-3, seed=4)
+    a = load_problem(_hip(), prob, **kw)
+    b = load_problem(_oracle(), prob, **kw)
+    a.init_weights(); b.init_weights()
+    np.testing.assert_allclose(a.train_epoch(0), b.train_epoch(0), rtol=1e-4)
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=1e-4, atol=1e-6)
+    rows = np.random.default_rng(1).integers(0, 333, 201).astype(np.int32)
+    np.testing.assert_allclose(a.predict(rows), b.predict(rows), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
+
+
 def test_injected_permutation_and_partial_batch():
     prob = make_problem(n=131, g=300, Ds=[50, 60], H=64, O=64, seed=8)
     kw = dict(batch_size=64, dropout_rate=0.2, learning_rate=5e-4, seed=77)
