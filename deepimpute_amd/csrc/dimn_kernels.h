@@ -207,7 +207,7 @@ __device__ __forceinline__ void hidden_act(int act, float a, float& f, float& df
 // Training-path versions on the hardware exp2/log2/rcp units (v_exp_f32, v_log_f32, v_rcp_f32):
 // t = exp(-|x|) in (0,1];  softplus = max(x,0) + log1p(t);  sigmoid = x>=0 ? 1/(1+t) : t/(1+t).
 // log1p(t) switches to its series below 2^-12 so tiny outputs keep their relative accuracy.  They feed
-// only the loss and dZ (absolute error ~1e-7), inference keeps libm's expf/log1pf (k_predict).
+// only the loss and dZ (absolute error ~1e-7); the inference kernels use softplus_out (within ~3 ulp of libm's).
 __device__ __forceinline__ void softplus_sigmoid_fast(float x, float& sp, float& sg) {
     const float t = __expf(-fabsf(x));
     const float l = t < 2.44140625e-4f ? t * (1.0f - 0.5f * t) : __logf(1.0f + t);
