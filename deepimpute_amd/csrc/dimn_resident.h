@@ -138,6 +138,9 @@ __device__ __forceinline__ bool res_unwritten(f32x4 x) {
 // One whole wave waits until piece 0 of each of `n` tiles (base + i * stride bytes) is written; false on abort / timeout.
 // The bulk loads that follow validate every piece again (res_fix): the canary only keeps the polling traffic small.
 __device__ __forceinline__ bool res_poll(__amdgpu_buffer_rsrc_t r, uint32_t base, int n, uint32_t stride, unsigned* abort_w) {
+#ifdef DIMN_RES_NOCANARY   // test build (tests/test_gpu_configs.py): no canary, so the bulk requests leave early and res_fix's retry path runs all the time
+    return true;
+#endif
     const int lane = threadIdx.x & 63;
     unsigned spins = 0;
     for (;;) {
@@ -158,6 +161,7 @@ __device__ __forceinline__ bool res_poll(__amdgpu_buffer_rsrc_t r, uint32_t base
 __device__ __forceinline__ void res_fix(f32x4& x, __amdgpu_buffer_rsrc_t r, uint32_t off, unsigned* abort_w) {
     unsigned spins = 0;
     while (__builtin_amdgcn_ballot_w64(res_unwritten(x)) != 0) {
+        asm volatile("" ::: "memory");                       // the reload is a new observation of memory
         x = res_ld(r, off);
         if (++spins > DIMN_RES_SPIN_LIMIT) { __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }

@@ -143,3 +143,22 @@ def test_resident_epoch_kernel_matches_streaming_at_8gpu_share():
     np.testing.assert_allclose(a[3], c[3], rtol=1e-4, atol=1e-6)
     for x, y, name in zip(a[4], c[4], ("W1", "b1", "W2", "b2")):
         np.testing.assert_allclose(x, y, rtol=1e-3, atol=1e-6, err_msg=name)
+
+
+def test_resident_hand_off_retry_path():
+    """The sentinel hand-off of the register-resident kernel under stress: libdimn_nocanary.so is the same library without
+    the canary polls, so the bulk requests of every hand-off leave before most of the data has landed and res_fix's
+    re-request loop -- which a normal run almost never enters -- carries the protocol.  The R variants of the parity
+    tests and the 8-GPU-share test must pass unchanged."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(os.path.dirname(here), "deepimpute_amd", "csrc", "libdimn_nocanary.so")
+    if not os.path.exists(lib):
+        pytest.skip("libdimn_nocanary.so not built (make -C deepimpute_amd/csrc)")
+    env = dict(os.environ, DIMN_LIB_PATH=lib)
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_gpu_configs.py"), "-q", "-x",
+                          "-m", "gpu", "-k", "(second_layer_paths and R) or resident_epoch_kernel"], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert " passed" in res.stdout and "failed" not in res.stdout
