@@ -123,6 +123,7 @@ struct dimn_handle_s {
     std::vector<Work> work;
     std::vector<MidWork> midwork;          // work table of the fused second-layer kernel (k_mid_fused)
     int mid_fused = 0, mid_slices = 0;     // 1: RED -> MFB -> RED2 -> B1F1; 0: RED -> MF -> MB -> B1F1
+    int mid_keep = 0;                      // 1: k_mid_fused<true> (the W2 column blocks stay in LDS between its phases)
     MidWork* d_midwork = nullptr; int32_t* d_midk = nullptr; float* d_P2 = nullptr;
     std::vector<std::vector<int32_t>> pred, targ;
     int nslots = 0;
@@ -279,6 +280,9 @@ static void build_mid(dimn_handle h) {
             h->midwork.push_back(m);
         }
     h->mid_fused = 1;
+    int tmax = 0;
+    for (auto& m : h->midwork) tmax = std::max(tmax, m.ot1 - m.ot0);
+    h->mid_keep = tmax <= 6 && !(getenv("DIMN_MID_KEEP") && atoi(getenv("DIMN_MID_KEEP")) == 0);
 }
 
 static void build_resident(dimn_handle h) {
@@ -452,7 +456,8 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
             dimn_destroy(h);
             return fail(DIMN_ERR_HIP, "dimn_create: descriptor upload failed");
         }
-        (void)hipFuncSetAttribute((const void*)k_mid_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_mid_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_mid_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     auto zero = [&](void* p, size_t bytes) { return hipMemset(p, 0, bytes) == hipSuccess ? 0 : fail(DIMN_ERR_HIP, "hipMemset failed"); };
     TRY(zero(h->d_W1, w1 * 4)); TRY(zero(h->d_M1, w1 * 4)); TRY(zero(h->d_V1, w1 * 4));
@@ -965,9 +970,11 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     if (h->mid_fused) {
         // RED -> MFB (whole second layer, W2 streamed once) -> RED2 (dD partials -> dA, Adam(b1))
         const size_t lds = ((size_t)DIMN_TB * DIMN_MID_LDD + DIMN_MID_TMAX * 1024 + 8 * 1024 + 8 + 64) * sizeof(float);
-        hipLaunchKernelGGL(k_mid_fused, dim3(nk * (unsigned)h->mid_slices), dim3(512), lds, st, h->d_midwork + (size_t)ln.k0 * h->mid_slices,
-                           h->d_W2, h->d_M2, h->d_V2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_P2,
-                           h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary);
+#define LAUNCH_MFB(KEEPV) hipLaunchKernelGGL(k_mid_fused<KEEPV>, dim3(nk * (unsigned)h->mid_slices), dim3(512), lds, st, h->d_midwork + (size_t)ln.k0 * h->mid_slices, \
+                                             h->d_W2, h->d_M2, h->d_V2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_P2,        \
+                                             h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary)
+        if (h->mid_keep) LAUNCH_MFB(true); else LAUNCH_MFB(false);      // keep: every slice <= 6 tiles, W2 read once (DIMN_MID_KEEP=0: off)
+#undef LAUNCH_MFB
         hipLaunchKernelGGL(k_reduce_dd, dim3((unsigned)ceil_div(dm.Hp, 64), nk), dim3(1024), 0, st, h->d_midk, h->d_P2, h->d_Dd,
                            h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, ln.k0, (const float*)h->d_G);
     } else {

@@ -741,6 +741,11 @@ __device__ unsigned long long g_mid_tl[512 * 8 * 8];
 #define MID_STAMP(i)
 #endif
 
+// KEEP (every slice of the launch has T <= 6 tiles): the W2 column blocks that phase 1 loaded stay on the chip -- after phase 1
+// the units' owners copy them from registers into the LDS that Dd and the transpose buffers occupied (96 KB at T = 6), and
+// phase 2 takes the OLD W2 of a tile from there instead of reading it from memory a second time: 24 instead of 28 bytes per
+// W2 parameter, and a set of the phase-2 ring is 16 registers (m, v) instead of 24.
+template <bool KEEP>
 __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ mwork,
                                                    float* __restrict__ W2, float* __restrict__ M2, float* __restrict__ V2,
                                                    float* __restrict__ b2w, float* __restrict__ b2m, float* __restrict__ b2v,
@@ -754,9 +759,10 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
     const int k = mw.k, ot0 = mw.ot0, ot1 = mw.ot1, ot_last = mw.ot1 - 1;
     const int Hp = dm.Hp, OT = dm.OT, Op = dm.Op;
     constexpr int ldd = DIMN_MID_LDD;
-    float* ddl = lds;                                        // Dd [64][ldd]
-    float* dzl = lds + DIMN_TB * ldd;                        // dZ tiles [T][64 b][16 o]
-    float* wsl = dzl + DIMN_MID_TMAX * 1024;                 // per-wave W2 transpose buffers [8][4 tiles]
+    float* dzl = lds;                                        // dZ tiles [T][64 b][16 o]
+    float* ddl = dzl + DIMN_MID_TMAX * 1024;                 // Dd [64][ldd]
+    float* wsl = ddl + DIMN_TB * ldd;                        // per-wave W2 transpose buffers [8][4 tiles]
+    float* w2l = ddl;                                        // KEEP: W2 column blocks [T <= 6][16 hidden tiles][256] over Dd + the transpose buffers (24 832 >= 24 576 floats)
     float* lsl = wsl + 8 * 1024;                             // loss partials [8 waves]
     float* gbl = lsl + 8;                                    // bias-gradient row parts of the shared units [8 waves][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -823,13 +829,17 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
         for (int i = 0; i < 4; ++i) yt[i] = *(const f32x4*)(Y + ((int64_t)k * n_cells + rid[i]) * Op + 16 * oc + 4 * (lane & 3));
         bias = b2w[bi]; b2m0 = b2m[bi]; b2v0 = b2v[bi];
     }
-    struct Set { f32x4 w[2], m[2], v[2]; };
+    struct Set { f32x4 w[KEEP ? 1 : 2], m[2], v[2]; };       // (KEEP: w comes from LDS when the tile is processed)
     const int64_t tbase = (int64_t)k * Hp * Op + li * 16 + 4 * lj;
     auto tidx = [&](int ht, int ot) { return tbase + ((int64_t)(2 * wave + ht) * OT + ot) * 256; };
     auto fetch = [&](Set& st, int ot) {
         const int o2 = ot < ot_last ? ot : ot_last;
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht) { const int64_t i = tidx(ht, o2); st.w[ht] = *(const f32x4*)(W2 + i); st.m[ht] = DIMN_LD_MV(M2 + i); st.v[ht] = DIMN_LD_MV(V2 + i); }
+        for (int ht = 0; ht < 2; ++ht) {
+            const int64_t i = tidx(ht, o2);
+            if constexpr (!KEEP) st.w[ht] = *(const f32x4*)(W2 + i);
+            st.m[ht] = DIMN_LD_MV(M2 + i); st.v[ht] = DIMN_LD_MV(V2 + i);
+        }
     };
     Set A, B, C, D;                                          // four named sets: three tiles in flight
     fetch(A, ot0);
@@ -942,6 +952,14 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
     for (int m4 = 0; m4 < 4; ++m4)
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht) dacc[m4][ht] = zero4;
+    if constexpr (KEEP) {
+        __syncthreads();                                     // every wave holds its Dd operands: Dd and the transpose buffers are free
+        if (p1 && part == 0) {                               // the unit's column block, tiles in their natural [h][o] form
+#pragma unroll
+            for (int ht = 0; ht < 16; ++ht) *(f32x4*)(w2l + (u * 16 + ht) * 256 + lane * 4) = wt[ht];
+        }
+        __syncthreads();
+    }
 
     auto step = [&](Set& cur, Set& nx3, int ot) {
         fetch(nx3, ot + 3);                                  // into the set the previous tile has just released
@@ -959,20 +977,24 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
         for (int m4 = 0; m4 < 4; ++m4) zf[m4] = *(const f32x4*)(zb + (16 * m4 + li) * 16 + 4 * lj);   // dZ[b][o = 4lj+r]
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht) {
+            f32x4 wold;
+            if constexpr (KEEP) wold = *(const f32x4*)(w2l + ((ot - ot0) * 16 + 2 * wave + ht) * 256 + li * 16 + 4 * lj);
+            else wold = cur.w[ht];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int m4 = 0; m4 < 4; ++m4) dacc[m4][ht] = MFMA16(zf[m4][r], cur.w[ht][r], dacc[m4][ht]);   // OLD W2
-            adam4(cur.w[ht], cur.m[ht], cur.v[ht], g[ht], ap);
+                for (int m4 = 0; m4 < 4; ++m4) dacc[m4][ht] = MFMA16(zf[m4][r], wold[r], dacc[m4][ht]);        // OLD W2
+            adam4(wold, cur.m[ht], cur.v[ht], g[ht], ap);
             const int64_t i = tidx(ht, ot);
-            DIMN_ST_STATE(W2 + i, cur.w[ht]); DIMN_ST_STATE(M2 + i, cur.m[ht]); DIMN_ST_STATE(V2 + i, cur.v[ht]);
+            DIMN_ST_STATE(W2 + i, wold); DIMN_ST_STATE(M2 + i, cur.m[ht]); DIMN_ST_STATE(V2 + i, cur.v[ht]);
         }
     };
 #pragma unroll
     for (int ht = 0; ht < 2; ++ht) {
-        asm volatile("" : "+v"(A.w[ht]), "+v"(A.m[ht]), "+v"(A.v[ht]));
-        asm volatile("" : "+v"(B.w[ht]), "+v"(B.m[ht]), "+v"(B.v[ht]));
-        asm volatile("" : "+v"(C.w[ht]), "+v"(C.m[ht]), "+v"(C.v[ht]));
+        if constexpr (!KEEP) asm volatile("" : "+v"(A.w[ht]), "+v"(B.w[ht]), "+v"(C.w[ht]));
+        asm volatile("" : "+v"(A.m[ht]), "+v"(A.v[ht]));
+        asm volatile("" : "+v"(B.m[ht]), "+v"(B.v[ht]));
+        asm volatile("" : "+v"(C.m[ht]), "+v"(C.v[ht]));
     }
     MID_STAMP(4)
     int ot = ot0;

@@ -62,9 +62,9 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dmw, mw.data(), mw.size() * sizeof(MidWork), hipMemcpyHostToDevice)); CK(hipMemcpy(dmk, midk.data(), midk.size() * 4, hipMemcpyHostToDevice));
         float* P2 = dalloc(mw.size() * 64 * 256, 0.f, 11);
         const size_t ldsb = ((size_t)64 * DIMN_MID_LDD + 8 * 1024 + 8 * 1024 + 8 + 64) * 4;
-        CK(hipFuncSetAttribute((const void*)k_mid_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CK(hipFuncSetAttribute((const void*)k_mid_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         printf("fused: %zu workgroups (%d slices per sub-net)\n", mw.size(), Sm);
-        T("k_mid_fused (warm)", k_mid_fused, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0)
+        T("k_mid_fused (warm)", k_mid_fused<false>, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0)
         T("k_reduce_dd", k_reduce_dd, dim3(4, K), dim3(1024), 0, 0, dmk, P2, Dd, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 0, (const float*)nullptr)
         // cold: 1 GB of unrelated traffic between launches, as the W1 update does in a real step
         float* big = dalloc((size_t)256 << 20, 1.f, 12);
@@ -74,7 +74,7 @@ int main(int argc, char** argv) {
             float ms;
             hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, big, (size_t)256 << 20, 1.f, 13u + it);
             CK(hipEventRecord(ea));
-            hipLaunchKernelGGL(k_mid_fused, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
+            hipLaunchKernelGGL(k_mid_fused<false>, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
             CK(hipEventRecord(eb)); CK(hipEventSynchronize(eb)); CK(hipEventElapsedTime(&ms, ea, eb)); cold_f += ms;
             hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, big, (size_t)256 << 20, 1.f, 33u + it);
             CK(hipEventRecord(ea));
@@ -88,7 +88,7 @@ int main(int argc, char** argv) {
         printf("cold (after 1 GB of other traffic): k_mid_fused %.1f us   k_mid_fwd<16> %.1f us   k_mid_bwd<1,4> %.1f us\n", 1e3 * cold_f / R, 1e3 * cold_mf / R, 1e3 * cold_mb / R);
         // phase timeline of one cold launch
         hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, big, (size_t)256 << 20, 1.f, 99u);
-        hipLaunchKernelGGL(k_mid_fused, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
+        hipLaunchKernelGGL(k_mid_fused<false>, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
         CK(hipDeviceSynchronize());
         std::vector<unsigned long long> tl(512 * 8 * 8); CK(hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_mid_tl), tl.size() * 8));
         double ph[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tmin = ~0ull, tmax = 0; const size_t nw = mw.size() * 8;
