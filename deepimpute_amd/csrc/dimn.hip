@@ -150,7 +150,7 @@ struct dimn_handle_s {
     float *d_full = nullptr, *d_stage = nullptr; int64_t full_cap = 0;   // root's gathered predictions
     double* d_red = nullptr; int red_cap = 0;                            // all-reduce scratch
     // register-resident epoch kernel (dimn_resident.h): chosen at create when the sub-nets of this handle fit the CUs
-    int res_G = 0, res_S1 = 0, res_T1 = 0;                                // 0: not eligible
+    int res_G = 0, res_S1 = 0, res_T1 = 0, res_Kg = 0;                    // 0: not eligible; Kg: sub-nets per epoch launch
     float *d_res_P = nullptr, *d_res_D = nullptr, *d_res_b1 = nullptr, *d_res_alpha = nullptr;
     unsigned* d_res_flags = nullptr; double* d_res_loss = nullptr; int64_t res_alpha_cap = 0;
     double tm_res_ms = 0; int64_t tm_res_steps = 0;
@@ -285,33 +285,55 @@ static void build_mid(dimn_handle h) {
     h->mid_keep = tmax <= 6 && !(getenv("DIMN_MID_KEEP") && atoi(getenv("DIMN_MID_KEEP")) == 0);
 }
 
-static void build_resident(dimn_handle h) {
-    // Register-resident epoch kernel (dimn_resident.h): every sub-net gets G = 16*S1 co-resident workgroups (hidden tile x
-    // D-split), one per CU; eligible when all K*G fit the CUs, the W1 slice of a wave is at most 7 tiles (register
-    // budget), the output tiles fit the G workgroups, and the shapes are the ones the kernel is written for
-    // (H padded to 256, relu, H % 4 == 0).  DIMN_RESIDENT=0 disables it, =1 is the default (auto).
-    h->res_G = h->res_S1 = h->res_T1 = 0;
+static bool resident_plan(dimn_handle h, int Kg, int& S1o, int& T1o) {
+    // the decomposition of one launch over Kg sub-nets: D-splits per hidden tile, W1 tiles per wave; false: not eligible
     const Dims& dm = h->dm;
-    if (const char* e = getenv("DIMN_RESIDENT")) if (atoi(e) == 0) return;
-    if (dm.HT != 16 || (dm.H & 3) != 0 || h->B > DIMN_TB || h->prec) return;      // (the resident kernel reads an fp32 X arena)
-    int S1 = std::min(8, h->ncu / std::max(1, h->K) / 16);
+    int S1 = std::min(8, h->ncu / std::max(1, Kg) / 16);
     if (const char* e = getenv("DIMN_RES_S1")) S1 = std::min(S1, std::max(1, atoi(e)));      // tests: other decompositions
-    if (S1 < 1 || dm.OT > 16 * S1) return;
+    if (S1 < 1 || dm.OT > 16 * S1) return false;
     int maxchunk = 0, minchunk = 1 << 30;
     for (auto& s : h->sn) { maxchunk = std::max(maxchunk, s.nchunk); minchunk = std::min(minchunk, s.nchunk); }
     if (minchunk < S1) S1 = std::max(1, minchunk);
-    if (dm.OT > 16 * S1) return;
+    if (dm.OT > 16 * S1) return false;
     const int per_wg = ceil_div(maxchunk, S1);
     const int T1 = ceil_div(per_wg + 1, 8);                  // +1: the integer split of nchunk may give one workgroup one more
-    if (T1 > 7) return;
+    if (T1 > 7) return false;
     const int T1c = T1 <= 2 ? 2 : (T1 <= 4 ? 4 : 7);         // the kernel instance; res_chunk_range() never gives a split more than 8 * T1c chunks
     for (auto& s : h->sn)
         for (int sp = 0; sp < S1; ++sp) {
             int cb, ce;
             res_chunk_range(s.nchunk, S1, (dm.OT + 15) >> 4, 8 * T1c, sp, cb, ce);
-            if (ce - cb > 8 * T1c || ce - cb < 1 || cb < 0 || ce > s.nchunk) return;
+            if (ce - cb > 8 * T1c || ce - cb < 1 || cb < 0 || ce > s.nchunk) return false;
         }
-    h->res_G = 16 * S1; h->res_S1 = S1; h->res_T1 = T1c;
+    S1o = S1; T1o = T1c;
+    return true;
+}
+
+static void build_resident(dimn_handle h) {
+    // Register-resident epoch kernel (dimn_resident.h): every sub-net gets G = 16*S1 co-resident workgroups (hidden tile x
+    // D-split), one per CU; eligible when the workgroups of a launch fit the CUs, the W1 slice of a wave is at most 7 tiles
+    // (register budget), the output tiles fit the G workgroups, and the shapes are the ones the kernel is written for
+    // (H padded to 256, relu, H % 4 == 0).  Sub-nets share nothing, so a handle whose state does not fit at once trains its
+    // sub-nets in GROUPS, one epoch launch per group after the other: at 10 sub-nets of D ~ 2400 (one rank of a 4-GPU job)
+    // two launches of 5 cost 2 x 26 us per optimiser step against 70 us for the four streaming launches, three launches at
+    // 15 sub-nets 77 against 87 us; from four groups on the streaming kernels are as fast (DIMN_RES_GROUPS: the largest group
+    // count taken, default 3).
+    // DIMN_RESIDENT=0 disables the kernel, =1 is the default (auto).
+    h->res_G = h->res_S1 = h->res_T1 = 0; h->res_Kg = 0;
+    const Dims& dm = h->dm;
+    if (const char* e = getenv("DIMN_RESIDENT")) if (atoi(e) == 0) return;
+    if (dm.HT != 16 || (dm.H & 3) != 0 || h->B > DIMN_TB || h->prec) return;      // (the resident kernel reads an fp32 X arena)
+    int max_groups = 3, min_groups = 1;
+    if (const char* e = getenv("DIMN_RES_GROUPS")) max_groups = std::max(1, atoi(e));
+    if (const char* e = getenv("DIMN_RES_MIN_GROUPS")) min_groups = std::max(1, atoi(e));      // tests: groups on small problems
+    min_groups = std::min(min_groups, h->K);
+    for (int groups = min_groups; groups <= std::min(std::max(max_groups, min_groups), h->K); ++groups) {
+        const int Kg = ceil_div(h->K, groups);
+        int S1 = 0, T1c = 0;
+        if (!resident_plan(h, Kg, S1, T1c)) continue;
+        h->res_G = 16 * S1; h->res_S1 = S1; h->res_T1 = T1c; h->res_Kg = Kg;
+        return;
+    }
 }
 
 static int create_common(const dimn_config* cfg, const int32_t* D, bool general, dimn_handle* out) {
@@ -1126,7 +1148,6 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
     p.rate = h->cfg.dropout_rate; p.scale = 1.0f / (1.0f - h->cfg.dropout_rate);
     p.seed = h->cfg.seed; p.epoch = (uint32_t)epoch; p.G = h->res_G; p.S1 = h->res_S1; p.loss_binary = h->cfg.loss_binary;
     const size_t lds = (size_t)DIMN_RES_LDS_FLOATS * sizeof(float);
-    const dim3 grid((unsigned)(h->K * h->res_G));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) { e0 = next_event(h); e1 = next_event(h); next_event(h); }
     if (e0 && e1) (void)hipEventRecord(e0, h->stream);
@@ -1143,11 +1164,16 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
         (void)hipFuncSetAttribute((const void*)k_epoch_resident<T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_epoch_resident<T, S>), grid, dim3(DIMN_RES_THREADS), lds, h->stream, p);                       \
     } while (0)
-    // <7, 3>: one rank of the 8-GPU job (5 sub-nets of D ~ 2400 on 256 CUs); the others take the D-split count at run time
-    if (h->res_T1 == 7 && h->res_S1 == 3) RES_LAUNCH(7, 3);
-    else if (h->res_T1 == 2) RES_LAUNCH(2, 0);
-    else if (h->res_T1 == 4) RES_LAUNCH(4, 0);
-    else RES_LAUNCH(7, 0);
+    // one launch per group of res_Kg sub-nets (all of them when they fit at once), one after the other on the stream
+    for (int k0 = 0; k0 < h->K; k0 += h->res_Kg) {
+        p.k0 = k0;
+        const dim3 grid((unsigned)(std::min(h->res_Kg, h->K - k0) * h->res_G));
+        // <7, 3>: one rank of the 8-GPU job (5 sub-nets of D ~ 2400 on 256 CUs); the others take the D-split count at run time
+        if (h->res_T1 == 7 && h->res_S1 == 3) RES_LAUNCH(7, 3);
+        else if (h->res_T1 == 2) RES_LAUNCH(2, 0);
+        else if (h->res_T1 == 4) RES_LAUNCH(4, 0);
+        else RES_LAUNCH(7, 0);
+    }
 #undef RES_LAUNCH
     HIPCHK(hipGetLastError());
     if (e0 && e1) (void)hipEventRecord(e1, h->stream);

@@ -100,6 +100,7 @@ struct ResParams {
     float omb1, omb2, eps, rate, scale;
     uint64_t seed; uint32_t epoch;
     int32_t G, S1, loss_binary;
+    int32_t k0;                     // first sub-net of this launch (a handle may train its sub-nets in groups, one launch each)
 };
 
 __device__ __forceinline__ f32x4 res_ld(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
@@ -203,7 +204,8 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
 
     const Dims dm = p.dm;
     const int G = p.G, S1 = S1C > 0 ? S1C : p.S1;
-    const int k = blockIdx.x / G, wi = blockIdx.x - k * G;
+    const int kl = blockIdx.x / G, wi = blockIdx.x - kl * G;
+    const int k = p.k0 + kl;                                 // sub-net of the handle (every array below is indexed by it)
     const int ht = wi & 15, sp = wi >> 4;
     const bool is_o = wi < dm.OT;
     const int ot = is_o ? wi : 0;

@@ -70,7 +70,7 @@ def test_two_epochs_match_oracle(H, O, B, Ds, p):
     np.testing.assert_allclose(pa, pb, rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("mid", ["1", "0", "1:6", "1:4", "1:10", "R", "R:1", "R:2"])     # fused (auto slices), two-kernel, fused with 6 / 4 / 10 slices; R: register-resident epoch kernel (auto / 1 / 2 D-splits)
+@pytest.mark.parametrize("mid", ["1", "0", "1:6", "1:4", "1:10", "R", "R:1", "R:2", "RG"])     # fused (auto slices), two-kernel, fused with 6 / 4 / 10 slices; R: register-resident epoch kernel (auto / 1 / 2 D-splits; RG: sub-nets in groups of two, one launch each)
 @pytest.mark.parametrize("O,B,Ds,p", [
     (512, 64, [300, 150, 77], 0.2),     # the default architecture: H = 256, O = 512
     (500, 37, [97, 260], 0.3),          # ragged output width and partial batches
@@ -83,6 +83,8 @@ def test_h256_both_second_layer_paths_match_oracle(O, B, Ds, p, mid, monkeypatch
         monkeypatch.setenv("DIMN_RESIDENT", "1")
         if ":" in mid:
             monkeypatch.setenv("DIMN_RES_S1", mid.split(":")[1])
+        if mid == "RG":
+            monkeypatch.setenv("DIMN_RES_MIN_GROUPS", "2")
     else:
         monkeypatch.setenv("DIMN_RESIDENT", "0")
         monkeypatch.setenv("DIMN_MID", mid.split(":")[0])
@@ -99,7 +101,7 @@ def test_h256_both_second_layer_paths_match_oracle(O, B, Ds, p, mid, monkeypatch
         np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
     # which path ran: [7] = optimiser steps executed by the register-resident epoch kernel
     resident_steps = a.get_timers()[7]
-    if mid == "R" or (mid == "R:1" and O <= 256) or mid == "R:2":
+    if mid in ("R", "RG") or (mid == "R:1" and O <= 256) or mid == "R:2":
         assert resident_steps == a.step_count() > 0
     else:
         assert resident_steps == 0
