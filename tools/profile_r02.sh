@@ -19,6 +19,7 @@ DIMN_RESIDENT=0 timeout 400 python bench.py --limit-subnets 5 --no-cpu-baseline 
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_k5 -o run -- $B --limit-subnets 5 --epochs 4 > /dev/null 2>> $O/prof.err
 python tools/kstats.py $O/prof_k5 > $O/kernel_stats_k5.txt 2>&1
 for k in 10 20; do timeout 400 python bench.py --limit-subnets $k --no-cpu-baseline --epochs 6 --steps 1 > $O/bench_k$k.json 2>> $O/bench.err; done
+DIMN_RESIDENT=0 timeout 400 python bench.py --limit-subnets 10 --no-cpu-baseline --epochs 6 --steps 1 > $O/bench_k10_streaming.json 2>> $O/bench.err
 timeout 300 python bench.py --config cfg2 > $O/bench_cfg2.json 2>> $O/bench.err
 rm -rf $O/prof $O/prof_k5 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_mfma
 ls -la $O
