@@ -744,7 +744,9 @@ __device__ unsigned long long g_mid_tl[512 * 8 * 8];
 // KEEP (every slice of the launch has T <= 6 tiles): the W2 column blocks that phase 1 loaded stay on the chip -- after phase 1
 // the units' owners copy them from registers into the LDS that Dd and the transpose buffers occupied (96 KB at T = 6), and
 // phase 2 takes the OLD W2 of a tile from there instead of reading it from memory a second time: 24 instead of 28 bytes per
-// W2 parameter, and a set of the phase-2 ring is 16 registers (m, v) instead of 24.
+// W2 parameter.  And with w out of the phase-2 sets, m and v of ALL the slice's tiles fit in registers (96): they are requested
+// at the start of the kernel and travel under the load burst and phase 1, so phase 2 is compute + stores only (it runs at its
+// MFMA floor, tools/k_probe_mid.hip).  40.1 -> 36.4 us per launch at 40 sub-nets x 6 slices (tools/ab_mid_allmv.sh).
 template <bool KEEP>
 __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ mwork,
                                                    float* __restrict__ W2, float* __restrict__ M2, float* __restrict__ V2,
@@ -841,10 +843,16 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
             st.m[ht] = DIMN_LD_MV(M2 + i); st.v[ht] = DIMN_LD_MV(V2 + i);
         }
     };
-    Set A, B, C, D;                                          // four named sets: three tiles in flight
-    fetch(A, ot0);
-    fetch(B, ot0 + 1);
-    fetch(C, ot0 + 2);
+    Set A, B, C, D;                                          // !KEEP: four named sets, three tiles in flight
+    Set all[KEEP ? 6 : 1];                                   // KEEP: m and v of EVERY tile of the slice (<= 6) are requested here, 96 registers:
+    if constexpr (KEEP) {                                    // phase 2 then only computes and stores -- its reads travel under the load
+#pragma unroll                                               // burst and phase 1, when the memory system is not busy (the sixth tile's after phase 1, when
+        for (int i = 0; i < 5; ++i) fetch(all[i], ot0 + i);  // the registers of the W2 column block are free: all six up front spill 28 registers)
+    } else {
+        fetch(A, ot0);
+        fetch(B, ot0 + 1);
+        fetch(C, ot0 + 2);
+    }
 
     float lsum = 0.f;
     auto phase1 = [&](auto nmc) {
@@ -958,12 +966,15 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
 #pragma unroll
             for (int ht = 0; ht < 16; ++ht) *(f32x4*)(w2l + (u * 16 + ht) * 256 + lane * 4) = wt[ht];
         }
+        fetch(all[5], ot0 + 5);
         __syncthreads();
     }
 
     auto step = [&](Set& cur, Set& nx3, int ot) {
-        fetch(nx3, ot + 3);                                  // into the set the previous tile has just released
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!KEEP) {
+            fetch(nx3, ot + 3);                              // into the set the previous tile has just released
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const float* zb = dzl + (ot - ot0) * 1024;
         f32x4 g[2] = {zero4, zero4};
 #pragma unroll
@@ -989,25 +1000,32 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
             DIMN_ST_STATE(W2 + i, wold); DIMN_ST_STATE(M2 + i, cur.m[ht]); DIMN_ST_STATE(V2 + i, cur.v[ht]);
         }
     };
+    if constexpr (KEEP) {
+        MID_STAMP(4)
 #pragma unroll
-    for (int ht = 0; ht < 2; ++ht) {
-        if constexpr (!KEEP) asm volatile("" : "+v"(A.w[ht]), "+v"(B.w[ht]), "+v"(C.w[ht]));
-        asm volatile("" : "+v"(A.m[ht]), "+v"(A.v[ht]));
-        asm volatile("" : "+v"(B.m[ht]), "+v"(B.v[ht]));
-        asm volatile("" : "+v"(C.m[ht]), "+v"(C.v[ht]));
-    }
-    MID_STAMP(4)
-    int ot = ot0;
-    for (; ot + 4 <= ot1; ot += 4) {
-        step(A, D, ot);
-        step(B, A, ot + 1);
-        step(C, B, ot + 2);
-        step(D, C, ot + 3);
-    }
-    if (ot < ot1) {
-        step(A, D, ot);
-        if (ot + 1 < ot1) step(B, A, ot + 1);
-        if (ot + 2 < ot1) step(C, B, ot + 2);
+        for (int i = 0; i < 6; ++i)
+            if (i < T) step(all[i], all[i], ot0 + i);        // (wave-uniform; straight-line code: the compiler counts the exact vmcnt of every tile)
+    } else {
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+            asm volatile("" : "+v"(A.w[ht]), "+v"(B.w[ht]), "+v"(C.w[ht]));
+            asm volatile("" : "+v"(A.m[ht]), "+v"(A.v[ht]));
+            asm volatile("" : "+v"(B.m[ht]), "+v"(B.v[ht]));
+            asm volatile("" : "+v"(C.m[ht]), "+v"(C.v[ht]));
+        }
+        MID_STAMP(4)
+        int ot = ot0;
+        for (; ot + 4 <= ot1; ot += 4) {
+            step(A, D, ot);
+            step(B, A, ot + 1);
+            step(C, B, ot + 2);
+            step(D, C, ot + 3);
+        }
+        if (ot < ot1) {
+            step(A, D, ot);
+            if (ot + 1 < ot1) step(B, A, ot + 1);
+            if (ot + 2 < ot1) step(C, B, ot + 2);
+        }
     }
     MID_STAMP(5)
     float* p2 = P2 + (int64_t)mw.slot * DIMN_TB * Hp;

@@ -1,6 +1,9 @@
 // k_probe_mid.hip -- standalone timing of the middle kernels (RED / MF / MB) on cfg3-shaped
 // synthetic state (K=40, H=256, O=512, n=50000).  Diagnostics only.
 #define DIMN_MID_TL 1
+#ifndef PROBE_KEEP
+#define PROBE_KEEP true
+#endif
 #include "../deepimpute_amd/csrc/dimn_kernels.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -54,7 +57,7 @@ int main(int argc, char** argv) {
     T("k_mid_bwd<true,1,16>", (k_mid_bwd<true, 1, 16>), dim3(16, K), dim3(1024), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 2, 0, (const float*)nullptr)
     T("k_mid_bwd<true,2>", (k_mid_bwd<true, 2, 8>), dim3(8, K), dim3(512), 0, 0, Dd, dZ, W2, M2, V2, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 4, 0, (const float*)nullptr)
     {   // fused second layer: work table as dimn.hip's build_mid
-        const int Sm = std::max(4, std::min(8, 256 / K));
+        const int Sm = std::max(4, std::min(8, 256 / K));     // K = 40: 6 slices of 5-6 tiles (KEEP eligible)
         std::vector<MidWork> mw; std::vector<int32_t> midk(2 * K);
         for (int k = 0; k < K; ++k) { midk[2 * k] = k * Sm; midk[2 * k + 1] = Sm;
             for (int i = 0; i < Sm; ++i) mw.push_back(MidWork{k, 32 * i / Sm, 32 * (i + 1) / Sm, k * Sm + i, i}); }
@@ -62,9 +65,9 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dmw, mw.data(), mw.size() * sizeof(MidWork), hipMemcpyHostToDevice)); CK(hipMemcpy(dmk, midk.data(), midk.size() * 4, hipMemcpyHostToDevice));
         float* P2 = dalloc(mw.size() * 64 * 256, 0.f, 11);
         const size_t ldsb = ((size_t)64 * DIMN_MID_LDD + 8 * 1024 + 8 * 1024 + 8 + 64) * 4;
-        CK(hipFuncSetAttribute((const void*)k_mid_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CK(hipFuncSetAttribute((const void*)k_mid_fused<PROBE_KEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         printf("fused: %zu workgroups (%d slices per sub-net)\n", mw.size(), Sm);
-        T("k_mid_fused (warm)", k_mid_fused<false>, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0)
+        T("k_mid_fused (warm)", k_mid_fused<PROBE_KEEP>, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0)
         T("k_reduce_dd", k_reduce_dd, dim3(4, K), dim3(1024), 0, 0, dmk, P2, Dd, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 0, (const float*)nullptr)
         // cold: 1 GB of unrelated traffic between launches, as the W1 update does in a real step
         float* big = dalloc((size_t)256 << 20, 1.f, 12);
@@ -74,7 +77,7 @@ int main(int argc, char** argv) {
             float ms;
             hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, big, (size_t)256 << 20, 1.f, 13u + it);
             CK(hipEventRecord(ea));
-            hipLaunchKernelGGL(k_mid_fused<false>, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
+            hipLaunchKernelGGL(k_mid_fused<PROBE_KEEP>, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
             CK(hipEventRecord(eb)); CK(hipEventSynchronize(eb)); CK(hipEventElapsedTime(&ms, ea, eb)); cold_f += ms;
             hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, big, (size_t)256 << 20, 1.f, 33u + it);
             CK(hipEventRecord(ea));
@@ -88,7 +91,7 @@ int main(int argc, char** argv) {
         printf("cold (after 1 GB of other traffic): k_mid_fused %.1f us   k_mid_fwd<16> %.1f us   k_mid_bwd<1,4> %.1f us\n", 1e3 * cold_f / R, 1e3 * cold_mf / R, 1e3 * cold_mb / R);
         // phase timeline of one cold launch
         hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, big, (size_t)256 << 20, 1.f, 99u);
-        hipLaunchKernelGGL(k_mid_fused<false>, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
+        hipLaunchKernelGGL(k_mid_fused<PROBE_KEEP>, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
         CK(hipDeviceSynchronize());
         std::vector<unsigned long long> tl(512 * 8 * 8); CK(hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_mid_tl), tl.size() * 8));
         double ph[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tmin = ~0ull, tmax = 0; const size_t nw = mw.size() * 8;
