@@ -484,7 +484,9 @@ def main():
             mine = preds[offs[0]:offs[0] + counts[0]]
             step_flops = cfg["B"] * sum(4.0 * len(p) * H_ + 6.0 * H_ * O_ for p in mine)
             ach = step_flops / (lane_step_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "k_epoch_resident (one launch per epoch: W, m, v of both layers in registers/LDS)",
+            # (a rank whose sub-nets do not fit the register file at once trains them in up to three groups, one launch each per
+            #  epoch: avg_launch_ms is then the epoch's launches together, steps_per_launch the optimiser steps they cover)
+            roofline = {"bound": "mfma", "kernel": "k_epoch_resident (one launch per epoch and group of <= 5 sub-nets: W, m, v of both layers in registers/LDS)",
                         "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
                         "traffic": None, "algorithmic_flops_per_step": step_flops, "avg_launch_ms": timers[6] / max(1, args.steps * args.epochs),
                         "launches": args.steps * args.epochs, "steps_per_launch": steps_per_epoch, "job_mfma": job_mfma}
