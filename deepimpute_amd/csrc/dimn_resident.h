@@ -5,8 +5,8 @@
 // One persistent launch then runs a WHOLE EPOCH of model.fit (reference deepimpute/multinet.py:238-244):
 // every workgroup keeps its slice of W1/m/v (and of W2/m/v) in registers for all ~743 optimiser steps, so
 // no optimiser state moves through HBM at all; per step the workgroups of one sub-net exchange only small
-// activation tiles through L2/MALL (write-through stores + arrival counters, no grid-wide barrier: sub-nets
-// share nothing, multinet.py:132-146).  The four launches per step of the streaming path (RED, MF, MB, B1F1 --
+// activation tiles through the memory-side cache (write-through stores validated by the readers, no grid-wide barrier:
+// sub-nets share nothing, multinet.py:132-146).  The four launches per step of the streaming path (RED, MF, MB, B1F1 --
 // each latency-bound at this size) disappear.
 //
 // Decomposition of sub-net k over G = 16*S1 workgroups (512 threads = 8 waves x 256 VGPRs, one per CU):
@@ -15,16 +15,21 @@
 //                        registers, forward partial P[64][16] of the NEXT batch (k-slot trick, dimn_kernels.h).
 //   role 2 (first OT):   workgroup ot owns the W2 column block [all 16 hidden tiles][output tile ot], two tiles
 //                        per wave.  Per step: Dd = dropout(relu(sum_s P + b1)), Z tile, softplus, wMSE, dZ,
-//                        Adam(b2), W2 gradient + Adam in registers, dD partial [64][256] over its 16 outputs.
+//                        Adam(b2), dD partial [64][256] over its 16 outputs (published), then the W2 gradient + Adam on the
+//                        column block, which lives in LDS.
 // Exchange per step and sub-net (the only inter-workgroup traffic):
 //   P partials   G x [64][16]  (role 1 -> role 2, and to the S1 siblings of a hidden tile for the relu gate);
 //                the split-0 workgroup of a hidden tile adds b1 to its partial, so A = sum_s P_s everywhere
 //   dD partials  OT x 16 x [64][16]  (role 2 -> role 1: workgroup (ht, s) sums tile ht over the OT producers)
-// Both through 16-byte sc0 sc1 (write-through) stores, a vmcnt(0) drain, and ONE relaxed agent-scope counter
-// per sub-net and direction; consumers poll that counter with one lane and read with sc0 sc1 loads (L1 is
-// never refreshed by other CUs' stores, L2s of different XCDs are not coherent: MI355X guide, Guideline 16).
-// Counters are monotonic over the epoch (zeroed by the host before the launch); every spin is bounded and
-// a timeout raises an abort word that makes every workgroup leave, so a lost workgroup cannot hang the GPU.
+// Both through 16-byte sc0 sc1 (write-through) stores and sc0 sc1 loads (L1 is never refreshed by other CUs' stores, the L2s
+// of different XCDs are not coherent: MI355X guide, Guideline 16).  Hand-off protocol (DIMN_RES_SENT, the default): a slot
+// is filled with all-ones words before its producer writes it, so a consumer sees in the DATA whether a piece has arrived
+// (res_poll on one piece per producer tile, then res_fix on every piece where it is consumed): no store drain, no barrier,
+// no arrival counter on the producer side.  Slots of step t: P in t % 3, dD in t % 2; a producer re-arms the slot whose
+// readers have provably finished (see the step loop).  DIMN_RES_SENT=0 keeps the first protocol -- stores, vmcnt(0) drain,
+// one relaxed agent-scope counter per sub-net and direction, one-lane polls -- which costs ~8 us more per step.
+// Every spin is bounded; a timeout raises an abort word that the host turns into an error, so a lost workgroup cannot
+// hang the GPU.  A handle with more sub-nets than fit at once runs one launch per GROUP of sub-nets (ResParams.k0).
 //
 // All arithmetic is the exact-fp32 path of the streaming kernels (v_mfma_f32_16x16x4_f32, adam4, the Philox
 // dropout streams, softplus_sigmoid_fast): only summation orders differ.
