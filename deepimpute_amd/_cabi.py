@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_BATCH = 64
 COMM_ID_BYTES = 128
 # hidden-layer activations the kernels implement (ids = DIMN_ACT_* of include/dimn.h; Keras names)
@@ -90,6 +90,7 @@ GPU_ONLY = {
     "predict_device": [_H, _pi, _i64, C.POINTER(C.c_void_p)],
     "synchronize": [_H],
     "get_timers": [_H, _pd, _i32],
+    "training_precision": [_H],
     "set_profiling": [_H, _i32],
     "comm_unique_id": [_pu8],
     "comm_init": [_H, _pu8, _i32, _i32],

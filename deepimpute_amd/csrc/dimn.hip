@@ -21,7 +21,7 @@
 #include "dimn_general.h"
 #include "dimn_csv.h"
 
-#define DIMN_ABI_VERSION 3
+#define DIMN_ABI_VERSION 4
 
 // DIMN_TRACE=1: stage times of the host-heavy entry points on stderr (diagnostic)
 struct Trace {
@@ -124,6 +124,7 @@ struct dimn_handle_s {
     std::vector<MidWork> midwork;          // work table of the fused second-layer kernel (k_mid_fused)
     int mid_fused = 0, mid_slices = 0;     // 1: RED -> MFB -> RED2 -> B1F1; 0: RED -> MF -> MB -> B1F1
     int mid_keep = 0;                      // 1: k_mid_fused<true> (the W2 column blocks stay in LDS between its phases)
+    int train_bf16 = 0;                    // 1: precision bf16 and the fused second layer runs its three GEMMs on the bf16 matrix cores
     MidWork* d_midwork = nullptr; int32_t* d_midk = nullptr; float* d_P2 = nullptr;
     std::vector<std::vector<int32_t>> pred, targ;
     int nslots = 0;
@@ -283,6 +284,7 @@ static void build_mid(dimn_handle h) {
     int tmax = 0;
     for (auto& m : h->midwork) tmax = std::max(tmax, m.ot1 - m.ot0);
     h->mid_keep = tmax <= 6 && !(getenv("DIMN_MID_KEEP") && atoi(getenv("DIMN_MID_KEEP")) == 0);
+    h->train_bf16 = h->mid_keep && h->prec == DIMN_PREC_BF16 && !(getenv("DIMN_TRAIN_BF16") && atoi(getenv("DIMN_TRAIN_BF16")) == 0);
 }
 
 static bool resident_plan(dimn_handle h, int Kg, int& S1o, int& T1o) {
@@ -480,6 +482,7 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
         }
         (void)hipFuncSetAttribute((const void*)k_mid_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)k_mid_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_mid_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     auto zero = [&](void* p, size_t bytes) { return hipMemset(p, 0, bytes) == hipSuccess ? 0 : fail(DIMN_ERR_HIP, "hipMemset failed"); };
     TRY(zero(h->d_W1, w1 * 4)); TRY(zero(h->d_M1, w1 * 4)); TRY(zero(h->d_V1, w1 * 4));
@@ -995,7 +998,12 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
 #define LAUNCH_MFB(KEEPV) hipLaunchKernelGGL(k_mid_fused<KEEPV>, dim3(nk * (unsigned)h->mid_slices), dim3(512), lds, st, h->d_midwork + (size_t)ln.k0 * h->mid_slices, \
                                              h->d_W2, h->d_M2, h->d_V2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_P2,        \
                                              h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary)
-        if (h->mid_keep) LAUNCH_MFB(true); else LAUNCH_MFB(false);      // keep: every slice <= 6 tiles, W2 read once (DIMN_MID_KEEP=0: off)
+        // keep: every slice <= 6 tiles, W2 read once (DIMN_MID_KEEP=0: off); with precision bf16 its GEMMs take bf16 operands
+        if (h->mid_keep && h->train_bf16) {
+            hipLaunchKernelGGL((k_mid_fused<true, true>), dim3(nk * (unsigned)h->mid_slices), dim3(512), lds, st, h->d_midwork + (size_t)ln.k0 * h->mid_slices,
+                               h->d_W2, h->d_M2, h->d_V2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_P2,
+                               h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary);
+        } else if (h->mid_keep) LAUNCH_MFB(true); else LAUNCH_MFB(false);
 #undef LAUNCH_MFB
         hipLaunchKernelGGL(k_reduce_dd, dim3((unsigned)ceil_div(dm.Hp, 64), nk), dim3(1024), 0, st, h->d_midk, h->d_P2, h->d_Dd,
                            h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, ln.k0, (const float*)h->d_G);
@@ -1475,6 +1483,11 @@ extern "C" int dimn_set_profiling(dimn_handle h, int32_t on) {
     h->profiling = on != 0;
     return DIMN_OK;
 }
+extern "C" int dimn_training_precision(dimn_handle h) {
+    if (!h) return fail(DIMN_ERR_ARG, "dimn_training_precision: null handle");
+    return h->train_bf16 ? DIMN_PREC_BF16 : DIMN_PREC_F32;
+}
+
 extern "C" int dimn_get_timers(dimn_handle h, double* out4, int32_t reset) {
     if (!h || !out4) return fail(DIMN_ERR_ARG, "null argument");
     out4[0] = h->tm_step_ms; out4[1] = (double)h->tm_steps; out4[2] = h->tm_w1_ms; out4[3] = (double)h->tm_w1;

@@ -43,6 +43,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
 
 // ---- bf16 X arena (precision DIMN_PREC_BF16: BASELINE configs[4]) -------------------------------------------------
 // The gathered predictor blocks X_k may be stored in bfloat16 (half the arena and half the X traffic; the weights, the
@@ -72,6 +73,10 @@ __host__ __device__ static inline float bf16_to_f32(bf16_t b) { union { float f;
 template <typename XT> __device__ __forceinline__ XT x_store(float f);
 template <> __device__ __forceinline__ float x_store<float>(float f) { return f; }
 template <> __device__ __forceinline__ bf16_t x_store<bf16_t>(float f) { return f32_to_bf16(f); }
+// four floats -> the bf16 operand of one v_mfma_f32_16x16x16_bf16, rounded to nearest even: the compiler turns the vector cast
+// into two v_cvt_pk_bf16_f32 and knows their hazards (hand-written as inline asm the MFMA that followed read the operand too early)
+typedef __bf16 bf16x4n __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4 pk4(f32x4 v) { return __builtin_bit_cast(bf16x4, __builtin_convertvector(v, bf16x4n)); }
 
 // Streamed optimiser state (read once, written once per step).  DIMN_NT bit 0 marks all of B1F1's state loads, bit 4
 // only its m and v loads, bit 1 the state stores non-temporal; bit 2 the split-K partial stores of B1F1, bit 3 the dD
@@ -747,7 +752,10 @@ __device__ unsigned long long g_mid_tl[512 * 8 * 8];
 // W2 parameter.  And with w out of the phase-2 sets, m and v of ALL the slice's tiles fit in registers (96): they are requested
 // at the start of the kernel and travel under the load burst and phase 1, so phase 2 is compute + stores only (it runs at its
 // MFMA floor, tools/k_probe_mid.hip).  40.1 -> 36.4 us per launch at 40 sub-nets x 6 slices (tools/ab_mid_allmv.sh).
-template <bool KEEP>
+// BF (with KEEP, handles of precision bf16): the three GEMMs of the layer take bf16 operands -- Dd, W2, dZ rounded to nearest even
+// in registers, one v_mfma_f32_16x16x16_bf16 where four fp32 MFMAs were (the k-slot register groups ARE its operands), fp32
+// accumulation, fp32 master weights and Adam state.  oracle/dimo.c restates the rounding (dimo_set_training_bf16).
+template <bool KEEP, bool BF = false>
 __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ mwork,
                                                    float* __restrict__ W2, float* __restrict__ M2, float* __restrict__ V2,
                                                    float* __restrict__ b2w, float* __restrict__ b2m, float* __restrict__ b2v,
@@ -877,10 +885,16 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
                 f32x4 a4[NM];
 #pragma unroll
                 for (int j = 0; j < NM; ++j) a4[j] = *(const f32x4*)(arow + 16 * j * ldd + 16 * (4 * rd + t));
+                if constexpr (BF) {
+                    const bf16x4 bp = pk4((f32x4){bq[t][0], bq[t][1], bq[t][2], bq[t][3]});
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                    for (int j = 0; j < NM; ++j) acc[j] = MFMA_BF16(pk4(a4[j]), bp, acc[j]);
+                } else {
 #pragma unroll
-                    for (int j = 0; j < NM; ++j) acc[j] = MFMA16(a4[j][r], bq[t][r], acc[j]);
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < NM; ++j) acc[j] = MFMA16(a4[j][r], bq[t][r], acc[j]);
+                }
             }
         }
         // targets: row-major float4 pieces -> this wave's rows of the unit tile -> MFMA C layout (the rows are
@@ -955,6 +969,13 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
     for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht) ddf[kb][ht] = ddl[(4 * kb + lj) * ldd + 16 * (2 * wave + ht) + li];
+    bf16x4 ddp[BF ? 4 : 1][2];                               // BF: the same operands, four batch rows per lane and instruction
+    if constexpr (BF) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht) ddp[q][ht] = pk4((f32x4){ddf[4 * q][ht], ddf[4 * q + 1][ht], ddf[4 * q + 2][ht], ddf[4 * q + 3][ht]});
+    }
     f32x4 dacc[4][2];
 #pragma unroll
     for (int m4 = 0; m4 < 4; ++m4)
@@ -977,11 +998,20 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
         }
         const float* zb = dzl + (ot - ot0) * 1024;
         f32x4 g[2] = {zero4, zero4};
+        if constexpr (BF) {
 #pragma unroll
-        for (int kb = 0; kb < 16; ++kb) {
-            const float az = zb[64 * kb + lane];                             // dZ^T[o = li][b = 4kb+lj]
+            for (int q = 0; q < 4; ++q) {                                    // batch rows 16q + 4i + lj in k-slot i of lane (.., lj)
+                const bf16x4 ap = pk4((f32x4){zb[64 * (4 * q) + lane], zb[64 * (4 * q + 1) + lane], zb[64 * (4 * q + 2) + lane], zb[64 * (4 * q + 3) + lane]});
 #pragma unroll
-            for (int ht = 0; ht < 2; ++ht) g[ht] = MFMA16(az, ddf[kb][ht], g[ht]);
+                for (int ht = 0; ht < 2; ++ht) g[ht] = MFMA_BF16(ap, ddp[q][ht], g[ht]);
+            }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 16; ++kb) {
+                const float az = zb[64 * kb + lane];                         // dZ^T[o = li][b = 4kb+lj]
+#pragma unroll
+                for (int ht = 0; ht < 2; ++ht) g[ht] = MFMA16(az, ddf[kb][ht], g[ht]);
+            }
         }
         f32x4 zf[4];
 #pragma unroll
@@ -991,10 +1021,16 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
             f32x4 wold;
             if constexpr (KEEP) wold = *(const f32x4*)(w2l + ((ot - ot0) * 16 + 2 * wave + ht) * 256 + li * 16 + 4 * lj);
             else wold = cur.w[ht];
+            if constexpr (BF) {
+                const bf16x4 wp = pk4(wold);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int m4 = 0; m4 < 4; ++m4) dacc[m4][ht] = MFMA_BF16(pk4(zf[m4]), wp, dacc[m4][ht]);      // OLD W2
+            } else {
 #pragma unroll
-                for (int m4 = 0; m4 < 4; ++m4) dacc[m4][ht] = MFMA16(zf[m4][r], wold[r], dacc[m4][ht]);        // OLD W2
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int m4 = 0; m4 < 4; ++m4) dacc[m4][ht] = MFMA16(zf[m4][r], wold[r], dacc[m4][ht]);    // OLD W2
+            }
             adam4(wold, cur.m[ht], cur.v[ht], g[ht], ap);
             const int64_t i = tidx(ht, ot);
             DIMN_ST_STATE(W2 + i, wold); DIMN_ST_STATE(M2 + i, cur.m[ht]); DIMN_ST_STATE(V2 + i, cur.v[ht]);
@@ -1879,7 +1915,6 @@ __global__ __launch_bounds__(256) void k_val_metrics(const float* __restrict__ p
 // before the launch (W1b: chunk-blocked like W1; W2t: [o][h], so a lane's four h's are contiguous); the hidden
 // activations are rounded to bf16 when they are staged in LDS.  Biases, softplus, the loss: fp32.
 // ---------------------------------------------------------------------------------------
-#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
 
 __global__ __launch_bounds__(256) void k_prep_bf16(const SubnetDev* __restrict__ sn, const float* __restrict__ W1, const float* __restrict__ W2,
                                                    bf16_t* __restrict__ W1b, bf16_t* __restrict__ W2t, Dims dm) {

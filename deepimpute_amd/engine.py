@@ -147,6 +147,12 @@ class Engine:
         self._check(self._f["train_epoch"](self._h, int(epoch), p_i32(perm), p_f64(loss)))
         return loss
 
+    @property
+    def training_precision(self):
+        """"bf16" when the second layer's training GEMMs run on the bf16 matrix cores (precision bf16 on the fused kernel), else "fp32"."""
+        fn = self._f.get("training_precision")
+        return "bf16" if fn is not None and fn(self._h) == 1 else "fp32"
+
     def val_loss(self):
         v = np.empty(self.K, np.float64)
         self._check(self._f["val_loss"](self._h, p_f64(v)))

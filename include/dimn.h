@@ -222,6 +222,12 @@ int dimn_synchronize(dimn_handle h);
  * register-resident epoch launches (few sub-nets per GPU), [7] optimiser steps they ran.
  * bench.py's live roofline figure. */
 int dimn_get_timers(dimn_handle h, double* out8, int32_t reset);
+
+/* The operand format of the TRAINING GEMMs of the second layer (multinet.py:139-146 under model.fit, :238): DIMN_PREC_BF16 when
+ * the handle was created with precision bf16 and runs the fused second-layer kernel with its bf16 matrix-core variant
+ * (Dd, W2, dZ rounded to nearest even per GEMM, fp32 accumulation, fp32 master weights and Adam state), else DIMN_PREC_F32.
+ * The first layer's training GEMMs and the optimiser are fp32 on every path.  ABI 4. */
+int dimn_training_precision(dimn_handle h);
 int dimn_set_profiling(dimn_handle h, int32_t on);
 
 /* ---- multi-GPU: sub-nets sharded over ranks, RCCL over xGMI (no reference analogue:

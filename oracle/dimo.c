@@ -70,6 +70,7 @@ struct dimo_handle_s {
     int64_t t;                        /* Adam step counter */
     int act;                          /* hidden activation, DIMN_ACT_* (multinet.py:137) */
     int infer_bf16;                   /* precision bf16: inference/validation GEMM operands rounded to bfloat16 (fp32 accumulate) */
+    int train_bf16;                   /* restates k_mid_fused<KEEP, BF>: the three TRAINING GEMMs of the second layer take bf16 operands */
 };
 typedef struct dimo_handle_s* dimo_handle;
 
@@ -248,6 +249,7 @@ static inline float bf16_round(float f) {
     return c.f;
 }
 int dimo_set_inference_bf16(struct dimo_handle_s* h, int32_t on) { h->infer_bf16 = on != 0; return DIMN_OK; }
+int dimo_set_training_bf16(struct dimo_handle_s* h, int32_t on) { h->train_bf16 = on != 0; return DIMN_OK; }
 
 /* Forward of one row of one sub-net.  x[D] in; a[H] pre-activation, dd[H] hidden output
  * after relu(+dropout when keep != NULL), z[O] pre-softplus out. */
@@ -256,6 +258,7 @@ static void forward_row(const struct dimo_handle_s* h, const subnet* s, const re
     const int H = h->H, O = h->O, D = s->D;
     const real scale = keep ? (real)(1.0f / (1.0f - h->cfg.dropout_rate)) : (real)1;
     const int q = !keep && h->infer_bf16;               /* inference on the bf16 matrix cores: operands rounded, fp32 accumulate */
+    const int q2 = q || (keep && h->train_bf16);        /* second layer: also in training when it runs on the bf16 matrix cores */
     for (int j = 0; j < H; ++j) a[j] = 0;
     for (int d = 0; d < D; ++d) {                       /* S1: a = x W1 + b1 */
         const real xv = x[d];
@@ -271,9 +274,9 @@ static void forward_row(const struct dimo_handle_s* h, const subnet* s, const re
     }
     for (int o = 0; o < O; ++o) z[o] = 0;
     for (int j = 0; j < H; ++j) {
-        const real dv = q ? (real)bf16_round((float)dd[j]) : dd[j];
+        const real dv = q2 ? (real)bf16_round((float)dd[j]) : dd[j];
         const real* w = s->W2 + (size_t)j * O;
-        if (q) for (int o = 0; o < O; ++o) z[o] += dv * (real)bf16_round((float)w[o]);
+        if (q2) for (int o = 0; o < O; ++o) z[o] += dv * (real)bf16_round((float)w[o]);
         else for (int o = 0; o < O; ++o) z[o] += dv * w[o];
     }
     for (int o = 0; o < O; ++o) z[o] += s->b2[o];
@@ -369,7 +372,8 @@ int dimo_train_step(dimo_handle h, const int32_t* rows, int32_t b_act, const uin
             for (int j = 0; j < H; ++j) {
                 const real* w = s->W2 + (size_t)j * O;
                 real acc = 0;
-                for (int o = 0; o < O; ++o) acc += dz[o] * w[o];
+                if (h->train_bf16) for (int o = 0; o < O; ++o) acc += (real)bf16_round((float)dz[o]) * (real)bf16_round((float)w[o]);
+                else for (int o = 0; o < O; ++o) acc += dz[o] * w[o];
                 if (h->act == DIMN_ACT_RELU) {
                     dA[j] = (keep[j] && a[j] > 0) ? acc * scale : 0;
                 } else {
@@ -386,7 +390,10 @@ int dimo_train_step(dimo_handle h, const int32_t* rows, int32_t b_act, const uin
             subnet* s = &h->s[k];
             for (int o = 0; o < O; ++o) {
                 real g = 0;
-                for (int b = 0; b < b_act; ++b) g += s->dd[(size_t)b * H + j] * s->dz[(size_t)b * O + o];
+                if (h->train_bf16)
+                    for (int b = 0; b < b_act; ++b) g += (real)bf16_round((float)s->dd[(size_t)b * H + j]) * (real)bf16_round((float)s->dz[(size_t)b * O + o]);
+                else
+                    for (int b = 0; b < b_act; ++b) g += s->dd[(size_t)b * H + j] * s->dz[(size_t)b * O + o];
                 const size_t e = (size_t)j * O + o;
                 adam1(&s->W2[e], &s->m[2][e], &s->v[2][e], g, alpha, omb1, omb2, eps);
             }

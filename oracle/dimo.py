@@ -31,13 +31,17 @@ def _load(fp64=False, path=None):
 class OracleEngine(Engine):
     """Same Python face as HipEngine, running the plain-loop C restatement on the CPU."""
 
-    def __init__(self, D, hidden, out_dim, fp64=False, lib_path=None, infer_bf16=False, **kw):
+    def __init__(self, D, hidden, out_dim, fp64=False, lib_path=None, infer_bf16=False, train_bf16=False, **kw):
         super().__init__(_load(fp64, lib_path), D, hidden, out_dim, **kw)
+        name = lib_path or os.path.join(_HERE, "libdimo64.so" if fp64 else "libdimo.so")
         if infer_bf16:               # restates k_predict_bf16: inference / validation GEMM operands rounded to bfloat16
-            name = lib_path or os.path.join(_HERE, "libdimo64.so" if fp64 else "libdimo.so")
             lib = C.CDLL(name)
             lib.dimo_set_inference_bf16.argtypes = [C.c_void_p, C.c_int32]
             lib.dimo_set_inference_bf16(self._h, 1)
+        if train_bf16:               # restates k_mid_fused<KEEP, BF>: the second layer's three training GEMMs on bf16 operands
+            lib = C.CDLL(name)
+            lib.dimo_set_training_bf16.argtypes = [C.c_void_p, C.c_int32]
+            lib.dimo_set_training_bf16(self._h, 1)
 
 
 def _load_general(fp64=False):

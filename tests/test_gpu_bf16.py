@@ -133,6 +133,37 @@ def test_bf16_matrix_core_inference_matches_oracle_rounding(H, O, B, Ds):
         e.close()
 
 
+def test_bf16_matrix_core_training_of_the_second_layer(monkeypatch):
+    """precision="bf16" on the fused second-layer kernel (k_mid_fused<KEEP, BF>): Z = Dd W2, gW2 = Dd^T dZ and dD = dZ W2^T take
+    bf16 operands (rounded to nearest even in registers, fp32 accumulation, fp32 master weights and Adam state).  The oracle
+    restates the rounding (train_bf16); what is left is the summation order and, rarely, an operand that rounds to the
+    neighbouring bf16 value.  Stated tolerance: training / validation loss 1e-3 relative, imputed values 5e-3 relative +
+    5e-4 absolute after two epochs; DIMN_TRAIN_BF16=0 keeps the fp32 matrix cores."""
+    monkeypatch.setenv("DIMN_MID", "1")
+    monkeypatch.setenv("DIMN_RESIDENT", "0")
+    prob = make_problem(n=330, g=700, Ds=[300, 150, 77], H=256, O=512, seed=11)
+    kw = dict(batch_size=64, dropout_rate=0.2, learning_rate=1e-3, seed=4242)
+    a = load_problem(_hip(), prob, precision="bf16", **kw)
+    assert a.training_precision == "bf16"
+    b = load_problem(_oracle(), prob, precision="bf16", infer_bf16=True, train_bf16=True, **kw)
+    c = load_problem(_oracle(), prob, precision="bf16", infer_bf16=True, **kw)           # fp32 training GEMMs
+    for e in (a, b, c):
+        e.init_weights()
+    for epoch in range(2):
+        la, lb, lc = a.train_epoch(epoch), b.train_epoch(epoch), c.train_epoch(epoch)
+        np.testing.assert_allclose(la, lb, rtol=1e-3)
+        np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-3)
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=5e-3, atol=5e-4)
+    # the rounding is really there: the HIP path sits closer to the oracle that rounds than to the one that does not
+    w_a, w_b, w_c = a.get_weights(0)[2], b.get_weights(0)[2], c.get_weights(0)[2]
+    assert np.abs(w_a - w_b).mean() < 0.5 * np.abs(w_a - w_c).mean()
+    monkeypatch.setenv("DIMN_TRAIN_BF16", "0")
+    d = load_problem(_hip(), prob, precision="bf16", **kw)
+    assert d.training_precision == "fp32"
+    for e in (a, b, c, d):
+        e.close()
+
+
 def test_multinet_streamed_and_bf16_through_the_shell(tmp_path):
     """MultiNet(stream_matrix=True) imputes exactly what the resident hand-over does; MultiNet(precision="bf16") stays close
     to fp32 (same early-stopping epoch on this problem, held-out correlation within 1e-2)."""
