@@ -269,7 +269,9 @@ static void build_mid(dimn_handle h) {
     S = std::max(S, ceil_div(dm.OT, DIMN_MID_TMAX));
     if (const char* e = getenv("DIMN_MID_SLICES")) S = std::max(ceil_div(dm.OT, DIMN_MID_TMAX), std::min(atoi(e), (int)dm.OT));   // tests
     if (S > dm.OT) return;
-    if (force < 0 && 5 * S * h->K < 3 * h->ncu) return;
+    // (precision bf16: the fused kernel has the bf16 matrix-core variant and wins from a quarter-filled GPU on -- configs[4]'s 8 sub-nets
+    //  per rank: 62.0 vs 63.8 us per step)
+    if (force < 0 && (h->prec == DIMN_PREC_BF16 ? 4 * S * h->K < h->ncu : 5 * S * h->K < 3 * h->ncu)) return;
     h->mid_slices = S;
     h->dm.LS = std::max((int)dm.OS, S);
     h->midwork.clear();
