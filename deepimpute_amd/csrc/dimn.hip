@@ -326,10 +326,12 @@ static void build_resident(dimn_handle h) {
     h->res_G = h->res_S1 = h->res_T1 = 0; h->res_Kg = 0;
     const Dims& dm = h->dm;
     if (const char* e = getenv("DIMN_RESIDENT")) if (atoi(e) == 0) return;
-    if (dm.HT != 16 || (dm.H & 3) != 0 || h->B > DIMN_TB || h->prec) return;      // (the resident kernel reads an fp32 X arena)
+    if (dm.HT != 16 || (dm.H & 3) != 0 || h->B > DIMN_TB) return;
     int max_groups = 3, min_groups = 1;
     if (const char* e = getenv("DIMN_RES_GROUPS")) max_groups = std::max(1, atoi(e));
     if (const char* e = getenv("DIMN_RES_MIN_GROUPS")) min_groups = std::max(1, atoi(e));      // tests: groups on small problems
+    if (h->prec && !getenv("DIMN_RES_GROUPS")) max_groups = 1;      // bf16 handles: the fused second layer has its bf16 matrix-core variant, and at
+                                                                     // configs[4]'s 8 sub-nets per rank two resident groups lose to it (65.8 vs 62.0 us per step)
     min_groups = std::min(min_groups, h->K);
     for (int groups = min_groups; groups <= std::min(std::max(max_groups, min_groups), h->K); ++groups) {
         const int Kg = ceil_div(h->K, groups);
@@ -1169,11 +1171,11 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
         hipLaunchKernelGGL(k_res_masks, dim3((unsigned)(steps * h->K)), dim3(512), 0, h->stream, h->d_sn, (unsigned*)h->d_res_b1, h->K, h->H,
                            (uint64_t)h->cfg.seed, (uint32_t)epoch, h->cfg.dropout_rate);
 #endif
-#define RES_LAUNCH(T, S)                                                                                                       \
-    do {                                                                                                                     \
-        (void)hipFuncSetAttribute((const void*)k_epoch_resident<T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_epoch_resident<T, S>), grid, dim3(DIMN_RES_THREADS), lds, h->stream, p);                       \
-    } while (0)
+#define RES_LAUNCH(T, S)                                                                                                           \
+    WITH_XT(h, {                                                                                                                 \
+        (void)hipFuncSetAttribute((const void*)k_epoch_resident<T, S, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_epoch_resident<T, S, XT>), grid, dim3(DIMN_RES_THREADS), lds, h->stream, p);                       \
+    })
     // one launch per group of res_Kg sub-nets (all of them when they fit at once), one after the other on the stream
     for (int k0 = 0; k0 < h->K; k0 += h->res_Kg) {
         p.k0 = k0;

@@ -82,7 +82,7 @@ __host__ __device__ static inline void res_chunk_range(int nchunk, int S1, int n
 
 struct ResParams {
     const SubnetDev* sn;
-    const float* X;                 // gathered predictors (arena)
+    const void* X;                  // gathered predictors (arena): float, or bfloat16 for handles of precision bf16 (template XT)
     const float* Y; int64_t n_cells;
     float *W1, *M1, *V1, *W2, *M2, *V2;
     float *b1w, *b1m, *b1v, *b2w, *b2m, *b2v;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512) void k_res_masks(const SubnetDev* __restrict__
 }
 #endif
 
-template <int T1, int S1C>   // W1 tiles per wave; D-splits (0: run-time p.S1)
+template <int T1, int S1C, typename XT = float>   // W1 tiles per wave; D-splits (0: run-time p.S1); element type of the X arena
 __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int ldd = DIMN_RES_LDD;
@@ -302,10 +302,10 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
     // The body of role 1: W1 gradient of batch t + Adam in registers (do_grad; bfr = dA[b = 4kb+lj][h = li]), then the
     // forward partial of batch t+1 with the fresh W1 (do_fwd).  xa/xb: the X_t / X_{t+1} tiles of the wave's first
     // chunk, requested by the caller (before its wait); xot/xon from xrows().
-    auto role1 = [&](const int tid, const uint32_t (&xot)[4], const uint32_t (&xon)[4], f32x4 (&xa)[4], f32x4 (&xb)[4], bool do_grad, bool do_fwd,
+    auto role1 = [&](const int tid, const uint32_t (&xot)[4], const uint32_t (&xon)[4], XRaw<XT> (&xa)[4], XRaw<XT> (&xb)[4], bool do_grad, bool do_fwd,
                      const float (&bfr)[16], const AdamP ap, uint32_t slot_out) {
         const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lj = lane >> 4;
-        const float* xk = p.X + s.xoff + 4 * (lane & 3);
+        const XT* xk = (const XT*)p.X + s.xoff + 4 * (lane & 3);
         float* xt = xst + wave * 2048;
         float* xn = xt + 1024;
         f32x4 pT[4] = {zero4, zero4, zero4, zero4};
@@ -314,12 +314,12 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             if (j > 0 && !tv[j]) break;                          // wave-uniform: a wave's tiles are its first ones (tile 0 always runs: it may be a clamped one)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                        // wave-private staging (in-order LDS, no barrier)
-                *(f32x4*)(xt + 256 * i + 4 * lane) = xa[i];
-                *(f32x4*)(xn + 256 * i + 4 * lane) = xb[i];
+                *(f32x4*)(xt + 256 * i + 4 * lane) = xa[i].get();
+                *(f32x4*)(xn + 256 * i + 4 * lane) = xb[i].get();
             }
             if (j + 1 < T1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { xa[i] = *(const f32x4*)(xk + xot[i] + 16 * tc[j + 1]); xb[i] = *(const f32x4*)(xk + xon[i] + 16 * tc[j + 1]); }
+                for (int i = 0; i < 4; ++i) { xa[i].load(xk + xot[i] + 16 * tc[j + 1]); xb[i].load(xk + xon[i] + 16 * tc[j + 1]); }
             }
             __builtin_amdgcn_sched_barrier(0);                   // the requests of the next tile leave before this tile's MFMAs
             if (do_grad) {
@@ -404,10 +404,10 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
         const int b0 = p.n_tr < B ? p.n_tr : B;
         AdamP ap0; ap0.alpha = 0.f; ap0.omb1 = p.omb1; ap0.omb2 = p.omb2; ap0.eps = p.eps;
         xrows(tid, 0, b0, xo0);
-        f32x4 xa[4], xb[4];
-        const float* xk = p.X + s.xoff + 4 * (lane & 3);
+        XRaw<XT> xa[4], xb[4];
+        const XT* xk = (const XT*)p.X + s.xoff + 4 * (lane & 3);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { xa[i] = *(const f32x4*)(xk + xo0[i] + 16 * tc[0]); xb[i] = xa[i]; }
+        for (int i = 0; i < 4; ++i) { xa[i].load(xk + xo0[i] + 16 * tc[0]); xb[i] = xa[i]; }
         __syncthreads();                                         // b1l written
         publish_mask(tid, 0);
         role1(tid, xo0, xo0, xa, xb, false, true, nob, ap0, 0u);
@@ -636,11 +636,11 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             uint32_t xon[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) xon[i] = b_next > 0 ? (uint32_t)rn[i] * (uint32_t)s.Dp : xo0[i];
-            f32x4 xa[4], xb[4];
+            XRaw<XT> xa[4], xb[4];
             {   // first X tiles of the tile loop, requested before the wait
-                const float* xk = p.X + s.xoff + 4 * (lane & 3);
+                const XT* xk = (const XT*)p.X + s.xoff + 4 * (lane & 3);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { xa[i] = *(const f32x4*)(xk + xo0[i] + 16 * tc[0]); xb[i] = *(const f32x4*)(xk + xon[i] + 16 * tc[0]); }
+                for (int i = 0; i < 4; ++i) { xa[i].load(xk + xo0[i] + 16 * tc[0]); xb[i].load(xk + xon[i] + 16 * tc[0]); }
             }
             // (tried: touching the next batch's X rows here / before the flagP wait, by asm loads or LDS-DMA, to move
             //  their HBM latency out of the tile loop: +3..5 us per step -- 16 hidden-tile workgroups fetch the same rows

@@ -25,7 +25,12 @@ def _oracle():
     (300, 512, 64, [260], 0.35),            # CLI default hidden = 300 (shared-staging B1F1)
     (150, 100, 37, [97, 64, 33], 0.2),      # generic B1F1, ragged everything, partial batches
 ])
-def test_bf16_x_arena_matches_oracle_on_rounded_inputs(H, O, B, Ds, p, monkeypatch):
+@pytest.mark.parametrize("resident", ["0", "1"])     # streaming kernels / register-resident epoch kernel (H = 256 only) on the bf16 arena
+def test_bf16_x_arena_matches_oracle_on_rounded_inputs(H, O, B, Ds, p, resident, monkeypatch):
+    if resident == "1" and H != 256:
+        pytest.skip("the resident kernel takes H = 256")
+    monkeypatch.setenv("DIMN_RESIDENT", resident)
+    monkeypatch.setenv("DIMN_TRAIN_BF16", "0")        # (and no bf16 training GEMMs, should the fused second layer be chosen)
     monkeypatch.setenv("DIMN_PREDICT_BF16", "0")      # this test pins the arena alone: inference GEMMs in fp32 too
     prob = make_problem(n=330, g=700, Ds=Ds, H=H, O=O, seed=11)
     kw = dict(batch_size=B, dropout_rate=p, learning_rate=1e-3, seed=4242, precision="bf16")
@@ -34,10 +39,12 @@ def test_bf16_x_arena_matches_oracle_on_rounded_inputs(H, O, B, Ds, p, monkeypat
     c = load_problem(_oracle(), prob, **dict(kw, precision="fp32"))
     for e in (a, b, c):
         e.init_weights()
+    a.set_profiling(True)
     for epoch in range(2):
         la, lb, lc = a.train_epoch(epoch), b.train_epoch(epoch), c.train_epoch(epoch)
         np.testing.assert_allclose(la, lb, rtol=1e-4)
         np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
+    assert (a.get_timers()[7] == a.step_count()) == (resident == "1")
     assert not np.allclose(lb, lc, rtol=1e-5)         # the rounding of the inputs is visible (and small)
     np.testing.assert_allclose(lb, lc, rtol=2e-2)
     for k in range(a.K):
