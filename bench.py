@@ -134,64 +134,93 @@ class FileRendezvous:
 
 
 class RcclBenchComm:
-    """The job's collectives on RCCL over xGMI (libdimn's dimn_comm_*)."""
+    """The job's collectives on RCCL over xGMI (libdimn's dimn_comm_*), with host clocks around them (both calls block until
+    the collective has finished on the handle's stream)."""
     kind = "rccl"
 
     def __init__(self, eng):
         self.eng = eng
+        self.reset()
 
-    def allreduce_sum(self, vec):
-        return self.eng.comm_allreduce_sum(vec)
+    def reset(self):
+        self.allreduce_s, self.allreduces, self.gather_s, self.gathers, self.gather_bytes = 0.0, 0, 0.0, 0, 0
+
+    def allreduce_sum(self, vec, timed=True):
+        t0 = time.perf_counter()
+        out = self.eng.comm_allreduce_sum(vec)
+        if timed:
+            self.allreduce_s += time.perf_counter() - t0
+            self.allreduces += 1
+        return out
 
     def gather(self, n, counts):
+        t0 = time.perf_counter()
         self.eng.comm_gather_predictions(n, counts, root=0, is_root=False)       # result stays in root's HBM
+        self.gather_s += time.perf_counter() - t0
+        self.gathers += 1
+        # bytes that cross xGMI into root: every peer's [n][K_r * O] fp32 block
+        self.gather_bytes += 4 * n * self.eng.O * (int(np.sum(counts)) - int(counts[0]))
 
     def close(self):
         self.eng.comm_destroy()
 
 
-class FileBenchComm:
-    """ONLY when RCCL cannot be brought up on this node (the line then says so in config.collectives): the two scalars per
-    epoch and the timing reductions go through files of the rendezvous directory and the gather of the prediction blocks is
-    SKIPPED -- the sub-nets still train and predict on their own GPUs, so the line remains a measurement of the sharded
-    compute, not of the complete job."""
-    kind = "files (RCCL unavailable: no gather)"
-
-    def __init__(self, rdzv):
-        self.rdzv, self.seq = rdzv, 0
-
-    def allreduce_sum(self, vec):
-        self.seq += 1
-        vec = np.asarray(vec, np.float64)
-        path = os.path.join(self.rdzv.dir, "ar%d_%d" % (self.seq, self.rdzv.rank))
-        with open(path + ".tmp", "wb") as f:
-            f.write(vec.tobytes())
-        os.replace(path + ".tmp", path)
-        total = np.zeros_like(vec)
-        for r in range(self.rdzv.world):
-            q = os.path.join(self.rdzv.dir, "ar%d_%d" % (self.seq, r))
-            t0 = time.time()
-            while not os.path.exists(q):
-                if time.time() - t0 > 600:
-                    raise TimeoutError("file all-reduce: rank %d never arrived" % r)
-                time.sleep(0.0005)
-            with open(q, "rb") as f:
-                total += np.frombuffer(f.read(), np.float64)
-        return total
-
-    def gather(self, n, counts):
-        pass
-
-    def close(self):
-        # rank 0 removes the directory afterwards: it must not do so before every rank has read the last files
-        if self.rdzv.rank != 0:
-            open(os.path.join(self.rdzv.dir, "done_%d" % self.rdzv.rank), "w").close()
-            return
+def file_vote(rdzv, name, value, timeout=600.0):
+    """Sum of one number per rank through files of the rendezvous directory.  Used ONLY to agree on whether RCCL came up on
+    every rank (a rank whose ncclCommInitRank failed cannot take part in an RCCL collective to say so); never a data path."""
+    path = os.path.join(rdzv.dir, "%s_%d" % (name, rdzv.rank))
+    with open(path + ".tmp", "w") as f:
+        f.write(repr(float(value)))
+    os.replace(path + ".tmp", path)
+    total = 0.0
+    for r in range(rdzv.world):
+        q = os.path.join(rdzv.dir, "%s_%d" % (name, r))
         t0 = time.time()
-        while not all(os.path.exists(os.path.join(self.rdzv.dir, "done_%d" % r)) for r in range(1, self.rdzv.world)):
-            if time.time() - t0 > 60:
-                break
+        while not os.path.exists(q):
+            if time.time() - t0 > timeout:
+                raise TimeoutError("rendezvous vote %s: rank %d never arrived" % (name, r))
             time.sleep(0.001)
+        with open(q) as f:
+            total += float(f.read())
+    return total
+
+
+def bring_up_rccl(eng, rdzv, rank, world):
+    """(RcclBenchComm, None) when every rank holds a working RCCL communicator, else (None, error string) on EVERY rank.
+    There is no other transport: without RCCL an N > 1 job has no gather and no global early-stopping quantity, so the
+    bench reports value null (rccl_failure_line) instead of a number."""
+    err = None
+    # RCCL prints a version banner on stdout at init; stdout must carry exactly one JSON line
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        uid = rdzv.broadcast_bytes("uid", eng.comm_unique_id().tobytes() if rank == 0 else None)
+        eng.comm_init(np.frombuffer(uid, np.uint8), world, rank)
+        eng.comm_allreduce_sum(np.zeros(1))
+        nranks, myrank = eng.comm_info()
+        if (nranks, myrank) != (world, rank):
+            err = "communicator reports ranks=%d rank=%d, launched as %d / %d" % (nranks, myrank, world, rank)
+    except Exception as e:
+        err = repr(e)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+    failed = file_vote(rdzv, "rccl_vote", 0.0 if err is None else 1.0)
+    if failed == 0:
+        return RcclBenchComm(eng), None
+    return None, err or "RCCL failed on %d other rank(s)" % int(failed)
+
+
+def rccl_failure_line(args, world, label, error):
+    """The line of an N > 1 run whose RCCL communicator did not come up: the contract's keys with value null, so that nothing
+    downstream can mistake it for a measurement."""
+    return {"metric": "cells/sec end-to-end impute (fit+predict)", "value": None, "unit": "cells/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": label, "parallelism": "subnets sharded x%d" % world, "collectives": None},
+            "rccl_error": error, "roofline": None, "cpu_baseline": None}
 
 
 def make_engine(cls, cfg, targets, preds, norm, train, val, counts, offs, rank, device_id, lr, stream=False, **kw):
@@ -341,8 +370,8 @@ def dropin_run(norm, epochs):
     from deepimpute_amd.multinet import MultiNet
     n, g = norm.shape
     raw = pd.DataFrame(np.rint(np.expm1(norm.astype(np.float64))), index=["c%d" % i for i in range(n)], columns=["g%d" % j for j in range(g)])
-    net = MultiNet(verbose=0, max_epochs=epochs, patience=10 ** 6)         # the bench fixes E epochs on every leg
-    with contextlib.redirect_stdout(io.StringIO()):
+    with contextlib.redirect_stdout(io.StringIO()):                       # (the reference's messages: stdout carries one JSON line)
+        net = MultiNet(verbose=0, max_epochs=epochs, patience=10 ** 6)     # the bench fixes E epochs on every leg
         t0 = time.perf_counter()
         net.fit(raw, NN_lim=g)
         t1 = time.perf_counter()
@@ -409,40 +438,28 @@ def main():
     comm = None
     if world > 1:
         rdzv = FileRendezvous(rank, world)
-        rccl_error = None
-        # RCCL prints a version banner on stdout at init; stdout must carry exactly one JSON line
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            uid = rdzv.broadcast_bytes("uid", eng.comm_unique_id().tobytes() if rank == 0 else None)
-            eng.comm_init(np.frombuffer(uid, np.uint8), world, rank)
-            eng.comm_allreduce_sum(np.zeros(1))
-        except Exception as e:                      # reported in the line; the job continues without the gather
-            rccl_error = repr(e)
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
-        # every rank must take the same road: one vote through the files
-        votes = FileBenchComm(rdzv).allreduce_sum(np.array([0.0 if rccl_error is None else 1.0]))
-        if votes[0] == 0:
-            comm = RcclBenchComm(eng)
-        else:
-            comm = FileBenchComm(rdzv)
-            comm.seq = 1
-            comm.error = rccl_error or "RCCL failed on another rank"
-            sys.stderr.write("bench.py rank %d: RCCL unavailable (%s); collectives through files, gather skipped\n" % (rank, comm.error))
+        comm, rccl_error = bring_up_rccl(eng, rdzv, rank, world)
+        if comm is None:
+            sys.stderr.write("bench.py rank %d: RCCL did not come up (%s): no measurement\n" % (rank, rccl_error))
+            if rank == 0:
+                print(json.dumps(rccl_failure_line(args, world, cfg["label"], rccl_error)))
+                sys.stdout.flush()
+            file_vote(rdzv, "bye", 0.0, timeout=60.0)            # nobody removes the directory under a rank still reading it
+            rdzv.cleanup()
+            eng.close()
+            sys.exit(3)
 
     def barrier():
         eng.synchronize()
         if comm:
-            comm.allreduce_sum(np.zeros(1))
+            comm.allreduce_sum(np.zeros(1), timed=False)
 
     for _ in range(args.warmup):
         impute_once(eng, args.epochs, comm, counts, n)
     eng.set_profiling(True)
     eng.get_timers(reset=True)
+    if comm:
+        comm.reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -450,10 +467,24 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     eng.set_profiling(False)
-    if comm:
-        times = np.zeros(world); times[rank] = dt
-        dt = float(comm.allreduce_sum(times).max())
     timers = eng.get_timers(reset=True)
+    per_rank = None
+    if comm:
+        # one row per rank, so that a multi-GPU line explains itself: wall time of the timed region, time per optimiser step on
+        # that rank's own stream (HIP events), its share of sub-nets, the all-reduce per epoch, predict, and the gather
+        mine = np.zeros((world, 7))
+        mine[rank] = [dt, (timers[6] / timers[7]) if timers[7] > 0 else timers[0] / max(1.0, timers[1]), counts[rank],
+                      1e3 * comm.allreduce_s / max(1, comm.allreduces), 1e3 * getattr(eng, "_bench_predict_s", 0.0),
+                      1e3 * comm.gather_s / max(1, comm.gathers), float(timers[7] > 0)]
+        allr = comm.allreduce_sum(mine.ravel(), timed=False).reshape(world, 7)
+        dt = float(allr[:, 0].max())
+        nranks, _ = eng.comm_info()
+        per_rank = {"nranks_ncclCommCount": nranks, "wall_s": [float(x) for x in allr[:, 0]], "lane_step_ms": [float(x) for x in allr[:, 1]],
+                    "subnets": [int(x) for x in allr[:, 2]], "allreduce_ms_per_epoch": [float(x) for x in allr[:, 3]],
+                    "predict_ms": [float(x) for x in allr[:, 4]], "gather_ms": [float(x) for x in allr[:, 5]],
+                    "resident_kernel": [bool(x) for x in allr[:, 6]],
+                    "gather_bytes_into_root": int(comm.gather_bytes // max(1, comm.gathers)),
+                    "gather_GBps_into_root": (comm.gather_bytes / comm.gather_s / 1e9) if comm.gather_s > 0 else None}
 
     result = None
     if rank == 0:
@@ -532,8 +563,9 @@ def main():
                                                  "val_loss": [float(x) for x in vh[-6:]]}
     if comm:
         if rank == 0 and result is not None:
-            result["config"]["collectives"] = comm.kind if comm.kind == "rccl" else {"kind": comm.kind, "rccl_error": getattr(comm, "error", None)}
-        comm.allreduce_sum(np.zeros(1))
+            result["config"]["collectives"] = "rccl"
+            result["config"]["per_rank"] = per_rank
+        comm.allreduce_sum(np.zeros(1), timed=False)
         comm.close()
         rdzv.cleanup()
     eng.close()

@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_BATCH = 64
 COMM_ID_BYTES = 128
 # hidden-layer activations the kernels implement (ids = DIMN_ACT_* of include/dimn.h; Keras names)
@@ -92,8 +92,10 @@ GPU_ONLY = {
     "get_timers": [_H, _pd, _i32],
     "training_precision": [_H],
     "set_profiling": [_H, _i32],
+    "path_info": [_H, _pi],
     "comm_unique_id": [_pu8],
     "comm_init": [_H, _pu8, _i32, _i32],
+    "comm_info": [_H, _pi],
     "comm_allreduce_sum": [_H, _pd, _i32],
     "comm_gather_predictions": [_H, _i64, _pi, _i32, _pf],
     "comm_destroy": [_H],

@@ -21,7 +21,7 @@
 #include "dimn_general.h"
 #include "dimn_csv.h"
 
-#define DIMN_ABI_VERSION 4
+#define DIMN_ABI_VERSION 5
 
 // DIMN_TRACE=1: stage times of the host-heavy entry points on stderr (diagnostic)
 struct Trace {
@@ -78,6 +78,8 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(ncclComm_t, int*) = nullptr;
+    int (*CommUserRank)(ncclComm_t, int*) = nullptr;
 };
 static Rccl g_rccl;
 static int rccl_bind() {
@@ -99,6 +101,8 @@ static int rccl_bind() {
     BIND(GroupStart, "ncclGroupStart");
     BIND(GroupEnd, "ncclGroupEnd");
     BIND(GetErrorString, "ncclGetErrorString");
+    BIND(CommCount, "ncclCommCount");
+    BIND(CommUserRank, "ncclCommUserRank");
 #undef BIND
     g_rccl.lib = lib;
     return DIMN_OK;
@@ -149,11 +153,14 @@ struct dimn_handle_s {
     float* d_out = nullptr; int64_t out_cap = 0; int64_t out_rows = 0;
     float* d_loss_part = nullptr; int64_t loss_part_cap = 0;
     float *d_full = nullptr, *d_stage = nullptr; int64_t full_cap = 0;   // root's gathered predictions
+    int64_t full_rows = 0, full_width = 0;                               // shape of the last gathered matrix (rows, K_global * O)
     double* d_red = nullptr; int red_cap = 0;                            // all-reduce scratch
     // register-resident epoch kernel (dimn_resident.h): chosen at create when the sub-nets of this handle fit the CUs
     int res_G = 0, res_S1 = 0, res_T1 = 0, res_Kg = 0;                    // 0: not eligible; Kg: sub-nets per epoch launch
     float *d_res_P = nullptr, *d_res_D = nullptr, *d_res_b1 = nullptr, *d_res_alpha = nullptr;
     unsigned* d_res_flags = nullptr; double* d_res_loss = nullptr; int64_t res_alpha_cap = 0;
+    float* d_res_snap = nullptr;           // the optimiser state before the running epoch launch (restored if the launch aborts)
+    int res_checked = 0;                   // 1: co-residency of a launch's workgroups verified against the occupancy of the kernel
     double tm_res_ms = 0; int64_t tm_res_steps = 0;
     double* pin_buf[4] = {nullptr, nullptr, nullptr, nullptr}; size_t pin_cap = 0;   // pinned bounce buffers of dimn_impute_finish, kept across calls
     hipStream_t stream = nullptr;          // lane 0's stream; also used by every non-training call
@@ -556,7 +563,7 @@ extern "C" int dimn_destroy(dimn_handle h) {
     DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage); DEV_FREE(h->d_red);
     for (auto& pb : h->pin_buf) if (pb) { (void)hipHostFree(pb); pb = nullptr; }
     DEV_FREE(h->d_W1b); DEV_FREE(h->d_W2t); DEV_FREE(h->d_W2tf);
-    DEV_FREE(h->d_res_P); DEV_FREE(h->d_res_D); DEV_FREE(h->d_res_b1); DEV_FREE(h->d_res_alpha); DEV_FREE(h->d_res_flags); DEV_FREE(h->d_res_loss);
+    DEV_FREE(h->d_res_P); DEV_FREE(h->d_res_D); DEV_FREE(h->d_res_b1); DEV_FREE(h->d_res_alpha); DEV_FREE(h->d_res_flags); DEV_FREE(h->d_res_loss); DEV_FREE(h->d_res_snap);
     for (auto& ln : h->lanes) (void)hipStreamDestroy(ln.stream);
     delete h;
     return DIMN_OK;
@@ -1160,6 +1167,20 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
     p.rate = h->cfg.dropout_rate; p.scale = 1.0f / (1.0f - h->cfg.dropout_rate);
     p.seed = h->cfg.seed; p.epoch = (uint32_t)epoch; p.G = h->res_G; p.S1 = h->res_S1; p.loss_binary = h->cfg.loss_binary;
     const size_t lds = (size_t)DIMN_RES_LDS_FLOATS * sizeof(float);
+    // The workgroups of a launch wait for each other, so all of them must be resident at once.  (1) the grid is checked against
+    // the kernel's occupancy on this device, and the launch is a COOPERATIVE one (the runtime refuses it unless the whole grid
+    // fits the device; DIMN_RES_COOP=0: plain launch); (2) the state the launch will overwrite is snapshotted first, so that a
+    // launch that still times out (a GPU shared with another process) is undone and the epoch re-run on the streaming kernels.
+    const size_t w2n = (size_t)h->K * dm.Hp * dm.Op, nb1 = (size_t)3 * h->K * dm.Hp, nb2 = (size_t)3 * h->K * dm.Op;
+    const size_t snap_floats = 3 * (size_t)h->w1_total + 3 * w2n + nb1 + nb2;
+    if (!h->d_res_snap) CHK(dev_alloc(&h->d_res_snap, snap_floats));
+    {
+        float* d = h->d_res_snap;
+        const float* src[8] = {h->d_W1, h->d_M1, h->d_V1, h->d_W2, h->d_M2, h->d_V2, h->d_b1, h->d_b2};
+        const size_t cnt[8] = {(size_t)h->w1_total, (size_t)h->w1_total, (size_t)h->w1_total, w2n, w2n, w2n, nb1, nb2};
+        for (int i = 0; i < 8; ++i) { HIPCHK(hipMemcpyAsync(d, src[i], cnt[i] * 4, hipMemcpyDeviceToDevice, h->stream)); d += cnt[i]; }
+    }
+    const bool coop = !(getenv("DIMN_RES_COOP") && atoi(getenv("DIMN_RES_COOP")) == 0);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) { e0 = next_event(h); e1 = next_event(h); next_event(h); }
     if (e0 && e1) (void)hipEventRecord(e0, h->stream);
@@ -1173,11 +1194,22 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
 #endif
 #define RES_LAUNCH(T, S)                                                                                                           \
     WITH_XT(h, {                                                                                                                 \
-        (void)hipFuncSetAttribute((const void*)k_epoch_resident<T, S, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_epoch_resident<T, S, XT>), grid, dim3(DIMN_RES_THREADS), lds, h->stream, p);                       \
+        const void* fn_ = (const void*)k_epoch_resident<T, S, XT>;                                                               \
+        (void)hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
+        if (!h->res_checked) {                                                                                                   \
+            int per_cu_ = 0;                                                                                                     \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_, fn_, DIMN_RES_THREADS, lds) != hipSuccess) per_cu_ = 0;   \
+            if ((int64_t)per_cu_ * h->ncu < (int64_t)h->res_Kg * h->res_G) not_resident = true;                                  \
+        }                                                                                                                        \
+        if (!not_resident) {                                                                                                     \
+            void* args_[1] = {(void*)&p};                                                                                        \
+            if (coop) { if (hipLaunchCooperativeKernel(fn_, grid, dim3(DIMN_RES_THREADS), args_, (unsigned)lds, h->stream) != hipSuccess) not_resident = true; } \
+            else hipLaunchKernelGGL((k_epoch_resident<T, S, XT>), grid, dim3(DIMN_RES_THREADS), lds, h->stream, p);              \
+        }                                                                                                                        \
     })
+    bool not_resident = false;
     // one launch per group of res_Kg sub-nets (all of them when they fit at once), one after the other on the stream
-    for (int k0 = 0; k0 < h->K; k0 += h->res_Kg) {
+    for (int k0 = 0; k0 < h->K && !not_resident; k0 += h->res_Kg) {
         p.k0 = k0;
         const dim3 grid((unsigned)(std::min(h->res_Kg, h->K - k0) * h->res_G));
         // <7, 3>: one rank of the 8-GPU job (5 sub-nets of D ~ 2400 on 256 CUs); the others take the D-split count at run time
@@ -1187,7 +1219,8 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
         else RES_LAUNCH(7, 0);
     }
 #undef RES_LAUNCH
-    HIPCHK(hipGetLastError());
+    h->res_checked = 1;
+    (void)hipGetLastError();
     if (e0 && e1) (void)hipEventRecord(e1, h->stream);
     std::vector<unsigned> flags((size_t)2 * h->K + 1);
     std::vector<double> acc((size_t)h->K * dm.OT);
@@ -1196,12 +1229,24 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
     HIPCHK(hipStreamSynchronize(h->stream));
     if (e0 && e1) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { h->tm_res_ms += ms; h->tm_res_steps += steps; }
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && !not_resident && flags[(size_t)2 * h->K] == 0) { h->tm_res_ms += ms; h->tm_res_steps += steps; }
         h->ev_used = 0; h->ev_bytes.clear();
     }
-    if (flags[(size_t)2 * h->K] != 0)
-        return fail(DIMN_ERR_HIP, "dimn_train_epoch: the register-resident epoch kernel timed out waiting for a workgroup "
-                                  "(another process on this GPU?); weights are undefined -- re-initialise, or set DIMN_RESIDENT=0");
+    if (getenv("DIMN_RES_TEST_ABORT") && atoi(getenv("DIMN_RES_TEST_ABORT")) == (int)epoch + 1) flags[(size_t)2 * h->K] = 1;   // tests: pretend epoch N-1 timed out
+    if (not_resident || flags[(size_t)2 * h->K] != 0) {
+        // not all workgroups of a launch could be resident together (or one was lost to another tenant of this GPU): the state
+        // goes back to what it was before this epoch, the handle stops using the resident kernel, and the caller runs the epoch
+        // on the streaming kernels -- same numbers to fp32 rounding, no error for the user
+        fprintf(stderr, "libdimn: the register-resident epoch kernel %s; epoch %d re-runs on the streaming kernels and this handle keeps to them\n",
+                not_resident ? "cannot have all its workgroups resident on this device" : "timed out waiting for a workgroup (another process on this GPU?)", (int)epoch);
+        float* d = h->d_res_snap;
+        float* dst[8] = {h->d_W1, h->d_M1, h->d_V1, h->d_W2, h->d_M2, h->d_V2, h->d_b1, h->d_b2};
+        const size_t cnt[8] = {(size_t)h->w1_total, (size_t)h->w1_total, (size_t)h->w1_total, w2n, w2n, w2n, nb1, nb2};
+        for (int i = 0; i < 8; ++i) { HIPCHK(hipMemcpyAsync(dst[i], d, cnt[i] * 4, hipMemcpyDeviceToDevice, h->stream)); d += cnt[i]; }
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->res_G = 0;
+        return 1;                                              // > 0: "fell back", not an error
+    }
     h->t += steps;
     if (train_loss)
         for (int k = 0; k < h->K; ++k) {
@@ -1245,8 +1290,10 @@ extern "C" int dimn_train_epoch(dimn_handle h, int32_t epoch, const int32_t* per
         if (train_loss) for (int k = 0; k < h->K; ++k) train_loss[k] = ls[(size_t)k] / ((double)h->O * (double)h->n_tr);
         return DIMN_OK;
     }
-    if (h->res_G && h->act == DIMN_ACT_RELU && ((h->n_tr + h->B - 1) / h->B) * h->K * 2048 < (1ll << 31))      // (keep words of the epoch: 32-bit offsets)
-        return train_epoch_resident(h, epoch, train_loss);
+    if (h->res_G && h->act == DIMN_ACT_RELU && ((h->n_tr + h->B - 1) / h->B) * h->K * 2048 < (1ll << 31)) {    // (keep words of the epoch: 32-bit offsets)
+        const int rc = train_epoch_resident(h, epoch, train_loss);
+        if (rc <= 0) return rc;                                // done, or an error; 1: the launch was undone -> the streaming kernels below
+    }
     HIPCHK(hipMemsetAsync(h->d_loss_acc, 0, (size_t)h->K * dm.LS * sizeof(double), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));     // every lane reads the row list and accumulates into d_loss_acc
     // d_loss_acc accumulates sum(w e^2) per step; the per-step means are weighted by b_act,
@@ -1401,6 +1448,9 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
     const float* pred = from_gathered ? h->d_full : h->d_out;
     if (!pred || h->out_rows != n_rows) return fail(DIMN_ERR_STATE, "dimn_impute_finish: run dimn_predict_device (and the gather) over the same %lld rows first", (long long)n_rows);
     if (!from_gathered && S != (int64_t)h->K * h->O) return fail(DIMN_ERR_ARG, "dimn_impute_finish: %lld slots listed, the prediction has %lld", (long long)S, (long long)h->K * h->O);
+    if (from_gathered && (S != h->full_width || n_rows != h->full_rows))
+        return fail(DIMN_ERR_ARG, "dimn_impute_finish: %lld slots over %lld rows listed, the gathered matrix is %lld x %lld", (long long)S, (long long)n_rows,
+                    (long long)h->full_rows, (long long)h->full_width);
     for (int64_t j = 0; j < g; ++j) if (gene_off[j] > gene_off[j + 1]) return fail(DIMN_ERR_ARG, "dimn_impute_finish: gene_off not monotone");
     for (int64_t s = 0; s < S; ++s) if (gene_slot[s] < 0 || gene_slot[s] >= S) return fail(DIMN_ERR_ARG, "dimn_impute_finish: slot out of range");
     CHK(use_device(h));
@@ -1492,6 +1542,19 @@ extern "C" int dimn_training_precision(dimn_handle h) {
     return h->train_bf16 ? DIMN_PREC_BF16 : DIMN_PREC_F32;
 }
 
+extern "C" int dimn_path_info(dimn_handle h, int32_t* out8) {
+    if (!h || !out8) return fail(DIMN_ERR_ARG, "dimn_path_info: null argument");
+    out8[0] = h->gen ? 2 : (h->res_G ? 1 : 0);                 // 0 streaming kernels, 1 register-resident epoch kernel, 2 general path
+    out8[1] = h->res_G ? ceil_div(h->K, h->res_Kg) : 0;        // resident: epoch launches (groups of sub-nets) per epoch
+    out8[2] = h->res_S1;                                        // resident: D-splits per hidden tile
+    out8[3] = h->mid_fused;                                     // streaming: 1 fused second layer (RED -> MFB -> RED2), 0 two kernels (MF + MB)
+    out8[4] = h->mid_fused ? h->mid_slices : 0;                 // ... output slices per sub-net
+    out8[5] = h->mid_keep;                                      // ... W2 column blocks kept in LDS between the phases
+    out8[6] = h->train_bf16;                                    // second-layer training GEMMs on the bf16 matrix cores
+    out8[7] = h->dm.HT == 16 ? 1 : (h->dm.HT == 20 ? 2 : 0);    // first layer: 1 ring B1F1 (H = 256), 2 shared-staging (H = 300), 0 generic
+    return DIMN_OK;
+}
+
 extern "C" int dimn_get_timers(dimn_handle h, double* out4, int32_t reset) {
     if (!h || !out4) return fail(DIMN_ERR_ARG, "null argument");
     out4[0] = h->tm_step_ms; out4[1] = (double)h->tm_steps; out4[2] = h->tm_w1_ms; out4[3] = (double)h->tm_w1;
@@ -1519,6 +1582,15 @@ extern "C" int dimn_comm_init(dimn_handle h, const uint8_t* id, int32_t n_ranks,
     memcpy(&u, id, sizeof u);
     NCCLCHK(g_rccl.CommInitRank(&h->comm, n_ranks, u, rank));
     h->n_ranks = n_ranks; h->rank = rank;
+    return DIMN_OK;
+}
+extern "C" int dimn_comm_info(dimn_handle h, int32_t* out2) {
+    if (!h || !out2) return fail(DIMN_ERR_ARG, "dimn_comm_info: null argument");
+    if (!h->comm) return fail(DIMN_ERR_STATE, "dimn_comm_info: dimn_comm_init first");
+    int n = 0, r = -1;
+    NCCLCHK(g_rccl.CommCount(h->comm, &n));
+    NCCLCHK(g_rccl.CommUserRank(h->comm, &r));
+    out2[0] = n; out2[1] = r;
     return DIMN_OK;
 }
 extern "C" int dimn_comm_allreduce_sum(dimn_handle h, double* v, int32_t n) {
@@ -1580,6 +1652,7 @@ extern "C" int dimn_comm_gather_predictions(dimn_handle h, int64_t n_rows, const
                                     (size_t)counts[r] * O * 4, (size_t)n_rows, hipMemcpyDeviceToDevice, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->full_rows = n_rows; h->full_width = ktot * O;
     if (out && need > 0) HIPCHK(hipMemcpy(out, h->d_full, (size_t)need * 4, hipMemcpyDeviceToHost));
     return DIMN_OK;
 }

@@ -28,8 +28,8 @@
 // no arrival counter on the producer side.  Slots of step t: P in t % 3, dD in t % 2; a producer re-arms the slot whose
 // readers have provably finished (see the step loop).  DIMN_RES_SENT=0 keeps the first protocol -- stores, vmcnt(0) drain,
 // one relaxed agent-scope counter per sub-net and direction, one-lane polls -- which costs ~8 us more per step.
-// Every spin is bounded; a timeout raises an abort word that the host turns into an error, so a lost workgroup cannot
-// hang the GPU.  A handle with more sub-nets than fit at once runs one launch per GROUP of sub-nets (ResParams.k0).
+// Every wait is bounded in wall-clock time; a timeout raises an abort word, the host then restores the pre-epoch state and
+// re-runs the epoch on the streaming kernels, so a lost workgroup can neither hang the GPU nor fail a fit.  A handle with more sub-nets than fit at once runs one launch per GROUP of sub-nets (ResParams.k0).
 //
 // All arithmetic is the exact-fp32 path of the streaming kernels (v_mfma_f32_16x16x4_f32, adam4, the Philox
 // dropout streams, softplus_sigmoid_fast): only summation orders differ.
@@ -39,6 +39,11 @@
 #define DIMN_RES_THREADS 512
 #define DIMN_RES_LDD 260          // LDS row stride of Dd (as k_mid_fused)
 #define DIMN_RES_SPIN_LIMIT (1u << 22)
+// every wait is bounded in WALL-CLOCK time (s_memrealtime: the 100 MHz constant clock), not in polls: a workgroup that does not
+// hear from a producer for this long raises the abort word, every other wait sees it and leaves, the host undoes the launch
+#ifndef DIMN_RES_WAIT_TICKS
+#define DIMN_RES_WAIT_TICKS 150000000ull      // 1.5 s
+#endif
 #ifndef DIMN_RES_AUX
 #define DIMN_RES_AUX 17           // sc0 sc1 on every exchanged 16-byte access
 #endif
@@ -119,11 +124,12 @@ __device__ __forceinline__ void res_st(__amdgpu_buffer_rsrc_t r, uint32_t byte_o
 // One lane waits until *flag >= target (relaxed agent-scope polls, s_sleep between them); false on abort.
 __device__ __forceinline__ bool res_wait(unsigned* flag, unsigned target, unsigned* abort_w) {
     unsigned spins = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 255u) == 0u) {
             if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-            if (spins > DIMN_RES_SPIN_LIMIT) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > DIMN_RES_WAIT_TICKS) {
                 __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;
             }
@@ -149,6 +155,7 @@ __device__ __forceinline__ bool res_poll(__amdgpu_buffer_rsrc_t r, uint32_t base
 #endif
     const int lane = threadIdx.x & 63;
     unsigned spins = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
         bool missing = false;
         for (int i = lane; i < n; i += 64) missing |= res_unwritten(res_ld(r, base + (uint32_t)i * stride));
@@ -156,7 +163,7 @@ __device__ __forceinline__ bool res_poll(__amdgpu_buffer_rsrc_t r, uint32_t base
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 63u) == 0u) {
             if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-            if (spins > DIMN_RES_SPIN_LIMIT) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > DIMN_RES_WAIT_TICKS) {
                 __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;
             }

@@ -21,6 +21,11 @@ def _fns():
     return _lib.load()
 
 
+# pandas' default na_values (pandas.io.parsers: STR_NA_VALUES): an index label among them becomes NaN in pd.read_csv
+_PANDAS_NA = frozenset(["", "#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN", "<NA>", "N/A", "NA",
+                        "NULL", "NaN", "None", "n/a", "nan", "null"])
+
+
 def read_csv(path):
     """pd.read_csv(path, index_col=0)."""
     try:
@@ -42,8 +47,13 @@ def read_csv(path):
     name, cols, rows = text[0], text[1:1 + g.value], text[1 + g.value:]
     if len(set(cols)) != len(cols) or any(c == "" or c != c.strip() for c in cols + rows):
         return pd.read_csv(path, index_col=0)          # pandas mangles duplicate / blank names: let it
+    if any(r in _PANDAS_NA for r in rows):
+        return pd.read_csv(path, index_col=0)          # pandas turns these row labels into NaN: its result, not ours
     if all(_INT.match(r) for r in rows):
-        index = pd.Index(np.array([int(r) for r in rows], np.int64))      # pandas infers an integer index
+        try:
+            index = pd.Index(np.array([int(r) for r in rows], np.int64))  # pandas infers an integer index
+        except OverflowError:
+            return pd.read_csv(path, index_col=0)      # beyond int64: pandas' own inference (uint64 / object)
     else:
         try:
             [float(r) for r in rows]

@@ -297,6 +297,15 @@ class HipEngine(Engine):
                                              code, float(ceiling), int(bool(from_gathered)), p_f64(out)))
         return out
 
+    def path_info(self):
+        """The kernels dimn_create chose for this handle (include/dimn.h dimn_path_info), as a dict."""
+        out = np.zeros(8, np.int32)
+        self._check(self._f["path_info"](self._h, p_i32(out)))
+        keys = ("path", "resident_groups", "resident_splits", "mid_fused", "mid_slices", "mid_keep", "train_bf16", "first_layer")
+        d = dict(zip(keys, (int(x) for x in out)))
+        d["path"] = ("streaming", "resident", "general")[d["path"]]
+        return d
+
     def synchronize(self):
         self._check(self._f["synchronize"](self._h))
 
@@ -317,6 +326,12 @@ class HipEngine(Engine):
     def comm_init(self, uid, n_ranks, rank):
         uid = np.ascontiguousarray(uid, dtype=np.uint8)
         self._check(self._f["comm_init"](self._h, p_u8(uid), int(n_ranks), int(rank)))
+
+    def comm_info(self):
+        """(ranks, rank) as the RCCL communicator itself reports them (ncclCommCount / ncclCommUserRank)."""
+        out = np.zeros(2, np.int32)
+        self._check(self._f["comm_info"](self._h, p_i32(out)))
+        return int(out[0]), int(out[1])
 
     def comm_allreduce_sum(self, vec):
         v = np.ascontiguousarray(vec, dtype=np.float64).copy()

@@ -22,6 +22,7 @@ There is no CPU fallback: without libdimn.so and a GPU, fit()/predict() raise.
 import glob
 import json
 import os
+import re
 import tempfile
 import warnings
 
@@ -178,6 +179,12 @@ def _loss_name(loss):
     exit(1)
 
 
+def _shard_rank(path):
+    """r of .../model.rank<r>.npz, None for anything else."""
+    m = re.fullmatch(r"model\.rank(\d+)\.npz", os.path.basename(path))
+    return int(m.group(1)) if m else None
+
+
 # ------------------------------------------------------------------------------- the estimator
 class MultiNet:
     def __init__(self, learning_rate=1e-4, batch_size=64, max_epochs=500, patience=5, ncores=-1,
@@ -190,8 +197,10 @@ class MultiNet:
         self.verbose = verbose
         self.seed = seed
         self.device_id = device_id                 # extension: which GPU
-        # extensions (BASELINE configs[4]): "bf16" stores the gathered predictor blocks in bfloat16 and runs inference /
-        # validation on the bf16 matrix cores (weights, Adam state, targets, training GEMMs stay fp32); stream_matrix
+        # extensions (BASELINE configs[4]): "bf16" stores the gathered predictor blocks in bfloat16, runs inference /
+        # validation on the bf16 matrix cores and gives the training GEMMs bf16 operands wherever the engine has the
+        # bf16 matrix-core kernel for them (engine.training_precision / engine.path_info() say where); weights (fp32
+        # master copies), Adam state, targets and every accumulation stay fp32; stream_matrix
         # hands the log1p matrix over in row blocks through pinned buffers so that it never resides on the GPU
         # (None: automatically, for matrices above 32 GB)
         self.precision = precision
@@ -263,15 +272,26 @@ class MultiNet:
             raise OSError("DIMN_MODEL_FORMAT=%s but no HDF5 library was found (set DIMN_LIBHDF5)" % want)
         return want if want in ("npz", "h5", "both") else ("h5" if keras_io.available() else "npz")
 
+    def _sharded_outputdir(self, comm):
+        """A sharded job writes per-rank shards into ONE directory.  The default output_prefix is a per-process temporary
+        directory (the reference's `tempfile.mkdtemp()` default, multinet.py:60), which every rank would create for itself:
+        with more than one rank it is replaced by a directory named after the job (launcher pid + start time + MASTER_PORT:
+        the same string on every rank, sharded._job_tag) -- an explicit output_prefix is used as given."""
+        if comm is not None and comm.world > 1 and self.outputdir == _SCRATCH:
+            from .sharded import _job_tag
+            self.outputdir = os.path.join(tempfile.gettempdir(), "dimn_model_%d_%s" % (os.getuid(), _job_tag()))
+        return self.outputdir
+
     def save(self, model):
         """model.json (rank 0; the Keras functional-model JSON of build()'s network, our own metadata under the extra key
         "deepimpute_amd") + the weights in Keras layout: model.h5 as Keras save_weights writes it (keras_io.py) or, without
         an HDF5 library, model.npz keyed by GLOBAL sub-net index.  A sharded job writes model.rank<r>.npz per rank (one
         node, one file system), from which rank 0 assembles model.h5; a fresh MultiNet under any world size can load() either."""
         from . import keras_io
-        os.makedirs(self.outputdir, exist_ok=True)
         comm = self._comm
         rank, world = (comm.rank, comm.world) if comm is not None else (0, 1)
+        self._sharded_outputdir(comm)
+        os.makedirs(self.outputdir, exist_ok=True)
         fmt = self._model_format()
         layers = _parse_architecture(self.NN_parameters['architecture'])
         dims = [len(p) for p in self.predictors] if getattr(self, "predictors", None) is not None else list(model.D)
@@ -286,18 +306,36 @@ class MultiNet:
             arrays = model.get_weights(k)
             for i, arr in enumerate(arrays):
                 blobs["%s%d_%d" % ("Wb"[i % 2], i // 2 + 1, self._first_subnet + k)] = arr
-        for stale in (glob.glob(os.path.join(self.outputdir, "model.rank*.npz")) if world == 1 else []) + \
-                ([os.path.join(self.outputdir, "model.npz" if fmt == "h5" else "model.h5")] if rank == 0 and fmt != "both" else []):
-            if os.path.exists(stale):
-                os.remove(stale)                         # never leave weights of an older fit beside the new ones
+        # never leave weights of an older fit beside the new ones: the other format's file, and the shards of ranks this job
+        # does not have (a refit into the same directory with fewer ranks would otherwise leave model.rank<r>.npz, r >= world,
+        # whose sub-net indices overlap the fresh shards)
+        if rank == 0:
+            stale = [path for path in glob.glob(os.path.join(self.outputdir, "model.rank*.npz")) if _shard_rank(path) is None or _shard_rank(path) >= (world if world > 1 else 0)]
+            if fmt != "both":
+                stale.append(os.path.join(self.outputdir, "model.npz" if fmt == "h5" else "model.h5"))
+            for path in stale:
+                if os.path.exists(path):
+                    os.remove(path)
+        problem = ""
         if world > 1:
             np.savez(os.path.join(self.outputdir, "model.rank%d.npz" % rank), **blobs)
             comm.barrier()                               # every shard is on disk
-            if rank == 0 and fmt != "npz":
+            if rank == 0:
                 blobs = {}
-                for path in sorted(glob.glob(os.path.join(self.outputdir, "model.rank*.npz"))):
+                for r in range(world):                   # exactly this job's shards, in rank order
+                    path = os.path.join(self.outputdir, "model.rank%d.npz" % r)
+                    if not os.path.exists(path):
+                        problem += " %s is missing (ranks must share output_prefix=%r)" % (os.path.basename(path), self.outputdir)
+                        continue
                     with np.load(path) as z:
                         blobs.update({f: z[f] for f in z.files})
+                n_dense = len(layers) + 1
+                missing = [key for k in range(len(dims)) for l in range(1, n_dense + 1) for key in ("W%d_%d" % (l, k), "b%d_%d" % (l, k)) if key not in blobs]
+                if missing and not problem:
+                    problem = " the shards lack %d arrays (first: %s)" % (len(missing), missing[0])
+            # every rank learns of a failed assembly BEFORE the final barrier, and every rank raises
+            if comm.allreduce_sum(np.array([1.0 if problem else 0.0]))[0] > 0:
+                raise OSError("MultiNet.save: rank 0 could not assemble the sharded weights in %s:%s" % (self.outputdir, problem or " (see rank 0)"))
         elif fmt != "h5":
             np.savez(os.path.join(self.outputdir, "model.npz"), **blobs)
         if rank == 0 and fmt != "npz":
@@ -314,7 +352,10 @@ class MultiNet:
             keras_io.write_weights_h5(os.path.join(self.outputdir, "model.h5"), order, weights)
         if comm is not None:
             comm.barrier()                               # every file is on disk when any rank returns
-        print("Saved model to disk in {}".format(self.outputdir))
+        written = {"h5": "model.json + model.h5 (Keras save_weights layout)", "npz": "model.json + model.npz (no HDF5 library found: set DIMN_LIBHDF5, "
+                   "or DIMN_MODEL_FORMAT=h5 to insist)" if not os.environ.get("DIMN_MODEL_FORMAT") else "model.json + model.npz",
+                   "both": "model.json + model.h5 + model.npz"}[fmt]
+        print("Saved model to disk in {}".format(self.outputdir) + " [%s%s]" % (written, "; shards model.rank0..%d.npz" % (world - 1) if world > 1 else ""))
 
     def load(self):
         """The engine holding the fitted weights: the live one if this object trained it, else rebuilt from outputdir
@@ -322,6 +363,9 @@ class MultiNet:
         pair (a Keras model.json without our metadata + model.h5; loss and batch size then stay as constructed)."""
         if self._engine is None:
             from . import keras_io
+            if isinstance(self._comm_spec, str) and self.outputdir == _SCRATCH and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+                from .sharded import _job_tag                 # the directory a sharded fit of this job wrote to (_sharded_outputdir)
+                self.outputdir = os.path.join(tempfile.gettempdir(), "dimn_model_%d_%s" % (os.getuid(), _job_tag()))
             with open(os.path.join(self.outputdir, "model.json")) as fh:
                 doc = json.load(fh)
             dense_names = None
@@ -346,7 +390,8 @@ class MultiNet:
                     engine.set_weights(g - self._first_subnet, *arrays)
                 wanted.clear()
             else:
-                files = sorted(glob.glob(os.path.join(self.outputdir, "model.rank*.npz"))) or [os.path.join(self.outputdir, "model.npz")]
+                shards = [path for path in glob.glob(os.path.join(self.outputdir, "model.rank*.npz")) if _shard_rank(path) is not None]
+                files = sorted(shards, key=_shard_rank) or [os.path.join(self.outputdir, "model.npz")]
                 for path in files:
                     with np.load(path) as z:
                         for g in sorted(wanted):

@@ -61,8 +61,11 @@ typedef struct dimn_config {
     uint64_t seed;            /* multinet.py:77; keys the Philox streams                */
     int32_t precision;        /* DIMN_PREC_F32 (reference: float32 everywhere) or DIMN_PREC_BF16: the gathered predictor
                                  blocks X_k are stored in bfloat16 (round to nearest even) and the inference / validation
-                                 GEMMs run on the bf16 matrix cores with fp32 accumulation; weights, Adam state, targets
-                                 and the training GEMMs stay fp32 (BASELINE configs[4]) */
+                                 GEMMs run on the bf16 matrix cores with fp32 accumulation; the TRAINING GEMMs take bf16
+                                 operands (fp32 accumulation) wherever the handle runs a kernel that has the bf16
+                                 matrix-core variant -- dimn_training_precision() / dimn_path_info() say which; weights
+                                 (fp32 master copies), Adam state, targets and every accumulation stay fp32
+                                 (BASELINE configs[4]: "bf16 MFMA with fp32 accumulate") */
 } dimn_config;
 #define DIMN_PREC_F32 0
 #define DIMN_PREC_BF16 1
@@ -229,12 +232,21 @@ int dimn_get_timers(dimn_handle h, double* out8, int32_t reset);
  * The first layer's training GEMMs and the optimiser are fp32 on every path.  ABI 4. */
 int dimn_training_precision(dimn_handle h);
 int dimn_set_profiling(dimn_handle h, int32_t on);
+/* Which kernels the library chose for this handle (the automatic decision of dimn_create; DESIGN.md has the table): out8 =
+ * [0] 0 streaming kernels / 1 register-resident epoch kernel / 2 general path, [1] resident: launches (sub-net groups) per epoch,
+ * [2] resident: D-splits per hidden tile, [3] streaming: 1 fused second layer / 0 two kernels, [4] its slices per sub-net,
+ * [5] W2 kept in LDS between its phases, [6] second-layer training GEMMs on the bf16 matrix cores, [7] first-layer kernel
+ * (1 ring, 2 shared staging, 0 generic).  A handle whose resident launch had to be undone reports 0 from then on.  ABI 5. */
+int dimn_path_info(dimn_handle h, int32_t* out8);
 
 /* ---- multi-GPU: sub-nets sharded over ranks, RCCL over xGMI (no reference analogue:
  * the reference is single-process, multinet.py:222-223 only sets TF CPU threads) ---- */
 #define DIMN_COMM_ID_BYTES 128
 int dimn_comm_unique_id(uint8_t* id /* [DIMN_COMM_ID_BYTES] */);
 int dimn_comm_init(dimn_handle h, const uint8_t* id, int32_t n_ranks, int32_t rank);
+/* What the communicator itself reports: out2 = {ncclCommCount, ncclCommUserRank} (bench.py prints it, so a multi-GPU line
+ * names the ranks RCCL really connected).  ABI 5. */
+int dimn_comm_info(dimn_handle h, int32_t* out2);
 /* In-place sum over ranks of a small host vector (per-epoch val-loss for the global
  * early-stopping decision, multinet.py:242-243). */
 int dimn_comm_allreduce_sum(dimn_handle h, double* v, int32_t n);

@@ -185,3 +185,82 @@ def check_general_kat(cls, loss, rtol, atol, **kw):
             np.testing.assert_allclose(vW, z["%s/vW_%d_%d" % (loss, k, l)], rtol=10 * rtol, atol=atol * 1e-4, err_msg="%s v k=%d l=%d" % (loss, k, l))
         np.testing.assert_allclose(pred[:, k * O:(k + 1) * O], z["%s/predict_%d" % (loss, k)], rtol=rtol, atol=atol, err_msg="%s predict k=%d" % (loss, k))
     eng.close()
+
+
+def relu_flip_units(hip, orc, k, rtol=1e-3, atol=2e-5):
+    """Hidden units of sub-net k whose first-layer column / bias differ between two engines beyond the weight tolerance."""
+    Wa, ba = hip.get_weights(k)[:2]
+    Wb, bb = orc.get_weights(k)[:2]
+    bad_w = ~np.all(np.abs(Wa - Wb) <= atol + rtol * np.abs(Wb), axis=0)
+    bad_b = ~(np.abs(ba - bb) <= atol + rtol * np.abs(bb))
+    return np.flatnonzero(bad_w | bad_b)
+
+
+def assert_relu_flip_mechanism(oracle_cls, norm, pred_k, targ_k, k_global, units, train, steps, H, O, flip_slack=16.0, **kw):
+    """The mechanism behind a (rare) one-unit disagreement of two fp32 paths that sum a first-layer dot product in different
+    orders: relu'(a) is discontinuous at a = 0.  The fp64 oracle replays steps 0 .. steps-2 of epoch 0 of sub-net `k_global`
+    alone (Philox streams are keyed by GLOBAL sub-net index), and for every unit in `units` the pre-activation of some row of
+    the LAST batch must lie within the reordering error of an fp32 dot product of zero: |a| <= flip_slack * eps32 * (sum_i
+    |x_i w_i| + |b|).  Returns the (row, unit, a, bound) records."""
+    o64 = oracle_cls([len(pred_k)], H, O, fp64=True, subnet_offset=int(k_global), **kw)
+    o64.set_matrix(norm)
+    o64.set_indices(0, pred_k, targ_k)
+    o64.gather(True)
+    o64.set_split(train, train[:1])
+    o64.init_weights()
+    B = o64.B
+    perm = o64.epoch_permutation(0)
+    for t in range(steps - 1):
+        o64.train_step(train[perm[t * B:(t + 1) * B]], epoch_key=0, step_key=t, want_loss=False)
+    W1, b1 = o64.get_weights(0)[:2]
+    o64.close()
+    rows = train[perm[(steps - 1) * B:steps * B]]
+    X = norm[rows][:, pred_k]
+    if str(kw.get("precision", "fp32")).lower() in ("bf16", "bfloat16"):      # the arena stores the predictors rounded to nearest even
+        u = np.ascontiguousarray(X, np.float32).view(np.uint32)
+        X = (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+    X = X.astype(np.float64)
+    out = []
+    for u in units:
+        w = W1[:, u].astype(np.float64)
+        a = X @ w + float(b1[u])
+        bound = flip_slack * np.finfo(np.float32).eps * (np.abs(X) @ np.abs(w) + abs(float(b1[u])))
+        i = int(np.argmin(np.abs(a) / bound))
+        assert abs(a[i]) <= bound[i], "unit %d of sub-net %d: no pre-activation of the last batch is within reordering error of zero " \
+                                      "(closest: row %d, a = %.3e, bound %.3e) -- not a relu flip" % (u, k_global, rows[i], a[i], bound[i])
+        out.append((int(rows[i]), int(u), float(a[i]), float(bound[i])))
+    return out
+
+
+def graft_units(dst, src, k, units):
+    """Give sub-net k of engine `dst` the first-layer column and bias of engine `src` for the listed hidden units (everything
+    else of dst stays): the comparison that follows is then 'everything once that unit is masked'."""
+    W1, b1, W2, b2 = [np.array(x) for x in dst.get_weights(k)]
+    S1, sb1 = src.get_weights(k)[:2]
+    W1[:, units] = S1[:, units]
+    b1[units] = sb1[units]
+    dst.set_weights(k, W1, b1, W2, b2)
+
+
+def check_reference_wmse(cls, rtol, **kw):
+    """The loss an engine reports for an optimiser step (lr = 0, no dropout) against the REFERENCE's own wMSE
+    (deepimpute/multinet.py:36-41, both `binary` values) evaluated by tests/golden/make_wmse.py on the same batches."""
+    z = np.load(os.path.join(GOLDEN, "kat_wmse.npz"))
+    D = int(z["pred"].size)
+    for binary in (False, True):
+        eng = cls([D], int(z["H"]), int(z["O"]), batch_size=64, dropout_rate=0.0, learning_rate=0.0, seed=int(z["seed"]),
+                  loss_binary=binary, **kw)
+        eng.set_matrix(z["norm"])
+        eng.set_indices(0, z["pred"], z["targ"])
+        eng.gather(True)
+        n = z["norm"].shape[0]
+        eng.set_split(np.arange(n - 10, dtype=np.int32), np.arange(n - 10, n, dtype=np.int32))
+        eng.init_weights()
+        for i in range(2):
+            rows = z["rows_%d" % i]
+            np.testing.assert_allclose(eng.predict(rows), z["y_pred_%d" % i], rtol=1e-5, atol=1e-6)      # same y_pred as the fixture's
+            loss = eng.train_step(rows, epoch_key=0, step_key=i)
+            want = z["wmse_binary_%d" % i] if binary else z["wmse_%d" % i]
+            np.testing.assert_allclose(loss[0], want, rtol=rtol, err_msg="wMSE(binary=%s) batch %d" % (binary, i))
+            np.testing.assert_allclose(eng.predict(rows), z["y_pred_%d" % i], rtol=1e-5, atol=1e-6)      # lr = 0: nothing moved
+        eng.close()

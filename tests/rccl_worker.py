@@ -12,7 +12,43 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+def big_shapes(out_path):
+    """BASELINE configs[3] shapes on the wire: the K = 40 sub-nets of the 50k x 20k job (D_k ~ 2 400) sharded over the ranks --
+    20 per rank at world 2 -- two optimiser steps, validation, predict of 1 024 cells and the strided placement of every
+    rank's [n][K_r * 512] block into root's [n][40 * 512] matrix."""
+    import bench
+    from deepimpute_amd.engine import HipEngine
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    cfg = dict(bench.CONFIGS["cfg3"], n=1024)
+    norm = bench.synth_counts(cfg["n"], cfg["g"], seed=0, threads=8)
+    targets, preds = bench.synth_indices(cfg["g"], cfg["O"], seed=0)
+    K = targets.shape[0]
+    counts, offs = bench.shard(K, world)
+    train, val = np.arange(0, 64 + 37, dtype=np.int32), np.arange(900, 1024, dtype=np.int32)
+    eng = bench.make_engine(HipEngine, cfg, targets, preds, norm, train, val, counts, offs, rank, local, 1e-3)
+    rdzv = bench.FileRendezvous(rank, world)
+    comm, err = bench.bring_up_rccl(eng, rdzv, rank, world)
+    assert comm is not None, err
+    assert eng.comm_info() == (world, rank)
+    vsum = bench.impute_once(eng, 1, comm, counts, cfg["n"])
+    full = eng.comm_gather_predictions(cfg["n"], counts, root=0, is_root=rank == 0)
+    stats = (comm.gather_bytes, comm.gathers)
+    comm.allreduce_sum(np.zeros(1))
+    comm.close()
+    rdzv.cleanup()
+    eng.close()
+    if rank == 0:
+        assert full.shape == (cfg["n"], K * cfg["O"])
+        assert stats == (4 * cfg["n"] * cfg["O"] * (K - counts[0]), 1)
+        np.savez(out_path, vsum=vsum, full=full[::3])
+    else:
+        assert full is None
+
+
 def main(out_path):
+    if os.environ.get("DIMN_RCCL_WORKER_MODE") == "big":
+        return big_shapes(out_path)
     import bench
     from deepimpute_amd.engine import HipEngine
     from deepimpute_amd.multinet import MultiNet

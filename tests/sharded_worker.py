@@ -29,12 +29,22 @@ def main(out_path):
     mu = rng.lognormal(0.5, 1.2, size=g)
     raw = pd.DataFrame(rng.poisson(rng.gamma(2.0, mu / 2.0, size=(n, g))).astype(np.float64),
                        index=["c%d" % i for i in range(n)], columns=["g%d" % j for j in range(g)])
-    net = MultiNet(engine_factory=OracleEngine, comm=comm, seed=17, sub_outputdim=64, ncores=1, verbose=0,
-                   max_epochs=6, patience=2, learning_rate=2e-3, output_prefix=out_path + ".dir",
-                   architecture=[{"type": "dense", "neurons": 32, "activation": "relu"}, {"type": "dropout", "rate": 0.2}])
+    default_dir = os.environ.get("SHARDED_WORKER_MODE") == "default_dir"      # no output_prefix: the per-process temporary default
+    where = {} if default_dir else {"output_prefix": out_path + ".dir"}
+    kw = dict(engine_factory=OracleEngine, comm=comm, seed=17, sub_outputdim=64, ncores=1, verbose=0,
+              architecture=[{"type": "dense", "neurons": 32, "activation": "relu"}, {"type": "dropout", "rate": 0.2}])
+    net = MultiNet(max_epochs=6, patience=2, learning_rate=2e-3, **where, **kw)
     net.fit(raw, NN_lim=300)
     imputed = net.predict(raw)
     rank = 0 if comm is None else comm.rank
+    if default_dir:
+        # a FRESH object of the same job finds the shards the fit wrote (every rank resolved the same shared directory)
+        again = MultiNet(**({"output_prefix": net.outputdir}), **kw)
+        again.predictors, again.targets = net.predictors, net.targets
+        reloaded = again.predict(raw)
+        if rank == 0:
+            assert np.array_equal(reloaded.values, imputed.values)
+            assert sorted(f for f in os.listdir(net.outputdir) if f.startswith("model.rank")) == ["model.rank%d.npz" % r for r in range(world)]
     if rank == 0:
         np.savez(out_path, imputed=imputed.values, epochs=net.trained_epochs, val=np.array(net.history["val_loss"]),
                  loss=np.array(net.history["loss"]), K=len(net.predictors),

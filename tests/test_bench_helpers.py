@@ -58,3 +58,52 @@ def test_file_rendezvous_hands_the_payload_to_every_rank(monkeypatch, tmp_path):
     assert got == {0: b"\x01\x02payload", 1: b"\x01\x02payload", 2: b"\x01\x02payload"}
     ranks[0].cleanup()
     assert not os.path.exists(ranks[0].dir)
+
+
+def test_rccl_failure_yields_a_null_value_line_on_every_rank(monkeypatch):
+    """An N > 1 run whose RCCL communicator does not come up must not look like a measurement: every rank learns of the
+    failure (file vote), and the line rank 0 prints has value null and names the error."""
+    import argparse
+    monkeypatch.setenv("MASTER_PORT", "5%d" % (os.getpid() % 10000))
+
+    class FakeEngine:
+        def __init__(self, rank, broken):
+            self.rank, self.broken = rank, broken
+
+        def comm_unique_id(self):
+            return np.arange(128, dtype=np.uint8)
+
+        def comm_init(self, uid, world, rank):
+            assert np.array_equal(uid, np.arange(128, dtype=np.uint8))
+            if self.broken:
+                raise RuntimeError("ncclCommInitRank failed: unhandled system error")
+
+        def comm_allreduce_sum(self, v):
+            return v
+
+        def comm_info(self):
+            return 3, self.rank
+
+    for broken_rank in (None, 1):
+        rd = [bench.FileRendezvous(r, 3) for r in range(3)]
+        got = {}
+
+        def run(r):
+            got[r] = bench.bring_up_rccl(FakeEngine(r, r == broken_rank), rd[r], r, 3)
+        th = [threading.Thread(target=run, args=(r,)) for r in range(3)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        rd[0].cleanup()
+        if broken_rank is None:
+            assert all(isinstance(got[r][0], bench.RcclBenchComm) and got[r][1] is None for r in range(3))
+        else:
+            assert all(got[r][0] is None and got[r][1] for r in range(3))
+            assert "ncclCommInitRank" in got[1][1] and "other rank" in got[0][1]
+    args = argparse.Namespace(steps=2, warmup=1, precision="fp32")
+    line = bench.rccl_failure_line(args, 8, "50k x 20k", "boom")
+    assert line["value"] is None and line["ms_per_step"] is None and line["rccl_error"] == "boom" and line["n_gpus"] == 8
+    for key in ("metric", "unit", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line
+    assert not hasattr(bench, "FileBenchComm")          # no transport other than RCCL can produce a number

@@ -76,3 +76,19 @@ def test_round_trip_of_a_larger_matrix_is_threaded_and_exact(tmp_path):
     ints = pd.DataFrame(vals, index=frame.index, columns=frame.columns)
     ints.to_csv(str(b))
     pd.testing.assert_frame_equal(csvio.read_csv(str(b)), pd.read_csv(str(b), index_col=0), check_exact=True)
+
+
+def test_row_labels_pandas_treats_as_missing_or_huge_go_to_pandas(tmp_path):
+    """Row labels in pandas' NA set become NaN in pd.read_csv's index, all-integer labels beyond int64 become uint64/object:
+    in both cases read_csv must return exactly what pandas returns."""
+    import pandas as pd
+    from deepimpute_amd import csvio
+    for name, rows in (("na", ["c0", "NA", "null", "c3"]), ("big", ["1", "99999999999999999999999", "3", "4"])):
+        path = str(tmp_path / (name + ".csv"))
+        with open(path, "w") as f:
+            f.write(",g0,g1\n")
+            for i, r in enumerate(rows):
+                f.write("%s,%d,%d\n" % (r, i, 2 * i))
+        want = pd.read_csv(path, index_col=0)
+        got = csvio.read_csv(path)
+        pd.testing.assert_frame_equal(got, want)

@@ -1,8 +1,14 @@
-"""GPU parity at the shapes of BASELINE.json configs[1] (5k x 5k, K = 10, D_k ~ 1935, H = 256, O = 512) and a
+"""GPU parity against the oracle at the real shapes of BASELINE.json configs[1] (5k x 5k, K = 10, D_k ~ 1935, H = 256, O = 512),
+configs[2] (K = 40, D_k ~ 2400), one rank's share of configs[3] (5 sub-nets, resident kernel) and of configs[4] (g = 30 000,
+8 sub-nets, bf16, streamed), and a
 long-horizon drift check of the fast-math pieces of the HIP path (1-ulp v_rcp/v_sqrt in Adam, hardware exp/log in
 the training softplus) against the fp64 build of the oracle.  Run on the MI355X box: pytest -m gpu."""
+import os
+
 import numpy as np
 import pytest
+
+from helpers import assert_relu_flip_mechanism, graft_units, relu_flip_units
 
 pytestmark = pytest.mark.gpu
 
@@ -55,23 +61,142 @@ def test_cfg2_shapes_match_oracle(mid, monkeypatch):
     assert a.step_count() == b.step_count() == 4
     if mid == "R":
         assert a.get_timers()[7] == 4                          # the resident kernel ran (two launches of five sub-nets per epoch)
-    # (R: the resident kernel sums the forward partials of three D-splits in its own order, and in the partial fourth batch one
-    #  pre-activation of sub-net 3 -- hidden unit 52, a unit with no gradient in the first three steps -- lands on the other
-    #  side of zero than in the oracle: the relu gate of that one (row, unit) flips, the unit's 1 958 input weights move by up
-    #  to 0.7 lr differently and the sub-net's validation loss by 1.8e-4.  Measured: fp64 oracle, fp32 oracle and the streaming
-    #  kernels agree there to 1e-7, every other unit of every sub-net agrees to 1e-6 on all four paths; with dropout 0, lr 1e-4,
-    #  a full fourth batch or one step less nothing flips.  A discontinuity of relu under reordering, not an arithmetic error.)
-    np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=3e-4 if mid == "R" else 1e-4)
-    for k in (0, 4, 9):
+    # The resident kernel sums the forward partials of its D-splits in its own order.  On this problem that once moved one
+    # pre-activation of the partial fourth batch (sub-net 3, hidden unit 52; |a| ~ 1e-7) to the other side of zero: the relu
+    # gate of that one (row, unit) flips and the unit's 1 958 input weights take a different Adam step.  That is a
+    # discontinuity of relu under reordering, not an arithmetic error -- and the test ASSERTS that mechanism instead of
+    # granting a budget: any first-layer column that misses the weight tolerance must belong to a unit whose pre-activation,
+    # replayed by the fp64 oracle, lies within the reordering error of zero in the last batch; with those units grafted from
+    # the oracle, everything -- validation loss, every weight, every imputed value -- must meet the north_star tolerance.
+    flipped = {}
+    for k in range(K):
+        units = relu_flip_units(a, b, k)
+        if units.size:
+            flipped[k] = units
+    assert sum(u.size for u in flipped.values()) <= 2, flipped
+    for k, units in flipped.items():
+        rec = assert_relu_flip_mechanism(_oracle(), norm, preds[k], targets[k], k, units, train[:3 * 64 + 21], 4, cfg["H"], cfg["O"],
+                                         batch_size=cfg["B"], dropout_rate=0.2, learning_rate=1e-3, seed=1234)
+        print("relu flip (mechanism asserted): sub-net %d" % k, rec)
+        graft_units(a, b, k, units)
+    np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
+    for k in range(K):
         for x, y, name in zip(a.get_weights(k), b.get_weights(k), ("W1", "b1", "W2", "b2")):
             np.testing.assert_allclose(x, y, rtol=1e-3, atol=2e-5, err_msg="%s k=%d" % (name, k))
     rows = np.arange(7, 7 + 256 * 19, 19, dtype=np.int32)
-    pa, pb = a.predict(rows), b.predict(rows)
-    if mid == "R":                           # nine sub-nets at the north_star tolerance, the one with the flipped gate within 2 %
-        err = (np.abs(pa - pb) / (1e-4 * np.abs(pb) + 1e-6)).reshape(len(rows), K, cfg["O"]).max(axis=(0, 2))
-        assert (err <= 1.0).sum() >= K - 1 and (err <= 200.0).all(), err
-    else:
-        np.testing.assert_allclose(pa, pb, rtol=1e-4, atol=1e-6)      # north_star tolerance
+    np.testing.assert_allclose(a.predict(rows), b.predict(rows), rtol=1e-4, atol=1e-6)      # north_star tolerance
+    a.close(); b.close()
+
+
+def _compare_with_oracle(a, b, norm, preds, targets, ks, train, steps, cfg, kw, rows, tol=None, max_flips=2):
+    """One epoch of `steps` optimiser steps (the last one partial) on both engines, then validation, weights and predict at the
+    tolerances of test_two_epochs_match_oracle; a first-layer column that misses the weight tolerance must be a relu flip of
+    the last batch (helpers.assert_relu_flip_mechanism) and is grafted from the oracle before the remaining comparisons."""
+    tol = dict(dict(loss=1e-4, w_rtol=1e-3, w_atol=2e-5, p_rtol=1e-4, p_atol=1e-6), **(tol or {}))
+    np.testing.assert_allclose(a.train_epoch(0), b.train_epoch(0), rtol=tol["loss"])
+    assert a.step_count() == b.step_count() == steps
+    flipped = {}
+    for i in range(len(ks)):
+        units = relu_flip_units(a, b, i, tol["w_rtol"], tol["w_atol"])
+        if units.size:
+            flipped[i] = units
+    assert sum(u.size for u in flipped.values()) <= max_flips, flipped
+    for i, units in flipped.items():
+        rec = assert_relu_flip_mechanism(_oracle(), norm, preds[ks[i]], targets[ks[i]], ks[i], units, train, steps, cfg["H"], cfg["O"], **kw)
+        print("relu flip (mechanism asserted): sub-net %d" % ks[i], rec)
+        graft_units(a, b, i, units)
+    np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=tol["loss"])
+    for i in range(len(ks)):
+        for x, y, name in zip(a.get_weights(i), b.get_weights(i), ("W1", "b1", "W2", "b2")):
+            np.testing.assert_allclose(x, y, rtol=tol["w_rtol"], atol=tol["w_atol"], err_msg="%s k=%d" % (name, ks[i]))
+    np.testing.assert_allclose(a.predict(rows), b.predict(rows), rtol=tol["p_rtol"], atol=tol["p_atol"])
+    return flipped
+
+
+def _cfg3_sample(n_cells):
+    """The predictor / target lists of the 50k x 20k job (bench.synth_indices(20000, 512): K = 40, D_k ~ 2 390-2 420) over the
+    first n_cells cells of a matrix from the same generator (the oracle's cost is per row; the shapes that select kernels --
+    K, D_k, H, O, batch -- are the full job's)."""
+    import bench
+    cfg = dict(bench.CONFIGS["cfg3"])
+    norm = bench.synth_counts(n_cells, cfg["g"], seed=0)
+    targets, preds = bench.synth_indices(cfg["g"], cfg["O"], seed=0)
+    return cfg, norm, targets, preds
+
+
+def _load(cls, cfg, norm, preds, targets, ks, train, val, streamed=False, **kw):
+    e = cls([len(preds[k]) for k in ks], cfg["H"], cfg["O"], subnet_offset=ks[0], **kw)
+    for i, k in enumerate(ks):
+        e.set_indices(i, preds[k], targets[k])
+    e.set_matrix(norm, **({"streamed": True} if streamed else {}))
+    e.gather(True)
+    e.set_split(train, val)
+    e.init_weights()
+    return e
+
+
+def test_cfg3_shapes_match_oracle():
+    """BASELINE configs[2] -- the config the metric is quoted on -- at its real shapes against the ORACLE: all K = 40 sub-nets
+    with the D_k of the 50k x 20k job, H = 256, O = 512, batch 64, on whatever path the library picks by itself (no DIMN_*
+    switch: ring B1F1 + the fused second layer in 6-tile slices): 3 full + 1 partial optimiser step, validation over 250 cells,
+    predict of 256 cells.  (Four oracle steps of this size cost ~3 s on the box's cores.)"""
+    cfg, norm, targets, preds = _cfg3_sample(2048)
+    K = targets.shape[0]
+    assert K == 40 and 2300 < min(map(len, preds)) and max(map(len, preds)) < 2500
+    train = np.arange(0, 3 * 64 + 21, dtype=np.int32) * 7 % 1700
+    val = np.arange(1700, 1950, dtype=np.int32)
+    rows = np.arange(3, 3 + 256 * 8, 8, dtype=np.int32) % 2048
+    kw = dict(batch_size=cfg["B"], dropout_rate=0.2, learning_rate=1e-3, seed=1234)
+    a = _load(_hip(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
+    b = _load(_oracle(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
+    a.set_profiling(True)
+    _compare_with_oracle(a, b, norm, preds, targets, list(range(K)), train, 4, cfg, kw, rows)
+    t = a.get_timers()
+    assert t[7] == 0 and t[1] >= 1            # the streaming kernels ran (step_launch times one step in eight), no resident launch
+    a.close(); b.close()
+
+
+def test_cfg4_8gpu_share_resident_matches_oracle():
+    """BASELINE configs[3], one rank's share of the 8-GPU job (sub-nets 10-14 of the 40, global Philox keys) on the path the
+    library picks for it -- the register-resident epoch kernel -- against the ORACLE (not against the streaming kernels): 5 full
+    + 1 partial optimiser step, validation, predict; two epochs' worth of hand-off slots (t % 3, t % 2) are cycled."""
+    cfg, norm, targets, preds = _cfg3_sample(2048)
+    ks = list(range(10, 15))
+    train = (np.arange(0, 5 * 64 + 33, dtype=np.int32) * 5) % 1800
+    val = np.arange(1800, 2048, dtype=np.int32)
+    rows = np.arange(0, 2048, 8, dtype=np.int32)
+    kw = dict(batch_size=cfg["B"], dropout_rate=0.2, learning_rate=1e-3, seed=1234)
+    a = _load(_hip(), cfg, norm, preds, targets, ks, train, val, **kw)
+    b = _load(_oracle(), cfg, norm, preds, targets, ks, train, val, **kw)
+    a.set_profiling(True)
+    _compare_with_oracle(a, b, norm, preds, targets, ks, train, 6, cfg, kw, rows)
+    assert a.get_timers()[7] == 6             # every step inside the resident launch
+    a.close(); b.close()
+
+
+def test_cfg5_share_shapes_match_oracle():
+    """BASELINE configs[4], one rank's share at its real shapes: g = 30 000 genes, 8 of the K = 59 sub-nets (D_k ~ 2 450 from
+    bench.synth_indices(30000, 512)), precision bf16 (bf16 X arena, bf16 matrix cores), the matrix STREAMED from host memory
+    (three ~128 MB row blocks), on the path the library picks; 3 full + 1 partial step, validation, predict against the oracle
+    in the matching rounding modes at the tolerances DESIGN section 3b states for them."""
+    import bench
+    cfg = dict(bench.CONFIGS["cfg5"])
+    n = 3072
+    norm = bench.synth_counts(n, cfg["g"], seed=0)                       # 369 MB -> 3 streamed blocks
+    targets, preds = bench.synth_indices(cfg["g"], cfg["O"], seed=0)
+    assert targets.shape[0] == 59
+    ks = list(range(8, 16))                                              # rank 1 of 8: 59 = 8+8+8+7+7+7+7+7
+    assert 2300 < min(len(preds[k]) for k in ks) and max(len(preds[k]) for k in ks) < 2600
+    train = (np.arange(0, 3 * 64 + 21, dtype=np.int32) * 11) % 2700
+    val = np.arange(2700, 2950, dtype=np.int32)
+    rows = np.arange(0, n, 12, dtype=np.int32)
+    kw = dict(batch_size=cfg["B"], dropout_rate=0.2, learning_rate=1e-3, seed=1234, precision="bf16")
+    a = _load(_hip(), cfg, norm, preds, targets, ks, train, val, streamed=True, **kw)
+    bf_train = a.training_precision == "bf16"
+    b = _load(_oracle(), cfg, norm, preds, targets, ks, train, val, infer_bf16=True, train_bf16=bf_train, **kw)
+    # DESIGN 3b: bf16 inference operands 5e-4 on losses / 2e-3 + 2e-4 on imputed values; bf16 training operands 1e-3 / 5e-3 + 5e-4
+    tol = dict(loss=1e-3, w_rtol=5e-3, w_atol=1e-4, p_rtol=5e-3, p_atol=5e-4) if bf_train else dict(loss=5e-4, p_rtol=2e-3, p_atol=2e-4)
+    _compare_with_oracle(a, b, norm, preds, targets, ks, train, 4, cfg, kw, rows, tol=tol, max_flips=0 if bf_train else 2)
     a.close(); b.close()
 
 
@@ -193,6 +318,29 @@ def test_resident_groups_are_independent_launches(monkeypatch):
             assert np.array_equal(x, y)
 
 
+def test_resident_launch_that_aborts_is_undone_and_rerun_on_the_streaming_kernels(monkeypatch, capfd):
+    """A resident epoch launch that times out (a GPU shared with another process: DIMN_RES_TEST_ABORT makes the host treat
+    the launch of epoch 1 as timed out) must not fail the fit: the pre-epoch state is restored, the epoch re-runs on the
+    streaming kernels and the handle stays on them -- all three epochs still match the oracle."""
+    from helpers import make_problem, load_problem
+    monkeypatch.setenv("DIMN_RESIDENT", "1")
+    monkeypatch.setenv("DIMN_RES_TEST_ABORT", "2")
+    prob = make_problem(n=500, g=900, Ds=[300, 280], H=256, O=512, seed=5, val_frac=0.1)
+    kw = dict(batch_size=64, dropout_rate=0.2, learning_rate=1e-3, seed=99)
+    a, b = load_problem(_hip(), prob, **kw), load_problem(_oracle(), prob, **kw)
+    a.init_weights(); b.init_weights()
+    a.set_profiling(True)
+    ran_resident = []
+    for epoch in range(3):
+        np.testing.assert_allclose(a.train_epoch(epoch), b.train_epoch(epoch), rtol=1e-4)
+        ran_resident.append(a.get_timers()[7] > 0)
+    assert ran_resident == [True, True, False]          # epoch 1 launched (and was undone), epoch 2 never tried
+    assert "re-runs on the streaming kernels" in capfd.readouterr().err
+    np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=1e-4, atol=1e-6)
+    a.close(); b.close()
+
+
 def test_resident_hand_off_retry_path():
     """The sentinel hand-off of the register-resident kernel under stress: libdimn_nocanary.so is the same library without
     the canary polls, so the bulk requests of every hand-off leave before most of the data has landed and res_fix's
@@ -210,3 +358,38 @@ def test_resident_hand_off_retry_path():
                           "-m", "gpu", "-k", "(second_layer_paths and R) or resident_epoch_kernel"], env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
     assert " passed" in res.stdout and "failed" not in res.stdout
+
+
+@pytest.mark.parametrize("K,precision,want", [
+    (5, "fp32", dict(path="resident", resident_groups=1, resident_splits=3)),        # one rank of the 8-GPU job
+    (10, "fp32", dict(path="resident", resident_groups=2)),                          # 4-GPU share: two groups of 5
+    (20, "fp32", dict(path="streaming", mid_fused=1, mid_keep=1, first_layer=1)),    # 2-GPU share
+    (40, "fp32", dict(path="streaming", mid_fused=1, mid_slices=6, mid_keep=1, train_bf16=0, first_layer=1)),   # the single-GPU job
+    (40, "bf16", dict(path="streaming", mid_fused=1, mid_slices=6, train_bf16=1)),
+])
+def test_automatic_path_choice(K, precision, want, monkeypatch):
+    """The kernels dimn_create picks BY ITSELF (no DIMN_* variable set) for the sub-net counts a rank of the 50k x 20k job
+    sees at 8 / 4 / 2 / 1 GPUs -- DESIGN.md's decision table, asserted through dimn_path_info, and that a short epoch on
+    that path really runs it (timer slot [7] counts the steps of resident launches)."""
+    import bench
+    for name in list(os.environ):
+        if name.startswith("DIMN_") and name not in ("DIMN_LIB_PATH", "DIMN_HOST_THREADS"):
+            monkeypatch.delenv(name)
+    cfg = dict(bench.CONFIGS["cfg3"])
+    targets, preds = bench.synth_indices(cfg["g"], cfg["O"], seed=0)
+    norm = bench.synth_counts(256, cfg["g"], seed=0)
+    ks = list(range(K))
+    train, val = np.arange(0, 64 + 30, dtype=np.int32), np.arange(200, 256, dtype=np.int32)
+    kw = dict(batch_size=64, dropout_rate=0.2, learning_rate=1e-4, seed=1234)
+    if precision != "fp32":
+        kw["precision"] = precision
+    e = _load(_hip(), cfg, norm, preds, targets, ks, train, val, **kw)
+    info = e.path_info()
+    for key, value in want.items():
+        assert info[key] == value, (key, info)
+    assert e.training_precision == ("bf16" if info["train_bf16"] else "fp32")
+    e.set_profiling(True)
+    assert np.isfinite(e.train_epoch(0)).all()
+    t = e.get_timers()
+    assert (t[7] == 2) == (info["path"] == "resident"), (t, info)
+    e.close()

@@ -343,3 +343,10 @@ def test_full_size_properties():
         np.testing.assert_allclose(vlp, vl[k0:k1], rtol=1e-6)
         np.testing.assert_allclose(predp, pred[:, k0 * O:k1 * O], rtol=1e-5, atol=1e-7)
         part.close()
+
+
+def test_hip_loss_equals_the_references_own_wmse():
+    """dimn_train_step's loss_out (lr = 0, dropout 0) against the REFERENCE's own wMSE (deepimpute/multinet.py:36-41, both
+    `binary` values; tests/golden/kat_wmse.npz from make_wmse.py) on a full and a partial batch."""
+    from helpers import check_reference_wmse
+    check_reference_wmse(_hip(), rtol=1e-5)

@@ -28,12 +28,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_job(world, out, timeout=900):
+def _run_job(world, out, timeout=900, mode=""):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", DIMN_HOST_THREADS="4")
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", DIMN_HOST_THREADS="4", DIMN_RCCL_WORKER_MODE=mode)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "rccl_worker.py"), out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True))
     logs = []
@@ -75,6 +75,18 @@ def test_rccl_sharded_job_equals_single_rank(tmp_path, single, world):
     np.testing.assert_allclose(multi["full"], single["full"], rtol=1e-4, atol=1e-6)
 
 
+def test_rccl_gather_at_cfg3_share_shapes(tmp_path):
+    """The first multi-GPU box also checks the big-shape gather: 40 sub-nets of the 50k x 20k job, 20 per rank at world 2
+    ([n][20 * 512] blocks placed side by side in root's [n][40 * 512] matrix), against the same job in one process."""
+    one = _run_job(1, str(tmp_path / "big1.npz"), mode="big")
+    assert one["full"].shape[1] == 40 * 512 and np.isfinite(one["full"]).all()
+    if _ndev() < 2:
+        pytest.skip("needs 2 GPUs, %d visible (the 1-rank leg ran)" % _ndev())
+    two = _run_job(2, str(tmp_path / "big2.npz"), mode="big")
+    np.testing.assert_allclose(two["vsum"], one["vsum"], rtol=2e-5)
+    np.testing.assert_allclose(two["full"], one["full"], rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("world", [1, 2])
 def test_bench_contract_line(tmp_path, world):
     """`bench.py --gpus N` as the driver launches it prints exactly one JSON line with the contract's keys."""
@@ -101,3 +113,7 @@ def test_bench_contract_line(tmp_path, world):
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in rec, key
     assert rec["n_gpus"] == world and rec["value"] > 0 and rec["roofline"]["achieved"] > 0
+    if world > 1:
+        pr = rec["config"]["per_rank"]
+        assert rec["config"]["collectives"] == "rccl" and pr["nranks_ncclCommCount"] == world
+        assert len(pr["lane_step_ms"]) == world and all(x > 0 for x in pr["lane_step_ms"]) and pr["gather_bytes_into_root"] > 0

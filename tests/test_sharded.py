@@ -20,12 +20,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, out):
+def _run(world, out, mode=""):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2", SHARDED_WORKER_MODE=mode)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = [p.communicate(timeout=600)[0] for p in procs]
@@ -50,3 +50,23 @@ def test_gloo_sharded_equals_single_process(tmp_path, world):
     np.testing.assert_allclose(multi["loss"], single["loss"], rtol=1e-12)
     assert np.array_equal(multi["imputed"], single["imputed"])
     np.testing.assert_allclose(multi["metrics"], single["metrics"], rtol=1e-12)
+
+
+def test_sharded_fit_without_output_prefix_shares_one_directory(tmp_path):
+    """MultiNet's default output_prefix is a per-process temporary directory: a sharded job must still put every rank's
+    shard into ONE directory (named after the job), assemble them on rank 0 and let a fresh object load them."""
+    multi = _run(2, str(tmp_path / "dd.npz"), mode="default_dir")
+    single = _run(1, str(tmp_path / "single.npz"))
+    assert np.array_equal(multi["imputed"], single["imputed"])
+
+
+def test_refit_with_fewer_ranks_removes_stale_shards(tmp_path):
+    """Shards of ranks the current job does not have (an older fit with more ranks into the same directory) must not
+    survive: their global sub-net indices overlap the fresh shards'."""
+    out = str(tmp_path / "w2.npz")
+    os.makedirs(out + ".dir")
+    for r in (2, 10):
+        np.savez(os.path.join(out + ".dir", "model.rank%d.npz" % r), W1_0=np.full((3, 3), 7.0, np.float32))
+    _run(2, out)
+    left = sorted(f for f in os.listdir(out + ".dir") if f.startswith("model.rank"))
+    assert left == ["model.rank0.npz", "model.rank1.npz"], left
