@@ -71,6 +71,10 @@ struct dimo_handle_s {
     int act;                          /* hidden activation, DIMN_ACT_* (multinet.py:137) */
     int infer_bf16;                   /* precision bf16: inference/validation GEMM operands rounded to bfloat16 (fp32 accumulate) */
     int train_bf16;                   /* restates k_mid_fused<KEEP, BF>: the three TRAINING GEMMs of the second layer take bf16 operands */
+    /* Test instrument (tests/helpers.py, relu flips): up to 8 (sub-net, epoch, step, batch position, hidden unit) whose relu
+     * gate is taken on the OTHER side of zero.  Used only where the fp64 replay shows the pre-activation within fp32
+     * summation-order error of zero, i.e. where its sign is not defined at fp32 precision. */
+    int n_inv; int32_t inv[8][5];
 };
 typedef struct dimo_handle_s* dimo_handle;
 
@@ -250,6 +254,12 @@ static inline float bf16_round(float f) {
 }
 int dimo_set_inference_bf16(struct dimo_handle_s* h, int32_t on) { h->infer_bf16 = on != 0; return DIMN_OK; }
 int dimo_set_training_bf16(struct dimo_handle_s* h, int32_t on) { h->train_bf16 = on != 0; return DIMN_OK; }
+int dimo_invert_gate(struct dimo_handle_s* h, int32_t k, int32_t epoch, int32_t step, int32_t b, int32_t unit) {
+    if (!h || h->n_inv >= 8 || k < 0 || k >= h->K || unit < 0 || unit >= h->H) return DIMN_ERR_ARG;
+    const int32_t rec[5] = {k, epoch, step, b, unit};
+    memcpy(h->inv[h->n_inv++], rec, sizeof rec);
+    return DIMN_OK;
+}
 
 /* Forward of one row of one sub-net.  x[D] in; a[H] pre-activation, dd[H] hidden output
  * after relu(+dropout when keep != NULL), z[O] pre-softplus out. */
@@ -339,6 +349,12 @@ int dimo_train_step(dimo_handle h, const int32_t* rows, int32_t b_act, const uin
             real* a = s->a + (size_t)b * H; real* dd = s->dd + (size_t)b * H;
             real* z = s->z + (size_t)b * O; real* dz = s->dz + (size_t)b * O;
             forward_row(h, s, x, keep, a, dd, z);
+            for (int i = 0; i < h->n_inv; ++i)              /* test instrument: a pre-activation at fp32 noise level, taken on the other side */
+                if (h->inv[i][0] == k && h->inv[i][1] == epoch_key && h->inv[i][2] == step_key && h->inv[i][3] == b) {
+                    const int j = h->inv[i][4];
+                    a[j] = a[j] > 0 ? (real)-1e-30 : (real)1e-30;
+                    dd[j] = (keep[j] && a[j] > 0) ? a[j] * scale : 0;
+                }
             const float* yr = h->norm + (size_t)rows[b] * h->g;
             double loss = 0;
             for (int o = 0; o < O; ++o) {

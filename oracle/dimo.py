@@ -34,6 +34,7 @@ class OracleEngine(Engine):
     def __init__(self, D, hidden, out_dim, fp64=False, lib_path=None, infer_bf16=False, train_bf16=False, **kw):
         super().__init__(_load(fp64, lib_path), D, hidden, out_dim, **kw)
         name = lib_path or os.path.join(_HERE, "libdimo64.so" if fp64 else "libdimo.so")
+        self._lib_name = name
         if infer_bf16:               # restates k_predict_bf16: inference / validation GEMM operands rounded to bfloat16
             lib = C.CDLL(name)
             lib.dimo_set_inference_bf16.argtypes = [C.c_void_p, C.c_int32]
@@ -42,6 +43,15 @@ class OracleEngine(Engine):
             lib = C.CDLL(name)
             lib.dimo_set_training_bf16.argtypes = [C.c_void_p, C.c_int32]
             lib.dimo_set_training_bf16(self._h, 1)
+
+
+    def invert_gate(self, k, epoch, step, b, unit):
+        """Test instrument (oracle/dimo.c dimo_invert_gate): take the relu gate of (sub-net k, epoch, step, batch position b,
+        hidden unit) on the other side of zero -- for pre-activations the fp64 replay shows to be at fp32 noise level."""
+        lib = C.CDLL(self._lib_name)
+        lib.dimo_invert_gate.argtypes = [C.c_void_p] + [C.c_int32] * 5
+        if lib.dimo_invert_gate(self._h, int(k), int(epoch), int(step), int(b), int(unit)) != 0:
+            raise ValueError("invert_gate: bad argument or more than 8 inversions")
 
 
 def _load_general(fp64=False):

@@ -196,12 +196,17 @@ def relu_flip_units(hip, orc, k, rtol=1e-3, atol=2e-5):
     return np.flatnonzero(bad_w | bad_b)
 
 
-def assert_relu_flip_mechanism(oracle_cls, norm, pred_k, targ_k, k_global, units, train, steps, H, O, flip_slack=16.0, **kw):
-    """The mechanism behind a (rare) one-unit disagreement of two fp32 paths that sum a first-layer dot product in different
-    orders: relu'(a) is discontinuous at a = 0.  The fp64 oracle replays steps 0 .. steps-2 of epoch 0 of sub-net `k_global`
-    alone (Philox streams are keyed by GLOBAL sub-net index), and for every unit in `units` the pre-activation of some row of
-    the LAST batch must lie within the reordering error of an fp32 dot product of zero: |a| <= flip_slack * eps32 * (sum_i
-    |x_i w_i| + |b|).  Returns the (row, unit, a, bound) records."""
+def _round_bf16(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+
+
+def find_relu_flip_candidates(oracle_cls, norm, pred_k, targ_k, k_global, units, train, steps, H, O, slack=4.0, **kw):
+    """The mechanism behind a (rare) disagreement of two fp32 paths that sum a first-layer dot product in different orders:
+    relu'(a) is discontinuous at a = 0.  The fp64 oracle replays epoch 0 of sub-net `k_global` alone (Philox streams are keyed
+    by GLOBAL sub-net index) and reports every (step, batch position, unit) among `units` whose pre-activation lies within the
+    reordering error of an fp32 dot product of zero: |a| <= slack * eps32 * (sum_i |x_i w_i| + |b|) -- the places where the
+    SIGN of a is not defined at fp32 precision.  Records (step, b, unit, a, bound), closest to zero first."""
     o64 = oracle_cls([len(pred_k)], H, O, fp64=True, subnet_offset=int(k_global), **kw)
     o64.set_matrix(norm)
     o64.set_indices(0, pred_k, targ_k)
@@ -210,36 +215,38 @@ def assert_relu_flip_mechanism(oracle_cls, norm, pred_k, targ_k, k_global, units
     o64.init_weights()
     B = o64.B
     perm = o64.epoch_permutation(0)
-    for t in range(steps - 1):
-        o64.train_step(train[perm[t * B:(t + 1) * B]], epoch_key=0, step_key=t, want_loss=False)
-    W1, b1 = o64.get_weights(0)[:2]
-    o64.close()
-    rows = train[perm[(steps - 1) * B:steps * B]]
-    X = norm[rows][:, pred_k]
-    if str(kw.get("precision", "fp32")).lower() in ("bf16", "bfloat16"):      # the arena stores the predictors rounded to nearest even
-        u = np.ascontiguousarray(X, np.float32).view(np.uint32)
-        X = (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
-    X = X.astype(np.float64)
+    units = np.asarray(units)
     out = []
-    for u in units:
-        w = W1[:, u].astype(np.float64)
-        a = X @ w + float(b1[u])
-        bound = flip_slack * np.finfo(np.float32).eps * (np.abs(X) @ np.abs(w) + abs(float(b1[u])))
-        i = int(np.argmin(np.abs(a) / bound))
-        assert abs(a[i]) <= bound[i], "unit %d of sub-net %d: no pre-activation of the last batch is within reordering error of zero " \
-                                      "(closest: row %d, a = %.3e, bound %.3e) -- not a relu flip" % (u, k_global, rows[i], a[i], bound[i])
-        out.append((int(rows[i]), int(u), float(a[i]), float(bound[i])))
-    return out
+    for t in range(steps):
+        rows = train[perm[t * B:(t + 1) * B]]
+        W1, b1 = o64.get_weights(0)[:2]
+        X = norm[rows][:, pred_k]
+        if str(kw.get("precision", "fp32")).lower() in ("bf16", "bfloat16"):      # the arena stores the predictors rounded to nearest even
+            X = _round_bf16(X)
+        X = X.astype(np.float64)
+        w = W1[:, units].astype(np.float64)
+        a = X @ w + b1[units].astype(np.float64)
+        bound = slack * np.finfo(np.float32).eps * (np.abs(X) @ np.abs(w) + np.abs(b1[units].astype(np.float64)))
+        for i, j in zip(*np.nonzero(np.abs(a) <= bound)):
+            out.append((t, int(i), int(units[j]), float(a[i, j]), float(bound[i, j])))
+        o64.train_step(rows, epoch_key=0, step_key=t, want_loss=False)
+    o64.close()
+    return sorted(out, key=lambda r: abs(r[3]) / r[4])
 
 
-def graft_units(dst, src, k, units):
-    """Give sub-net k of engine `dst` the first-layer column and bias of engine `src` for the listed hidden units (everything
-    else of dst stays): the comparison that follows is then 'everything once that unit is masked'."""
-    W1, b1, W2, b2 = [np.array(x) for x in dst.get_weights(k)]
-    S1, sb1 = src.get_weights(k)[:2]
-    W1[:, units] = S1[:, units]
-    b1[units] = sb1[units]
-    dst.set_weights(k, W1, b1, W2, b2)
+def oracle_with_inverted_gates(oracle_cls, norm, pred_k, targ_k, k_global, train, val, H, O, inversions, **kw):
+    """The fp32 oracle of sub-net `k_global` alone, trained for epoch 0 with the listed (step, b, unit) relu gates taken on the
+    other side of zero (oracle/dimo.c dimo_invert_gate: a test instrument for pre-activations at fp32 noise level)."""
+    o = oracle_cls([len(pred_k)], H, O, subnet_offset=int(k_global), **kw)
+    o.set_matrix(norm)
+    o.set_indices(0, pred_k, targ_k)
+    o.gather(True)
+    o.set_split(train, val)
+    o.init_weights()
+    for step, b, unit in inversions:
+        o.invert_gate(0, 0, step, b, unit)
+    loss = o.train_epoch(0)
+    return o, loss
 
 
 def check_reference_wmse(cls, rtol, **kw):

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import assert_relu_flip_mechanism, graft_units, relu_flip_units
+from helpers import find_relu_flip_candidates, oracle_with_inverted_gates, relu_flip_units
 
 pytestmark = pytest.mark.gpu
 
@@ -57,59 +57,68 @@ def test_cfg2_shapes_match_oracle(mid, monkeypatch):
         engines.append(e)
     a, b = engines
     a.set_profiling(True)
-    np.testing.assert_allclose(a.train_epoch(0), b.train_epoch(0), rtol=1e-4)
-    assert a.step_count() == b.step_count() == 4
+    rows = np.arange(7, 7 + 256 * 19, 19, dtype=np.int32)
+    kw = dict(batch_size=cfg["B"], dropout_rate=0.2, learning_rate=1e-3, seed=1234)
+    # (R: on this problem the resident kernel's summation order puts one pre-activation of sub-net 3 -- hidden unit 52, third
+    #  batch, a = -6.5e-7 in the fp64 replay, a tenth of the fp32 reordering bound -- on the other side of zero: see
+    #  _compare_with_oracle for how the test treats that)
+    _compare_with_oracle(a, b, norm, preds, targets, list(range(K)), train[:3 * 64 + 21], val, 4, cfg, kw, rows)
     if mid == "R":
         assert a.get_timers()[7] == 4                          # the resident kernel ran (two launches of five sub-nets per epoch)
-    # The resident kernel sums the forward partials of its D-splits in its own order.  On this problem that once moved one
-    # pre-activation of the partial fourth batch (sub-net 3, hidden unit 52; |a| ~ 1e-7) to the other side of zero: the relu
-    # gate of that one (row, unit) flips and the unit's 1 958 input weights take a different Adam step.  That is a
-    # discontinuity of relu under reordering, not an arithmetic error -- and the test ASSERTS that mechanism instead of
-    # granting a budget: any first-layer column that misses the weight tolerance must belong to a unit whose pre-activation,
-    # replayed by the fp64 oracle, lies within the reordering error of zero in the last batch; with those units grafted from
-    # the oracle, everything -- validation loss, every weight, every imputed value -- must meet the north_star tolerance.
-    flipped = {}
-    for k in range(K):
-        units = relu_flip_units(a, b, k)
-        if units.size:
-            flipped[k] = units
-    assert sum(u.size for u in flipped.values()) <= 2, flipped
-    for k, units in flipped.items():
-        rec = assert_relu_flip_mechanism(_oracle(), norm, preds[k], targets[k], k, units, train[:3 * 64 + 21], 4, cfg["H"], cfg["O"],
-                                         batch_size=cfg["B"], dropout_rate=0.2, learning_rate=1e-3, seed=1234)
-        print("relu flip (mechanism asserted): sub-net %d" % k, rec)
-        graft_units(a, b, k, units)
-    np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
-    for k in range(K):
-        for x, y, name in zip(a.get_weights(k), b.get_weights(k), ("W1", "b1", "W2", "b2")):
-            np.testing.assert_allclose(x, y, rtol=1e-3, atol=2e-5, err_msg="%s k=%d" % (name, k))
-    rows = np.arange(7, 7 + 256 * 19, 19, dtype=np.int32)
-    np.testing.assert_allclose(a.predict(rows), b.predict(rows), rtol=1e-4, atol=1e-6)      # north_star tolerance
     a.close(); b.close()
 
 
-def _compare_with_oracle(a, b, norm, preds, targets, ks, train, steps, cfg, kw, rows, tol=None, max_flips=2):
+def _compare_with_oracle(a, b, norm, preds, targets, ks, train, val, steps, cfg, kw, rows, tol=None, oracle_kw=None):
     """One epoch of `steps` optimiser steps (the last one partial) on both engines, then validation, weights and predict at the
-    tolerances of test_two_epochs_match_oracle; a first-layer column that misses the weight tolerance must be a relu flip of
-    the last batch (helpers.assert_relu_flip_mechanism) and is grafted from the oracle before the remaining comparisons."""
+    tolerances of test_two_epochs_match_oracle, sub-net by sub-net.
+
+    Two fp32 paths that sum a first-layer dot product in different orders can put a pre-activation that is zero to fp32
+    precision on different sides of zero; relu'(a) is discontinuous there, so that one (row, unit) takes a different Adam
+    step and everything downstream in that sub-net moves with it.  The test does not grant a budget for that: a sub-net
+    with a first-layer column outside the weight tolerance must (1) show, in the fp64 replay, a pre-activation of a
+    flagged unit within fp32 reordering error of zero (helpers.find_relu_flip_candidates), and (2) agree with the oracle
+    at the FULL tolerances once the oracle takes exactly that gate on the other side (dimo_invert_gate)."""
+    import itertools
     tol = dict(dict(loss=1e-4, w_rtol=1e-3, w_atol=2e-5, p_rtol=1e-4, p_atol=1e-6), **(tol or {}))
-    np.testing.assert_allclose(a.train_epoch(0), b.train_epoch(0), rtol=tol["loss"])
+    O = cfg["O"]
+    la, lb = a.train_epoch(0), b.train_epoch(0)
     assert a.step_count() == b.step_count() == steps
+    va, vb = a.val_loss(), b.val_loss()
+    pa, pb = a.predict(rows), b.predict(rows)
+
+    def same(i, o, j, lo, vo, po):
+        np.testing.assert_allclose(la[i], lo, rtol=tol["loss"], err_msg="train loss k=%d" % ks[i])
+        np.testing.assert_allclose(va[i], vo, rtol=tol["loss"], err_msg="val loss k=%d" % ks[i])
+        for x, y, name in zip(a.get_weights(i), o.get_weights(j), ("W1", "b1", "W2", "b2")):
+            np.testing.assert_allclose(x, y, rtol=tol["w_rtol"], atol=tol["w_atol"], err_msg="%s k=%d" % (name, ks[i]))
+        np.testing.assert_allclose(pa[:, i * O:(i + 1) * O], po, rtol=tol["p_rtol"], atol=tol["p_atol"], err_msg="predict k=%d" % ks[i])
+
     flipped = {}
     for i in range(len(ks)):
         units = relu_flip_units(a, b, i, tol["w_rtol"], tol["w_atol"])
-        if units.size:
-            flipped[i] = units
-    assert sum(u.size for u in flipped.values()) <= max_flips, flipped
-    for i, units in flipped.items():
-        rec = assert_relu_flip_mechanism(_oracle(), norm, preds[ks[i]], targets[ks[i]], ks[i], units, train, steps, cfg["H"], cfg["O"], **kw)
-        print("relu flip (mechanism asserted): sub-net %d" % ks[i], rec)
-        graft_units(a, b, i, units)
-    np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=tol["loss"])
-    for i in range(len(ks)):
-        for x, y, name in zip(a.get_weights(i), b.get_weights(i), ("W1", "b1", "W2", "b2")):
-            np.testing.assert_allclose(x, y, rtol=tol["w_rtol"], atol=tol["w_atol"], err_msg="%s k=%d" % (name, ks[i]))
-    np.testing.assert_allclose(a.predict(rows), b.predict(rows), rtol=tol["p_rtol"], atol=tol["p_atol"])
+        if units.size == 0:
+            same(i, b, i, lb[i], vb[i], pb[:, i * O:(i + 1) * O])
+            continue
+        assert len(flipped) < 2, "more than two sub-nets off: not the rare event this path is for"
+        args = (_oracle(), norm, preds[ks[i]], targets[ks[i]], ks[i])
+        cands = find_relu_flip_candidates(*args, units, train, steps, cfg["H"], O, **kw, **(oracle_kw or {}))
+        assert cands, "sub-net %d: units %s miss the weight tolerance and no pre-activation of theirs is within fp32 reordering " \
+                      "error of zero in any step -- not a relu flip" % (ks[i], units.tolist())
+        last = None
+        for inv in [c for c in itertools.chain(((x,) for x in cands[:4]), itertools.combinations(cands[:4], 2))]:
+            o, lo = oracle_with_inverted_gates(*args, train, val, cfg["H"], O, [r[:3] for r in inv], **kw, **(oracle_kw or {}))
+            try:
+                same(i, o, 0, lo[0], o.val_loss()[0], o.predict(rows))
+                flipped[ks[i]] = inv
+                break
+            except AssertionError as e:
+                last = e
+            finally:
+                o.close()
+        else:
+            raise last
+    if flipped:
+        print("relu flips (mechanism asserted, oracle re-run with the gate on the other side): (step, batch position, unit, a, bound)", flipped)
     return flipped
 
 
@@ -150,7 +159,7 @@ def test_cfg3_shapes_match_oracle():
     a = _load(_hip(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
     b = _load(_oracle(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
     a.set_profiling(True)
-    _compare_with_oracle(a, b, norm, preds, targets, list(range(K)), train, 4, cfg, kw, rows)
+    _compare_with_oracle(a, b, norm, preds, targets, list(range(K)), train, val, 4, cfg, kw, rows)
     t = a.get_timers()
     assert t[7] == 0 and t[1] >= 1            # the streaming kernels ran (step_launch times one step in eight), no resident launch
     a.close(); b.close()
@@ -169,7 +178,7 @@ def test_cfg4_8gpu_share_resident_matches_oracle():
     a = _load(_hip(), cfg, norm, preds, targets, ks, train, val, **kw)
     b = _load(_oracle(), cfg, norm, preds, targets, ks, train, val, **kw)
     a.set_profiling(True)
-    _compare_with_oracle(a, b, norm, preds, targets, ks, train, 6, cfg, kw, rows)
+    _compare_with_oracle(a, b, norm, preds, targets, ks, train, val, 6, cfg, kw, rows)
     assert a.get_timers()[7] == 6             # every step inside the resident launch
     a.close(); b.close()
 
@@ -196,7 +205,7 @@ def test_cfg5_share_shapes_match_oracle():
     b = _load(_oracle(), cfg, norm, preds, targets, ks, train, val, infer_bf16=True, train_bf16=bf_train, **kw)
     # bf16 inference operands 5e-4 on losses / 2e-3 + 2e-4 on imputed values; bf16 training operands 1e-3 / 5e-3 + 5e-4
     tol = dict(loss=1e-3, w_rtol=5e-3, w_atol=1e-4, p_rtol=5e-3, p_atol=5e-4) if bf_train else dict(loss=5e-4, p_rtol=2e-3, p_atol=2e-4)
-    _compare_with_oracle(a, b, norm, preds, targets, ks, train, 4, cfg, kw, rows, tol=tol, max_flips=0 if bf_train else 2)
+    _compare_with_oracle(a, b, norm, preds, targets, ks, train, val, 4, cfg, kw, rows, tol=tol, oracle_kw=dict(infer_bf16=True, train_bf16=bf_train))
     a.close(); b.close()
 
 
