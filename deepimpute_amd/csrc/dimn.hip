@@ -157,7 +157,7 @@ struct dimn_handle_s {
     double* d_red = nullptr; int red_cap = 0;                            // all-reduce scratch
     // register-resident epoch kernel (dimn_resident.h): chosen at create when the sub-nets of this handle fit the CUs
     int res_G = 0, res_S1 = 0, res_T1 = 0, res_Kg = 0;                    // 0: not eligible; Kg: sub-nets per epoch launch
-    float *d_res_P = nullptr, *d_res_D = nullptr, *d_res_b1 = nullptr, *d_res_alpha = nullptr;
+    float *d_res_P = nullptr, *d_res_D = nullptr, *d_res_T = nullptr, *d_res_A = nullptr, *d_res_b1 = nullptr, *d_res_alpha = nullptr;
     unsigned* d_res_flags = nullptr; double* d_res_loss = nullptr; int64_t res_alpha_cap = 0;
     float* d_res_snap = nullptr;           // the optimiser state before the running epoch launch (restored if the launch aborts)
     int res_checked = 0;                   // 1: co-residency of a launch's workgroups verified against the occupancy of the kernel
@@ -313,7 +313,7 @@ static bool resident_plan(dimn_handle h, int Kg, int& S1o, int& T1o) {
     for (auto& s : h->sn)
         for (int sp = 0; sp < S1; ++sp) {
             int cb, ce;
-            res_chunk_range(s.nchunk, S1, (dm.OT + 15) >> 4, 8 * T1c, sp, cb, ce);
+            res_chunk_range(s.nchunk, S1, sp, cb, ce);
             if (ce - cb > 8 * T1c || ce - cb < 1 || cb < 0 || ce > s.nchunk) return false;
         }
     S1o = S1; T1o = T1c;
@@ -474,9 +474,10 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
     }
     if (!h->predict_bf16) TRY(dev_alloc(&h->d_W2tf, w2n));
     if (h->res_G) {
-        TRY(dev_alloc(&h->d_res_P, (size_t)DIMN_RES_PSLOTS * h->K * h->res_G * 1024));
-        TRY(dev_alloc(&h->d_res_D, (size_t)DIMN_RES_DSLOTS * h->K * dm.OT * 16 * 1024));
-        if (!DIMN_RES_SENT) TRY(dev_alloc(&h->d_res_b1, (size_t)3 * h->K * 512));     // dropout keep words [3][K][512] (sentinel protocol: per epoch, below)
+        TRY(dev_alloc(&h->d_res_P, (size_t)DIMN_RES_SLOTS * h->K * h->res_G * 1024));          // forward partials (siblings -> manager)
+        TRY(dev_alloc(&h->d_res_D, (size_t)DIMN_RES_SLOTS * h->K * dm.OT * 16 * 1024));        // dD partials (role 2 -> manager)
+        TRY(dev_alloc(&h->d_res_T, (size_t)DIMN_RES_SLOTS * h->K * 16 * 1024));                // Dd tiles (manager -> role 2)
+        TRY(dev_alloc(&h->d_res_A, (size_t)DIMN_RES_SLOTS * h->K * 16 * 1024));                // dA tiles (manager -> siblings)
         TRY(dev_alloc(&h->d_res_flags, (size_t)2 * h->K + 1));
         TRY(dev_alloc(&h->d_res_loss, (size_t)h->K * dm.OT));
     }
@@ -563,7 +564,7 @@ extern "C" int dimn_destroy(dimn_handle h) {
     DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage); DEV_FREE(h->d_red);
     for (auto& pb : h->pin_buf) if (pb) { (void)hipHostFree(pb); pb = nullptr; }
     DEV_FREE(h->d_W1b); DEV_FREE(h->d_W2t); DEV_FREE(h->d_W2tf);
-    DEV_FREE(h->d_res_P); DEV_FREE(h->d_res_D); DEV_FREE(h->d_res_b1); DEV_FREE(h->d_res_alpha); DEV_FREE(h->d_res_flags); DEV_FREE(h->d_res_loss); DEV_FREE(h->d_res_snap);
+    DEV_FREE(h->d_res_P); DEV_FREE(h->d_res_D); DEV_FREE(h->d_res_T); DEV_FREE(h->d_res_A); DEV_FREE(h->d_res_b1); DEV_FREE(h->d_res_alpha); DEV_FREE(h->d_res_flags); DEV_FREE(h->d_res_loss); DEV_FREE(h->d_res_snap);
     for (auto& ln : h->lanes) (void)hipStreamDestroy(ln.stream);
     delete h;
     return DIMN_OK;
@@ -1139,10 +1140,8 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
         HIPCHK(hipStreamSynchronize(h->stream));
         DEV_FREE(h->d_res_alpha);
         CHK(dev_alloc(&h->d_res_alpha, (size_t)steps));
-        if (DIMN_RES_SENT) {                                     // the keep words of a whole epoch: [steps][K][512]
-            DEV_FREE(h->d_res_b1);
-            CHK(dev_alloc(&h->d_res_b1, (size_t)steps * h->K * 512));
-        }
+        DEV_FREE(h->d_res_b1);                                   // the keep words of a whole epoch: [steps][K][512]
+        CHK(dev_alloc(&h->d_res_b1, (size_t)steps * h->K * 512));
         h->res_alpha_cap = steps;
     }
     std::vector<float> alpha((size_t)steps);
@@ -1161,7 +1160,7 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
     p.b1w = h->d_b1; p.b1m = h->d_b1 + kh; p.b1v = h->d_b1 + 2 * kh;
     p.b2w = h->d_b2; p.b2m = h->d_b2 + ko; p.b2v = h->d_b2 + 2 * ko;
     p.rows = h->d_epoch_rows; p.n_tr = (int32_t)h->n_tr; p.B = h->B; p.steps = steps;
-    p.alpha = h->d_res_alpha; p.Ppart = h->d_res_P; p.Dpart = h->d_res_D; p.maskw = (unsigned*)h->d_res_b1;
+    p.alpha = h->d_res_alpha; p.Ppart = h->d_res_P; p.Dpart = h->d_res_D; p.DdT = h->d_res_T; p.dAT = h->d_res_A; p.maskw = (unsigned*)h->d_res_b1;
     p.flags = h->d_res_flags; p.loss = h->d_res_loss; p.dm = dm;
     p.omb1 = 1.0f - h->cfg.beta1; p.omb2 = 1.0f - h->cfg.beta2; p.eps = h->cfg.eps;
     p.rate = h->cfg.dropout_rate; p.scale = 1.0f / (1.0f - h->cfg.dropout_rate);
@@ -1184,14 +1183,14 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) { e0 = next_event(h); e1 = next_event(h); next_event(h); }
     if (e0 && e1) (void)hipEventRecord(e0, h->stream);
-#if DIMN_RES_SENT
     // sentinel protocol: every exchange slot starts "not written" (all-ones words); the keep words of the epoch come from their own kernel
-    HIPCHK(hipMemsetAsync(h->d_res_P, 0xff, (size_t)DIMN_RES_PSLOTS * h->K * h->res_G * 4096, h->stream));
-    HIPCHK(hipMemsetAsync(h->d_res_D, 0xff, (size_t)DIMN_RES_DSLOTS * h->K * dm.OT * 65536, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_res_P, 0xff, (size_t)DIMN_RES_SLOTS * h->K * h->res_G * 4096, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_res_D, 0xff, (size_t)DIMN_RES_SLOTS * h->K * dm.OT * 65536, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_res_T, 0xff, (size_t)DIMN_RES_SLOTS * h->K * 65536, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_res_A, 0xff, (size_t)DIMN_RES_SLOTS * h->K * 65536, h->stream));
     if (h->cfg.dropout_rate > 0.f)
         hipLaunchKernelGGL(k_res_masks, dim3((unsigned)(steps * h->K)), dim3(512), 0, h->stream, h->d_sn, (unsigned*)h->d_res_b1, h->K, h->H,
                            (uint64_t)h->cfg.seed, (uint32_t)epoch, h->cfg.dropout_rate);
-#endif
 #define RES_LAUNCH(T, S)                                                                                                           \
     WITH_XT(h, {                                                                                                                 \
         const void* fn_ = (const void*)k_epoch_resident<T, S, XT>;                                                               \

@@ -41,12 +41,18 @@ fn = _lib.library().dimn_debug_res_timeline
 fn.argtypes = [C.c_void_p, C.c_int]
 assert fn(buf, n * 16) == 0
 tl = np.frombuffer(buf, np.uint64).reshape(n, 16).astype(np.float64) / steps
-names = ["A pre-wait", "A wait P", "A Dd build", "A Z+loss", "A gW2+dD+publish", "B pre-wait", "B wait D", "B dD sum+dA", "B tile loop",
-         "B P reduce+publish", "loop top", "A gW2 after publish", "B X requests", "-", "-", "-"]
+names = ["M1 P gather + Dd tile", "A wait Dd", "A Dd tiles -> LDS", "A Z+loss", "A dD^T + publish", "pre-wait (X requests)", "wait dD / dA", "M2 dD sum + dA / dA tile",
+         "tile loop", "P reduce + publish", "loop top", "A gW2 + Adam", "-", "-", "-", "-"]
+S1 = G // 16
 wi = np.arange(n) % G
-for label, sel in (("role 1+2 workgroups (wi < 32)", wi < 32), ("role 1 only workgroups", wi >= 32)):
+sp = wi // 16
+groups = [("role 2 + sibling (wi < 32, not manager)", (wi < 32) & (sp < S1 - 1)), ("manager (last split)", sp == S1 - 1),
+          ("sibling only", (wi >= 32) & (sp < S1 - 1))]
+for label, sel in groups:
+    if not sel.any():
+        continue
     print(label)
-    for i, nm in enumerate(names[:13]):
+    for i, nm in enumerate(names[:12]):
         v = tl[sel, i]
-        print("  %-20s mean %8.0f clk  min %8.0f  max %8.0f" % (nm, v.mean(), v.min(), v.max()))
-    print("  total %.0f clk per step" % tl[sel, :13].sum(axis=1).mean())
+        print("  %-28s mean %8.0f clk  min %8.0f  max %8.0f" % (nm, v.mean(), v.min(), v.max()))
+    print("  total %.0f clk per step" % tl[sel, :12].sum(axis=1).mean())
