@@ -161,6 +161,7 @@ struct dimn_handle_s {
     unsigned* d_res_flags = nullptr; double* d_res_loss = nullptr; int64_t res_alpha_cap = 0;
     float* d_res_snap = nullptr;           // the optimiser state before the running epoch launch (restored if the launch aborts)
     int res_checked = 0;                   // 1: co-residency of a launch's workgroups verified against the occupancy of the kernel
+    int res_bf16 = 0;                      // 1: precision bf16 -> the resident kernel runs EVERY training GEMM on the bf16 matrix cores (template BF)
     double tm_res_ms = 0; int64_t tm_res_steps = 0;
     double* pin_buf[4] = {nullptr, nullptr, nullptr, nullptr}; size_t pin_cap = 0;   // pinned bounce buffers of dimn_impute_finish, kept across calls
     hipStream_t stream = nullptr;          // lane 0's stream; also used by every non-training call
@@ -330,21 +331,20 @@ static void build_resident(dimn_handle h) {
     // 15 sub-nets 77 against 87 us; from four groups on the streaming kernels are as fast (DIMN_RES_GROUPS: the largest group
     // count taken, default 3).
     // DIMN_RESIDENT=0 disables the kernel, =1 is the default (auto).
-    h->res_G = h->res_S1 = h->res_T1 = 0; h->res_Kg = 0;
+    h->res_G = h->res_S1 = h->res_T1 = 0; h->res_Kg = 0; h->res_bf16 = 0;
     const Dims& dm = h->dm;
     if (const char* e = getenv("DIMN_RESIDENT")) if (atoi(e) == 0) return;
     if (dm.HT != 16 || (dm.H & 3) != 0 || h->B > DIMN_TB) return;
     int max_groups = 3, min_groups = 1;
     if (const char* e = getenv("DIMN_RES_GROUPS")) max_groups = std::max(1, atoi(e));
     if (const char* e = getenv("DIMN_RES_MIN_GROUPS")) min_groups = std::max(1, atoi(e));      // tests: groups on small problems
-    if (h->prec && !getenv("DIMN_RES_GROUPS")) max_groups = 1;      // bf16 handles: the fused second layer has its bf16 matrix-core variant, and at
-                                                                     // configs[4]'s 8 sub-nets per rank two resident groups lose to it (65.8 vs 62.0 us per step)
     min_groups = std::min(min_groups, h->K);
     for (int groups = min_groups; groups <= std::min(std::max(max_groups, min_groups), h->K); ++groups) {
         const int Kg = ceil_div(h->K, groups);
         int S1 = 0, T1c = 0;
         if (!resident_plan(h, Kg, S1, T1c)) continue;
         h->res_G = 16 * S1; h->res_S1 = S1; h->res_T1 = T1c; h->res_Kg = Kg;
+        h->res_bf16 = h->prec == DIMN_PREC_BF16 && !(getenv("DIMN_TRAIN_BF16") && atoi(getenv("DIMN_TRAIN_BF16")) == 0);
         return;
     }
 }
@@ -1192,8 +1192,10 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
         hipLaunchKernelGGL(k_res_masks, dim3((unsigned)(steps * h->K)), dim3(512), 0, h->stream, h->d_sn, (unsigned*)h->d_res_b1, h->K, h->H,
                            (uint64_t)h->cfg.seed, (uint32_t)epoch, h->cfg.dropout_rate);
 #define RES_LAUNCH(T, S)                                                                                                           \
-    WITH_XT(h, {                                                                                                                 \
-        const void* fn_ = (const void*)k_epoch_resident<T, S, XT>;                                                               \
+    do { if (h->res_bf16) RES_LAUNCH_X(T, S, bf16_t, true) else WITH_XT(h, RES_LAUNCH_X(T, S, XT, false)); } while (0)
+#define RES_LAUNCH_X(T, S, XT, BFV)                                                                                                \
+    {                                                                                                                            \
+        const void* fn_ = (const void*)k_epoch_resident<T, S, XT, BFV>;                                                          \
         (void)hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
         if (!h->res_checked) {                                                                                                   \
             int per_cu_ = 0;                                                                                                     \
@@ -1203,9 +1205,9 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
         if (!not_resident) {                                                                                                     \
             void* args_[1] = {(void*)&p};                                                                                        \
             if (coop) { if (hipLaunchCooperativeKernel(fn_, grid, dim3(DIMN_RES_THREADS), args_, (unsigned)lds, h->stream) != hipSuccess) not_resident = true; } \
-            else hipLaunchKernelGGL((k_epoch_resident<T, S, XT>), grid, dim3(DIMN_RES_THREADS), lds, h->stream, p);              \
+            else hipLaunchKernelGGL((k_epoch_resident<T, S, XT, BFV>), grid, dim3(DIMN_RES_THREADS), lds, h->stream, p);         \
         }                                                                                                                        \
-    })
+    }
     bool not_resident = false;
     // one launch per group of res_Kg sub-nets (all of them when they fit at once), one after the other on the stream
     for (int k0 = 0; k0 < h->K && !not_resident; k0 += h->res_Kg) {
@@ -1218,6 +1220,7 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
         else RES_LAUNCH(7, 0);
     }
 #undef RES_LAUNCH
+#undef RES_LAUNCH_X
     h->res_checked = 1;
     (void)hipGetLastError();
     if (e0 && e1) (void)hipEventRecord(e1, h->stream);
@@ -1538,7 +1541,7 @@ extern "C" int dimn_set_profiling(dimn_handle h, int32_t on) {
 }
 extern "C" int dimn_training_precision(dimn_handle h) {
     if (!h) return fail(DIMN_ERR_ARG, "dimn_training_precision: null handle");
-    return h->train_bf16 ? DIMN_PREC_BF16 : DIMN_PREC_F32;
+    return (h->res_G ? h->res_bf16 : h->train_bf16) ? DIMN_PREC_BF16 : DIMN_PREC_F32;
 }
 
 extern "C" int dimn_path_info(dimn_handle h, int32_t* out8) {
@@ -1549,7 +1552,7 @@ extern "C" int dimn_path_info(dimn_handle h, int32_t* out8) {
     out8[3] = h->mid_fused;                                     // streaming: 1 fused second layer (RED -> MFB -> RED2), 0 two kernels (MF + MB)
     out8[4] = h->mid_fused ? h->mid_slices : 0;                 // ... output slices per sub-net
     out8[5] = h->mid_keep;                                      // ... W2 column blocks kept in LDS between the phases
-    out8[6] = h->train_bf16;                                    // second-layer training GEMMs on the bf16 matrix cores
+    out8[6] = h->res_G ? 2 * h->res_bf16 : h->train_bf16;      // training GEMMs on the bf16 matrix cores: 1 the second layer's (fused kernel), 2 all (resident kernel)
     out8[7] = h->dm.HT == 16 ? 1 : (h->dm.HT == 20 ? 2 : 0);    // first layer: 1 ring B1F1 (H = 256), 2 shared-staging (H = 300), 0 generic
     return DIMN_OK;
 }

@@ -70,7 +70,8 @@ struct dimo_handle_s {
     int64_t t;                        /* Adam step counter */
     int act;                          /* hidden activation, DIMN_ACT_* (multinet.py:137) */
     int infer_bf16;                   /* precision bf16: inference/validation GEMM operands rounded to bfloat16 (fp32 accumulate) */
-    int train_bf16;                   /* restates k_mid_fused<KEEP, BF>: the three TRAINING GEMMs of the second layer take bf16 operands */
+    int train_bf16;                   /* 1 restates k_mid_fused<KEEP, BF>: the three TRAINING GEMMs of the second layer take bf16 operands;
+                                         2 restates k_epoch_resident<.., BF>: the two training GEMMs of the first layer as well */
     /* Test instrument (tests/helpers.py, relu flips): up to 8 (sub-net, epoch, step, batch position, hidden unit) whose relu
      * gate is taken on the OTHER side of zero.  Used only where the fp64 replay shows the pre-activation within fp32
      * summation-order error of zero, i.e. where its sign is not defined at fp32 precision. */
@@ -253,7 +254,7 @@ static inline float bf16_round(float f) {
     return c.f;
 }
 int dimo_set_inference_bf16(struct dimo_handle_s* h, int32_t on) { h->infer_bf16 = on != 0; return DIMN_OK; }
-int dimo_set_training_bf16(struct dimo_handle_s* h, int32_t on) { h->train_bf16 = on != 0; return DIMN_OK; }
+int dimo_set_training_bf16(struct dimo_handle_s* h, int32_t on) { h->train_bf16 = on < 0 ? 0 : (on > 2 ? 2 : on); return DIMN_OK; }
 int dimo_invert_gate(struct dimo_handle_s* h, int32_t k, int32_t epoch, int32_t step, int32_t b, int32_t unit) {
     if (!h || h->n_inv >= 8 || k < 0 || k >= h->K || unit < 0 || unit >= h->H) return DIMN_ERR_ARG;
     const int32_t rec[5] = {k, epoch, step, b, unit};
@@ -267,13 +268,13 @@ static void forward_row(const struct dimo_handle_s* h, const subnet* s, const re
                         const uint8_t* keep, real* a, real* dd, real* z) {
     const int H = h->H, O = h->O, D = s->D;
     const real scale = keep ? (real)(1.0f / (1.0f - h->cfg.dropout_rate)) : (real)1;
-    const int q = !keep && h->infer_bf16;               /* inference on the bf16 matrix cores: operands rounded, fp32 accumulate */
-    const int q2 = q || (keep && h->train_bf16);        /* second layer: also in training when it runs on the bf16 matrix cores */
+    const int q2 = (!keep && h->infer_bf16) || (keep && h->train_bf16);        /* second layer on the bf16 matrix cores: operands rounded, fp32 accumulate */
+    const int q = (!keep && h->infer_bf16) || (keep && h->train_bf16 == 2);    /* first layer likewise (inference; training on the resident bf16 kernel) */
     for (int j = 0; j < H; ++j) a[j] = 0;
     for (int d = 0; d < D; ++d) {                       /* S1: a = x W1 + b1 */
         const real xv = x[d];
         const real* w = s->W1 + (size_t)d * H;
-        if (q) for (int j = 0; j < H; ++j) a[j] += xv * (real)bf16_round((float)w[j]);
+        if (q) { const real xq = (real)bf16_round((float)xv); for (int j = 0; j < H; ++j) a[j] += xq * (real)bf16_round((float)w[j]); }
         else for (int j = 0; j < H; ++j) a[j] += xv * w[j];
     }
     for (int j = 0; j < H; ++j) {
@@ -447,7 +448,8 @@ int dimo_train_step(dimo_handle h, const int32_t* rows, int32_t b_act, const uin
                 for (int b = 0; b < b_act; ++b) {
                     const real xv = s->x[(size_t)b * D + d];
                     const real* da = s->dA + (size_t)b * H;
-                    for (int j = 0; j < H; ++j) gr[j] += xv * da[j];
+                    if (h->train_bf16 == 2) { const real xq = (real)bf16_round((float)xv); for (int j = 0; j < H; ++j) gr[j] += xq * (real)bf16_round((float)da[j]); }
+                    else for (int j = 0; j < H; ++j) gr[j] += xv * da[j];
                 }
                 for (int j = 0; j < H; ++j) adam1(&wrow[j], &mrow[j], &vrow[j], gr[j], alpha, omb1, omb2, eps);
             }

@@ -39,10 +39,10 @@ class OracleEngine(Engine):
             lib = C.CDLL(name)
             lib.dimo_set_inference_bf16.argtypes = [C.c_void_p, C.c_int32]
             lib.dimo_set_inference_bf16(self._h, 1)
-        if train_bf16:               # restates k_mid_fused<KEEP, BF>: the second layer's three training GEMMs on bf16 operands
-            lib = C.CDLL(name)
+        if train_bf16:               # 1 / True restates k_mid_fused<KEEP, BF>: the second layer's three training GEMMs on bf16 operands;
+            lib = C.CDLL(name)       # 2 restates k_epoch_resident<.., BF>: the first layer's two training GEMMs as well
             lib.dimo_set_training_bf16.argtypes = [C.c_void_p, C.c_int32]
-            lib.dimo_set_training_bf16(self._h, 1)
+            lib.dimo_set_training_bf16(self._h, int(train_bf16))
 
 
     def invert_gate(self, k, epoch, step, b, unit):

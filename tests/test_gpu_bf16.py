@@ -113,16 +113,18 @@ def test_general_path_on_bf16_arena_matches_general_oracle_rounded():
 
 
 @pytest.mark.parametrize("H,O,B,Ds", [(256, 512, 64, [300, 150, 77]), (300, 512, 64, [260]), (150, 100, 37, [97, 64, 33])])
-def test_bf16_matrix_core_inference_matches_oracle_rounding(H, O, B, Ds):
+def test_bf16_matrix_core_inference_matches_oracle_rounding(H, O, B, Ds, monkeypatch):
     """precision="bf16" in full: the arena in bf16 and model.predict / the validation pass on v_mfma_f32_16x16x16_bf16
     (k_predict_bf16: X, W1, the hidden activations and W2 as bfloat16 operands, fp32 accumulation).  The oracle restates
     exactly that rounding (infer_bf16); products of two bf16 values are exact in fp32, so what is left is the summation
     order -- and, rarely, a hidden activation that rounds to the neighbouring bf16 value (a 0.4 % step of one of the H
     terms of an output).  Stated tolerance: validation loss 5e-4 relative, imputed values 2e-3 relative + 2e-4 absolute;
     against the all-fp32 path the predictions move by < 2 % (the price of the format, not of the kernel)."""
+    monkeypatch.setenv("DIMN_TRAIN_BF16", "0")        # this test pins INFERENCE on the bf16 matrix cores: training GEMMs stay fp32
     prob = make_problem(n=330, g=700, Ds=Ds, H=H, O=O, seed=11)
     kw = dict(batch_size=B, dropout_rate=0.2, learning_rate=1e-3, seed=4242)
     a = load_problem(_hip(), prob, precision="bf16", **kw)
+    assert a.path_info()["train_bf16"] == 0
     b = load_problem(_oracle(), prob, precision="bf16", infer_bf16=True, **kw)
     c = load_problem(_hip(), prob, precision="fp32", **kw)
     for e in (a, b, c):
@@ -168,6 +170,38 @@ def test_bf16_matrix_core_training_of_the_second_layer(monkeypatch):
     d = load_problem(_hip(), prob, precision="bf16", **kw)
     assert d.training_precision == "fp32"
     for e in (a, b, c, d):
+        e.close()
+
+
+@pytest.mark.parametrize("groups", ["1", "2"])
+def test_bf16_matrix_core_training_on_the_resident_kernel(groups, monkeypatch):
+    """precision="bf16" on the register-resident epoch kernel (k_epoch_resident<.., BF>): EVERY training GEMM of the step -- the
+    first layer's forward and W1 gradient, the second layer's three -- takes bf16 operands (the four k-slot values of four
+    fp32 matrix instructions rounded to nearest even in registers = one v_mfma_f32_16x16x16_bf16), fp32 accumulation, fp32
+    master weights and Adam state; also in two groups of sub-nets (one epoch launch each).  The oracle restates the rounding
+    (train_bf16 = 2); tolerances as for the fused second layer: losses 1e-3, imputed values 5e-3 + 5e-4 after two epochs."""
+    monkeypatch.setenv("DIMN_RESIDENT", "1")
+    monkeypatch.setenv("DIMN_RES_MIN_GROUPS", groups)
+    prob = make_problem(n=330, g=700, Ds=[300, 150, 77, 210], H=256, O=512, seed=11)
+    kw = dict(batch_size=64, dropout_rate=0.2, learning_rate=1e-3, seed=4242)
+    a = load_problem(_hip(), prob, precision="bf16", **kw)
+    info = a.path_info()
+    assert info["path"] == "resident" and info["train_bf16"] == 2 and info["resident_groups"] == int(groups) and a.training_precision == "bf16"
+    b = load_problem(_oracle(), prob, precision="bf16", infer_bf16=True, train_bf16=2, **kw)
+    c = load_problem(_oracle(), prob, precision="bf16", infer_bf16=True, **kw)           # fp32 training GEMMs
+    for e in (a, b, c):
+        e.init_weights()
+    a.set_profiling(True)
+    for epoch in range(2):
+        la, lb, lc = a.train_epoch(epoch), b.train_epoch(epoch), c.train_epoch(epoch)
+        np.testing.assert_allclose(la, lb, rtol=1e-3)
+        np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-3)
+    assert a.get_timers()[7] == a.step_count()
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=5e-3, atol=5e-4)
+    # the rounding is really there: the HIP path sits closer to the oracle that rounds than to the one that does not
+    w_a, w_b, w_c = a.get_weights(0)[0], b.get_weights(0)[0], c.get_weights(0)[0]
+    assert np.abs(w_a - w_b).mean() < 0.5 * np.abs(w_a - w_c).mean()
+    for e in (a, b, c):
         e.close()
 
 

@@ -202,13 +202,14 @@ def test_cfg5_share_shapes_match_oracle():
     rows = np.arange(0, n, 12, dtype=np.int32)
     kw = dict(batch_size=cfg["B"], dropout_rate=0.2, learning_rate=1e-4, seed=1234, precision="bf16")      # the config's own learning rate
     a = _load(_hip(), cfg, norm, preds, targets, ks, train, val, streamed=True, **kw)
-    bf_train = a.training_precision == "bf16"
+    bf_train = a.path_info()["train_bf16"]            # 0: fp32 training GEMMs, 1: the second layer's on bf16 operands (fused kernel), 2: all (resident kernel)
     b = _load(_oracle(), cfg, norm, preds, targets, ks, train, val, infer_bf16=True, train_bf16=bf_train, **kw)
     # bf16 inference operands 5e-4 on losses / 2e-3 + 2e-4 on imputed values; bf16 training operands 1e-3 / 5e-3 + 5e-4
     # (bf16 training operands: single weights are not compared -- where a gradient is at the rounding noise of its bf16 operands
     #  Adam's first steps move the weight by +-lr either way; the stated tolerances are on losses and imputed values)
     tol = dict(loss=1e-3, p_rtol=5e-3, p_atol=5e-4, weights=False) if bf_train else dict(loss=5e-4, p_rtol=2e-3, p_atol=2e-4)
     _compare_with_oracle(a, b, norm, preds, targets, ks, train, val, 4, cfg, kw, rows, tol=tol, oracle_kw=dict(infer_bf16=True, train_bf16=bf_train))
+    print("cfg5 share ran on", a.path_info())
     a.close(); b.close()
 
 

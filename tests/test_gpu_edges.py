@@ -92,9 +92,10 @@ def test_general_and_bf16_paths_on_degenerate_sizes():
     prob = make_problem(n=70, g=90, Ds=[5, 33], H=256, O=20, seed=8)
     prob["train"], prob["val"] = np.arange(0, 3, dtype=np.int32), np.arange(3, 70, dtype=np.int32)
     a = load_problem(_hip(), prob, batch_size=64, dropout_rate=0.2, learning_rate=1e-3, seed=5, precision="bf16")
-    b = load_problem(_oracle(), prob, batch_size=64, dropout_rate=0.2, learning_rate=1e-3, seed=5, precision="bf16", infer_bf16=True)
+    mode = a.path_info()["train_bf16"]               # which training GEMMs take bf16 operands on the path the library picked (2: all, resident kernel)
+    b = load_problem(_oracle(), prob, batch_size=64, dropout_rate=0.2, learning_rate=1e-3, seed=5, precision="bf16", infer_bf16=True, train_bf16=mode)
     a.init_weights(); b.init_weights()
-    np.testing.assert_allclose(a.train_epoch(0), b.train_epoch(0), rtol=1e-4)
-    np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=5e-4)
-    np.testing.assert_allclose(a.predict(), b.predict(), rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(a.train_epoch(0), b.train_epoch(0), rtol=1e-3 if mode else 1e-4)
+    np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-3 if mode else 5e-4)
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=5e-3 if mode else 2e-3, atol=5e-4 if mode else 2e-4)
     a.close(); b.close()
