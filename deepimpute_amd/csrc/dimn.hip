@@ -165,7 +165,14 @@ struct dimn_handle_s {
     double tm_res_ms = 0; int64_t tm_res_steps = 0;
     double* pin_buf[4] = {nullptr, nullptr, nullptr, nullptr}; size_t pin_cap = 0;   // pinned bounce buffers of dimn_impute_finish, kept across calls
     hipStream_t stream = nullptr;          // lane 0's stream; also used by every non-training call
-    struct Lane { hipStream_t stream; int k0, k1, w0, w1; };   // sub-nets [k0,k1), work items [w0,w1)
+    struct Lane {                          // sub-nets [k0,k1), work items [w0,w1)
+        hipStream_t stream; int k0, k1, w0, w1;
+        hipStream_t stream_w = nullptr;    // partitioned mode: the weight-update stream (its own CUs); nullptr: everything on `stream`
+        hipEvent_t ev_m[8] = {nullptr}, ev_w[8] = {nullptr};   // partitioned mode: "second layer of step t done" / "weight update of step t done" (rings)
+        int ev_i = 0;
+    };
+    int part = 0, part_cm = 0;             // DIMN_PART=<groups>: sub-net groups pipelined over two CU-masked streams (experiment)
+    hipStream_t st_part_m = nullptr, st_part_w = nullptr;
     std::vector<Lane> lanes;               // independent sub-net groups trained on concurrent streams
     int64_t t = 0;
     // profiling
@@ -214,32 +221,36 @@ static int dev_alloc(T** p, size_t count) {
 
 #include "dimn_general_host.inc"
 
-static void build_work(dimn_handle h) {
+static void build_work(dimn_handle h, int groups = 1, int64_t group_target = 0) {
     // Split every sub-net's chunk range into slices = workgroups of the W1 kernels.  The total is made
     // EXACTLY ncu * wg_per_cu (a partially filled last round of workgroups costs a whole round), shared
     // out in proportion to the chunk counts (largest remainder), subject to a minimum slice length: every
     // workgroup writes a 64-row split-K partial, so very fine slicing would drown the step in partials.
-    int64_t total_chunks = 0;
-    for (auto& s : h->sn) total_chunks += s.nchunk;
-    const int64_t target = (int64_t)h->ncu * h->wg_per_cu;
+    // (groups > 1: every contiguous group of sub-nets gets group_target workgroups of its own -- one launch per group.)
     std::vector<int> ns((size_t)h->K);
-    std::vector<std::pair<double, int>> frac;
-    int64_t assigned = 0;
-    // minimum chunks per slice: 8 when there is plenty of work per CU; down to 2 when a GPU owns only a
-    // few sub-nets (8-GPU sharding): the step is then latency-bound and parallelism beats partial traffic
-    int min_chunks = (int)std::min<int64_t>(8, std::max<int64_t>(2, total_chunks / std::max<int64_t>(1, target)));
-    if (const char* e = getenv("DIMN_MIN_CHUNKS")) min_chunks = std::max(1, atoi(e));
-    for (int k = 0; k < h->K; ++k) {
-        const double share = (double)target * h->sn[k].nchunk / (double)total_chunks;
-        const int cap = std::max(1, h->sn[k].nchunk / min_chunks);
-        ns[(size_t)k] = std::min(cap, std::max(1, (int)share));
-        assigned += ns[(size_t)k];
-        frac.push_back({share - (int)share, k});
-    }
-    std::sort(frac.begin(), frac.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
-    for (size_t i = 0; assigned < target && i < frac.size(); ++i) {
-        const int k = frac[i].second;
-        if (ns[(size_t)k] < std::max(1, h->sn[k].nchunk / min_chunks)) { ns[(size_t)k]++; assigned++; }
+    for (int gi = 0; gi < groups; ++gi) {
+        const int k0 = (int)((int64_t)h->K * gi / groups), k1 = (int)((int64_t)h->K * (gi + 1) / groups);
+        int64_t total_chunks = 0;
+        for (int k = k0; k < k1; ++k) total_chunks += h->sn[k].nchunk;
+        const int64_t target = groups > 1 ? group_target : (int64_t)h->ncu * h->wg_per_cu;
+        std::vector<std::pair<double, int>> frac;
+        int64_t assigned = 0;
+        // minimum chunks per slice: 8 when there is plenty of work per CU; down to 2 when a GPU owns only a
+        // few sub-nets (8-GPU sharding): the step is then latency-bound and parallelism beats partial traffic
+        int min_chunks = (int)std::min<int64_t>(8, std::max<int64_t>(2, total_chunks / std::max<int64_t>(1, target)));
+        if (const char* e = getenv("DIMN_MIN_CHUNKS")) min_chunks = std::max(1, atoi(e));
+        for (int k = k0; k < k1; ++k) {
+            const double share = (double)target * h->sn[k].nchunk / (double)total_chunks;
+            const int cap = std::max(1, h->sn[k].nchunk / min_chunks);
+            ns[(size_t)k] = std::min(cap, std::max(1, (int)share));
+            assigned += ns[(size_t)k];
+            frac.push_back({share - (int)share, k});
+        }
+        std::sort(frac.begin(), frac.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
+        for (size_t i = 0; assigned < target && i < frac.size(); ++i) {
+            const int k = frac[i].second;
+            if (ns[(size_t)k] < std::max(1, h->sn[k].nchunk / min_chunks)) { ns[(size_t)k]++; assigned++; }
+        }
     }
     h->work.clear();
     int slot = 0;
@@ -423,6 +434,25 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
     h->w1_total = w1;
     build_work(h);
     if (!general) { build_mid(h); build_resident(h); }
+    // Experiment (DIMN_PART=<groups>, DIMN_PART_CM=<CUs of the second layer>): a FIXED CU partition.  The sub-nets are cut into
+    // groups; the HBM-bound weight update (B1F1) of group g runs on one stream whose queue is masked to the "W" CUs while the
+    // latency-bound second-layer chain (RED -> MFB -> RED2) of another group runs on a stream masked to the "M" CUs; events order
+    // the two streams per group and step.  Only for handles on the streaming kernels with the fused second layer.
+    if (!general && !h->res_G && h->mid_fused && getenv("DIMN_PART") && atoi(getenv("DIMN_PART")) >= 2 && h->K >= 2 * atoi(getenv("DIMN_PART"))) {
+        h->part = atoi(getenv("DIMN_PART"));
+        h->part_cm = getenv("DIMN_PART_CM") ? std::max(8, std::min(h->ncu - 8, atoi(getenv("DIMN_PART_CM")))) : 96;
+        uint32_t mm[16] = {0}, mw[16] = {0};
+        for (int cu = 0; cu < h->ncu; ++cu) { if (cu < h->part_cm) mm[cu >> 5] |= 1u << (cu & 31); else mw[cu >> 5] |= 1u << (cu & 31); }
+        const uint32_t words = (uint32_t)((h->ncu + 31) / 32);
+        if (hipExtStreamCreateWithCUMask(&h->st_part_m, words, mm) != hipSuccess || hipExtStreamCreateWithCUMask(&h->st_part_w, words, mw) != hipSuccess) {
+            (void)hipGetLastError();
+            fprintf(stderr, "libdimn: DIMN_PART: hipExtStreamCreateWithCUMask failed; partitioned mode off\n");
+            if (h->st_part_m) (void)hipStreamDestroy(h->st_part_m);
+            h->st_part_m = h->st_part_w = nullptr; h->part = 0;
+        } else {
+            build_work(h, h->part, h->ncu - h->part_cm);       // every group's weight update: one workgroup per "W" CU
+        }
+    }
     // Sub-net lanes: independent sub-net groups on concurrent streams.  Default 1: with 2 lanes the
     // end-to-end rate is ~9 % higher on cfg3 (one lane's latency-bound kernels hide under the other's
     // weight update) but the two HBM-bound weight updates then share the bandwidth, which halves the
@@ -430,6 +460,7 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
     int n_lanes = 1;
     if (const char* e = getenv("DIMN_LANES")) n_lanes = std::max(1, atoi(e));
     n_lanes = std::min(n_lanes, h->K);
+    if (h->part) n_lanes = h->part;
 
     const size_t w2n = (size_t)h->K * dm.Hp * dm.Op;
 #define TRY(expr) do { int rc_ = (expr); if (rc_) { dimn_destroy(h); return rc_; } } while (0)
@@ -443,6 +474,14 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
         ln.k1 = (int)((int64_t)h->K * (l + 1) / n_lanes);
         ln.w0 = h->sn[ln.k0].slot0;
         ln.w1 = ln.k1 < h->K ? h->sn[ln.k1].slot0 : h->nslots;
+        if (h->part) {
+            ln.stream_w = h->st_part_w;
+            for (int i = 0; i < 8; ++i)
+                if (hipEventCreateWithFlags(&ln.ev_m[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ln.ev_w[i], hipEventDisableTiming) != hipSuccess) {
+                    delete h;
+                    return fail(DIMN_ERR_HIP, "dimn_create: hipEventCreate failed");
+                }
+        }
         h->lanes.push_back(ln);
     }
     h->stream = h->lanes[0].stream;
@@ -551,6 +590,8 @@ extern "C" int dimn_destroy(dimn_handle h) {
     if (!h) return DIMN_OK;
     (void)hipSetDevice(h->cfg.device_id);
     for (auto& ln : h->lanes) (void)hipStreamSynchronize(ln.stream);
+    if (h->st_part_m) (void)hipStreamSynchronize(h->st_part_m);
+    if (h->st_part_w) (void)hipStreamSynchronize(h->st_part_w);
     gen_free(h->gen); h->gen = nullptr;
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (auto e : h->ev) (void)hipEventDestroy(e);
@@ -565,7 +606,12 @@ extern "C" int dimn_destroy(dimn_handle h) {
     for (auto& pb : h->pin_buf) if (pb) { (void)hipHostFree(pb); pb = nullptr; }
     DEV_FREE(h->d_W1b); DEV_FREE(h->d_W2t); DEV_FREE(h->d_W2tf);
     DEV_FREE(h->d_res_P); DEV_FREE(h->d_res_D); DEV_FREE(h->d_res_T); DEV_FREE(h->d_res_A); DEV_FREE(h->d_res_b1); DEV_FREE(h->d_res_alpha); DEV_FREE(h->d_res_flags); DEV_FREE(h->d_res_loss); DEV_FREE(h->d_res_snap);
-    for (auto& ln : h->lanes) (void)hipStreamDestroy(ln.stream);
+    for (auto& ln : h->lanes) {
+        (void)hipStreamDestroy(ln.stream);
+        for (int i = 0; i < 8; ++i) { if (ln.ev_m[i]) (void)hipEventDestroy(ln.ev_m[i]); if (ln.ev_w[i]) (void)hipEventDestroy(ln.ev_w[i]); }
+    }
+    if (h->st_part_m) (void)hipStreamDestroy(h->st_part_m);
+    if (h->st_part_w) (void)hipStreamDestroy(h->st_part_w);
     delete h;
     return DIMN_OK;
 }
@@ -896,18 +942,18 @@ static hipEvent_t next_event(dimn_handle h) {
 }
 
 template <int NT>
-static void launch_fwd1(dimn_handle h, const dimn_handle_s::Lane& ln, const int32_t* rows, int b_act) {
-    WITH_XT(h, hipLaunchKernelGGL((k_fwd1<NT, XT>), dim3((unsigned)(ln.w1 - ln.w0)), dim3(256), 0, ln.stream, h->d_work + ln.w0, h->d_sn, (const XT*)h->d_X, h->d_W1,
+static void launch_fwd1(dimn_handle h, const dimn_handle_s::Lane& ln, hipStream_t st, const int32_t* rows, int b_act) {
+    WITH_XT(h, hipLaunchKernelGGL((k_fwd1<NT, XT>), dim3((unsigned)(ln.w1 - ln.w0)), dim3(256), 0, st, h->d_work + ln.w0, h->d_sn, (const XT*)h->d_X, h->d_W1,
                                   rows, b_act, h->d_P, h->dm));
 }
 template <int NT2>
-static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, const int32_t* rows, int b_act, const int32_t* rows_n, int b_next,
+static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, hipStream_t stw, const int32_t* rows, int b_act, const int32_t* rows_n, int b_next,
                       AdamP ap, hipEvent_t ev_begin, hipEvent_t ev_end) {
     const dim3 grid((unsigned)(ln.w1 - ln.w0));
     const Work* wk = h->d_work + ln.w0;
     // ev_begin/ev_end (timed launches only): hipExtLaunchKernelGGL stamps them with the kernel's own begin and end,
     // so the elapsed time is the launch's duration without the dispatch latency an event pair around it would add
-#define W1_LAUNCH(KERNEL, THREADS) hipExtLaunchKernelGGL((KERNEL), grid, dim3(THREADS), 0, ln.stream, ev_begin, ev_end, 0, wk, h->d_sn,      \
+#define W1_LAUNCH(KERNEL, THREADS) hipExtLaunchKernelGGL((KERNEL), grid, dim3(THREADS), 0, stw, ev_begin, ev_end, 0, wk, h->d_sn,      \
                                                          (const XT*)h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, \
                                                          (const float*)h->d_dA, h->d_P, h->dm, ap)
     WITH_XT(h, {
@@ -981,7 +1027,15 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     const float inv_n = (float)(1.0 / ((double)b_act * h->O));
     const size_t kh = (size_t)h->K * dm.Hp, ko = (size_t)h->K * dm.Op;
     const unsigned nk = (unsigned)(ln.k1 - ln.k0);
-    hipStream_t st = ln.stream;
+    // partitioned mode: the second-layer chain on the "M" stream, the weight update on the "W" stream, ordered per group by events
+    dimn_handle_s::Lane& lnm = const_cast<dimn_handle_s::Lane&>(ln);
+    hipStream_t st = ln.stream_w ? h->st_part_m : ln.stream;
+    hipStream_t stw = ln.stream_w ? ln.stream_w : ln.stream;
+    const int evi = lnm.ev_i;
+    if (ln.stream_w) {
+        lnm.ev_i = (evi + 1) & 7;
+        if (!need_fwd) HIPCHK(hipStreamWaitEvent(st, ln.ev_w[(evi + 7) & 7], 0));      // this step's forward partials come from the group's last weight update
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     // one step in eight is timed, on every lane, with HIP events on the lane's own stream: enough samples
     // for a mean, and the event traffic stays out of the way of the other seven
@@ -1001,7 +1055,7 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
         h->ev_bytes.push_back(by);
     }
 
-    if (need_fwd) { DISPATCH_NT(launch_fwd1, h, ln, d_rows, b_act); }
+    if (need_fwd) { DISPATCH_NT(launch_fwd1, h, ln, st, d_rows, b_act); }
     hipLaunchKernelGGL(k_reduce_act, dim3((unsigned)ceil_div(DIMN_TB * dm.Hp, 1024), nk), dim3(256), 0, st, h->d_sn, h->d_P, h->d_b1, d_mask,
                        h->d_Dd, dm, b_act, rate, scale, h->cfg.seed, epoch_key, step_key, ln.k0, h->act, h->d_G);
     if (h->mid_fused) {
@@ -1040,7 +1094,12 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     else { if (dm.OT == 4 * h->OTW) LAUNCH_MB(true, 4); else LAUNCH_MB(false, 4); }
 #undef LAUNCH_MB
     }
-    DISPATCH_NT2(launch_w1, h, ln, d_rows, b_act, d_rows_n, b_next, ap, e1, e2);   // e1/e2 (timed steps): the kernel's own begin/end
+    if (ln.stream_w) {
+        HIPCHK(hipEventRecord(ln.ev_m[evi], st));
+        HIPCHK(hipStreamWaitEvent(stw, ln.ev_m[evi], 0));
+    }
+    DISPATCH_NT2(launch_w1, h, ln, stw, d_rows, b_act, d_rows_n, b_next, ap, e1, e2);   // e1/e2 (timed steps): the kernel's own begin/end
+    if (ln.stream_w) HIPCHK(hipEventRecord(ln.ev_w[evi], stw));
     HIPCHK(hipGetLastError());
     return DIMN_OK;
 }
@@ -1049,6 +1108,8 @@ static int sync_lanes(dimn_handle h);
 static int sync_lanes_fwd(dimn_handle h) { return sync_lanes(h); }
 static int sync_lanes(dimn_handle h) {
     for (auto& ln : h->lanes) HIPCHK(hipStreamSynchronize(ln.stream));
+    if (h->st_part_m) HIPCHK(hipStreamSynchronize(h->st_part_m));
+    if (h->st_part_w) HIPCHK(hipStreamSynchronize(h->st_part_w));
     return DIMN_OK;
 }
 
@@ -1058,7 +1119,8 @@ static int collect_timers(dimn_handle h) {
         float a = 0, b = 0;
         if (hipEventElapsedTime(&a, h->ev[i], h->ev[i + 2]) == hipSuccess &&
             hipEventElapsedTime(&b, h->ev[i + 1], h->ev[i + 2]) == hipSuccess) {
-            h->tm_step_ms += a; h->tm_w1_ms += b; h->tm_steps++; h->tm_w1++;
+            if (!h->part) { h->tm_step_ms += a; h->tm_steps++; }      // (partitioned mode: steps of different groups overlap -- the epoch's wall time counts, dimn_train_epoch)
+            h->tm_w1_ms += b; h->tm_w1++;
             h->tm_w1_bytes += h->ev_bytes[i / 3];
         }
     }
@@ -1301,6 +1363,7 @@ extern "C" int dimn_train_epoch(dimn_handle h, int32_t epoch, const int32_t* per
     // d_loss_acc accumulates sum(w e^2) per step; the per-step means are weighted by b_act,
     // i.e. sum_steps (sum/(b_act*O))*b_act / n_tr = total / (O*n_tr)
     int step = 0;
+    const auto wall0 = std::chrono::steady_clock::now();
     for (int64_t i0 = 0; i0 < h->n_tr; i0 += h->B, ++step) {
         const int b_act = (int)std::min<int64_t>(h->B, h->n_tr - i0);
         const int64_t i1 = i0 + h->B;
@@ -1313,6 +1376,10 @@ extern "C" int dimn_train_epoch(dimn_handle h, int32_t epoch, const int32_t* per
         h->t += 1;
     }
     CHK(sync_lanes(h));
+    if (h->profiling && h->part) {
+        h->tm_step_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        h->tm_steps += step;
+    }
     if (h->profiling) collect_timers(h);
     if (train_loss) {
         std::vector<double> acc((size_t)h->K * dm.LS);
