@@ -105,6 +105,16 @@ GPU_ONLY = {
     "csv_scan": [C.c_char_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "csv_read": [C.c_char_p, _i64, _i64, C.POINTER(_i64), C.c_char_p, _i64],
     "csv_write": [C.c_char_p, _pd, _i64, _i64, C.c_char_p, C.c_char_p, C.c_char_p],
+    "counts_create": [_i32, _pd, _i64, _i64, _pd, C.POINTER(C.c_uint64), C.POINTER(_H)],
+    "counts_checksum": [_pd, _i64, _i64, C.POINTER(C.c_uint64)],
+    "counts_destroy": [_H],
+    "counts_select_predictors": [_H, _pi, _i64, _pi, _i32, _i32, _pi, _i32, _pi],
+    "counts_corr": [_H, _pi, _i64],
+    "counts_topk": [_H, _pi, _i32, _i32, _pi, _i32, _pi],
+    "set_matrix_counts": [_H, _H, _pf, _i64],
+    "col_stats_first": [_pd, _i64, _i64, _i64, _pd, _pd, _pd, _pd, _pd, _pi, _i32],
+    "col_stats_var": [_pd, _i64, _i64, _i64, _pd, _pd, _i32],
+    "col_stats": [_pd, _i64, _i64, _i64, _pd, _pd, _pd, _pi, _i32],
     "select_predictors": [_i32, _pd, _i64, _i64, _pi, _i32, _i32, _pi, _i32, _pi],
 }
 

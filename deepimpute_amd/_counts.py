@@ -1,0 +1,92 @@
+"""The raw count matrix resident on the GPU (include/dimn.h, dimn_counts_*): uploaded ONCE as float32, then read in place by
+the correlation / predictor selection, by the log1p hand-over of the engine (through a numpy-computed table) and by predict()'s
+restore / max step.  The reference passes the same frame through numpy four times (deepimpute/multinet.py:191, 20-34, 216,
+292-303); at 50k x 20k each pass -- and each 4-8 GB host-to-device copy of it -- costs a large part of a second next to two
+seconds of training.  Only for what the tool is specified for: a matrix of raw counts (non-negative integers); anything else
+makes `DeviceCounts.try_create` return None and MultiNet keeps its host path.  Nothing here does arithmetic on the data except
+`log1p_table`, which is numpy's own log1p."""
+import ctypes as C
+
+import numpy as np
+
+from . import _cabi
+
+
+class DeviceCounts:
+    def __init__(self, handle, n, g, vmax, checksum, device_id):
+        self.handle, self.n, self.g, self.vmax, self.checksum, self.device_id = handle, int(n), int(g), float(vmax), int(checksum), int(device_id)
+
+    @staticmethod
+    def try_create(values, device_id=0):
+        """Upload `values` ([cells, genes] float64, C-ordered) or return None: library missing, no GPU, or values that are
+        not counts (the library checks every element on the way)."""
+        if not isinstance(values, np.ndarray) or values.dtype != np.float64 or values.ndim != 2 or not values.flags.c_contiguous or values.size == 0:
+            return None
+        try:
+            from . import _lib
+            fns = _lib.load()
+        except (ImportError, OSError):
+            return None
+        h, vmax, cs = C.c_void_p(), C.c_double(), C.c_uint64()
+        rc = fns["counts_create"](int(device_id), _cabi.p_f64(values), values.shape[0], values.shape[1], C.byref(vmax), C.byref(cs), C.byref(h))
+        if rc != 0:
+            return None
+        return DeviceCounts(h, values.shape[0], values.shape[1], vmax.value, cs.value, device_id)
+
+    def matches(self, values):
+        """True when `values` is, bit for bit, the matrix that was uploaded (one threaded host pass: a position-dependent
+        checksum of the float64 bit patterns)."""
+        if self.handle is None or not isinstance(values, np.ndarray) or values.dtype != np.float64 or values.shape != (self.n, self.g) or not values.flags.c_contiguous:
+            return False
+        from . import _lib
+        cs = C.c_uint64()
+        if _lib.load()["counts_checksum"](_cabi.p_f64(values), self.n, self.g, C.byref(cs)) != 0:
+            return False
+        return cs.value == self.checksum
+
+    def log1p_table(self):
+        """float32(log1p(v)) for v = 0 .. max count, computed by numpy exactly as the reference computes
+        np.log1p(raw).astype(np.float32) element by element (multinet.py:216-217)."""
+        return np.log1p(np.arange(int(self.vmax) + 1, dtype=np.float64)).astype(np.float32)
+
+    def select_predictors(self, pool_cols, targ_pos, col_rank, ntop):
+        from . import _lib
+        fns = _lib.load()
+        pool_cols, targ_pos, col_rank = _cabi.i32(pool_cols), _cabi.i32(targ_pos), _cabi.i32(col_rank)
+        K, O = targ_pos.shape
+        picks = np.empty((K, O, int(ntop)), np.int32)
+        rc = fns["counts_select_predictors"](self.handle, _cabi.p_i32(pool_cols), pool_cols.size, _cabi.p_i32(targ_pos), K, O, _cabi.p_i32(col_rank),
+                                             int(ntop), _cabi.p_i32(picks))
+        if rc != 0:
+            raise RuntimeError("dimn_counts_select_predictors: " + fns["last_error"]().decode("utf-8", "replace"))
+        return picks
+
+    def corr(self, pool_cols):
+        """|corr| of the pool columns, left on the device for topk() (dimn_counts_corr)."""
+        from . import _lib
+        fns = _lib.load()
+        pool_cols = _cabi.i32(pool_cols)
+        if fns["counts_corr"](self.handle, _cabi.p_i32(pool_cols), pool_cols.size) != 0:
+            raise RuntimeError("dimn_counts_corr: " + fns["last_error"]().decode("utf-8", "replace"))
+
+    def topk(self, targ_pos, col_rank, ntop):
+        from . import _lib
+        fns = _lib.load()
+        targ_pos, col_rank = _cabi.i32(targ_pos), _cabi.i32(col_rank)
+        K, O = targ_pos.shape
+        picks = np.empty((K, O, int(ntop)), np.int32)
+        if fns["counts_topk"](self.handle, _cabi.p_i32(targ_pos), K, O, _cabi.p_i32(col_rank), int(ntop), _cabi.p_i32(picks)) != 0:
+            raise RuntimeError("dimn_counts_topk: " + fns["last_error"]().decode("utf-8", "replace"))
+        return picks
+
+    def close(self):
+        if self.handle is not None and self.handle:
+            from . import _lib
+            _lib.load()["counts_destroy"](self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

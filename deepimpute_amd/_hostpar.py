@@ -42,8 +42,69 @@ def _block_for(frame_or_shape, axis, target_bytes=32 << 20):
     return max(16, int(target_bytes // max(1, 8 * other)))
 
 
+def _native_col_stats(values, want_var=True):
+    """(mean, var, max) of the columns of a C-ordered float64 matrix through libdimn's host routine (dimn_col_stats:
+    pandas' order of operations, multi-threaded), or None when the library is not built / a NaN is present."""
+    if values.dtype != np.float64 or values.ndim != 2 or not values.flags.c_contiguous or values.shape[0] < 2 or values.shape[1] < 1:
+        return None
+    try:
+        from . import _cabi, _lib
+        fn = _lib.load()["col_stats"]
+    except (ImportError, OSError, KeyError):
+        return None
+    import ctypes as C
+    n, g = values.shape
+    mean, var = np.empty(g, np.float64), np.empty(g, np.float64) if want_var else None
+    vmax, has_nan = C.c_double(), C.c_int32()
+    rc = fn(_cabi.p_f64(values), n, g, g, _cabi.p_f64(mean), _cabi.p_f64(var), C.byref(vmax), C.byref(has_nan),
+            int(os.environ.get("DIMN_HOST_THREADS", "0") or 0))
+    if rc != 0 or has_nan.value:
+        return None
+    return mean, var, vmax.value
+
+
+def col_stats_first(values):
+    """First sweep of the gene statistics (dimn_col_stats_first): dict(mean, avg, cmin, cmax, vmax) of a NaN-free C-ordered
+    float64 matrix, or None (library missing, NaN present, another dtype / layout)."""
+    if os.environ.get("DIMN_HOST_STATS", "1") == "0" or not isinstance(values, np.ndarray) or values.dtype != np.float64 or values.ndim != 2 \
+            or not values.flags.c_contiguous or values.shape[0] < 2 or values.shape[1] < 1:
+        return None
+    try:
+        from . import _cabi, _lib
+        fn = _lib.load()["col_stats_first"]
+    except (ImportError, OSError, KeyError):
+        return None
+    import ctypes as C
+    n, g = values.shape
+    out = {k: np.empty(g, np.float64) for k in ("mean", "avg", "cmin", "cmax")}
+    vmax, has_nan = C.c_double(), C.c_int32()
+    rc = fn(_cabi.p_f64(values), n, g, g, _cabi.p_f64(out["mean"]), _cabi.p_f64(out["avg"]), _cabi.p_f64(out["cmin"]), _cabi.p_f64(out["cmax"]),
+            C.byref(vmax), C.byref(has_nan), int(os.environ.get("DIMN_HOST_THREADS", "0") or 0))
+    if rc != 0 or has_nan.value:
+        return None
+    out["vmax"] = vmax.value
+    return out
+
+
+def col_stats_var(values, avg):
+    """Second sweep (dimn_col_stats_var): DataFrame.var() of the columns from the averages of col_stats_first, to the bit."""
+    from . import _cabi, _lib
+    n, g = values.shape
+    var = np.empty(g, np.float64)
+    if _lib.load()["col_stats_var"](_cabi.p_f64(values), n, g, g, _cabi.p_f64(avg), _cabi.p_f64(var), int(os.environ.get("DIMN_HOST_THREADS", "0") or 0)) != 0:
+        raise RuntimeError("dimn_col_stats_var failed")
+    return var
+
+
 def column_var_mean(frame):
-    """(frame.var(), frame.mean()) -- pandas' own reductions on column blocks."""
+    """(frame.var(), frame.mean()): libdimn's host routine in pandas' order of operations (bit-identical, tests/test_shell.py)
+    for a NaN-free float64 frame, else pandas' own reductions on column blocks."""
+    values = frame.values if hasattr(frame, "values") else None
+    got = _native_col_stats(values) if values is not None and os.environ.get("DIMN_HOST_STATS", "1") != "0" else None
+    if got is not None:
+        mean, var, _ = got
+        return pd.Series(var, index=frame.columns), pd.Series(mean, index=frame.columns)
+
     def one(ab):
         part = frame.iloc[:, ab[0]:ab[1]]
         return part.var(), part.mean()
@@ -85,7 +146,10 @@ def take_columns(values, positions):
 
 
 def matrix_max(values):
-    """values.max() by row blocks (NaN propagates as in numpy)."""
+    """values.max(): libdimn's threaded host pass for a NaN-free float64 matrix, else numpy by row blocks (NaN propagates)."""
+    got = _native_col_stats(values, want_var=False) if os.environ.get("DIMN_HOST_STATS", "1") != "0" else None
+    if got is not None:
+        return np.float64(got[2])
     parts = pmap(lambda ab: values[ab[0]:ab[1]].max(), spans(values.shape[0], _block_for(values, 0)))
     return np.max(parts) if parts else values.max()
 

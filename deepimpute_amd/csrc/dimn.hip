@@ -20,6 +20,7 @@
 #include "dimn_resident.h"
 #include "dimn_general.h"
 #include "dimn_csv.h"
+#include "dimn_hoststats.h"
 
 #define DIMN_ABI_VERSION 5
 
@@ -114,6 +115,12 @@ static int rccl_bind() {
     } while (0)
 enum { kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0 };
 
+// the raw count matrix resident on the device (dimn_counts_*, below)
+struct dimn_counts_s {
+    int device = 0; int64_t n = 0, g = 0; float* d = nullptr; double vmax = 0; uint64_t checksum = 0;
+    double* d_corr = nullptr; int64_t corr_g = 0;     // |corr| of the last dimn_counts_corr pool, until dimn_counts_topk has used it
+};
+
 // ---- handle --------------------------------------------------------------------------------
 struct dimn_handle_s {
     dimn_config cfg;
@@ -187,6 +194,7 @@ struct dimn_handle_s {
     float* d_W2tf = nullptr;                                                // W2 in the operand form of k_predict's second layer (k_prep_w2t)
     int prec = 0;                          // DIMN_PREC_*: 1 = X arena in bfloat16, inference GEMMs on the bf16 matrix cores
     struct GenNet* gen = nullptr;          // != NULL: the general path (dimn_general.h) owns the network of this handle
+    struct dimn_counts_s* counts = nullptr;   // borrowed: the resident count matrix this handle's matrix came from (dimn_set_matrix_counts)
 };
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -617,6 +625,7 @@ extern "C" int dimn_destroy(dimn_handle h) {
 }
 
 extern "C" int dimn_set_matrix(dimn_handle h, const float* norm, int64_t n, int64_t g) {
+    if (h) h->counts = nullptr;
     if (!h || !norm || n < 1 || g < 1) return fail(DIMN_ERR_ARG, "dimn_set_matrix: bad argument");
     if (n > 0x7fffffffLL || g > 0x7fffffffLL) return fail(DIMN_ERR_UNSUP, "dimn_set_matrix: dimension exceeds int32");
     CHK(use_device(h));
@@ -732,6 +741,7 @@ extern "C" int dimn_gather(dimn_handle h, int32_t with_targets) {
 // block overlapping the gather of the previous one); the device never holds the matrix itself, only the gathered X_k
 // (fp32 or bf16) and Y_k blocks.  Replaces dimn_set_matrix + dimn_gather; needs every dimn_set_indices first.
 extern "C" int dimn_set_matrix_streamed(dimn_handle h, const float* norm, int64_t n, int64_t g, int32_t with_targets) {
+    if (h) h->counts = nullptr;
     if (!h || !norm || n < 1 || g < 1) return fail(DIMN_ERR_ARG, "dimn_set_matrix_streamed: bad argument");
     if (n > 0x7fffffffLL || g > 0x7fffffffLL) return fail(DIMN_ERR_UNSUP, "dimn_set_matrix_streamed: dimension exceeds int32");
     CHK(use_device(h));
@@ -1511,8 +1521,11 @@ extern "C" int dimn_val_metrics(dimn_handle h, double* out7) {
 // direction so that the PCIe copies of one block overlap the kernel and the host copies of its neighbours.
 extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_rows, int64_t g, const int32_t* gene_off,
                                   const int32_t* gene_slot, int32_t policy, double ceiling, int32_t from_gathered, double* out) {
-    if (!h || !raw || !gene_off || !gene_slot || !out || n_rows < 0 || g < 1 || policy < 0 || policy > 2)
+    if (!h || !gene_off || !gene_slot || !out || n_rows < 0 || g < 1 || policy < 0 || policy > 2)
         return fail(DIMN_ERR_ARG, "dimn_impute_finish: bad argument");
+    const bool resident = raw == nullptr;                  // raw == NULL: the observed counts are the resident matrix this handle was given (dimn_set_matrix_counts)
+    if (resident && (!h->counts || h->counts->n != n_rows || h->counts->g != g))
+        return fail(DIMN_ERR_STATE, "dimn_impute_finish: raw == NULL needs the count matrix of dimn_set_matrix_counts over the same %lld x %lld cells", (long long)n_rows, (long long)g);
     const int64_t S = gene_off[g];
     const float* pred = from_gathered ? h->d_full : h->d_out;
     if (!pred || h->out_rows != n_rows) return fail(DIMN_ERR_STATE, "dimn_impute_finish: run dimn_predict_device (and the gather) over the same %lld rows first", (long long)n_rows);
@@ -1536,7 +1549,7 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
     FIN_TRY(hipMalloc((void**)&dOff, (size_t)(g + 1) * 4));
     FIN_TRY(hipMalloc((void**)&dSlot, (size_t)std::max<int64_t>(S, 1) * 4));
     for (int b = 0; b < 2; ++b) {
-        FIN_TRY(hipMalloc((void**)&dRaw[b], (size_t)blk * g * 8));
+        if (!resident) FIN_TRY(hipMalloc((void**)&dRaw[b], (size_t)blk * g * 8));
         FIN_TRY(hipMalloc((void**)&dRes[b], (size_t)blk * g * 8));
         if (h->pin_cap < (size_t)blk * g * 8 && b == 0) {        // (re)allocate the four pinned buffers once per size
             for (auto& pb : h->pin_buf) if (pb) { (void)hipHostFree(pb); pb = nullptr; }
@@ -1555,7 +1568,10 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
     tr.lap("finish: allocations");
     const int lds_stage = (size_t)S * 4 <= 150 * 1024 ? 1 : 0;
     const size_t lds = lds_stage ? (size_t)S * 4 : 0;
-    if (rc == DIMN_OK && lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_impute_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc == DIMN_OK && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)k_impute_finish<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_impute_finish<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     const int64_t nblk = (n_rows + blk - 1) / blk;
     // software pipeline over blocks: [host copy in | H2D | kernel | D2H] of block i on stream i%2; the host copy out of
     // block i-2 happens when its event has fired, right before its bounce buffer is re-used
@@ -1570,11 +1586,16 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
         struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join_retire{retire};
         if (bi < nblk && rc == DIMN_OK) {
             const int64_t r0 = bi * blk, nr = std::min(blk, n_rows - r0);
-            parallel_memcpy(pIn[b], raw + r0 * g, (size_t)nr * g * 8);
+            if (!resident) parallel_memcpy(pIn[b], raw + r0 * g, (size_t)nr * g * 8);
             if (retire.joinable()) retire.join();        // pOut[b] is free again before this block's D2H is queued
-            FIN_TRY(hipMemcpyAsync(dRaw[b], pIn[b], (size_t)nr * g * 8, hipMemcpyHostToDevice, st[b]));
-            hipLaunchKernelGGL(k_impute_finish, dim3((unsigned)std::min<int64_t>(nr, 4096)), dim3(512), lds, st[b], pred, S, r0, dRaw[b], nr, g,
-                               dOff, dSlot, ceiling, policy, lds_stage, dRes[b]);
+            if (resident) {
+                hipLaunchKernelGGL(k_impute_finish<float>, dim3((unsigned)std::min<int64_t>(nr, 4096)), dim3(512), lds, st[b], pred, S, r0,
+                                   (const float*)(h->counts->d + r0 * g), nr, g, dOff, dSlot, ceiling, policy, lds_stage, dRes[b]);
+            } else {
+                FIN_TRY(hipMemcpyAsync(dRaw[b], pIn[b], (size_t)nr * g * 8, hipMemcpyHostToDevice, st[b]));
+                hipLaunchKernelGGL(k_impute_finish<double>, dim3((unsigned)std::min<int64_t>(nr, 4096)), dim3(512), lds, st[b], pred, S, r0, (const double*)dRaw[b], nr, g,
+                                   dOff, dSlot, ceiling, policy, lds_stage, dRes[b]);
+            }
             FIN_TRY(hipGetLastError());
             FIN_TRY(hipMemcpyAsync(pOut[b], dRes[b], (size_t)nr * g * 8, hipMemcpyDeviceToHost, st[b]));
             FIN_TRY(hipEventRecord(evOut[b], st[b]));
@@ -1752,6 +1773,35 @@ extern "C" int dimn_csv_write(const char* path, const double* values, int64_t n_
     return rc ? fail(DIMN_ERR_ARG, "dimn_csv_write(%s): %s", path, err.c_str()) : DIMN_OK;
 }
 
+// ---- per-gene statistics of fit()'s planning (multinet.py:191), host code, no GPU needed ----------
+extern "C" int dimn_col_stats(const double* a, int64_t n, int64_t g, int64_t ld, double* mean, double* var, double* vmax, int32_t* has_nan, int32_t threads) {
+    if (!a || !mean || !vmax || !has_nan || n < 1 || g < 1 || ld < g) return fail(DIMN_ERR_ARG, "dimn_col_stats: bad argument");
+    if (var && n < 2) return fail(DIMN_ERR_ARG, "dimn_col_stats: the variance needs two rows");
+    int hn = 0;
+    hoststats_run(a, n, g, ld, mean, var, vmax, &hn, threads > 0 ? threads : (int)std::min<unsigned>(64u, std::max(1u, std::thread::hardware_concurrency())));
+    *has_nan = hn;
+    return DIMN_OK;
+}
+
+// the same statistics as two calls, so that other work can run between the sweeps: dimn_col_stats_first (mean, nanvar's own
+// average, per-column minimum and maximum, matrix maximum, NaN), then dimn_col_stats_var (var from those averages)
+extern "C" int dimn_col_stats_first(const double* a, int64_t n, int64_t g, int64_t ld, double* mean, double* avg, double* cmin, double* cmax, double* vmax,
+                                    int32_t* has_nan, int32_t threads) {
+    if (!a || !mean || !avg || !cmin || !cmax || !vmax || !has_nan || n < 1 || g < 1 || ld < g) return fail(DIMN_ERR_ARG, "dimn_col_stats_first: bad argument");
+    int hn = 0;
+    hoststats_run(a, n, g, ld, mean, nullptr, vmax, &hn, threads > 0 ? threads : (int)std::min<unsigned>(64u, std::max(1u, std::thread::hardware_concurrency())), 1, avg, cmin, cmax);
+    *has_nan = hn;
+    return DIMN_OK;
+}
+extern "C" int dimn_col_stats_var(const double* a, int64_t n, int64_t g, int64_t ld, const double* avg, double* var, int32_t threads) {
+    if (!a || !avg || !var || n < 2 || g < 1 || ld < g) return fail(DIMN_ERR_ARG, "dimn_col_stats_var: bad argument");
+    double vmax = 0; int hn = 0;
+    std::vector<double> mean_unused((size_t)g);
+    hoststats_run(a, n, g, ld, mean_unused.data(), var, &vmax, &hn, threads > 0 ? threads : (int)std::min<unsigned>(64u, std::max(1u, std::thread::hardware_concurrency())), 2,
+                  const_cast<double*>(avg));
+    return DIMN_OK;
+}
+
 #ifdef DIMN_PRED_TL
 // diagnostic build only (tools/predict_timeline.py): phase clocks of k_predict, summed over waves since the last call
 extern "C" int dimn_debug_pred_timeline(unsigned long long* out) {
@@ -1842,12 +1892,24 @@ static int corr_on_device_streamed(const double* X, int64_t n, int64_t g, hipStr
 }
 
 // |corr| of the columns of host X[n][g] (fp64) into a fresh device matrix *dOutp [g][g]; the caller frees it.
-static int corr_on_device(const double* X, int64_t n, int64_t g, hipStream_t st, double** dOutp) {
+// device-resident source of the candidate columns: counts[n][ld] float32 (exact integers), column j of the pool = cols[j]
+struct CorrDevSrc { const float* counts; int64_t ld; const int32_t* d_cols; };
+__global__ __launch_bounds__(256) void k_counts_to_z(const float* __restrict__ counts, int64_t ld, const int32_t* __restrict__ cols, int64_t n, int64_t g,
+                                                     int64_t gp, double* __restrict__ Z) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= g) return;
+    const int32_t c = cols[j];
+    for (int64_t i = blockIdx.y; i < n; i += gridDim.y) Z[i * gp + j] = (double)counts[i * ld + c];
+}
+static int corr_on_device(const double* X, int64_t n, int64_t g, hipStream_t st, double** dOutp, const CorrDevSrc* src = nullptr) {
     const int64_t gp = (g + CORR_BT - 1) / CORR_BT * CORR_BT, np_ = (n + CORR_KC - 1) / CORR_KC * CORR_KC;
     {   // the resident form needs np*gp + 2 g^2 doubles; above the budget (default 64 GB) the matrix is streamed in row blocks
         double budget = 64.0;
         if (const char* e = getenv("DIMN_CORR_BUDGET_GB")) budget = atof(e);
-        if (((double)np_ * gp + 2.0 * gp * gp) * 8.0 > budget * 1073741824.0) return corr_on_device_streamed(X, n, g, st, dOutp);
+        if (((double)np_ * gp + 2.0 * gp * gp) * 8.0 > budget * 1073741824.0) {
+            if (src) return fail(DIMN_ERR_UNSUP, "corr: the resident-counts form does not stream (matrix beyond DIMN_CORR_BUDGET_GB)");
+            return corr_on_device_streamed(X, n, g, st, dOutp);
+        }
     }
     const int nb = (int)(gp / CORR_BT);
     double *dZ = nullptr, *dC = nullptr, *dOut = nullptr, *dMean = nullptr, *dPart = nullptr;
@@ -1868,7 +1930,11 @@ static int corr_on_device(const double* X, int64_t n, int64_t g, hipStream_t st,
     CORR_TRY(hipMalloc((void**)&dPairs, pairs.size() * sizeof(int2)));
     CORR_TRY(hipMemsetAsync(dZ, 0, (size_t)np_ * gp * 8, st));
     tr.lap("corr: device allocations");
-    {   // X (pageable) -> pinned bounce buffers on several host threads -> device rows of pitch gp, double-buffered
+    if (src) {      // the candidate columns are already on the device (dimn_counts): one conversion kernel instead of an 8 GB upload
+        hipLaunchKernelGGL(k_counts_to_z, dim3((unsigned)((g + 255) / 256), (unsigned)std::min<int64_t>(n, 2048)), dim3(256), 0, st, src->counts, src->ld, src->d_cols,
+                           n, g, gp, dZ);
+        CORR_TRY(hipGetLastError());
+    } else {   // X (pageable) -> pinned bounce buffers on several host threads -> device rows of pitch gp, double-buffered
         const int64_t blk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(128u << 20) / (g * 8)));
         double* pin[2] = {nullptr, nullptr};
         hipEvent_t ev[2] = {nullptr, nullptr};
@@ -1937,51 +2003,253 @@ extern "C" int dimn_abs_corrcoef(int32_t device_id, const double* X, int64_t n, 
 }
 
 // ---- next row: setPredictors on the device (multinet.py:344-365) ---------------------------
-extern "C" int dimn_select_predictors(int32_t device_id, const double* X, int64_t n, int64_t g, const int32_t* targ_pos, int32_t K, int32_t O,
-                                      const int32_t* col_rank, int32_t ntop, int32_t* out_idx) {
-    if (!X || !targ_pos || !col_rank || !out_idx || n < 2 || g < 1 || K < 1 || O < 1 || ntop < 1)
-        return fail(DIMN_ERR_ARG, "dimn_select_predictors: bad argument");
-    if (ntop > 16) return fail(DIMN_ERR_UNSUP, "dimn_select_predictors: ntop %d > 16 (use the host selection)", ntop);
+// top-`ntop` predictors of every target over a resident |corr| matrix dCorr[g][g]
+static int topk_core(const char* who, const double* dCorr, int64_t g, const int32_t* targ_pos, int32_t K, int32_t O, const int32_t* col_rank, int32_t ntop,
+                     int32_t* out_idx, hipStream_t st) {
+    if (ntop > 16) return fail(DIMN_ERR_UNSUP, "%s: ntop %d > 16 (use the host selection)", who, ntop);
     for (int64_t i = 0; i < (int64_t)K * O; ++i)
-        if (targ_pos[i] < 0 || targ_pos[i] >= g) return fail(DIMN_ERR_ARG, "dimn_select_predictors: target position out of range");
-    CHK(corr_device_ok("dimn_select_predictors", device_id));
+        if (targ_pos[i] < 0 || targ_pos[i] >= g) return fail(DIMN_ERR_ARG, "%s: target position out of range", who);
     const int NT = ntop <= 5 ? 5 : (ntop <= 8 ? 8 : 16);
     const size_t lds = ((((size_t)(g + 31) / 32) * 4 + 15) & ~(size_t)15) + (size_t)256 * NT * 16 + 64;
-    if (lds > 160 * 1024) return fail(DIMN_ERR_UNSUP, "dimn_select_predictors: %lld candidate genes exceed the LDS bitmap", (long long)g);
-    hipStream_t st = nullptr;
-    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    double* dOut = nullptr;
+    if (lds > 160 * 1024) return fail(DIMN_ERR_UNSUP, "%s: %lld candidate genes exceed the LDS bitmap", who, (long long)g);
     int32_t *dT = nullptr, *dR = nullptr, *dI = nullptr;
-    int rc = corr_on_device(X, n, g, st, &dOut);
+    int rc = DIMN_OK;
 #define SEL_TRY(expr) do { hipError_t e_ = (expr); if (rc == DIMN_OK && e_ != hipSuccess) rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
-    if (rc == DIMN_OK) {
-        SEL_TRY(hipMalloc((void**)&dT, (size_t)K * O * 4));
-        SEL_TRY(hipMalloc((void**)&dR, (size_t)g * 4));
-        SEL_TRY(hipMalloc((void**)&dI, (size_t)K * O * ntop * 4));
-    }
+    SEL_TRY(hipMalloc((void**)&dT, (size_t)K * O * 4));
+    SEL_TRY(hipMalloc((void**)&dR, (size_t)g * 4));
+    SEL_TRY(hipMalloc((void**)&dI, (size_t)K * O * ntop * 4));
     if (rc == DIMN_OK) {
         SEL_TRY(hipMemcpyAsync(dT, targ_pos, (size_t)K * O * 4, hipMemcpyHostToDevice, st));
         SEL_TRY(hipMemcpyAsync(dR, col_rank, (size_t)g * 4, hipMemcpyHostToDevice, st));
         const dim3 grid((unsigned)O, (unsigned)K);
         if (NT == 5) {
             (void)hipFuncSetAttribute((const void*)k_corr_topk<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_corr_topk<5>, grid, dim3(256), lds, st, dOut, g, dT, O, dR, dI, ntop);
+            hipLaunchKernelGGL(k_corr_topk<5>, grid, dim3(256), lds, st, dCorr, g, dT, O, dR, dI, ntop);
         } else if (NT == 8) {
             (void)hipFuncSetAttribute((const void*)k_corr_topk<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_corr_topk<8>, grid, dim3(256), lds, st, dOut, g, dT, O, dR, dI, ntop);
+            hipLaunchKernelGGL(k_corr_topk<8>, grid, dim3(256), lds, st, dCorr, g, dT, O, dR, dI, ntop);
         } else {
             (void)hipFuncSetAttribute((const void*)k_corr_topk<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_corr_topk<16>, grid, dim3(256), lds, st, dOut, g, dT, O, dR, dI, ntop);
+            hipLaunchKernelGGL(k_corr_topk<16>, grid, dim3(256), lds, st, dCorr, g, dT, O, dR, dI, ntop);
         }
         SEL_TRY(hipGetLastError());
         SEL_TRY(hipMemcpyAsync(out_idx, dI, (size_t)K * O * ntop * 4, hipMemcpyDeviceToHost, st));
         SEL_TRY(hipStreamSynchronize(st));
     }
 #undef SEL_TRY
-    if (dOut) (void)hipFree(dOut);
     if (dT) (void)hipFree(dT);
     if (dR) (void)hipFree(dR);
     if (dI) (void)hipFree(dI);
+    return rc;
+}
+static int select_predictors_core(const char* who, int32_t device_id, const double* X, const CorrDevSrc* src, int64_t n, int64_t g, const int32_t* targ_pos,
+                                  int32_t K, int32_t O, const int32_t* col_rank, int32_t ntop, int32_t* out_idx, hipStream_t st) {
+    if (ntop > 16) return fail(DIMN_ERR_UNSUP, "%s: ntop %d > 16 (use the host selection)", who, ntop);
+    double* dOut = nullptr;
+    int rc = corr_on_device(X, n, g, st, &dOut, src);
+    if (rc == DIMN_OK) rc = topk_core(who, dOut, g, targ_pos, K, O, col_rank, ntop, out_idx, st);
+    if (dOut) (void)hipFree(dOut);
+    return rc;
+}
+
+extern "C" int dimn_select_predictors(int32_t device_id, const double* X, int64_t n, int64_t g, const int32_t* targ_pos, int32_t K, int32_t O,
+                                      const int32_t* col_rank, int32_t ntop, int32_t* out_idx) {
+    if (!X || !targ_pos || !col_rank || !out_idx || n < 2 || g < 1 || K < 1 || O < 1 || ntop < 1)
+        return fail(DIMN_ERR_ARG, "dimn_select_predictors: bad argument");
+    CHK(corr_device_ok("dimn_select_predictors", device_id));
+    hipStream_t st = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const int rc = select_predictors_core("dimn_select_predictors", device_id, X, nullptr, n, g, targ_pos, K, O, col_rank, ntop, out_idx, st);
     (void)hipStreamDestroy(st);
+    return rc;
+}
+
+// ---- the raw counts resident on the device (extension of the drop-in; the reference passes the same 8 GB frame through numpy four
+// times: multinet.py:191 var/mean, :20-34 corrcoef, :216 log1p, :292-303 restore).  dimn_counts_create uploads the count matrix ONCE
+// as float32 -- host threads convert the float64 frame row block by row block into pinned buffers and verify on the way that every
+// value is a non-negative integer <= 2^22 (exact in float32; anything else: DIMN_ERR_UNSUP, the caller keeps the host path) -- and
+// every later stage reads it there: the correlation (converted to float64 on the device), log1p through a table the caller
+// computed with numpy (bit-identical to np.log1p(raw).astype(float32)), and predict()'s restore / max against the observed counts.
+static inline uint64_t counts_mix(uint64_t x) {      // splitmix64 finaliser
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+    return x;
+}
+// one host pass over rows [r0, r1): optional float32 copy, maximum, position-dependent checksum of the float64 bit patterns,
+// and whether every value is a count (non-negative integer <= 2^22)
+static void counts_scan(const double* raw, int64_t g, int64_t r0, int64_t r1, float* dst, double* vmax, uint64_t* sum, int* ok) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int64_t rows = r1 - r0;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw ? hw / 2 : 8, 32), rows * g / (1 << 20)));
+    std::vector<double> mx((size_t)nt, -INFINITY);
+    std::vector<uint64_t> cs((size_t)nt, 0);
+    std::vector<int> good((size_t)nt, 1);
+    auto work = [&](int t) {
+        const int64_t a = r0 + rows * t / nt, b = r0 + rows * (t + 1) / nt;
+        double m = -INFINITY; uint64_t h = 0; bool fine = true;
+        for (int64_t i = a; i < b; ++i) {
+            const double* src = raw + i * g;
+            float* out = dst ? dst + (i - r0) * g : nullptr;
+            const uint64_t base = (uint64_t)i * (uint64_t)g;
+            for (int64_t j = 0; j < g; ++j) {
+                const double x = src[j];
+                uint64_t bits;
+                memcpy(&bits, &x, 8);
+                h += counts_mix(bits + 0x9e3779b97f4a7c15ull * (base + (uint64_t)j + 1));
+                m = x > m ? x : m;
+                fine &= (x >= 0.0) & (x <= 4194304.0) & (x == (double)(int64_t)x);
+                if (out) out[j] = (float)x;
+            }
+        }
+        mx[(size_t)t] = m; cs[(size_t)t] = h; good[(size_t)t] = fine ? 1 : 0;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    for (int t = 0; t < nt; ++t) { *vmax = mx[(size_t)t] > *vmax ? mx[(size_t)t] : *vmax; *sum += cs[(size_t)t]; *ok &= good[(size_t)t]; }
+}
+extern "C" int dimn_counts_checksum(const double* raw, int64_t n, int64_t g, uint64_t* checksum) {
+    if (!raw || !checksum || n < 1 || g < 1) return fail(DIMN_ERR_ARG, "dimn_counts_checksum: bad argument");
+    double vmax = -INFINITY; uint64_t sum = 0; int ok = 1;
+    counts_scan(raw, g, 0, n, nullptr, &vmax, &sum, &ok);
+    *checksum = sum;
+    return DIMN_OK;
+}
+extern "C" int dimn_counts_destroy(dimn_counts c) {
+    if (!c) return DIMN_OK;
+    (void)hipSetDevice(c->device);
+    if (c->d) (void)hipFree(c->d);
+    if (c->d_corr) (void)hipFree(c->d_corr);
+    delete c;
+    return DIMN_OK;
+}
+extern "C" int dimn_counts_create(int32_t device_id, const double* raw, int64_t n, int64_t g, double* vmax_out, uint64_t* checksum_out, dimn_counts* out) {
+    if (!raw || !out || n < 1 || g < 1) return fail(DIMN_ERR_ARG, "dimn_counts_create: bad argument");
+    CHK(corr_device_ok("dimn_counts_create", device_id));
+    dimn_counts c = new dimn_counts_s();
+    c->device = device_id; c->n = n; c->g = g; c->vmax = -INFINITY;
+    float* pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;
+    int rc = DIMN_OK, ok = 1;
+    const int64_t blk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(128u << 20) / (g * 4)));
+#define CNT_TRY(expr) do { hipError_t e_ = (expr); if (rc == DIMN_OK && e_ != hipSuccess) rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+    CNT_TRY(hipMalloc((void**)&c->d, (size_t)n * g * 4));
+    CNT_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+        CNT_TRY(hipHostMalloc((void**)&pin[b], (size_t)blk * g * 4, hipHostMallocDefault));
+        CNT_TRY(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
+    }
+    int64_t bi = 0;
+    for (int64_t r0 = 0; r0 < n && rc == DIMN_OK && ok; r0 += blk, ++bi) {
+        const int b = (int)(bi & 1);
+        const int64_t nr = std::min(blk, n - r0);
+        if (bi >= 2) CNT_TRY(hipEventSynchronize(ev[b]));
+        if (rc != DIMN_OK) break;
+        counts_scan(raw, g, r0, r0 + nr, pin[b], &c->vmax, &c->checksum, &ok);
+        CNT_TRY(hipMemcpyAsync(c->d + r0 * g, pin[b], (size_t)nr * g * 4, hipMemcpyHostToDevice, st));
+        CNT_TRY(hipEventRecord(ev[b], st));
+    }
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+#undef CNT_TRY
+    for (int b = 0; b < 2; ++b) { if (pin[b]) (void)hipHostFree(pin[b]); if (ev[b]) (void)hipEventDestroy(ev[b]); }
+    if (rc == DIMN_OK && !ok) rc = fail(DIMN_ERR_UNSUP, "dimn_counts_create: the matrix holds values that are not counts (non-negative integers <= 2^22)");
+    if (rc != DIMN_OK) { dimn_counts_destroy(c); return rc; }
+    if (vmax_out) *vmax_out = c->vmax;
+    if (checksum_out) *checksum_out = c->checksum;
+    *out = c;
+    return DIMN_OK;
+}
+// The same selection as two calls, so that the matrix product (which needs only the candidate pool) can run while the host is
+// still ranking genes: dimn_counts_corr leaves |corr| of the pool on the device, dimn_counts_topk selects from it and frees it.
+extern "C" int dimn_counts_corr(dimn_counts c, const int32_t* pool_cols, int64_t pool_n) {
+    if (!c || !pool_cols || pool_n < 1 || c->n < 2) return fail(DIMN_ERR_ARG, "dimn_counts_corr: bad argument");
+    for (int64_t j = 0; j < pool_n; ++j) if (pool_cols[j] < 0 || pool_cols[j] >= c->g) return fail(DIMN_ERR_ARG, "dimn_counts_corr: pool column out of range");
+    CHK(corr_device_ok("dimn_counts_corr", c->device));
+    if (c->d_corr) { (void)hipFree(c->d_corr); c->d_corr = nullptr; c->corr_g = 0; }
+    hipStream_t st = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    int32_t* dCols = nullptr;
+    int rc = DIMN_OK;
+    if (hipMalloc((void**)&dCols, (size_t)pool_n * 4) != hipSuccess || hipMemcpyAsync(dCols, pool_cols, (size_t)pool_n * 4, hipMemcpyHostToDevice, st) != hipSuccess)
+        rc = fail(DIMN_ERR_HIP, "dimn_counts_corr: pool upload failed");
+    if (rc == DIMN_OK) {
+        const CorrDevSrc src{c->d, c->g, dCols};
+        rc = corr_on_device(nullptr, c->n, pool_n, st, &c->d_corr, &src);
+        if (rc == DIMN_OK) c->corr_g = pool_n;
+    }
+    if (dCols) (void)hipFree(dCols);
+    (void)hipStreamDestroy(st);
+    return rc;
+}
+extern "C" int dimn_counts_topk(dimn_counts c, const int32_t* targ_pos, int32_t K, int32_t O, const int32_t* col_rank, int32_t ntop, int32_t* out_idx) {
+    if (!c || !targ_pos || !col_rank || !out_idx || K < 1 || O < 1 || ntop < 1) return fail(DIMN_ERR_ARG, "dimn_counts_topk: bad argument");
+    if (!c->d_corr) return fail(DIMN_ERR_STATE, "dimn_counts_topk: dimn_counts_corr first");
+    CHK(corr_device_ok("dimn_counts_topk", c->device));
+    hipStream_t st = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const int rc = topk_core("dimn_counts_topk", c->d_corr, c->corr_g, targ_pos, K, O, col_rank, ntop, out_idx, st);
+    (void)hipStreamDestroy(st);
+    (void)hipFree(c->d_corr); c->d_corr = nullptr; c->corr_g = 0;
+    return rc;
+}
+// setPredictors over the resident counts: the candidate pool = columns pool_cols[pool_n] of the count matrix
+extern "C" int dimn_counts_select_predictors(dimn_counts c, const int32_t* pool_cols, int64_t pool_n, const int32_t* targ_pos, int32_t K, int32_t O,
+                                             const int32_t* col_rank, int32_t ntop, int32_t* out_idx) {
+    if (!c || !pool_cols || !targ_pos || !col_rank || !out_idx || pool_n < 1 || K < 1 || O < 1 || ntop < 1 || c->n < 2)
+        return fail(DIMN_ERR_ARG, "dimn_counts_select_predictors: bad argument");
+    for (int64_t j = 0; j < pool_n; ++j) if (pool_cols[j] < 0 || pool_cols[j] >= c->g) return fail(DIMN_ERR_ARG, "dimn_counts_select_predictors: pool column out of range");
+    CHK(corr_device_ok("dimn_counts_select_predictors", c->device));
+    hipStream_t st = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    int32_t* dCols = nullptr;
+    int rc = DIMN_OK;
+    if (hipMalloc((void**)&dCols, (size_t)pool_n * 4) != hipSuccess || hipMemcpyAsync(dCols, pool_cols, (size_t)pool_n * 4, hipMemcpyHostToDevice, st) != hipSuccess)
+        rc = fail(DIMN_ERR_HIP, "dimn_counts_select_predictors: pool upload failed");
+    if (rc == DIMN_OK) {
+        const CorrDevSrc src{c->d, c->g, dCols};
+        rc = select_predictors_core("dimn_counts_select_predictors", c->device, nullptr, &src, c->n, pool_n, targ_pos, K, O, col_rank, ntop, out_idx, st);
+    }
+    if (dCols) (void)hipFree(dCols);
+    (void)hipStreamDestroy(st);
+    return rc;
+}
+// the log1p matrix of the engine from the resident counts: norm[i][j] = lut[(int)counts[i][j]], lut = float32(log1p(0..vmax)) as numpy computes it
+__global__ __launch_bounds__(256) void k_counts_lut(const float* __restrict__ counts, const float* __restrict__ lut, int64_t lut_n, int64_t total, float* __restrict__ norm) {
+    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; e < total; e += (int64_t)gridDim.x * 1024) {
+        if (e + 4 <= total) {
+            const f32x4 v = *(const f32x4*)(counts + e);
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int64_t i = (int64_t)v[r]; o[r] = lut[i < lut_n ? i : lut_n - 1]; }
+            *(f32x4*)(norm + e) = o;
+        } else {
+            for (int64_t q = e; q < total; ++q) { const int64_t i = (int64_t)counts[q]; norm[q] = lut[i < lut_n ? i : lut_n - 1]; }
+        }
+    }
+}
+extern "C" int dimn_set_matrix_counts(dimn_handle h, dimn_counts c, const float* lut, int64_t lut_n) {
+    if (!h || !c || !lut || lut_n < 1) return fail(DIMN_ERR_ARG, "dimn_set_matrix_counts: bad argument");
+    if (c->device != h->cfg.device_id) return fail(DIMN_ERR_ARG, "dimn_set_matrix_counts: the counts live on another device");
+    if ((double)lut_n <= c->vmax) return fail(DIMN_ERR_ARG, "dimn_set_matrix_counts: the table has %lld entries, the largest count is %.0f", (long long)lut_n, c->vmax);
+    if (c->n > 0x7fffffffLL || c->g > 0x7fffffffLL) return fail(DIMN_ERR_UNSUP, "dimn_set_matrix_counts: dimension exceeds int32");
+    CHK(use_device(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (!h->d_norm || h->n != c->n || h->g != c->g) {
+        DEV_FREE(h->d_norm);
+        CHK(dev_alloc(&h->d_norm, (size_t)c->n * c->g));
+    }
+    if (c->n != h->n) { h->n_tr = 0; h->n_val = 0; h->train_rows.clear(); h->val_rows.clear(); }
+    h->n = c->n; h->g = c->g; h->gathered = false; h->streamed = false;
+    float* dLut = nullptr;
+    CHK(dev_alloc(&dLut, (size_t)lut_n));
+    int rc = DIMN_OK;
+    if (hipMemcpyAsync(dLut, lut, (size_t)lut_n * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = fail(DIMN_ERR_HIP, "dimn_set_matrix_counts: table upload failed");
+    if (rc == DIMN_OK) {
+        hipLaunchKernelGGL(k_counts_lut, dim3(4096), dim3(256), 0, h->stream, (const float*)c->d, (const float*)dLut, lut_n, c->n * c->g, h->d_norm);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(DIMN_ERR_HIP, "dimn_set_matrix_counts: table kernel failed");
+    }
+    (void)hipFree(dLut);
+    if (rc == DIMN_OK) h->counts = c;
     return rc;
 }

@@ -1837,8 +1837,9 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
 // The prediction row [S] is staged once in LDS (coalesced) and gathered per gene from there; raw and the result are
 // streamed coalesced in float64.  goff[g+1] / gslot[S]: the slots of every output column (CSR, ascending slot order).
 // ---------------------------------------------------------------------------------------
+template <typename RT>      // raw counts: float64 streamed from the host, or float32 resident on the device (dimn_counts: exact integers)
 __global__ __launch_bounds__(512) void k_impute_finish(const float* __restrict__ pred, int64_t S, int64_t pred_row0,
-                                                       const double* __restrict__ raw, int64_t n_rows, int64_t g,
+                                                       const RT* __restrict__ raw, int64_t n_rows, int64_t g,
                                                        const int32_t* __restrict__ goff, const int32_t* __restrict__ gslot,
                                                        double ceiling, int policy, int lds_stage, double* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float prow[];
@@ -1850,10 +1851,10 @@ __global__ __launch_bounds__(512) void k_impute_finish(const float* __restrict__
             __syncthreads();
         }
         const float* src = lds_stage ? prow : pr;
-        const double* rr = raw + i * g;
+        const RT* rr = raw + i * g;
         double* orow = out + i * g;
         for (int64_t j = threadIdx.x; j < g; j += 512) {
-            const double x = rr[j];
+            const double x = (double)rr[j];
             const int s0 = goff[j], s1 = goff[j + 1];
             double v;
             if (s1 > s0) {

@@ -288,14 +288,28 @@ class HipEngine(Engine):
 
     def impute_finish(self, raw, gene_off, gene_slot, policy, ceiling, from_gathered=False):
         """predict()'s post-processing on the device over the last predict_device() result (include/dimn.h);
-        raw [cells, genes] float64 -> the finished [cells, genes] float64 matrix."""
-        raw = np.ascontiguousarray(raw, dtype=np.float64)
+        raw [cells, genes] float64 -> the finished [cells, genes] float64 matrix.  raw = None: the observed counts are the
+        resident matrix of set_matrix_counts()."""
+        if raw is None:
+            shape = (self.n_cells, self.n_genes)
+        else:
+            raw = np.ascontiguousarray(raw, dtype=np.float64)
+            shape = raw.shape
         gene_off, gene_slot = i32(gene_off), i32(gene_slot)
-        out = np.empty(raw.shape, np.float64)
+        out = np.empty(shape, np.float64)
         code = {None: 0, "restore": 1, "max": 2}.get(policy, 0)
-        self._check(self._f["impute_finish"](self._h, p_f64(raw), raw.shape[0], raw.shape[1], p_i32(gene_off), p_i32(gene_slot),
+        self._check(self._f["impute_finish"](self._h, p_f64(raw), shape[0], shape[1], p_i32(gene_off), p_i32(gene_slot),
                                              code, float(ceiling), int(bool(from_gathered)), p_f64(out)))
         return out
+
+    def set_matrix_counts(self, counts):
+        """The log1p matrix of this engine from a resident count matrix (_counts.DeviceCounts): log1p through numpy's own table,
+        on the device; gather() follows as after set_matrix().  The engine remembers the counts (impute_finish(raw=None))."""
+        lut = counts.log1p_table()
+        self._check(self._f["set_matrix_counts"](self._h, counts.handle, p_f32(lut), lut.size))
+        self.n_cells, self.n_genes = counts.n, counts.g
+        self._streamed = False
+        self._dev_counts = counts                # keeps the device matrix alive as long as this engine may read it
 
     def path_info(self):
         """The kernels dimn_create chose for this handle (include/dimn.h dimn_path_info), as a dict."""

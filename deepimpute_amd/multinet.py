@@ -68,9 +68,10 @@ def _abs_corrcoef(values, backend="auto", device_id=0):
         return np.abs(np.corrcoef(values.T))
 
 
-def _candidate_pool(raw, n_pred=None, _var_mean=None):
+def _candidate_pool(raw, n_pred=None, _var_mean=None, labels_only=False):
     """(labels, values) of the candidate predictor genes of get_distance_matrix (multinet.py:20-30): genes with
-    std/mean > 0, or the `n_pred` genes with the largest ratio; values = their raw columns [cells, pool]."""
+    std/mean > 0, or the `n_pred` genes with the largest ratio; values = their raw columns [cells, pool]
+    (labels_only: None instead -- the caller reads the columns from the device-resident counts)."""
     var, mean = _var_mean if _var_mean is not None else _hostpar.column_var_mean(raw)
     ratio = np.sqrt(var) / mean
     ratio[np.isinf(ratio)] = 0
@@ -79,6 +80,8 @@ def _candidate_pool(raw, n_pred=None, _var_mean=None):
     else:
         print("Using {} predictors".format(n_pred))
         keep = ratio.sort_values(ascending=False).index[:n_pred]
+    if labels_only:
+        return keep, None
     if keep.equals(raw.columns):
         return keep, raw.values
     return keep, _hostpar.take_columns(raw.values, raw.columns.get_indexer(keep))
@@ -96,11 +99,13 @@ def get_distance_matrix(raw, n_pred=None, backend="auto", device_id=0, _var_mean
 
 
 class _ColumnsOnly:
-    """What setTargets() reads of its `data` argument: `.columns` and `.shape[1]`."""
+    """What setTargets() reads of its `data` argument: `.columns` and `.shape[1]` (and, for fit()'s own bookkeeping when the
+    log1p matrix lives on the device only, `.index` / `.shape`)."""
 
-    def __init__(self, labels):
+    def __init__(self, labels, index=None, shape=None):
         self.columns = pd.Index(labels)
-        self.shape = (0, len(self.columns))
+        self.index = index
+        self.shape = tuple(shape) if shape is not None else (0, len(self.columns))
 
 
 def _gpu_visible():
@@ -121,14 +126,15 @@ def wMSE(y_true, y_pred, binary=False):
     return np.mean(w * np.square(y_true - y_pred))
 
 
-def inspect_data(data):
-    """Guards of multinet.py:43-63: unique cell / gene labels, and raw (not log) counts."""
+def inspect_data(data, _max=None):
+    """Guards of multinet.py:43-63: unique cell / gene labels, and raw (not log) counts (`_max`: the matrix maximum when the
+    caller already holds it)."""
     problems = (("cell", data.index), ("gene", data.columns))
     for what, labels in problems:
         if sum(labels.duplicated()):
             print("ERROR: duplicated {0} labels. Please provide unique {0} labels.".format(what))
             exit(1)
-    top = _hostpar.matrix_max(data.values)
+    top = _hostpar.matrix_max(data.values) if _max is None else _max
     if top < 10:
         print("ERROR: max value = {}. Is your data log-transformed? Please provide raw counts".format(top))
         exit(1)
@@ -177,6 +183,23 @@ def _loss_name(loss):
         return name
     print('Unknown loss: {}. Aborting.'.format(loss))       # multinet.py:160-161 (keras.losses names beyond mse / mae are not implemented)
     exit(1)
+
+
+class _Stages(dict):
+    """Wall time per stage of the last fit() / predict() (extension: MultiNet.timings; bench.py reports it)."""
+
+    def stage(self, name):
+        import contextlib
+        import time
+
+        @contextlib.contextmanager
+        def cm():
+            t0 = time.perf_counter()
+            try:
+                yield
+            finally:
+                self[name] = self.get(name, 0.0) + time.perf_counter() - t0
+        return cm()
 
 
 def _shard_rank(path):
@@ -431,41 +454,75 @@ class MultiNet:
     # -- fit: planning on the host, training on the GPU --
     def fit(self, raw, cell_subset=1, NN_lim=None, genes_to_impute=None, n_pred=None, ntop=5,
             minVMR=0.5, mode='random'):
-        inspect_data(raw)
-        if self.seed is not None:
-            np.random.seed(self.seed)
-        if cell_subset != 1:
-            # fraction below 1, absolute cell count otherwise (the CLI passes a float)
-            raw = raw.sample(frac=cell_subset) if cell_subset < 1 else raw.sample(int(cell_subset))
-
-        # variance over (1 + mean), most variable first, strictly positive (multinet.py:191-192)
-        var, mean = _hostpar.column_var_mean(raw)
-        gene_metric = (var / (1 + mean)).sort_values(ascending=False)
-        gene_metric = gene_metric[gene_metric > 0]
-        if genes_to_impute is None:
-            genes_to_impute = self.filter_genes(gene_metric, minVMR, NN_lim=NN_lim)
+        tm = self.timings = _Stages()
+        # Fast path (a frame of raw counts, one GPU, resident matrix): the first sweep of the gene statistics also yields the matrix
+        # maximum inspect_data() asks for and the candidate pool of the correlation (genes that vary, with a positive mean); the
+        # upload of the counts and the g x g matrix product then run on a helper thread while this thread finishes the statistics
+        # and picks the genes -- every number is the one the plain sequence below computes (checked where a guess is involved).
+        upload, spec_pool, first = None, None, None
+        if cell_subset == 1 and self._counts_path_applies(raw):
+            with tm.stage("fit.gene_statistics"):
+                first = _hostpar.col_stats_first(raw.values)
+        if first is not None:
+            with tm.stage("fit.inspect_data"):
+                inspect_data(raw, _max=first["vmax"])
+            if self.seed is not None:
+                np.random.seed(self.seed)
+            if n_pred is None:
+                spec_pool = np.flatnonzero((first["cmax"] > first["cmin"]) & (first["mean"] > 0)).astype(np.int32)
+            upload = self._start_counts_upload(raw, spec_pool)
+            with tm.stage("fit.gene_statistics"):
+                var = pd.Series(_hostpar.col_stats_var(raw.values, first["avg"]), index=raw.columns)
+                mean = pd.Series(first["mean"], index=raw.columns)
         else:
-            genes_to_impute = self._pad_gene_list(genes_to_impute, gene_metric)
+            upload = self._start_counts_upload(raw) if cell_subset == 1 else (lambda: None)
+            with tm.stage("fit.inspect_data"):
+                inspect_data(raw)
+            if self.seed is not None:
+                np.random.seed(self.seed)
+            if cell_subset != 1:
+                # fraction below 1, absolute cell count otherwise (the CLI passes a float)
+                raw = raw.sample(frac=cell_subset) if cell_subset < 1 else raw.sample(int(cell_subset))
+
+            # variance over (1 + mean), most variable first, strictly positive (multinet.py:191-192)
+            with tm.stage("fit.gene_statistics"):
+                var, mean = _hostpar.column_var_mean(raw)
+        with tm.stage("fit.gene_selection"):
+            gene_metric = (var / (1 + mean)).sort_values(ascending=False)
+            gene_metric = gene_metric[gene_metric > 0]
+            if genes_to_impute is None:
+                genes_to_impute = self.filter_genes(gene_metric, minVMR, NN_lim=NN_lim)
+            else:
+                genes_to_impute = self._pad_gene_list(genes_to_impute, gene_metric)
 
         # setTargets only looks at the column labels; the reference hands it raw.reindex(columns=...),
         # a full copy of the matrix (multinet.py:212) -- `_ColumnsOnly` carries the same labels (even an empty
         # DataFrame with 20k columns costs pandas half a second to build)
-        self.setTargets(_ColumnsOnly(genes_to_impute), mode=mode)
+        with tm.stage("fit.gene_selection"):
+            self.setTargets(_ColumnsOnly(genes_to_impute), mode=mode)
         # get_distance_matrix + setPredictors (multinet.py:211-214; neither draws random numbers, so their order
         # against setTargets is free): fused on the GPU -- the g x g correlation never comes back to the host --
         # whenever a GPU is visible; otherwise, and for the shapes the kernel does not take, the two public
         # functions below run as in the reference.
-        if not (_gpu_visible() and self._set_predictors_device(raw, n_pred, ntop, (var, mean))):
-            correlations = get_distance_matrix(raw, n_pred=n_pred, device_id=self.device_id, _var_mean=(var, mean))
-            self.setPredictors(correlations, ntop=ntop)
+        with tm.stage("fit.counts_upload_wait"):
+            dev_counts = upload()
+        with tm.stage("fit.correlation+predictors"):
+            if not (_gpu_visible() and self._set_predictors_device(raw, n_pred, ntop, (var, mean), counts=dev_counts, corr_pool=spec_pool)):
+                correlations = get_distance_matrix(raw, n_pred=n_pred, device_id=self.device_id, _var_mean=(var, mean))
+                self.setPredictors(correlations, ntop=ntop)
 
         print("Normalization")
-        norm_data = _hostpar.log1p_float32(raw)
+        with tm.stage("fit.log1p"):
+            # with the counts resident, log1p happens on the device (numpy's table); the frame below then only carries the labels
+            norm_data = _hostpar.log1p_float32(raw) if dev_counts is None else _ColumnsOnly(raw.columns, raw.index, raw.shape)
         np.random.seed(self.seed)                      # second seeding, multinet.py:219
 
         print("Building network")
-        self._release_engine()
-        engine, comm, counts = self._build_shard([len(p) for p in self.predictors])
+        with tm.stage("fit.build"):
+            self._release_engine()
+            engine, comm, counts = self._build_shard([len(p) for p in self.predictors])
+        t_split = tm.stage("fit.split")
+        t_split.__enter__()
 
         held_out = np.random.choice(norm_data.index, int(_VALIDATION_FRACTION * norm_data.shape[0]), replace=False)
         # train_cells = np.setdiff1d(index, test_cells) (multinet.py:229) is label-sorted and unique; inspect_data()
@@ -476,19 +533,30 @@ class MultiNet:
         is_train[rows_val] = False
         by_label = np.argsort(norm_data.index.values, kind="stable")
         rows_train = by_label[is_train[by_label]]
+        t_split.__exit__(None, None, None)
 
-        self._bind_columns(engine, norm_data.columns)
-        self._hand_over(engine, norm_data.values, True)
-        engine.set_split(rows_train, rows_val)
-        engine.init_weights(0 if self.seed is None else self.seed)
+        with tm.stage("fit.hand_over"):
+            self._bind_columns(engine, norm_data.columns)
+            if dev_counts is not None and hasattr(engine, "set_matrix_counts"):
+                engine.set_matrix_counts(dev_counts)
+                engine.gather(True)
+                self._resident = (dev_counts, raw.columns)   # predict() of the same frame finds everything in place
+            else:
+                if dev_counts is not None:                   # an engine without the entry point (tests: oracle engines)
+                    dev_counts.close()
+                    dev_counts, norm_data = None, _hostpar.log1p_float32(raw)
+                self._hand_over(engine, norm_data.values, True)
+            engine.set_split(rows_train, rows_val)
+            engine.init_weights(0 if self.seed is None else self.seed)
 
         print("Fitting with {} cells".format(norm_data.shape[0]))
-        if comm.world == 1:
-            epochs, loss_curve, val_curve = engine.fit(self.NN_parameters["max_epochs"], self.NN_parameters["patience"])
-        else:
-            from .sharded import fit_sharded
-            epochs, loss_curve, val_curve = fit_sharded(engine, comm, self.NN_parameters["max_epochs"],
-                                                        self.NN_parameters["patience"])
+        with tm.stage("fit.train"):
+            if comm.world == 1:
+                epochs, loss_curve, val_curve = engine.fit(self.NN_parameters["max_epochs"], self.NN_parameters["patience"])
+            else:
+                from .sharded import fit_sharded
+                epochs, loss_curve, val_curve = fit_sharded(engine, comm, self.NN_parameters["max_epochs"],
+                                                            self.NN_parameters["patience"])
         self.history = {"loss": [float(x) for x in loss_curve], "val_loss": [float(x) for x in val_curve]}
         if self.verbose:
             for i, (a, b) in enumerate(zip(loss_curve, val_curve), start=1):
@@ -498,9 +566,55 @@ class MultiNet:
 
         self._engine = engine
         self._counts = counts
-        self.save(engine)
-        self.test_metrics = self._held_out_metrics(engine, norm_data, held_out, rows_val)
+        with tm.stage("fit.save"):
+            self.save(engine)
+        with tm.stage("fit.held_out_metrics"):
+            self.test_metrics = self._held_out_metrics(engine, norm_data, held_out, rows_val)
+        with tm.stage("fit.free"):
+            del norm_data, var, mean, gene_metric
         return self
+
+    def _counts_path_applies(self, raw):
+        """The resident-counts path is for: one GPU (no sharded / streamed job), the product engine, a C-ordered float64 frame
+        that fits the device (DIMN_RESIDENT_COUNTS=0 switches it off).  Whether the VALUES are counts is decided by the upload."""
+        values = getattr(raw, "values", None)
+        return not (os.environ.get("DIMN_RESIDENT_COUNTS", "1") == "0" or self._comm_spec is not None or self._engine_factory is not None or self.stream_matrix
+                    or not isinstance(values, np.ndarray) or values.dtype != np.float64 or not values.flags.c_contiguous
+                    or values.size * 4 > (32 << 30) or not _gpu_visible())
+
+    def _start_counts_upload(self, raw, corr_pool=None):
+        """Begin uploading raw's counts to the GPU on a helper thread (ctypes releases the GIL) -- and, with `corr_pool`, the
+        |corr| matrix of those columns right behind it -- and return a function that waits for it and gives the
+        _counts.DeviceCounts, or None where the fast path does not apply / the values are not counts."""
+        self._drop_resident()
+        values = getattr(raw, "values", None)
+        if not self._counts_path_applies(raw):
+            return lambda: None
+        import threading
+        from ._counts import DeviceCounts
+        box = {}
+
+        def work():
+            try:
+                box["counts"] = DeviceCounts.try_create(values, self.device_id)
+                if box["counts"] is not None and corr_pool is not None and len(corr_pool) >= 2 and values.shape[0] >= 2:
+                    box["counts"].corr(corr_pool)
+                    box["counts"].corr_ready = True
+            except Exception as exc:                          # the host path takes over; a real failure shows up there
+                box["error"] = exc
+        thread = threading.Thread(target=work, name="dimn-counts-upload")
+        thread.start()
+
+        def wait():
+            thread.join()
+            return box.get("counts")
+        return wait
+
+    def _drop_resident(self):
+        held = getattr(self, "_resident", None)
+        self._resident = None
+        if held is not None:
+            held[0].close()
 
     def _release_engine(self):
         """Close the live communicator (a collective: every rank of a sharded job calls fit/close alike),
@@ -511,6 +625,7 @@ class MultiNet:
         if self._engine is not None:
             self._engine.close()
             self._engine = None
+        self._drop_resident()                           # (after the engine that read them)
 
     def close(self):
         """Extension: release the GPU (and, in a sharded job, the RCCL communicator) now instead of at exit."""
@@ -597,9 +712,38 @@ class MultiNet:
 
     # -- predict: forward on the GPU, post-processing as multinet.py:282-310 --
     def predict(self, raw, imputed_only=False, policy="restore"):
-        engine = self.load()
-        self._bind_columns(engine, raw.columns)
-        self._hand_over(engine, _hostpar.log1p_float32(raw).values, False)     # float32(log1p(raw)): what Keras is fed
+        tm = self.timings = _Stages(getattr(self, "timings", None) or {})
+        for key in [k for k in tm if k.startswith("predict.")]:
+            del tm[key]
+        with tm.stage("predict.load"):
+            engine = self.load()
+        # The counts of this very frame may still be on the GPU from fit() (verified bit for bit by a checksum pass), or go there
+        # now in one upload; the engine then takes log1p, the forward pass and the restore / max step from that one copy.
+        resident = None
+        with tm.stage("predict.counts"):
+            held = getattr(self, "_resident", None)
+            values = getattr(raw, "values", None)
+            if held is not None and getattr(engine, "_dev_counts", None) is held[0] and raw.columns.equals(held[1]) and held[0].matches(values):
+                resident = held[0]                       # same cells, same columns, same numbers: X_k is already gathered
+            else:
+                wait = self._start_counts_upload(raw) if hasattr(engine, "set_matrix_counts") else (lambda: None)
+                fresh = wait()
+                if fresh is not None:
+                    self._bind_columns(engine, raw.columns)
+                    engine.set_matrix_counts(fresh)
+                    engine.gather(False)
+                    self._resident = (fresh, raw.columns)
+                    resident = fresh
+        if resident is None:
+            self._bind_columns(engine, raw.columns)
+            with tm.stage("predict.log1p"):
+                norm = _hostpar.log1p_float32(raw).values                          # float32(log1p(raw)): what Keras is fed
+            with tm.stage("predict.hand_over"):
+                self._hand_over(engine, norm, False)
+            with tm.stage("predict.free"):
+                del norm                                                           # (4 GB at 50k x 20k: unmapping it is not free)
+        t_plan = tm.stage("predict.plan")
+        t_plan.__enter__()
         # a gene may occupy several target slots: average them; the averaged columns are label-sorted,
         # like the reference's groupby(columns).mean() (multinet.py:282-284)
         slots = self.targets.flatten()
@@ -610,9 +754,13 @@ class MultiNet:
         elif policy == "max":
             print("Imputing data with 'max' policy")
         observed = raw.values
-        ceiling = 2 * np.log1p(_hostpar.matrix_max(observed))    # overflow guard, multinet.py:292 (log1p is monotonic)
+        t_plan.__exit__(None, None, None)
+        with tm.stage("predict.matrix_max"):
+            top = resident.vmax if resident is not None else _hostpar.matrix_max(observed)
+            ceiling = 2 * np.log1p(top)                               # overflow guard, multinet.py:292 (log1p is monotonic)
 
-        values = self._finish_on_device(engine, observed, where[slot_gene], policy, ceiling)
+        with tm.stage("predict.forward+finish"):
+            values = self._finish_on_device(engine, observed, where[slot_gene], policy, ceiling, resident=resident is not None)
         if values is False:
             return None                                  # sharded job: rank 0 returns the frame
         if values is None:                               # engines without the device epilogue (tests: oracle / fake engines)
@@ -620,10 +768,11 @@ class MultiNet:
             if block is None:
                 return None
             values = self._finish_on_host(block, observed, slot_gene, len(genes), where, policy, ceiling)
-        imputed = pd.DataFrame(values, index=raw.index, columns=raw.columns)
-        return imputed.loc[:, genes] if imputed_only else imputed
+        with tm.stage("predict.frame"):
+            imputed = pd.DataFrame(values, index=raw.index, columns=raw.columns)
+            return imputed.loc[:, genes] if imputed_only else imputed
 
-    def _finish_on_device(self, engine, observed, slot_col, policy, ceiling):
+    def _finish_on_device(self, engine, observed, slot_col, policy, ceiling, resident=False):
         """predict()'s post-processing as the device epilogue dimn_impute_finish (multinet.py:282-305): the K*O network
         outputs never come to the host, only the finished [cells, genes] float64 frame does.  None: this engine has no
         such epilogue (the host path runs); False: sharded job, this rank is not the root."""
@@ -641,6 +790,8 @@ class MultiNet:
             engine.comm_gather_predictions(engine.n_cells, self._counts, root=0, is_root=False)   # stays in root's HBM
             if comm.rank != 0:
                 return False
+        if resident:                                     # the observed counts are the engine's resident matrix: nothing to upload
+            return engine.impute_finish(None, gene_off, order, policy, ceiling, from_gathered=sharded)
         return engine.impute_finish(_hostpar.as_float64(observed), gene_off, order, policy, ceiling, from_gathered=sharded)
 
     def _finish_on_host(self, block, observed, slot_gene, n_genes, where, policy, ceiling):
@@ -700,7 +851,7 @@ class MultiNet:
         else:
             self.targets = np.random.choice(data.columns, shape, replace=False)
 
-    def _set_predictors_device(self, raw, n_pred, ntop, var_mean):
+    def _set_predictors_device(self, raw, n_pred, ntop, var_mean, counts=None, corr_pool=None):
         """get_distance_matrix + setPredictors as ONE device job (dimn_select_predictors: fp64-MFMA |corr| of the
         candidate genes, then a top-`ntop` select per target over the resident matrix; multinet.py:20-34, 344-365).
         Same predictor lists as setPredictors() -- |corr| descending, ties in label order, first-occurrence unique --
@@ -709,8 +860,8 @@ class MultiNet:
         whose targets cover the whole pool (the reference's warning path)."""
         if ntop > 16:
             return False
-        pool, values = _candidate_pool(raw, n_pred, var_mean)
-        if not pool.is_unique or values.shape[0] < 2:
+        pool, values = _candidate_pool(raw, n_pred, var_mean, labels_only=counts is not None)
+        if not pool.is_unique or raw.shape[0] < 2:
             return False
         targets = np.asarray(self.targets)
         K, O = targets.shape
@@ -724,12 +875,19 @@ class MultiNet:
         fns = _lib.load()
         rank = np.empty(len(pool), np.int32)
         rank[np.argsort(pool.values, kind="stable")] = np.arange(len(pool), dtype=np.int32)
-        x = _hostpar.as_float64(values)
-        picks = np.empty((K, O, ntop), np.int32)
-        rc = fns["select_predictors"](int(self.device_id), _cabi.p_f64(x), x.shape[0], x.shape[1], _cabi.p_i32(rows), K, O,
-                                      _cabi.p_i32(rank), int(ntop), _cabi.p_i32(picks))
-        if rc != 0:
-            raise RuntimeError("dimn_select_predictors: " + fns["last_error"]().decode("utf-8", "replace"))
+        if counts is not None:                       # the candidate columns are read from the resident counts: no 8 GB upload
+            pool_cols = raw.columns.get_indexer(pool).astype(np.int32)
+            if corr_pool is not None and getattr(counts, "corr_ready", False) and np.array_equal(pool_cols, corr_pool):
+                picks = counts.topk(rows, rank, ntop)          # the matrix product ran beside the gene statistics, over exactly this pool
+            else:
+                picks = counts.select_predictors(pool_cols, rows, rank, ntop)
+        else:
+            x = _hostpar.as_float64(values)
+            picks = np.empty((K, O, ntop), np.int32)
+            rc = fns["select_predictors"](int(self.device_id), _cabi.p_f64(x), x.shape[0], x.shape[1], _cabi.p_i32(rows), K, O,
+                                          _cabi.p_i32(rank), int(ntop), _cabi.p_i32(picks))
+            if rc != 0:
+                raise RuntimeError("dimn_select_predictors: " + fns["last_error"]().decode("utf-8", "replace"))
         self.predictors = []
         for net in range(K):
             flat = picks[net].reshape(-1)

@@ -198,7 +198,8 @@ int dimn_predict_device(dimn_handle h, const int32_t* rows, int64_t n_rows, void
  * (from_gathered != 0: over root's gathered matrix of dimn_comm_gather_predictions): per output gene the mean of its
  * target slots (float32, slot order), genes without a slot keep log1p(raw); values above `ceiling`
  * (2 * max log1p(raw), multinet.py:292) or NaN -> 0; expm1; policy 1 "restore" / 2 "max" / 0 none against raw.
- *   raw        host [n_rows][g] float64 (the observed counts, columns in output order), streamed in by row blocks
+ *   raw        host [n_rows][g] float64 (the observed counts, columns in output order), streamed in by row blocks;
+ *              NULL: the resident counts of dimn_set_matrix_counts (same cells, same columns)
  *   gene_off   [g+1], gene_slot [gene_off[g]]: the prediction slots (columns of np.hstack(predicted)) of every gene
  *   out        host [n_rows][g] float64, streamed out by row blocks (pinned bounce buffers, copies overlap the kernel)
  */
@@ -287,6 +288,43 @@ int dimn_csv_read(const char* path, int64_t n_rows, int64_t n_cols, int64_t* val
  * exponent is < -4 or >= 16), NaN -> "", labels NUL-separated; byte-identical to DataFrame.to_csv for unquoted labels. */
 int dimn_csv_write(const char* path, const double* values, int64_t n_rows, int64_t n_cols, const char* index_name,
                    const char* col_labels, const char* row_labels);
+
+/* ---- the raw count matrix resident on the device (extension of the drop-in; the reference passes the same frame through numpy
+ * four times: multinet.py:191 var / mean, :20-34 corrcoef, :216 log1p, :292-303 restore).  ABI 5. ----------
+ * dimn_counts_create: raw host [n][g] float64 -> device float32, uploaded ONCE through pinned buffers; every value must be a
+ *   non-negative integer <= 2^22 (exact in float32), else DIMN_ERR_UNSUP and the caller keeps the host path.  *vmax = the matrix
+ *   maximum (multinet.py:55, :292), *checksum = a position-dependent 64-bit sum of the float64 bit patterns (dimn_counts_checksum
+ *   recomputes it from a host frame: "is this the frame that was uploaded?").
+ * dimn_counts_select_predictors: dimn_select_predictors with X = columns pool_cols[pool_n] of the resident matrix (converted to
+ *   float64 on the device: same numbers, no 8 GB upload).
+ * dimn_set_matrix_counts: replaces dimn_set_matrix: norm = lut[count], lut[v] = float32(log1p(v)) for v = 0 .. lut_n - 1 as the
+ *   CALLER computed it (numpy on the host: bit-identical to np.log1p(raw).astype(float32), multinet.py:216-217); the handle
+ *   remembers the counts, and dimn_impute_finish(raw = NULL) then takes the observed values from them.  The counts object must
+ *   outlive every handle bound to it. */
+typedef struct dimn_counts_s* dimn_counts;
+int dimn_counts_create(int32_t device_id, const double* raw, int64_t n, int64_t g, double* vmax, uint64_t* checksum, dimn_counts* out);
+int dimn_counts_checksum(const double* raw, int64_t n, int64_t g, uint64_t* checksum);
+int dimn_counts_destroy(dimn_counts c);
+int dimn_counts_select_predictors(dimn_counts c, const int32_t* pool_cols, int64_t pool_n, const int32_t* targ_pos, int32_t K, int32_t O,
+                                  const int32_t* col_rank, int32_t ntop, int32_t* out_idx);
+/* the same selection as two calls (the matrix product needs only the candidate pool, so it can run while the host still ranks
+ * genes): dimn_counts_corr leaves |corr| of the pool on the device, dimn_counts_topk selects from it and frees it */
+int dimn_counts_corr(dimn_counts c, const int32_t* pool_cols, int64_t pool_n);
+int dimn_counts_topk(dimn_counts c, const int32_t* targ_pos, int32_t K, int32_t O, const int32_t* col_rank, int32_t ntop, int32_t* out_idx);
+int dimn_set_matrix_counts(dimn_handle h, dimn_counts c, const float* lut, int64_t lut_n);
+
+/* ---- the per-gene statistics fit() orders genes by (multinet.py:191 `raw.var() / (1 + raw.mean())`), host code ----------
+ * mean[g], var[g] (ddof 1; NULL: skipped) of the columns of a[n][ld] in pandas' own order of operations (two sequential sums
+ * over the rows per column, no fused multiply-add: bit-identical to DataFrame.mean() / .var() on a NaN-free float64 frame),
+ * *vmax = the matrix maximum (multinet.py:292), *has_nan != 0: a NaN was seen (the caller then uses pandas: skipna).
+ * threads <= 0: up to 64.  ABI 5. */
+int dimn_col_stats(const double* a, int64_t n, int64_t g, int64_t ld, double* mean, double* var, double* vmax,
+                   int32_t* has_nan, int32_t threads);
+/* the same numbers as two calls, so that other work can run between the two sweeps over the matrix: first mean[g], nanvar's own
+ * average avg[g], the per-column minimum / maximum, the matrix maximum and the NaN flag; then var[g] from those averages */
+int dimn_col_stats_first(const double* a, int64_t n, int64_t g, int64_t ld, double* mean, double* avg, double* cmin, double* cmax,
+                         double* vmax, int32_t* has_nan, int32_t threads);
+int dimn_col_stats_var(const double* a, int64_t n, int64_t g, int64_t ld, const double* avg, double* var, int32_t threads);
 
 #ifdef __cplusplus
 }

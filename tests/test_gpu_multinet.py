@@ -157,3 +157,42 @@ def test_cli_with_batch_128_and_hidden_512(tmp_path):
     assert out.shape == raw.shape and np.isfinite(out.values).all()
     pos = raw.values > 0
     assert np.array_equal(out.values[pos], raw.values[pos])
+
+
+def test_resident_counts_path_equals_host_path(tmp_path, monkeypatch):
+    """fit() / predict() with the raw counts uploaded ONCE and read in place on the GPU (correlation, log1p through numpy's
+    table, restore against the observed counts) must give, bit for bit, what the host path gives -- same predictor lists, same
+    training history, same imputed frame -- for the frame that was fitted (found resident again by its checksum), for another
+    frame (uploaded afresh), for a frame edited in place after fit (the checksum notices), and it must step aside for data
+    that are not counts."""
+    from deepimpute_amd.multinet import MultiNet
+    raw = _raw(n=260, g=520, seed=3)
+    kw = dict(sub_outputdim=64, seed=11, ncores=1, verbose=0, max_epochs=4, patience=10, learning_rate=1e-3)
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DIMN_RESIDENT_COUNTS", mode)
+        net = MultiNet(output_prefix=str(tmp_path / mode), **kw).fit(raw, NN_lim=200)
+        assert (getattr(net, "_resident", None) is not None) == (mode == "1")
+        same = net.predict(raw)
+        used_resident = "predict.log1p" not in net.timings
+        assert used_resident == (mode == "1")
+        other = raw.iloc[::-1].copy()                                   # another frame: same genes, cells in reverse order
+        flipped = net.predict(other, policy="max")
+        edited = raw.copy()
+        edited.iloc[5, 7] += 3.0
+        after_edit = net.predict(edited)
+        runs[mode] = (net.predictors, net.history, same, flipped, after_edit, net.test_metrics)
+        net.close()
+    a, b = runs["1"], runs["0"]
+    assert len(a[0]) == len(b[0]) and all(list(x) == list(y) for x, y in zip(a[0], b[0]))
+    assert a[1] == b[1]
+    for i in (2, 3, 4):
+        assert a[i].index.equals(b[i].index) and np.array_equal(a[i].values, b[i].values), i
+    assert a[5] == b[5]
+    assert a[4].iloc[5, 7] == raw.iloc[5, 7] + 3.0                     # the edited count was restored, not the stale resident one
+    # not counts: the upload declines, the host path runs
+    monkeypatch.setenv("DIMN_RESIDENT_COUNTS", "1")
+    scaled = raw * 1.5
+    net = MultiNet(output_prefix=str(tmp_path / "s"), **kw).fit(scaled, NN_lim=200)
+    assert getattr(net, "_resident", None) is None and np.isfinite(net.predict(scaled).values).all()
+    net.close()

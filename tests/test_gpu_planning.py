@@ -17,7 +17,7 @@ def test_device_predictor_selection_matches_reference_capture(name, tmp_path, mo
     raw = shell._raw(name)
     used = []
     real = MultiNet._set_predictors_device
-    monkeypatch.setattr(MultiNet, "_set_predictors_device", lambda self, *a: used.append(real(self, *a)) or used[-1])
+    monkeypatch.setattr(MultiNet, "_set_predictors_device", lambda self, *a, **k: used.append(real(self, *a, **k)) or used[-1])
     net = MultiNet(output_prefix=str(tmp_path), engine_factory=shell.FakeEngine, **meta["ctor"])
     net.fit(raw, **dict(meta["fit"]))
     assert used == [True], "the fused device selection did not run"
@@ -67,14 +67,14 @@ def test_device_postprocessing_matches_host_path(name, tmp_path, monkeypatch):
     used = []
     real = MultiNet._finish_on_device
 
-    def spy(self, *a):
-        used.append(real(self, *a))
+    def spy(self, *a, **k):
+        used.append(real(self, *a, **k))
         return used[-1]
     for policy in ("restore", "max", None):
         monkeypatch.setattr(MultiNet, "_finish_on_device", spy)
         dev = net.predict(raw, policy=policy)
         assert used and used[-1] is not None and used[-1] is not False
-        monkeypatch.setattr(MultiNet, "_finish_on_device", lambda self, *a: None)
+        monkeypatch.setattr(MultiNet, "_finish_on_device", lambda self, *a, **k: None)
         host = net.predict(raw, policy=policy)
         assert list(dev.columns) == list(host.columns) and list(dev.index) == list(host.index)
         a, b = dev.values, host.values

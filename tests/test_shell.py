@@ -267,3 +267,26 @@ def test_predict_row_blocks_do_not_change_the_result(monkeypatch):
     monkeypatch.setenv("DIMN_HOST_THREADS", "3")
     for p, want in whole.items():
         assert np.array_equal(net.predict(raw, policy=p).values, want, equal_nan=True)
+
+
+@pytest.mark.parametrize("kind", ["counts", "real"])
+def test_native_gene_statistics_are_pandas_to_the_bit(kind):
+    """fit() orders the genes by raw.var() / (1 + raw.mean()) (reference multinet.py:191): libdimn's threaded host routine
+    (dimn_col_stats) must give pandas' numbers to the bit -- mean as a sequential sum over the rows, var as nanvar computes it
+    (its own pairwise-summed average, pairwise-summed squared deviations, numpy's 8192-element chunks) -- for row counts on
+    both sides of every block boundary of numpy's pairwise summation; a NaN sends the call back to pandas."""
+    from deepimpute_amd import _hostpar
+    rng = np.random.default_rng(5)
+    for n, g in ((2, 5), (7, 3), (8, 3), (129, 70), (1024, 64), (5000, 130), (8192, 9), (8193, 64), (20011, 33)):
+        a = rng.poisson(rng.gamma(2.0, 1.5, size=(n, g))).astype(np.float64) if kind == "counts" else rng.normal(size=(n, g)) * 1e3 + 5
+        raw = pd.DataFrame(a, columns=["g%d" % j for j in range(g)])
+        assert _hostpar._native_col_stats(raw.values) is not None            # the native routine is what runs
+        var, mean = _hostpar.column_var_mean(raw)
+        assert np.array_equal(var.values, raw.var().values), (n, g)
+        assert np.array_equal(mean.values, raw.mean().values), (n, g)
+        assert var.index.equals(raw.columns) and mean.index.equals(raw.columns)
+        assert _hostpar.matrix_max(raw.values) == raw.values.max()
+    raw.iloc[3, 2] = np.nan
+    assert _hostpar._native_col_stats(raw.values) is None
+    var, mean = _hostpar.column_var_mean(raw)
+    assert np.array_equal(var.values, raw.var().values) and np.array_equal(mean.values, raw.mean().values)
