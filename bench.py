@@ -309,6 +309,7 @@ def cpu_baseline(cfg, targets, preds, norm, train, val, epochs, lr, budget_s=20.
 
     rows_of = lambda i: (np.arange(B, dtype=np.int32) + (i * B) % (n_sample - B)).astype(np.int32)
     best = None
+    tried = []                # every configuration that was timed: threads used -> extrapolated cells/s (all physical cores is one of them)
     # --- BLAS port, small search over (concurrent sub-nets) x (BLAS threads) ---
     try:
         from threadpoolctl import threadpool_limits
@@ -324,6 +325,7 @@ def cpu_baseline(cfg, targets, preds, norm, train, val, epochs, lr, budget_s=20.
                 t_step, cnt = timed_steps(lambda i: port.train_step(rows_of(i)), budget_s * 0.15)
                 t0 = time.time(); port.predict(np.arange(512)); t_row = (time.time() - t0) / 512
             notes.append("np_port[blas=%d x pool=%d]: %.4f s/step, %.2e s/row" % (blas, min(K, cores), t_step, t_row))
+            tried.append({"port": "np_port", "threads": blas * min(K, cores), "cells_per_s": n / (epochs * (steps_per_epoch * t_step + val.size * t_row) + n * t_row)})
             if best is None or t_step < best[0]:
                 best = (t_step, t_row, "oracle/np_port.py (OpenBLAS, %d BLAS threads x %d concurrent sub-nets)" % (blas, min(K, cores)), cnt,
                         blas * min(K, cores))
@@ -345,6 +347,7 @@ def cpu_baseline(cfg, targets, preds, norm, train, val, epochs, lr, budget_s=20.
         t_step, cnt = timed_steps(lambda i: eng.train_step(rows_of(i), epoch_key=0, step_key=i), budget_s * 0.3)
         t0 = time.time(); eng.predict(np.arange(256, dtype=np.int32)); t_row = (time.time() - t0) / 256
         notes.append("dimo.c[OpenMP %d threads]: %.4f s/step, %.2e s/row" % (cores, t_step, t_row))
+        tried.append({"port": "dimo.c", "threads": cores, "cells_per_s": n / (epochs * (steps_per_epoch * t_step + val.size * t_row) + n * t_row)})
         if best is None or t_step < best[0]:
             best = (t_step, t_row, "oracle/dimo.c (OpenMP, %d threads)" % cores, cnt, cores)
         eng.close()
@@ -356,7 +359,11 @@ def cpu_baseline(cfg, targets, preds, norm, train, val, epochs, lr, budget_s=20.
         raise RuntimeError("; ".join(notes))
     t_step, t_row, which, cnt, threads = best
     t_full = epochs * (steps_per_epoch * t_step + val.size * t_row) + n * t_row
+    most = max(tried, key=lambda r: (r["threads"], r["cells_per_s"]))
     return {"value": n / t_full, "unit": "cells/s", "cores": min(threads, cores), "kind": "port", "host_threads_available": cores,
+            "all_cores": {"value": most["cells_per_s"], "threads": most["threads"], "port": most["port"],
+                          "note": "the configuration that used the most host threads (BASELINE.md section 3); `value` is the fastest configuration"},
+            "configurations": tried,
             "sample": "%s: %d train steps at %.4f s/step + forward at %.2e s/row on a %d-cell sample, extrapolated to "
                       "%d epochs x %d steps + validation + predict of %d cells. All timings: %s"
                       % (which, cnt, t_step, t_row, n_sample, epochs, steps_per_epoch, n, "; ".join(notes))}
@@ -378,10 +385,44 @@ def dropin_run(norm, epochs):
         out = net.predict(raw)
         t2 = time.perf_counter()
     assert out.shape == raw.shape and net.trained_epochs == epochs
+    metrics = {k: float(v) for k, v in (net.test_metrics or {}).items()}      # multinet.py:251-262: Pearson r / MSE on the held-out cells' positive targets
+    stages = {k: round(float(v), 4) for k, v in getattr(net, "timings", {}).items()}
     net.close()
     return {"fit_s": t1 - t0, "predict_s": t2 - t1, "cells_per_s": n / (t2 - t0), "subnets": len(net.predictors), "epochs": int(net.trained_epochs),
+            "test_metrics": metrics, "stages_s": stages,
             "note": "MultiNet.fit + predict on the same matrix as raw counts: host planning, host<->device copies of the counts and of the "
                     "imputed frame included"}
+
+
+def accuracy_pair(cfg, targets, preds, norm, epochs, lr, n_cells=1536, n_subnets=2):
+    """The accuracy half of the metric ("MSE vs ref"): the held-out metrics fit() reports (multinet.py:251-262: Pearson r and MSE
+    between the validation cells' positive target values and their predictions) after the SAME E epochs on the SAME problem --
+    the first `n_subnets` sub-nets over the first `n_cells` cells, 5 % held out, same seeds -- from the HIP engine and from the
+    CPU port (oracle/dimo.c, the restatement of the reference's Keras path).  Outside the timed region."""
+    from deepimpute_amd.engine import HipEngine
+    from oracle.dimo import OracleEngine
+    sub = np.ascontiguousarray(norm[:n_cells])
+    train, val = split_rows(n_cells, seed=0)
+    t_sub, p_sub = targets[:n_subnets], preds[:n_subnets]
+    out = {}
+    for name, cls in (("hip", HipEngine), ("cpu_port", OracleEngine)):
+        t0 = time.time()
+        eng = make_engine(cls, cfg, t_sub, p_sub, sub, train, val, [n_subnets], [0], 0, 0, lr)
+        eng.gather(True)
+        eng.init_weights()
+        for e in range(epochs):
+            eng.train_epoch(e)
+        vl = float(np.sum(eng.val_loss()))
+        guess = eng.predict(val).reshape(-1).astype(np.float64)
+        truth = np.hstack([sub[np.ix_(val, t_sub[k])] for k in range(n_subnets)]).reshape(-1).astype(np.float64)
+        pos = truth > 0
+        truth, guess = truth[pos], guess[pos]
+        out[name] = {"correlation": float(np.corrcoef(truth, guess)[0, 1]), "MSE": float(np.mean((truth - guess) ** 2)), "val_loss": vl,
+                     "seconds": time.time() - t0}
+        eng.close()
+    out["relative_difference"] = {k: abs(out["hip"][k] - out["cpu_port"][k]) / abs(out["cpu_port"][k]) for k in ("correlation", "MSE", "val_loss")}
+    out["sample"] = "%d sub-nets x %d cells (5 %% held out), %d epochs, same seeds / Philox streams on both" % (n_subnets, n_cells, epochs)
+    return out
 
 
 def main():
@@ -394,6 +435,7 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in MultiNet.fit+predict run (config.dropin)")
+    ap.add_argument("--no-accuracy", action="store_true", help="skip the HIP vs CPU-port held-out metrics after E epochs on a sub-problem (accuracy)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--limit-subnets", type=int, default=0, help="diagnostic: keep only the first N sub-nets (what one rank of an N-GPU job sees)")
     ap.add_argument("--hidden", type=int, default=0, help="diagnostic: hidden width (default: the config's 256; the reference CLI defaults to 300)")
@@ -577,6 +619,11 @@ def main():
             result["config"]["dropin"] = dropin_run(norm, args.epochs)
         except Exception as e:
             result["config"]["dropin"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_accuracy and not args.no_cpu_baseline and not args.limit_subnets and not args.hidden and args.precision == "fp32":
+        try:
+            result["accuracy"] = accuracy_pair(cfg, targets, preds, norm, args.epochs, args.lr)
+        except Exception as e:
+            result["accuracy"] = {"error": repr(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

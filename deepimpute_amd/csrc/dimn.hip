@@ -986,8 +986,19 @@ static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, f
     if (h->predict_bf16) {                         // bf16 matrix cores (precision bf16): fresh bf16 images of the weights, then the forward
         hipLaunchKernelGGL(k_prep_bf16, dim3(256, (unsigned)h->K), dim3(256), 0, h->stream, h->d_sn, (const float*)h->d_W1, (const float*)h->d_W2,
                            h->d_W1b, h->d_W2t, h->dm);
+        if (h->dm.Hp <= 256 && !(getenv("DIMN_PREDICT_R2") && atoi(getenv("DIMN_PREDICT_R2")) != 0)) {
+            // 128 rows per workgroup, 32-deep bf16 matrix instructions, X staged through LDS (dimn_kernels.h); loss slots stay 64-row tiles
+            const unsigned tiles128 = (unsigned)((n_rows + DIMN_PB_M - 1) / DIMN_PB_M);
+            const int hq = (h->dm.Hp + 31) & ~31;
+            const size_t ldsb = std::max<size_t>((size_t)2 * DIMN_PB_M * DIMN_PB_XLD * 2, (size_t)DIMN_PB_M * (hq + 8) * 2) + 64;
+            (void)hipFuncSetAttribute((const void*)k_predict_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+            hipLaunchKernelGGL(k_predict_bf16, dim3(tiles128, (unsigned)h->K), dim3(256), ldsb, h->stream, h->d_sn, (const bf16_t*)h->d_X, (const bf16_t*)h->d_W1b,
+                               (const float*)h->d_b1, (const bf16_t*)h->d_W2t, (const float*)h->d_b2, rows, n_rows, out, (const float*)h->d_Y, h->n, loss_part,
+                               (int64_t)tiles, h->dm, h->cfg.loss_binary, h->act);
+            return;
+        }
         const size_t ldsb = (size_t)DIMN_TB * (h->dm.Hp + 4) * 2 + 16;
-        hipLaunchKernelGGL(k_predict_bf16<NT>, dim3(tiles, (unsigned)h->K), dim3(256), ldsb, h->stream, h->d_sn, (const bf16_t*)h->d_X, (const bf16_t*)h->d_W1b,
+        hipLaunchKernelGGL(k_predict_bf16_r2<NT>, dim3(tiles, (unsigned)h->K), dim3(256), ldsb, h->stream, h->d_sn, (const bf16_t*)h->d_X, (const bf16_t*)h->d_W1b,
                            (const float*)h->d_b1, (const bf16_t*)h->d_W2t, (const float*)h->d_b2, rows, n_rows, out, (const float*)h->d_Y, h->n, loss_part, h->dm,
                            h->cfg.loss_binary, h->act);
         return;

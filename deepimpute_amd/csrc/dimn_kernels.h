@@ -1933,8 +1933,276 @@ __global__ __launch_bounds__(256) void k_prep_bf16(const SubnetDev* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// model.predict / the validation pass on the bf16 matrix cores (precision bf16), round 3: 128 rows per workgroup, both GEMMs on
+// v_mfma_f32_16x16x32_bf16 (32-deep: half the instructions and operand fetches per flop of the 16-deep form).
+//   * 4 waves; wave w owns hidden columns [64w, 64w + 64) of the first layer for all 128 rows (8 x 4 accumulator tiles) and, in
+//     the second layer, four output tiles per pass -- 32 matrix instructions per 32-deep step against 8 LDS reads (A) and four
+//     16-byte global loads (B, from the bf16 weight images in L2).  Round 2's kernel (64 rows, 16-deep, every operand an 8-byte
+//     global load) issued one vector-memory instruction per matrix instruction: 215 TFLOP/s, VMEM-issue bound.
+//   * X tile [128][32] of every step staged ONCE per workgroup through a double-buffered LDS ring (two 16-byte pieces per thread,
+//     requested one step ahead); the hidden activations [128][Hp] are rounded to bf16 into the same LDS (aliasing the ring).
+//   * A lane's eight k's of an operand are eight CONSECUTIVE k's on both operands -- which of the 32 k's of the instruction they
+//     occupy does not matter for a dot product (the k-slot argument of this file), so no layout of the 32-deep instruction is
+//     assumed beyond "A and B use the same one".
+// W1b: bf16 image of the chunk-blocked W1 ([Dp/16][Hp][16]); W2t: bf16 [Op][Hp] (k_prep_bf16).  loss_part: [K][lp_stride]
+// slots of 64-row tiles (the host sums them); a 128-row workgroup fills two.
+// ---------------------------------------------------------------------------------------
+typedef __bf16 bf16x8n __attribute__((ext_vector_type(8)));
+#define DIMN_PB_M 128
+#define DIMN_PB_XLD 40                 // bf16 per staged X row: 32 + 8 of padding (80 bytes)
+#ifndef DIMN_PB_NT
+#define DIMN_PB_NT 0        // plain 16-byte stores: 5.82 vs 6.04 ms with non-temporal ones
+#endif
+#if DIMN_PB_NT
+#define DIMN_PB_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define DIMN_PB_STORE(p, v) (*(p) = (v))
+#endif
+#ifndef DIMN_PB_WPS
+#define DIMN_PB_WPS 2
+#endif
+__global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetDev* __restrict__ sn, const bf16_t* __restrict__ X,
+                                                         const bf16_t* __restrict__ W1b, const float* __restrict__ b1,
+                                                         const bf16_t* __restrict__ W2t, const float* __restrict__ b2,
+                                                         const int32_t* __restrict__ rows, int64_t n_rows,
+                                                         float* __restrict__ out, const float* __restrict__ Y, int64_t n_cells,
+                                                         float* __restrict__ loss_part, int64_t lp_stride, Dims dm, int loss_binary, int act) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pl_lds[];
+    bf16_t* xs = (bf16_t*)pl_lds;                                // X ring [2][128][XLD]                       20 480 B
+    bf16_t* ddl = (bf16_t*)pl_lds;                               // hidden activations [128][ld2] (aliases the ring once the first layer is done)
+    const int Hp = dm.Hp, Hq = (Hp + 31) & ~31;                  // hidden width padded to whole 32-deep steps
+    const int ld2 = Hq + 8;
+    float* redl = (float*)(pl_lds + (size_t)DIMN_PB_M * ld2 * 2);   // [4] loss partials
+    const int k = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * DIMN_PB_M;
+    const SubnetDev s = sn[k];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+    // ---- first layer: A = X W1 over 32-deep steps ----
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = zero4;
+    const int nsteps = (s.nchunk + 1) >> 1;
+    // staging: 512 pieces of 16 bytes (row p >> 2, quarter p & 3), two per thread
+    const bf16_t* xp[2];
+    int xdst[2], xq[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int p = tid + 256 * e, row = p >> 2, q = p & 3;
+        const int64_t i = r0 + row;
+        const int64_t src = i < n_rows ? (rows ? (int64_t)rows[i] : i) : 0;           // rows past the end read row 0 and are dropped
+        xp[e] = X + s.xoff + src * s.Dp;
+        xdst[e] = row * DIMN_PB_XLD + 8 * q;
+        xq[e] = q;
+    }
+    auto xload = [&](int step, u32x4v (&xr)[2]) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int c = 2 * step + (xq[e] >> 1);
+            c = c < s.nchunk ? c : s.nchunk - 1;                                       // an odd chunk count: the second half of the last step re-reads the
+            xr[e] = *(const u32x4v*)(xp[e] + 16 * c + 8 * (xq[e] & 1));                // last chunk (its W1 operand is zeroed below)
+        }
+    };
+    // W1 operand of column tile ct at a step: eight consecutive d's of hidden unit h = 64 wave + 16 ct + li from chunk 2 step + (lj >> 1)
+    const int64_t cstride = (int64_t)Hp * 16;
+    const bf16_t* wb[4];
+    bool hv[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int h = 64 * wave + 16 * ct + li;
+        hv[ct] = h < Hp;
+        wb[ct] = W1b + s.w1off + (int64_t)(hv[ct] ? h : 0) * 16 + 8 * (lj & 1);
+    }
+    // (no masking of the W1 operands: a loaded value consumed at once would pin the wait for it right behind the request.  A hidden
+    //  column beyond Hp only produces accumulators the epilogue discards; the half step beyond an odd chunk count is zeroed on
+    //  the X side, where the value is touched anyway when it goes to LDS)
+    auto bload = [&](int step, u32x4v (&b)[4]) {
+        int c = 2 * step + (lj >> 1);
+        c = c < s.nchunk ? c : s.nchunk - 1;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) b[ct] = *(const u32x4v*)(wb[ct] + c * cstride);
+    };
+    auto xstore = [&](int step, int buf, const u32x4v (&xr)[2]) {     // the pieces of `step` -> ring buffer `buf`; chunks past the sub-net's last one as zeros
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const unsigned m = (2 * step + (xq[e] >> 1)) < s.nchunk ? 0xffffffffu : 0u;
+            *(u32x4v*)(xs + buf * DIMN_PB_M * DIMN_PB_XLD + xdst[e]) = (u32x4v){xr[e][0] & m, xr[e][1] & m, xr[e][2] & m, xr[e][3] & m};
+        }
+    };
+    auto mma1 = [&](const bf16_t* xt, const u32x4v (&b)[4]) {
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt) {
+            const bf16x8n a = *(const bf16x8n*)(xt + (16 * rt + li) * DIMN_PB_XLD + 8 * lj);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8n, b[ct]), acc[rt][ct], 0, 0, 0);
+        }
+    };
+    {
+        // Software pipeline: the W1 operands of step s+2 and the X pieces of step s+3 are requested while step s computes -- three
+        // named sets each, the loop unrolled by three so that every set index is a constant (a rotated or run-time-indexed set
+        // would be a register copy that waits for the load, or scratch).  One step = 32 matrix instructions (~0.4 us for the two
+        // co-resident workgroups of a SIMD): one step of distance does not cover even an L2 round trip (measured: the first
+        // matrix instruction of every step waited for its operand), an X row piece comes from HBM.  The W1 requests go first:
+        // waits are in order, and the W1 operand of step s must not queue behind the X pieces requested with it.
+        u32x4v XR[3][2], BR[3][4];
+        const int last = nsteps - 1;
+        auto clampi = [&](int v) { return v < last ? v : last; };
+        bload(0, BR[0]); bload(clampi(1), BR[1]);
+        xload(0, XR[0]); xload(clampi(1), XR[1]); xload(clampi(2), XR[2]);
+        xstore(0, 0, XR[0]);
+        __syncthreads();
+#ifndef DIMN_PB_ABL
+#define DIMN_PB_ABL 0          // diagnostic builds: 1 no W1 requests in the loop, 2 no X requests, 4 no barrier / LDS store, 8 no matrix instructions
+#endif
+#define PB_STEP(S, U)                                                                                                                  \
+        {                                                                                                                              \
+            if (!(DIMN_PB_ABL & 1)) bload(clampi((S) + 2), BR[((U) + 2) % 3]);                                                         \
+            if (!(DIMN_PB_ABL & 2)) xload(clampi((S) + 3), XR[(U) % 3]);                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+            if (!(DIMN_PB_ABL & 8)) mma1(xs + ((S) & 1) * DIMN_PB_M * DIMN_PB_XLD, BR[(U) % 3]);                                       \
+            if (!(DIMN_PB_ABL & 4)) { xstore(clampi((S) + 1), ((S) + 1) & 1, XR[((U) + 1) % 3]); __syncthreads(); }                    \
+        }
+        int step = 0;
+        for (; step + 3 <= nsteps; step += 3) { PB_STEP(step, 0) PB_STEP(step + 1, 1) PB_STEP(step + 2, 2) }
+        // 0..2 steps left (same code, guarded; the requests past the last step re-read it)
+        if (step < nsteps) PB_STEP(step, 0)
+        if (step + 1 < nsteps) PB_STEP(step + 1, 1)
+#undef PB_STEP
+        // (every PB_STEP ends with a barrier: every wave is done with the ring -- the activations take its place)
+    }
+    // bias + activation, rounded to bf16 into LDS; columns [Hp, Hq) zero
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int h = 64 * wave + 16 * ct + li;
+        if (h < Hq) {
+            const float bias = h < Hp ? b1[(int64_t)k * Hp + h] : 0.f;
+#pragma unroll
+            for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[rt][ct][r] + bias;
+                    float f = v > 0.f ? v : 0.f, df;
+                    if (act != 0) { hidden_act(act, v, f, df); }
+                    if (h >= dm.H) f = 0.f;                      // (also the columns [H, Hq): their accumulators are not meaningful)
+                    ddl[(16 * rt + 4 * lj + r) * ld2 + h] = f32_to_bf16(f);
+                }
+        }
+    }
+    __syncthreads();                                             // (the four waves cover 256 hidden columns: launch_predict sends Hp > 256 to the round-2 kernel)
+
+    // ---- second layer: Z = Dd W2, 16 output tiles per pass (4 per wave) ----
+    float lsum0 = 0.f, lsum1 = 0.f;
+    const bf16_t* w2k = W2t + (int64_t)k * Hp * dm.Op;
+    const int nsteps2 = Hq >> 5;
+    for (int ot0 = 0; ot0 < dm.OT; ot0 += 16) {
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = zero4;
+        const bf16_t* w2p[4];
+        bool ov[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const int ot = ot0 + 4 * wave + ct;
+            ov[ct] = ot < dm.OT;
+            w2p[ct] = w2k + (int64_t)(16 * (ov[ct] ? ot : 0) + li) * Hp;
+        }
+        // (W2 operands: requested one step ahead into two named sets; a half step beyond Hp re-reads valid weights against the zero
+        //  columns [Hp, Hq) of the activations)
+        auto b2load = [&](int st, u32x4v (&b)[4]) {
+            int h0 = 32 * st + 8 * lj;
+            h0 = h0 < Hp ? h0 : 0;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) b[ct] = *(const u32x4v*)(w2p[ct] + h0);
+        };
+        auto mma2 = [&](int st, const u32x4v (&b)[4]) {
+#pragma unroll
+            for (int rt = 0; rt < 8; ++rt) {
+                const bf16x8n a = *(const bf16x8n*)(ddl + (16 * rt + li) * ld2 + 32 * st + 8 * lj);
+#pragma unroll
+                // Z^T tile = W2t (A: 16 outputs x 32 hidden) x Dd^T (B: 32 hidden x 16 batch rows): the SAME two register operands as for
+                // Z = Dd W2, handed over in the other order -- the accumulator of a lane is then four CONSECUTIVE OUTPUTS of one batch row
+                // (acc[rt][ct][r] = Z[b = 16 rt + li][o = 16 ot + 4 lj + r]): one 16-byte store per lane instead of four 4-byte ones
+                for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8n, b[ct]), a, acc[rt][ct], 0, 0, 0);
+            }
+        };
+        {
+            u32x4v C0[4], C1[4];
+            b2load(0, C0);
+            int st = 0;
+            for (; st + 2 <= nsteps2; st += 2) {
+                b2load(st + 1, C1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma2(st, C0);
+                b2load(st + 2 < nsteps2 ? st + 2 : st + 1, C0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma2(st + 1, C1);
+            }
+            if (st < nsteps2) mma2(st, C0);
+        }
+        // epilogue: bias, softplus, store / loss.  A lane holds outputs o0 .. o0+3 of batch row 16 rt + li; the four output tiles of a
+        // wave are adjacent (64 outputs = 256 contiguous bytes of a row of `out`), written tile after tile for each row tile
+        const bool vec_ok = (dm.O & 3) == 0;
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt) {
+            const int64_t i = r0 + 16 * rt + li;
+            const bool row_ok = i < n_rows;
+            const int64_t row = row_ok ? (rows ? (int64_t)rows[i] : i) : 0;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int o0 = 16 * (ot0 + 4 * wave + ct) + 4 * lj;
+                if (!ov[ct] || !row_ok || o0 >= dm.O) continue;
+                f32x4 yh;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yh[r] = softplus_out(acc[rt][ct][r] + b2[(int64_t)k * dm.Op + o0 + r]);      // (b2 is padded to Op)
+                // (measured: the cheaper two-transcendental softplus of the training kernels changes nothing here -- 5.8 ms either way;
+                //  without softplus AND without the stores the kernel takes 3.9 ms: epilogue and GEMMs overlap across the two
+                //  workgroups of a CU, and what remains is the request stream of the first layer)
+                if (out) {
+                    float* dst = out + (i * dm.K + k) * dm.O + o0;
+                    if (vec_ok) DIMN_PB_STORE((f32x4*)dst, yh);
+                    else
+                        for (int r = 0; r < 4; ++r) if (o0 + r < dm.O) dst[r] = yh[r];
+                }
+                if (loss_part) {
+                    const float* yrow = Y + ((int64_t)k * n_cells + row) * dm.Op + o0;
+                    float acc_l = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (o0 + r < dm.O) {
+                            const float y = yrow[r];
+                            const float w = loss_binary ? (y > 0.f ? 1.f : 0.f) : y;
+                            const float e = y - yh[r];
+                            acc_l += w * e * e;
+                        }
+                    if (rt < 4) lsum0 += acc_l; else lsum1 += acc_l;
+                }
+            }
+        }
+    }
+    if (loss_part) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lsum0 += __shfl_xor(lsum0, off); lsum1 += __shfl_xor(lsum1, off); }
+        __syncthreads();                                         // (the activations are no longer read: redl may alias nothing, but keep the order explicit)
+        if (lane == 0) { redl[wave] = lsum0; redl[4 + wave] = lsum1; }
+        __syncthreads();
+        if (tid == 0) {
+            const int64_t t64 = 2 * (int64_t)blockIdx.x;
+            loss_part[(int64_t)k * lp_stride + t64] = redl[0] + redl[1] + redl[2] + redl[3];
+            if (t64 + 1 < lp_stride) loss_part[(int64_t)k * lp_stride + t64 + 1] = redl[4] + redl[5] + redl[6] + redl[7];
+        }
+    }
+}
+
+// the round-2 form (64 rows per workgroup, 16-deep instructions, every operand an 8-byte global load): hidden widths beyond 256
 template <int NT>
-__global__ __launch_bounds__(256) void k_predict_bf16(const SubnetDev* __restrict__ sn, const bf16_t* __restrict__ X,
+__global__ __launch_bounds__(256) void k_predict_bf16_r2(const SubnetDev* __restrict__ sn, const bf16_t* __restrict__ X,
                                                       const bf16_t* __restrict__ W1b, const float* __restrict__ b1,
                                                       const bf16_t* __restrict__ W2t, const float* __restrict__ b2,
                                                       const int32_t* __restrict__ rows, int64_t n_rows,
