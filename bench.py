@@ -252,7 +252,10 @@ def impute_once(eng, epochs, comm=None, counts=None, n=None):
     vsum = 0.0
     ident = np.arange(eng.n_train, dtype=np.int32) if os.environ.get("DIMN_BENCH_IDENTITY_PERM") else None   # diagnostic only
     for e in range(epochs):
+        t_e = time.perf_counter()
         eng.train_epoch(e, ident)
+        eng._bench_train_s = getattr(eng, "_bench_train_s", 0.0) + time.perf_counter() - t_e      # (train_epoch returns the losses: it has synchronised)
+        eng._bench_train_steps = getattr(eng, "_bench_train_steps", 0) + -(-eng.n_train // eng.B)
         v = eng.val_loss()
         if comm is not None:                       # global early-stopping quantity (multinet.py:242-243)
             v = comm.allreduce_sum(np.array([v.sum()]))
@@ -394,13 +397,18 @@ def dropin_run(norm, epochs):
                     "imputed frame included"}
 
 
-def accuracy_pair(cfg, targets, preds, norm, epochs, lr, n_cells=1536, n_subnets=2):
+def accuracy_pair(cfg, targets, preds, norm, epochs, lr, n_cells=1024, n_subnets=2):
     """The accuracy half of the metric ("MSE vs ref"): the held-out metrics fit() reports (multinet.py:251-262: Pearson r and MSE
     between the validation cells' positive target values and their predictions) after the SAME E epochs on the SAME problem --
     the first `n_subnets` sub-nets over the first `n_cells` cells, 5 % held out, same seeds -- from the HIP engine and from the
     CPU port (oracle/dimo.c, the restatement of the reference's Keras path).  Outside the timed region."""
+    import ctypes
     from deepimpute_amd.engine import HipEngine
     from oracle.dimo import OracleEngine
+    try:        # the oracle's OpenMP regions are tiny: on a 256-thread host fork/join dominates (250 s instead of ~15 s for this leg)
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(min(32, os.cpu_count() or 1))
+    except OSError:
+        pass
     sub = np.ascontiguousarray(norm[:n_cells])
     train, val = split_rows(n_cells, seed=0)
     t_sub, p_sub = targets[:n_subnets], preds[:n_subnets]
@@ -442,6 +450,8 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="bf16: X arena in bfloat16, inference / validation on the bf16 matrix cores")
     ap.add_argument("--stream", action="store_true", help="stream the matrix from host memory in row blocks (it never resides on the GPU)")
     ap.add_argument("--cells", type=int, default=0, help="diagnostic: override the config's cell count")
+    ap.add_argument("--batch", type=int, default=0, help="diagnostic: batch size (default: the config's 64; above 64 the general path runs, as for deepImpute --batch-size 128)")
+    ap.add_argument("--general", action="store_true", help="diagnostic: force the general path (dimn_create_general) at the config's shapes")
     ap.add_argument("--early-stop-probe", action="store_true", help="also run the early-stopped fit once and report its epoch count")
     args = ap.parse_args()
 
@@ -464,6 +474,12 @@ def main():
     if args.cells:
         cfg["n"] = args.cells
         cfg["label"] += " [cells=%d]" % args.cells
+    if args.batch:
+        cfg["B"] = args.batch
+        cfg["label"] += " [batch=%d]" % args.batch
+    general = args.general or cfg["B"] > 64 or cfg["H"] > 384
+    if general:
+        cfg["label"] += " [general path]"
     n, g = cfg["n"], cfg["g"]
     t_gen = time.time()
     norm = synth_counts(n, g, seed=0)
@@ -475,7 +491,15 @@ def main():
     counts, offs = shard(K, world)
     t_gen = time.time() - t_gen
 
-    eng = make_engine(HipEngine, cfg, targets, preds, norm, train, val, counts, offs, rank, local_rank, args.lr, stream=args.stream,
+    if general:
+        from deepimpute_amd.engine import HipGeneralEngine
+
+        def general_factory(D, hidden, out_dim, dropout_rate=0.2, **kw):      # the one-hidden-layer model through dimn_create_general
+            return HipGeneralEngine(D, [(hidden, "relu", dropout_rate)], out_dim, **kw)
+        engine_cls = general_factory
+    else:
+        engine_cls = HipEngine
+    eng = make_engine(engine_cls, cfg, targets, preds, norm, train, val, counts, offs, rank, local_rank, args.lr, stream=args.stream,
                       **({"precision": "bf16"} if args.precision == "bf16" else {}))
     comm = None
     if world > 1:
@@ -500,6 +524,7 @@ def main():
         impute_once(eng, args.epochs, comm, counts, n)
     eng.set_profiling(True)
     eng.get_timers(reset=True)
+    eng._bench_train_s, eng._bench_train_steps = 0.0, 0
     if comm:
         comm.reset()
     barrier()
@@ -585,7 +610,9 @@ def main():
             "config": {"workload": cfg["label"], "cells": n, "genes": g, "subnets": K, "epochs_per_fit": args.epochs,
                        "train_steps_per_epoch": steps_per_epoch, "parallelism": "subnets sharded x%d" % world,
                        "final_val_loss": vsum, "subnet_lanes": int(timers[5]), "matrix": "streamed from host (pinned row blocks)" if args.stream else "resident",
-                       "lane_step_ms": lane_step_ms},
+                       "lane_step_ms": lane_step_ms,
+                       # host wall time of the train_epoch calls per optimiser step (every path, also the general one, which has no event timers)
+                       "train_step_ms_wall": 1e3 * eng._bench_train_s / max(1, eng._bench_train_steps)},
             "roofline": roofline,
         }
         # the forward over all cells (model.predict), the MFMA-bound kernel of the path: fp32 matrix cores, or bf16 ones with --precision bf16
@@ -611,7 +638,7 @@ def main():
         comm.close()
         rdzv.cleanup()
     eng.close()
-    if rank == 0 and world == 1 and not args.no_dropin and not args.limit_subnets and not args.hidden:
+    if rank == 0 and world == 1 and not args.no_dropin and not args.limit_subnets and not args.hidden and not general:
         # The drop-in surface on the SAME matrix, outside the timed region: deepimpute_amd.multinet.MultiNet.fit + predict,
         # host planning included (gene selection, |corr| + predictor selection, split, save, held-out metrics, post-processing;
         # raw counts and the returned frame live on the host, so this figure includes the PCIe copies `value` excludes)
@@ -619,7 +646,7 @@ def main():
             result["config"]["dropin"] = dropin_run(norm, args.epochs)
         except Exception as e:
             result["config"]["dropin"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_accuracy and not args.no_cpu_baseline and not args.limit_subnets and not args.hidden and args.precision == "fp32":
+    if rank == 0 and world == 1 and not args.no_accuracy and not args.no_cpu_baseline and not args.limit_subnets and not args.hidden and not general and args.precision == "fp32":
         try:
             result["accuracy"] = accuracy_pair(cfg, targets, preds, norm, args.epochs, args.lr)
         except Exception as e:

@@ -32,7 +32,7 @@ __host__ __device__ static inline uint32_t gen_step_key(uint32_t step, int dl) {
 // gradients: rows = inputs of the layer, which differ per sub-net) and Ko is the inner dimension (the batch).
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ descs, int Mo, int Ko, GEpi ep) {
-    __shared__ float As[16][68], Bs[16][68];                  // [k][m], [k][n]; 68: conflict-free column reads by 16-lane groups
+    __shared__ __attribute__((aligned(16))) float As[16][68], Bs[16][68];   // [k][m], [k][n]; 68: conflict-free column reads by 16-lane groups, rows 16-byte aligned
     GDesc d = descs[blockIdx.z];
     const int M = Mo >= 0 ? Mo : d.K;
     if (Ko >= 0) d.K = Ko;
@@ -46,21 +46,44 @@ __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ desc
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < d.K; k0 += 16) {
-        // stage 64 x 16 of A and 16 x 64 of B (zero outside the matrices); the fast index of the load follows memory
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + 256 * q;
-            int m, k;
-            if (TA) { m = e & 63; k = e >> 6; } else { k = e & 15; m = e >> 4; }
-            const int gm = m0 + m, gk = k0 + k;
-            As[k][m] = (gm < M && gk < d.K) ? (TA ? d.A[(int64_t)gk * d.lda + gm] : d.A[(int64_t)gm * d.lda + gk]) : 0.f;
-            int n, kb;
-            if (TB) { kb = e & 15; n = e >> 4; } else { n = e & 63; kb = e >> 6; }
-            const int gn = n0 + n, gkb = k0 + kb;
-            Bs[kb][n] = (gn < d.N && gkb < d.K) ? (TB ? d.B[(int64_t)gn * d.ldb + gkb] : d.B[(int64_t)gkb * d.ldb + gn]) : 0.f;
+    // Staging (round 3): every thread moves ONE 16-byte piece of each operand per 16-deep tile -- four elements along the operand's
+    // memory-contiguous index (k for a row-major A / a transposed B, m or n otherwise) -- requested for the NEXT tile before the
+    // current one is multiplied (round 2: four scalar loads per operand, no overlap).  Pieces that cross an edge, or operands whose
+    // rows are not 16-byte aligned, fall back to four guarded scalar loads.
+    const bool a_k = !TA, b_k = TB;                              // the operand's contiguous index is k
+    const int a_maj = a_k ? tid >> 2 : tid >> 4, a_min = a_k ? (tid & 3) * 4 : (tid & 15) * 4;      // (m, k4) or (k, m4)
+    const int b_maj = b_k ? tid >> 2 : tid >> 4, b_min = b_k ? (tid & 3) * 4 : (tid & 15) * 4;      // (n, k4) or (k, n4)
+    const bool a_vec = (d.lda & 3) == 0 && ((uintptr_t)d.A & 15) == 0, b_vec = (d.ldb & 3) == 0 && ((uintptr_t)d.B & 15) == 0;
+    auto load_a = [&](int k0) -> f32x4 {
+        const int gmaj = a_k ? m0 + a_maj : k0 + a_maj, gmin = a_k ? k0 + a_min : m0 + a_min;
+        const int lim_maj = a_k ? M : d.K, lim_min = a_k ? d.K : M;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (gmaj < lim_maj) {
+            const float* p = d.A + (int64_t)gmaj * d.lda + gmin;
+            if (a_vec && gmin + 3 < lim_min) v = *(const f32x4*)p;
+            else
+                for (int r = 0; r < 4; ++r) if (gmin + r < lim_min) v[r] = p[r];
         }
+        return v;
+    };
+    auto load_b = [&](int k0) -> f32x4 {
+        const int gmaj = b_k ? n0 + b_maj : k0 + b_maj, gmin = b_k ? k0 + b_min : n0 + b_min;
+        const int lim_maj = b_k ? d.N : d.K, lim_min = b_k ? d.K : d.N;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (gmaj < lim_maj) {
+            const float* p = d.B + (int64_t)gmaj * d.ldb + gmin;
+            if (b_vec && gmin + 3 < lim_min) v = *(const f32x4*)p;
+            else
+                for (int r = 0; r < 4; ++r) if (gmin + r < lim_min) v[r] = p[r];
+        }
+        return v;
+    };
+    f32x4 ra = load_a(0), rb = load_b(0);
+    for (int k0 = 0; k0 < d.K; k0 += 16) {
+        if (a_k) { for (int r = 0; r < 4; ++r) As[a_min + r][a_maj] = ra[r]; } else *(f32x4*)&As[a_maj][a_min] = ra;
+        if (b_k) { for (int r = 0; r < 4; ++r) Bs[b_min + r][b_maj] = rb[r]; } else *(f32x4*)&Bs[b_maj][b_min] = rb;
         __syncthreads();
+        if (k0 + 16 < d.K) { ra = load_a(k0 + 16); rb = load_b(k0 + 16); }
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 4) {
             float a[2], b[2];
@@ -122,8 +145,11 @@ __global__ __launch_bounds__(256) void k_gen_gather_batch(const SubnetDev* __res
 }
 
 // Output layer: yhat = softplus(Z); the loss of build()'s `loss` (multinet.py:150-162) and dZ = dL/dZ in place.
-// grid (K), block 256.  out != NULL (predict): out[(row0 + b)][k*O + o] = yhat, no loss.  loss_sum[k] += sum of the
-// per-element loss terms (the caller divides by the element count); train != 0 writes dZ over Z.
+// grid (K, GEN_OUT_CH), block 256: workgroup (k, c) takes every GEN_OUT_CH-th stripe of 256 elements of sub-net k (round 2
+// launched ONE workgroup per sub-net: 40 of 256 CUs busy, 28 % of a general-path step).  out != NULL (predict):
+// out[(row0 + b)][k*O + o] = yhat, no loss.  loss_sum[k][c] += sum of the per-element loss terms of the workgroup's stripes (one
+// owner per slot: deterministic; the host adds the slots and divides by the element count); train != 0 writes dZ over Z.
+#define GEN_OUT_CH 16
 __global__ __launch_bounds__(256) void k_gen_output(float* __restrict__ Z, int ldz, int64_t z_stride, const float* __restrict__ Y, int64_t n_cells,
                                                     const int32_t* __restrict__ rows, int64_t row0, int b_cnt, Dims dm, int loss, int train,
                                                     float inv_n, double* __restrict__ loss_sum, float* __restrict__ out, int64_t out_row0, int k_off) {
@@ -131,7 +157,7 @@ __global__ __launch_bounds__(256) void k_gen_output(float* __restrict__ Z, int l
     const int k = blockIdx.x;
     float* z = Z + (int64_t)k * z_stride;
     double ls = 0.0;
-    for (int e = threadIdx.x; e < b_cnt * dm.O; e += 256) {
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < b_cnt * dm.O; e += 256 * GEN_OUT_CH) {
         const int b = e / dm.O, o = e - b * dm.O;
         const float zz = z[(int64_t)b * ldz + o];
         if (out) {
@@ -157,7 +183,7 @@ __global__ __launch_bounds__(256) void k_gen_output(float* __restrict__ Z, int l
     for (int off = 32; off > 0; off >>= 1) ls += __shfl_xor(ls, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ls;
     __syncthreads();
-    if (threadIdx.x == 0) loss_sum[k] += red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) loss_sum[(int64_t)k * GEN_OUT_CH + blockIdx.y] += red[0] + red[1] + red[2] + red[3];
 }
 
 // bias gradients: gb[n] = sum_b dZ[b][n]   (one workgroup per (sub-net, layer) entry of `descs`: C = gb, A = dZ, N, lda)

@@ -460,22 +460,33 @@ class MultiNet:
         # upload of the counts and the g x g matrix product then run on a helper thread while this thread finishes the statistics
         # and picks the genes -- every number is the one the plain sequence below computes (checked where a guess is involved).
         upload, spec_pool, first = None, None, None
+        pool_ready = None
         if cell_subset == 1 and self._counts_path_applies(raw):
+            import threading
+            pool_ready = threading.Event()
+            pool_box = {}
+            upload = self._start_counts_upload(raw, pool_box, pool_ready)      # the upload starts at once; the matrix product waits for the pool
             with tm.stage("fit.gene_statistics"):
                 first = _hostpar.col_stats_first(raw.values)
         if first is not None:
+            if n_pred is None:
+                spec_pool = np.flatnonzero((first["cmax"] > first["cmin"]) & (first["mean"] > 0)).astype(np.int32)
+                pool_box["pool"] = spec_pool
+            pool_ready.set()
             with tm.stage("fit.inspect_data"):
                 inspect_data(raw, _max=first["vmax"])
             if self.seed is not None:
                 np.random.seed(self.seed)
-            if n_pred is None:
-                spec_pool = np.flatnonzero((first["cmax"] > first["cmin"]) & (first["mean"] > 0)).astype(np.int32)
-            upload = self._start_counts_upload(raw, spec_pool)
             with tm.stage("fit.gene_statistics"):
                 var = pd.Series(_hostpar.col_stats_var(raw.values, first["avg"]), index=raw.columns)
                 mean = pd.Series(first["mean"], index=raw.columns)
         else:
-            upload = self._start_counts_upload(raw) if cell_subset == 1 else (lambda: None)
+            if pool_ready is not None:
+                pool_ready.set()                             # (the statistics routine declined, e.g. a NaN: the upload will decline too)
+            elif cell_subset == 1:
+                upload = self._start_counts_upload(raw)
+            else:
+                upload = lambda: None
             with tm.stage("fit.inspect_data"):
                 inspect_data(raw)
             if self.seed is not None:
@@ -582,10 +593,11 @@ class MultiNet:
                     or not isinstance(values, np.ndarray) or values.dtype != np.float64 or not values.flags.c_contiguous
                     or values.size * 4 > (32 << 30) or not _gpu_visible())
 
-    def _start_counts_upload(self, raw, corr_pool=None):
-        """Begin uploading raw's counts to the GPU on a helper thread (ctypes releases the GIL) -- and, with `corr_pool`, the
-        |corr| matrix of those columns right behind it -- and return a function that waits for it and gives the
-        _counts.DeviceCounts, or None where the fast path does not apply / the values are not counts."""
+    def _start_counts_upload(self, raw, pool_box=None, pool_ready=None):
+        """Begin uploading raw's counts to the GPU on a helper thread (ctypes releases the GIL) and return a function that waits
+        for it and gives the _counts.DeviceCounts, or None where the fast path does not apply / the values are not counts.
+        With `pool_ready` (a threading.Event) the helper goes on, once the event is set, to the |corr| matrix of the columns
+        pool_box["pool"] -- the caller sets it when the first sweep of its gene statistics has named the candidate pool."""
         self._drop_resident()
         values = getattr(raw, "values", None)
         if not self._counts_path_applies(raw):
@@ -597,12 +609,15 @@ class MultiNet:
         def work():
             try:
                 box["counts"] = DeviceCounts.try_create(values, self.device_id)
-                if box["counts"] is not None and corr_pool is not None and len(corr_pool) >= 2 and values.shape[0] >= 2:
-                    box["counts"].corr(corr_pool)
-                    box["counts"].corr_ready = True
+                if pool_ready is not None:
+                    pool_ready.wait(600.0)                   # (bounded: a caller that failed before naming the pool must not pin this thread)
+                    corr_pool = pool_box.get("pool")
+                    if box["counts"] is not None and corr_pool is not None and len(corr_pool) >= 2 and values.shape[0] >= 2:
+                        box["counts"].corr(corr_pool)
+                        box["counts"].corr_ready = True
             except Exception as exc:                          # the host path takes over; a real failure shows up there
                 box["error"] = exc
-        thread = threading.Thread(target=work, name="dimn-counts-upload")
+        thread = threading.Thread(target=work, name="dimn-counts-upload", daemon=True)
         thread.start()
 
         def wait():
