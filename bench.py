@@ -244,7 +244,10 @@ def impute_once(eng, epochs, comm=None, counts=None, n=None):
     """The timed unit: gather -> init -> E x (train epoch + validation) -> predict (-> gather).  With a streamed matrix
     (--stream) the hand-over IS the gather: the matrix crosses PCIe in row blocks inside the timed region."""
     if getattr(eng, "_bench_norm", None) is not None:
+        t_h = time.perf_counter()
         eng.set_matrix(eng._bench_norm, streamed=True, with_targets=True)
+        eng.synchronize()
+        eng._bench_handover_s = time.perf_counter() - t_h       # the matrix crosses PCIe in row blocks, each gathered on the device as it lands
         eng.set_split(*eng.set_split_later)
     else:
         eng.gather(True)
@@ -615,6 +618,10 @@ def main():
                        "train_step_ms_wall": 1e3 * eng._bench_train_s / max(1, eng._bench_train_steps)},
             "roofline": roofline,
         }
+        if getattr(eng, "_bench_handover_s", None):
+            result["config"]["streamed_handover"] = {"seconds": eng._bench_handover_s, "matrix_GB": norm.nbytes / 1e9,
+                                                    "host_to_device_GBps": norm.nbytes / 1e9 / eng._bench_handover_s,
+                                                    "note": "last impute: pageable host matrix -> pinned bounce buffers (threads) -> PCIe -> device gather, per ~128 MB row block"}
         # the forward over all cells (model.predict), the MFMA-bound kernel of the path: fp32 matrix cores, or bf16 ones with --precision bf16
         pred_s = getattr(eng, "_bench_predict_s", None)
         if pred_s:
