@@ -358,7 +358,10 @@ static void build_resident(dimn_handle h) {
     if (const char* e = getenv("DIMN_RES_GROUPS")) max_groups = std::max(1, atoi(e));
     if (const char* e = getenv("DIMN_RES_MIN_GROUPS")) min_groups = std::max(1, atoi(e));      // tests: groups on small problems
     min_groups = std::min(min_groups, h->K);
-    for (int groups = min_groups; groups <= std::min(std::max(max_groups, min_groups), h->K); ++groups) {
+    // (round 3: with the manager protocol a launch of five sub-nets costs 23.7 us per step, so FOUR groups of five -- the 2-GPU share of the
+    //  50k x 20k job -- take 94 us against 104 us for the streaming kernels; four groups of four (K = 16) only draw: 86 vs 84-88 us)
+    const bool four_of_five = !getenv("DIMN_RES_GROUPS") && max_groups == 3 && ceil_div(h->K, 4) == 5;
+    for (int groups = min_groups; groups <= std::min(std::max(four_of_five ? 4 : max_groups, min_groups), h->K); ++groups) {
         const int Kg = ceil_div(h->K, groups);
         int S1 = 0, T1c = 0;
         if (!resident_plan(h, Kg, S1, T1c)) continue;

@@ -376,7 +376,8 @@ def test_resident_hand_off_retry_path():
 @pytest.mark.parametrize("K,precision,want", [
     (5, "fp32", dict(path="resident", resident_groups=1, resident_splits=3)),        # one rank of the 8-GPU job
     (10, "fp32", dict(path="resident", resident_groups=2)),                          # 4-GPU share: two groups of 5
-    (20, "fp32", dict(path="streaming", mid_fused=1, mid_keep=1, first_layer=1)),    # 2-GPU share
+    (20, "fp32", dict(path="resident", resident_groups=4, resident_splits=3)),       # 2-GPU share: four groups of 5
+    (16, "fp32", dict(path="streaming", mid_fused=0, first_layer=1)),                 # four groups of 4 would only draw: the streaming kernels (two-kernel second layer)
     (40, "fp32", dict(path="streaming", mid_fused=1, mid_slices=6, mid_keep=1, train_bf16=0, first_layer=1)),   # the single-GPU job
     (40, "bf16", dict(path="streaming", mid_fused=1, mid_slices=6, train_bf16=1)),
 ])
