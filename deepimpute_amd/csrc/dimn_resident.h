@@ -16,8 +16,9 @@
 //   manager (s = S1-1):  one workgroup per hidden tile collects what belongs to the tile and publishes it ONCE:
 //                        M1: A = sum_s P_s + b1, Dd = dropout(relu(A)) -> the Dd tile;  M2: dD = sum over the OT output
 //                        tiles' partials, dA = gate * dD * scale -> the dA tile.  (Round 2 let every consumer reduce for
-//                        itself: every role-2 workgroup read all G partials, every role-1 workgroup all OT dD tiles -- 104 MB
-//                        of memory-side traffic per step at 5 sub-nets and 20k of 62k clocks; now ~21 MB.)
+//                        itself: every role-2 workgroup read all G partials, every role-1 workgroup all OT dD tiles -- 12.6 MB
+//                        of hand-off reads per sub-net and step, 20k of 62k clocks; now 4.3 MB.  PMC, 5 sub-nets: 104 -> 92 MB per
+//                        step in all -- the rest is the batch rows of X, which every XCD fetches for itself: profiles/r03_traffic_k5.json)
 //   role 2 (first OT):   workgroup ot owns the W2 column block [all 16 hidden tiles][output tile ot] in LDS.  Per step:
 //                        the 16 Dd tiles -> Z tile, softplus, wMSE, dZ, Adam(b2), the dD^T partial [64][256] over its 16
 //                        outputs with the OLD W2 (published), then the W2 gradient + Adam on the column block.
