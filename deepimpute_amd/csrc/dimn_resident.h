@@ -69,7 +69,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ unsigned long long g_res_tl[1024 * 16];
 #define RES_TL_DECL unsigned long long tl_acc[16] = {0}; unsigned long long tl_t = __builtin_amdgcn_s_memtime();
 #define RES_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl_acc[i] += t_ - tl_t; tl_t = t_; }
-#define RES_TL_FLUSH if (threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) g_res_tl[blockIdx.x * 16 + i_] = tl_acc[i_];
+#define RES_TL_FLUSH if (threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) g_res_tl[(kl * G + wi) * 16 + i_] = tl_acc[i_];
 #else
 #define RES_TL_DECL
 #define RES_STAMP(i)
@@ -234,7 +234,21 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
 
     const Dims dm = p.dm;
     const int G = p.G, S1 = S1C > 0 ? S1C : p.S1;
-    const int kl = blockIdx.x / G, wi = blockIdx.x - kl * G;
+    // Workgroup -> (sub-net, D-split, hidden tile): the plain order.  Observed (MI355X guide: "for speed only"): block b runs on XCD
+    // b % 8, so the sixteen hidden-tile workgroups of one (sub-net, D-split) -- which read the SAME batch rows of X -- sit on all
+    // eight XCDs and X reaches every L2 separately (PMC: ~49 of the 92 MB per step at 5 sub-nets).  Tried (DIMN_RES_XCD=1): blocks
+    // of one XCD for each such group (consecutive slots of the list "XCD 0's blocks, XCD 1's blocks, ...", a bijection).  The tile
+    // loop got ~9 % shorter, but a sub-net's 32 role-2 workgroups then read their 64 KB of Dd tiles through two XCDs' fabric ports
+    // instead of eight at the same moment: 24.7 vs 23.8 us per step (two A/B pairs, one box).  The plain order ships.
+#ifndef DIMN_RES_XCD
+#define DIMN_RES_XCD 0
+#endif
+    int slot = (int)blockIdx.x;
+    if (DIMN_RES_XCD) {
+        const int nb = (int)gridDim.x, x = slot & 7, j = slot >> 3, q = nb >> 3, r = nb & 7;      // XCD x holds q + 1 blocks if x < r, else q
+        slot = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int kl = slot / G, wi = slot - kl * G;
     const int k = p.k0 + kl;                                 // sub-net of the handle (every array below is indexed by it)
     const int ht = wi & 15, sp = wi >> 4;
     const bool is_o = wi < dm.OT;                            // role 2: owns output tile wi
