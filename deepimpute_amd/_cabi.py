@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_BATCH = 64
 COMM_ID_BYTES = 128
 # hidden-layer activations the kernels implement (ids = DIMN_ACT_* of include/dimn.h; Keras names)
@@ -111,6 +111,8 @@ GPU_ONLY = {
     "counts_select_predictors": [_H, _pi, _i64, _pi, _i32, _i32, _pi, _i32, _pi],
     "counts_corr": [_H, _pi, _i64],
     "counts_topk": [_H, _pi, _i32, _i32, _pi, _i32, _pi],
+    "counts_corr_read": [_H, _pd, _i64],
+    "counts_gene_stats": [_H, _pd, _pd, _pd, _pd],
     "set_matrix_counts": [_H, _H, _pf, _i64],
     "col_stats_first": [_pd, _i64, _i64, _i64, _pd, _pd, _pd, _pd, _pd, _pi, _i32],
     "col_stats_var": [_pd, _i64, _i64, _i64, _pd, _pd, _i32],

@@ -69,6 +69,26 @@ class DeviceCounts:
         if fns["counts_corr"](self.handle, _cabi.p_i32(pool_cols), pool_cols.size) != 0:
             raise RuntimeError("dimn_counts_corr: " + fns["last_error"]().decode("utf-8", "replace"))
 
+    def corr_read(self, pool_n):
+        """(tests / diagnostics) the |corr| matrix corr() left on the device."""
+        from . import _lib
+        fns = _lib.load()
+        out = np.empty((int(pool_n), int(pool_n)), np.float64)
+        if fns["counts_corr_read"](self.handle, _cabi.p_f64(out), int(pool_n)) != 0:
+            raise RuntimeError("dimn_counts_corr_read: " + fns["last_error"]().decode("utf-8", "replace"))
+        return out
+
+    def gene_stats(self):
+        """dict(mean, var, cmin, cmax) of the columns: DataFrame.mean() / .var() to the bit (dimn_counts_gene_stats), computed
+        from the resident copy; `vmax` is the matrix maximum the upload found."""
+        from . import _lib
+        fns = _lib.load()
+        out = {k: np.empty(self.g, np.float64) for k in ("mean", "var", "cmin", "cmax")}
+        if fns["counts_gene_stats"](self.handle, _cabi.p_f64(out["mean"]), _cabi.p_f64(out["var"]), _cabi.p_f64(out["cmin"]), _cabi.p_f64(out["cmax"])) != 0:
+            raise RuntimeError("dimn_counts_gene_stats: " + fns["last_error"]().decode("utf-8", "replace"))
+        out["vmax"] = self.vmax
+        return out
+
     def topk(self, targ_pos, col_rank, ntop):
         from . import _lib
         fns = _lib.load()

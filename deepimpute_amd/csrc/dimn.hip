@@ -21,8 +21,9 @@
 #include "dimn_general.h"
 #include "dimn_csv.h"
 #include "dimn_hoststats.h"
+#include "dimn_counts_dev.h"
 
-#define DIMN_ABI_VERSION 5
+#define DIMN_ABI_VERSION 6
 
 // DIMN_TRACE=1: stage times of the host-heavy entry points on stderr (diagnostic)
 struct Trace {
@@ -2093,7 +2094,9 @@ static inline uint64_t counts_mix(uint64_t x) {      // splitmix64 finaliser
 static void counts_scan(const double* raw, int64_t g, int64_t r0, int64_t r1, float* dst, double* vmax, uint64_t* sum, int* ok) {
     const unsigned hw = std::thread::hardware_concurrency();
     const int64_t rows = r1 - r0;
-    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw ? hw / 2 : 8, 32), rows * g / (1 << 20)));
+    const char* want_s = getenv("DIMN_COUNTS_THREADS");                                     // (diagnostic override)
+    const int want = want_s ? atoi(want_s) : 0;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(want > 0 ? (unsigned)want : std::min<unsigned>(hw ? hw / 2 : 8, 32), rows * g / (1 << 20)));
     std::vector<double> mx((size_t)nt, -INFINITY);
     std::vector<uint64_t> cs((size_t)nt, 0);
     std::vector<int> good((size_t)nt, 1);
@@ -2174,6 +2177,92 @@ extern "C" int dimn_counts_create(int32_t device_id, const double* raw, int64_t 
     *out = c;
     return DIMN_OK;
 }
+// |corr| of the pool columns from the resident counts on the int8 matrix cores (dimn_counts_dev.h part 2); *dOutp: [pool_n][pool_n] float64
+static int corr_counts_i8(dimn_counts c, const int32_t* dCols, int64_t pool_n, hipStream_t st, double** dOutp) {
+    const int P = c->vmax < 256.0 ? 1 : 2;
+    const int64_t n = c->n, gp = (pool_n + CI8_BT - 1) / CI8_BT * CI8_BT, KC = (n + CI8_KS - 1) / CI8_KS, plane_bytes = gp * KC * CI8_KS;
+    const int nb = (int)(gp / CI8_BT);
+    int8_t* dPlanes = nullptr;
+    long long *dSums = nullptr, *dC = nullptr;
+    double* dRoot = nullptr;
+    int2* dPairs = nullptr;
+    int rc = DIMN_OK;
+    std::vector<int2> pairs;
+    for (int i = 0; i < nb; ++i)
+        for (int j = i; j < nb; ++j) pairs.push_back(make_int2(i, j));
+    const int nblk = (int)std::min<int64_t>(64, (n + 255) / 256);
+    const size_t lds = (size_t)CI8_NBUF * 16 * P * 1024;
+#define CI8_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
+    Trace tr;
+    CI8_TRY(hipMalloc((void**)&dPlanes, (size_t)P * plane_bytes));
+    CI8_TRY(hipMalloc((void**)&dC, (size_t)pool_n * pool_n * 8));
+    CI8_TRY(hipMalloc((void**)&dSums, (size_t)gp * 8));
+    CI8_TRY(hipMalloc((void**)&dRoot, (size_t)gp * 8));
+    CI8_TRY(hipMalloc((void**)&dPairs, pairs.size() * sizeof(int2)));
+    CI8_TRY(hipMemsetAsync(dSums, 0, (size_t)gp * 8, st));
+    CI8_TRY(hipMemcpyAsync(dPairs, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+    tr.lap("corr i8: device allocations");
+    if (P == 1) {
+        CI8_TRY(hipFuncSetAttribute((const void*)k_ci8_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_ci8_planes<1>, dim3((unsigned)(gp / 64), (unsigned)KC), dim3(256), 0, st, c->d, c->g, dCols, n, pool_n, KC, dPlanes, plane_bytes);
+        hipLaunchKernelGGL(k_ci8_colsum, dim3((unsigned)((pool_n + 255) / 256), (unsigned)nblk), dim3(256), 0, st, c->d, c->g, dCols, n, pool_n, (n + nblk - 1) / nblk, 128ll, dSums);
+        hipLaunchKernelGGL(k_ci8_gemm<1>, dim3((unsigned)pairs.size()), dim3(256), lds, st, dPlanes, plane_bytes, KC, dPairs, dC, pool_n, pool_n);
+    } else {
+        CI8_TRY(hipFuncSetAttribute((const void*)k_ci8_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_ci8_planes<2>, dim3((unsigned)(gp / 64), (unsigned)KC), dim3(256), 0, st, c->d, c->g, dCols, n, pool_n, KC, dPlanes, plane_bytes);
+        hipLaunchKernelGGL(k_ci8_colsum, dim3((unsigned)((pool_n + 255) / 256), (unsigned)nblk), dim3(256), 0, st, c->d, c->g, dCols, n, pool_n, (n + nblk - 1) / nblk, 32896ll, dSums);
+        hipLaunchKernelGGL(k_ci8_gemm<2>, dim3((unsigned)pairs.size()), dim3(256), lds, st, dPlanes, plane_bytes, KC, dPairs, dC, pool_n, pool_n);
+    }
+    hipLaunchKernelGGL(k_ci8_diag, dim3((unsigned)((pool_n + 255) / 256)), dim3(256), 0, st, dC, pool_n, dSums, n, pool_n, dRoot);
+    hipLaunchKernelGGL(k_ci8_finish, dim3((unsigned)((pool_n + 255) / 256), (unsigned)pool_n), dim3(256), 0, st, dC, pool_n, dSums, dRoot, n, pool_n);
+    CI8_TRY(hipGetLastError());
+    CI8_TRY(hipStreamSynchronize(st));
+    tr.lap("corr i8: kernels");
+#undef CI8_TRY
+done:
+    if (dPlanes) (void)hipFree(dPlanes);
+    if (dSums) (void)hipFree(dSums);
+    if (dRoot) (void)hipFree(dRoot);
+    if (dPairs) (void)hipFree(dPairs);
+    if (rc != DIMN_OK) { if (dC) (void)hipFree(dC); return rc; }
+    *dOutp = (double*)dC;
+    return DIMN_OK;
+}
+// DataFrame.mean() / .var() / column extremes of the resident counts, to the bit (dimn_counts_dev.h part 1); each output [g] or NULL
+extern "C" int dimn_counts_gene_stats(dimn_counts c, double* mean, double* var, double* cmin, double* cmax) {
+    if (!c || c->n < 2) return fail(DIMN_ERR_ARG, "dimn_counts_gene_stats: bad argument");
+    CHK(corr_device_ok("dimn_counts_gene_stats", c->device));
+    const int64_t n = c->n, g = c->g;
+    const int chunks = (int)((n + 8191) / 8192);
+    double *dSum = nullptr, *dMin = nullptr, *dMax = nullptr, *dPart = nullptr, *dAvg = nullptr, *dVar = nullptr;
+    hipStream_t st = nullptr;
+    int rc = DIMN_OK;
+#define GS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
+    GS_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    GS_TRY(hipMalloc((void**)&dSum, (size_t)g * 8 * 5));
+    dMin = dSum + g; dMax = dMin + g; dAvg = dMax + g; dVar = dAvg + g;
+    GS_TRY(hipMalloc((void**)&dPart, (size_t)chunks * g * 8));
+    hipLaunchKernelGGL(k_cnt_seqsum, dim3((unsigned)((g + 63) / 64)), dim3(64), 0, st, c->d, n, g, dSum, dMin, dMax);
+    hipLaunchKernelGGL(k_cnt_div, dim3((unsigned)((g + 255) / 256)), dim3(256), 0, st, dSum, g, (double)n);
+    if (var) {
+        hipLaunchKernelGGL(k_cnt_pairwise<false>, dim3((unsigned)((g + 63) / 64), (unsigned)chunks), dim3(64), 0, st, c->d, n, g, (const double*)nullptr, dPart);
+        hipLaunchKernelGGL(k_cnt_chunks, dim3((unsigned)((g + 255) / 256)), dim3(256), 0, st, dPart, chunks, g, (double)n, dAvg);
+        hipLaunchKernelGGL(k_cnt_pairwise<true>, dim3((unsigned)((g + 63) / 64), (unsigned)chunks), dim3(64), 0, st, c->d, n, g, (const double*)dAvg, dPart);
+        hipLaunchKernelGGL(k_cnt_chunks, dim3((unsigned)((g + 255) / 256)), dim3(256), 0, st, dPart, chunks, g, (double)(n - 1), dVar);
+    }
+    GS_TRY(hipGetLastError());
+    if (mean) GS_TRY(hipMemcpyAsync(mean, dSum, (size_t)g * 8, hipMemcpyDeviceToHost, st));
+    if (var) GS_TRY(hipMemcpyAsync(var, dVar, (size_t)g * 8, hipMemcpyDeviceToHost, st));
+    if (cmin) GS_TRY(hipMemcpyAsync(cmin, dMin, (size_t)g * 8, hipMemcpyDeviceToHost, st));
+    if (cmax) GS_TRY(hipMemcpyAsync(cmax, dMax, (size_t)g * 8, hipMemcpyDeviceToHost, st));
+    GS_TRY(hipStreamSynchronize(st));
+#undef GS_TRY
+done:
+    if (dSum) (void)hipFree(dSum);
+    if (dPart) (void)hipFree(dPart);
+    if (st) (void)hipStreamDestroy(st);
+    return rc;
+}
 // The same selection as two calls, so that the matrix product (which needs only the candidate pool) can run while the host is
 // still ranking genes: dimn_counts_corr leaves |corr| of the pool on the device, dimn_counts_topk selects from it and frees it.
 extern "C" int dimn_counts_corr(dimn_counts c, const int32_t* pool_cols, int64_t pool_n) {
@@ -2188,8 +2277,13 @@ extern "C" int dimn_counts_corr(dimn_counts c, const int32_t* pool_cols, int64_t
     if (hipMalloc((void**)&dCols, (size_t)pool_n * 4) != hipSuccess || hipMemcpyAsync(dCols, pool_cols, (size_t)pool_n * 4, hipMemcpyHostToDevice, st) != hipSuccess)
         rc = fail(DIMN_ERR_HIP, "dimn_counts_corr: pool upload failed");
     if (rc == DIMN_OK) {
-        const CorrDevSrc src{c->d, c->g, dCols};
-        rc = corr_on_device(nullptr, c->n, pool_n, st, &c->d_corr, &src);
+        // integer counts below 65536: exactly, on the int8 matrix cores (dimn_counts_dev.h); anything else in float64 (dimn_corr.h)
+        const char* e = getenv("DIMN_CORR_I8");
+        if (c->vmax <= 65535.0 && !(e && atoi(e) == 0)) rc = corr_counts_i8(c, dCols, pool_n, st, &c->d_corr);
+        else {
+            const CorrDevSrc src{c->d, c->g, dCols};
+            rc = corr_on_device(nullptr, c->n, pool_n, st, &c->d_corr, &src);
+        }
         if (rc == DIMN_OK) c->corr_g = pool_n;
     }
     if (dCols) (void)hipFree(dCols);
@@ -2214,19 +2308,16 @@ extern "C" int dimn_counts_select_predictors(dimn_counts c, const int32_t* pool_
         return fail(DIMN_ERR_ARG, "dimn_counts_select_predictors: bad argument");
     for (int64_t j = 0; j < pool_n; ++j) if (pool_cols[j] < 0 || pool_cols[j] >= c->g) return fail(DIMN_ERR_ARG, "dimn_counts_select_predictors: pool column out of range");
     CHK(corr_device_ok("dimn_counts_select_predictors", c->device));
-    hipStream_t st = nullptr;
-    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    int32_t* dCols = nullptr;
-    int rc = DIMN_OK;
-    if (hipMalloc((void**)&dCols, (size_t)pool_n * 4) != hipSuccess || hipMemcpyAsync(dCols, pool_cols, (size_t)pool_n * 4, hipMemcpyHostToDevice, st) != hipSuccess)
-        rc = fail(DIMN_ERR_HIP, "dimn_counts_select_predictors: pool upload failed");
-    if (rc == DIMN_OK) {
-        const CorrDevSrc src{c->d, c->g, dCols};
-        rc = select_predictors_core("dimn_counts_select_predictors", c->device, nullptr, &src, c->n, pool_n, targ_pos, K, O, col_rank, ntop, out_idx, st);
-    }
-    if (dCols) (void)hipFree(dCols);
-    (void)hipStreamDestroy(st);
-    return rc;
+    const int rc = dimn_counts_corr(c, pool_cols, pool_n);
+    return rc != DIMN_OK ? rc : dimn_counts_topk(c, targ_pos, K, O, col_rank, ntop, out_idx);
+}
+// (tests / diagnostics) the |corr| matrix dimn_counts_corr left on the device: out[corr_g][corr_g]
+extern "C" int dimn_counts_corr_read(dimn_counts c, double* out, int64_t pool_n) {
+    if (!c || !out) return fail(DIMN_ERR_ARG, "dimn_counts_corr_read: bad argument");
+    if (!c->d_corr || c->corr_g != pool_n) return fail(DIMN_ERR_STATE, "dimn_counts_corr_read: dimn_counts_corr of %lld columns first", (long long)pool_n);
+    CHK(corr_device_ok("dimn_counts_corr_read", c->device));
+    HIPCHK(hipMemcpy(out, c->d_corr, (size_t)pool_n * pool_n * 8, hipMemcpyDeviceToHost));
+    return DIMN_OK;
 }
 // the log1p matrix of the engine from the resident counts: norm[i][j] = lut[(int)counts[i][j]], lut = float32(log1p(0..vmax)) as numpy computes it
 __global__ __launch_bounds__(256) void k_counts_lut(const float* __restrict__ counts, const float* __restrict__ lut, int64_t lut_n, int64_t total, float* __restrict__ norm) {

@@ -455,38 +455,41 @@ class MultiNet:
     def fit(self, raw, cell_subset=1, NN_lim=None, genes_to_impute=None, n_pred=None, ntop=5,
             minVMR=0.5, mode='random'):
         tm = self.timings = _Stages()
-        # Fast path (a frame of raw counts, one GPU, resident matrix): the first sweep of the gene statistics also yields the matrix
-        # maximum inspect_data() asks for and the candidate pool of the correlation (genes that vary, with a positive mean); the
-        # upload of the counts and the g x g matrix product then run on a helper thread while this thread finishes the statistics
-        # and picks the genes -- every number is the one the plain sequence below computes (checked where a guess is involved).
-        upload, spec_pool, first = None, None, None
-        pool_ready = None
+        # Fast path (a frame of raw counts, one GPU, resident matrix): the counts go to the device first, as float32 (exact), and
+        # everything the planning needs is computed from that copy -- the gene statistics (pandas' additions in pandas' order, one
+        # thread per gene: DataFrame.mean() / .var() to the bit), the candidate pool of the correlation (genes that vary, with a
+        # positive mean) and, on a helper thread while this one picks the genes, the g x g correlation itself (exact integer
+        # arithmetic on the int8 matrix cores).  Every number is the one the plain sequence below computes (checked where a guess
+        # is involved).  [Round 2 ran the upload BESIDE host statistics: the two compete for host memory bandwidth, 0.45 s
+        # together against 0.17 + 0.18 s one after the other; tools/dropin_probe.py.]
+        upload, spec_pool, first, dev_early = None, None, None, None
         if cell_subset == 1 and self._counts_path_applies(raw):
-            import threading
-            pool_ready = threading.Event()
-            pool_box = {}
-            upload = self._start_counts_upload(raw, pool_box, pool_ready)      # the upload starts at once; the matrix product waits for the pool
-            with tm.stage("fit.gene_statistics"):
-                first = _hostpar.col_stats_first(raw.values)
+            self._drop_resident()
+            with tm.stage("fit.counts_upload"):
+                from ._counts import DeviceCounts
+                dev_early = DeviceCounts.try_create(raw.values, self.device_id)
+            if dev_early is not None:
+                with tm.stage("fit.gene_statistics"):
+                    if raw.shape[0] < 2:
+                        first = None                         # (pandas' var of one row: the plain sequence below says what that is)
+                    elif os.environ.get("DIMN_DEVICE_STATS", "1") != "0":
+                        first = dev_early.gene_stats()
+                    else:                                    # the host routines (same numbers; dimn_hoststats.h)
+                        first = _hostpar.col_stats_first(raw.values)
+                        if first is not None:
+                            first["var"] = _hostpar.col_stats_var(raw.values, first["avg"])
         if first is not None:
             if n_pred is None:
                 spec_pool = np.flatnonzero((first["cmax"] > first["cmin"]) & (first["mean"] > 0)).astype(np.int32)
-                pool_box["pool"] = spec_pool
-            pool_ready.set()
+            upload = self._start_correlation(dev_early, spec_pool, raw.shape[0])
             with tm.stage("fit.inspect_data"):
                 inspect_data(raw, _max=first["vmax"])
             if self.seed is not None:
                 np.random.seed(self.seed)
-            with tm.stage("fit.gene_statistics"):
-                var = pd.Series(_hostpar.col_stats_var(raw.values, first["avg"]), index=raw.columns)
-                mean = pd.Series(first["mean"], index=raw.columns)
+            var = pd.Series(first["var"], index=raw.columns)
+            mean = pd.Series(first["mean"], index=raw.columns)
         else:
-            if pool_ready is not None:
-                pool_ready.set()                             # (the statistics routine declined, e.g. a NaN: the upload will decline too)
-            elif cell_subset == 1:
-                upload = self._start_counts_upload(raw)
-            else:
-                upload = lambda: None
+            upload = (lambda: dev_early)                     # (None unless the statistics declined after a successful upload)
             with tm.stage("fit.inspect_data"):
                 inspect_data(raw)
             if self.seed is not None:
@@ -515,7 +518,7 @@ class MultiNet:
         # against setTargets is free): fused on the GPU -- the g x g correlation never comes back to the host --
         # whenever a GPU is visible; otherwise, and for the shapes the kernel does not take, the two public
         # functions below run as in the reference.
-        with tm.stage("fit.counts_upload_wait"):
+        with tm.stage("fit.correlation_wait"):
             dev_counts = upload()
         with tm.stage("fit.correlation+predictors"):
             if not (_gpu_visible() and self._set_predictors_device(raw, n_pred, ntop, (var, mean), counts=dev_counts, corr_pool=spec_pool)):
@@ -592,6 +595,27 @@ class MultiNet:
         return not (os.environ.get("DIMN_RESIDENT_COUNTS", "1") == "0" or self._comm_spec is not None or self._engine_factory is not None or self.stream_matrix
                     or not isinstance(values, np.ndarray) or values.dtype != np.float64 or not values.flags.c_contiguous
                     or values.size * 4 > (32 << 30) or not _gpu_visible())
+
+    def _start_correlation(self, dev, pool, n_cells):
+        """|corr| of the candidate pool on a helper thread (ctypes releases the GIL; the work is on the GPU) while the caller
+        ranks genes on the host; returns a function that waits for it and gives `dev` back.  pool None: nothing to run ahead."""
+        import threading
+        box = {}
+
+        def work():
+            try:
+                if pool is not None and len(pool) >= 2 and n_cells >= 2:
+                    dev.corr(pool)
+                    dev.corr_ready = True
+            except Exception as exc:                          # the selection then runs the product itself and reports a real failure
+                box["error"] = exc
+        thread = threading.Thread(target=work, name="dimn-correlation", daemon=True)
+        thread.start()
+
+        def wait():
+            thread.join()
+            return dev
+        return wait
 
     def _start_counts_upload(self, raw, pool_box=None, pool_ready=None):
         """Begin uploading raw's counts to the GPU on a helper thread (ctypes releases the GIL) and return a function that waits

@@ -312,6 +312,14 @@ int dimn_counts_select_predictors(dimn_counts c, const int32_t* pool_cols, int64
 int dimn_counts_corr(dimn_counts c, const int32_t* pool_cols, int64_t pool_n);
 int dimn_counts_topk(dimn_counts c, const int32_t* targ_pos, int32_t K, int32_t O, const int32_t* col_rank, int32_t ntop, int32_t* out_idx);
 int dimn_set_matrix_counts(dimn_handle h, dimn_counts c, const float* lut, int64_t lut_n);
+/* ABI 6.  The correlation of resident counts below 65536 runs EXACTLY on the int8 matrix cores (integer numerator and radicands,
+ * one rounding each into float64; csrc/dimn_counts_dev.h), larger counts on the float64 kernel; DIMN_CORR_I8=0 forces the latter.
+ * dimn_counts_corr_read (tests / diagnostics): the matrix dimn_counts_corr left on the device, out[pool_n][pool_n].
+ * dimn_counts_gene_stats: multinet.py:191 `raw.var()` / `raw.mean()` of the resident counts and the column extremes, each [g] or
+ *   NULL -- the additions pandas performs, in pandas' order, one thread per gene: equal to DataFrame.mean() / .var() to the bit
+ *   (the float32 counts convert to float64 exactly). */
+int dimn_counts_corr_read(dimn_counts c, double* out, int64_t pool_n);
+int dimn_counts_gene_stats(dimn_counts c, double* mean, double* var, double* cmin, double* cmax);
 
 /* ---- the per-gene statistics fit() orders genes by (multinet.py:191 `raw.var() / (1 + raw.mean())`), host code ----------
  * mean[g], var[g] (ddof 1; NULL: skipped) of the columns of a[n][ld] in pandas' own order of operations (two sequential sums
