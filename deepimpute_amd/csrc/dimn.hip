@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -117,6 +118,39 @@ static int rccl_bind() {
 enum { kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0 };
 
 // the raw count matrix resident on the device (dimn_counts_*, below)
+// Process-wide pinned bounce buffers.  Pinning 4 x 128 MB costs ~90 ms, as much as moving 4 GB over PCIe, and every fit() makes a
+// new handle: the buffers are allocated once per process and LEASED to one pipeline at a time (dimn_counts_create, dimn_impute_finish);
+// a second pipeline running at the same moment allocates its own and frees them again.
+static std::mutex g_pin_mu;
+static void* g_pin_buf[4] = {nullptr, nullptr, nullptr, nullptr};
+static size_t g_pin_cap = 0;
+struct PinLease {
+    std::unique_lock<std::mutex> lock;
+    void* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool own = false;
+    // the first `count` (<= 4) buffers, `bytes` each; false (with the HIP error text in *err) when pinning fails
+    bool take(int count, size_t bytes, const char** err) {
+        lock = std::unique_lock<std::mutex>(g_pin_mu, std::try_to_lock);
+        own = !lock.owns_lock();
+        if (!own && g_pin_cap < bytes) {                 // the shared set grows: start again at the new size
+            for (auto& pb : g_pin_buf) if (pb) { (void)hipHostFree(pb); pb = nullptr; }
+            g_pin_cap = bytes;
+        }
+        void** dst = own ? buf : g_pin_buf;
+        for (int i = 0; i < count; ++i) {
+            if (!dst[i]) {
+                const hipError_t e = hipHostMalloc(&dst[i], own ? bytes : g_pin_cap, hipHostMallocDefault);
+                if (e != hipSuccess) { dst[i] = nullptr; *err = hipGetErrorString(e); return false; }
+            }
+            buf[i] = dst[i];
+        }
+        return true;
+    }
+    ~PinLease() {
+        if (own) for (auto& pb : buf) if (pb) (void)hipHostFree(pb);
+    }
+};
+
 struct dimn_counts_s {
     int device = 0; int64_t n = 0, g = 0; float* d = nullptr; double vmax = 0; uint64_t checksum = 0;
     double* d_corr = nullptr; int64_t corr_g = 0;     // |corr| of the last dimn_counts_corr pool, until dimn_counts_topk has used it
@@ -171,7 +205,6 @@ struct dimn_handle_s {
     int res_checked = 0;                   // 1: co-residency of a launch's workgroups verified against the occupancy of the kernel
     int res_bf16 = 0;                      // 1: precision bf16 -> the resident kernel runs EVERY training GEMM on the bf16 matrix cores (template BF)
     double tm_res_ms = 0; int64_t tm_res_steps = 0;
-    double* pin_buf[4] = {nullptr, nullptr, nullptr, nullptr}; size_t pin_cap = 0;   // pinned bounce buffers of dimn_impute_finish, kept across calls
     hipStream_t stream = nullptr;          // lane 0's stream; also used by every non-training call
     struct Lane {                          // sub-nets [k0,k1), work items [w0,w1)
         hipStream_t stream; int k0, k1, w0, w1;
@@ -615,7 +648,6 @@ extern "C" int dimn_destroy(dimn_handle h) {
     DEV_FREE(h->d_midwork); DEV_FREE(h->d_midk); DEV_FREE(h->d_P2); DEV_FREE(h->d_G);
     DEV_FREE(h->d_epoch_rows); DEV_FREE(h->d_val_rows); DEV_FREE(h->d_pred_rows); DEV_FREE(h->d_out);
     DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage); DEV_FREE(h->d_red);
-    for (auto& pb : h->pin_buf) if (pb) { (void)hipHostFree(pb); pb = nullptr; }
     DEV_FREE(h->d_W1b); DEV_FREE(h->d_W2t); DEV_FREE(h->d_W2tf);
     DEV_FREE(h->d_res_P); DEV_FREE(h->d_res_D); DEV_FREE(h->d_res_T); DEV_FREE(h->d_res_A); DEV_FREE(h->d_res_b1); DEV_FREE(h->d_res_alpha); DEV_FREE(h->d_res_flags); DEV_FREE(h->d_res_loss); DEV_FREE(h->d_res_snap);
     for (auto& ln : h->lanes) {
@@ -1560,19 +1592,18 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
     hipStream_t st[2] = {nullptr, nullptr};
     hipEvent_t evOut[2] = {nullptr, nullptr};
     int rc = DIMN_OK;
+    PinLease pins;
+    {
+        const char* why = "";
+        if (!pins.take(4, std::max<size_t>((size_t)(128u << 20), (size_t)blk * g * 8), &why)) return fail(DIMN_ERR_HIP, "dimn_impute_finish: pinning the bounce buffers failed: %s", why);
+    }
 #define FIN_TRY(expr) do { hipError_t e_ = (expr); if (rc == DIMN_OK && e_ != hipSuccess) rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
     FIN_TRY(hipMalloc((void**)&dOff, (size_t)(g + 1) * 4));
     FIN_TRY(hipMalloc((void**)&dSlot, (size_t)std::max<int64_t>(S, 1) * 4));
     for (int b = 0; b < 2; ++b) {
         if (!resident) FIN_TRY(hipMalloc((void**)&dRaw[b], (size_t)blk * g * 8));
         FIN_TRY(hipMalloc((void**)&dRes[b], (size_t)blk * g * 8));
-        if (h->pin_cap < (size_t)blk * g * 8 && b == 0) {        // (re)allocate the four pinned buffers once per size
-            for (auto& pb : h->pin_buf) if (pb) { (void)hipHostFree(pb); pb = nullptr; }
-            h->pin_cap = 0;
-            for (auto& pb : h->pin_buf) FIN_TRY(hipHostMalloc((void**)&pb, (size_t)blk * g * 8, hipHostMallocDefault));
-            if (rc == DIMN_OK) h->pin_cap = (size_t)blk * g * 8;
-        }
-        pIn[b] = h->pin_buf[b]; pOut[b] = h->pin_buf[2 + b];
+        pIn[b] = (double*)pins.buf[b]; pOut[b] = (double*)pins.buf[2 + b];
         FIN_TRY(hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking));
         FIN_TRY(hipEventCreateWithFlags(&evOut[b], hipEventDisableTiming));
     }
@@ -2149,12 +2180,17 @@ extern "C" int dimn_counts_create(int32_t device_id, const double* raw, int64_t 
     hipEvent_t ev[2] = {nullptr, nullptr};
     hipStream_t st = nullptr;
     int rc = DIMN_OK, ok = 1;
+    PinLease pins;
     const int64_t blk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(128u << 20) / (g * 4)));
 #define CNT_TRY(expr) do { hipError_t e_ = (expr); if (rc == DIMN_OK && e_ != hipSuccess) rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
     CNT_TRY(hipMalloc((void**)&c->d, (size_t)n * g * 4));
     CNT_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    {
+        const char* why = "";
+        if (rc == DIMN_OK && !pins.take(2, std::max<size_t>((size_t)(128u << 20), (size_t)blk * g * 4), &why)) rc = fail(DIMN_ERR_HIP, "dimn_counts_create: pinning the bounce buffers failed: %s", why);
+    }
     for (int b = 0; b < 2; ++b) {
-        CNT_TRY(hipHostMalloc((void**)&pin[b], (size_t)blk * g * 4, hipHostMallocDefault));
+        pin[b] = (float*)pins.buf[b];
         CNT_TRY(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
     }
     int64_t bi = 0;
@@ -2169,7 +2205,7 @@ extern "C" int dimn_counts_create(int32_t device_id, const double* raw, int64_t 
     }
     if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
 #undef CNT_TRY
-    for (int b = 0; b < 2; ++b) { if (pin[b]) (void)hipHostFree(pin[b]); if (ev[b]) (void)hipEventDestroy(ev[b]); }
+    for (int b = 0; b < 2; ++b) if (ev[b]) (void)hipEventDestroy(ev[b]);
     if (rc == DIMN_OK && !ok) rc = fail(DIMN_ERR_UNSUP, "dimn_counts_create: the matrix holds values that are not counts (non-negative integers <= 2^22)");
     if (rc != DIMN_OK) { dimn_counts_destroy(c); return rc; }
     if (vmax_out) *vmax_out = c->vmax;
