@@ -2303,6 +2303,7 @@ done:
 // still ranking genes: dimn_counts_corr leaves |corr| of the pool on the device, dimn_counts_topk selects from it and frees it.
 extern "C" int dimn_counts_corr(dimn_counts c, const int32_t* pool_cols, int64_t pool_n) {
     if (!c || !pool_cols || pool_n < 1 || c->n < 2) return fail(DIMN_ERR_ARG, "dimn_counts_corr: bad argument");
+    if (pool_n > 65535) return fail(DIMN_ERR_UNSUP, "dimn_counts_corr: more than 65535 candidate genes");
     for (int64_t j = 0; j < pool_n; ++j) if (pool_cols[j] < 0 || pool_cols[j] >= c->g) return fail(DIMN_ERR_ARG, "dimn_counts_corr: pool column out of range");
     CHK(corr_device_ok("dimn_counts_corr", c->device));
     if (c->d_corr) { (void)hipFree(c->d_corr); c->d_corr = nullptr; c->corr_g = 0; }

@@ -604,7 +604,7 @@ class MultiNet:
 
         def work():
             try:
-                if pool is not None and len(pool) >= 2 and n_cells >= 2:
+                if pool is not None and 2 <= len(pool) <= 65535 and n_cells >= 2:
                     dev.corr(pool)
                     dev.corr_ready = True
             except Exception as exc:                          # the selection then runs the product itself and reports a real failure
@@ -900,7 +900,7 @@ class MultiNet:
         if ntop > 16:
             return False
         pool, values = _candidate_pool(raw, n_pred, var_mean, labels_only=counts is not None)
-        if not pool.is_unique or raw.shape[0] < 2:
+        if not pool.is_unique or raw.shape[0] < 2 or len(pool) > 65535:      # (one grid row per candidate gene in the finishing kernels)
             return False
         targets = np.asarray(self.targets)
         K, O = targets.shape

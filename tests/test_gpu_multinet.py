@@ -169,13 +169,14 @@ def test_resident_counts_path_equals_host_path(tmp_path, monkeypatch):
     raw = _raw(n=260, g=520, seed=3)
     kw = dict(sub_outputdim=64, seed=11, ncores=1, verbose=0, max_epochs=4, patience=10, learning_rate=1e-3)
     runs = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("DIMN_RESIDENT_COUNTS", mode)
+    for mode in ("1", "1h", "0"):                                       # "1h": resident counts, statistics by the host routines
+        monkeypatch.setenv("DIMN_RESIDENT_COUNTS", mode[0])
+        monkeypatch.setenv("DIMN_DEVICE_STATS", "0" if mode == "1h" else "1")
         net = MultiNet(output_prefix=str(tmp_path / mode), **kw).fit(raw, NN_lim=200)
-        assert (getattr(net, "_resident", None) is not None) == (mode == "1")
+        assert (getattr(net, "_resident", None) is not None) == (mode[0] == "1")
         same = net.predict(raw)
         used_resident = "predict.log1p" not in net.timings
-        assert used_resident == (mode == "1")
+        assert used_resident == (mode[0] == "1")
         other = raw.iloc[::-1].copy()                                   # another frame: same genes, cells in reverse order
         flipped = net.predict(other, policy="max")
         edited = raw.copy()
@@ -183,12 +184,14 @@ def test_resident_counts_path_equals_host_path(tmp_path, monkeypatch):
         after_edit = net.predict(edited)
         runs[mode] = (net.predictors, net.history, same, flipped, after_edit, net.test_metrics)
         net.close()
-    a, b = runs["1"], runs["0"]
-    assert len(a[0]) == len(b[0]) and all(list(x) == list(y) for x, y in zip(a[0], b[0]))
-    assert a[1] == b[1]
-    for i in (2, 3, 4):
-        assert a[i].index.equals(b[i].index) and np.array_equal(a[i].values, b[i].values), i
-    assert a[5] == b[5]
+    for other_mode in ("0", "1h"):
+        a, b = runs["1"], runs[other_mode]
+        assert len(a[0]) == len(b[0]) and all(list(x) == list(y) for x, y in zip(a[0], b[0]))
+        assert a[1] == b[1]
+        for i in (2, 3, 4):
+            assert a[i].index.equals(b[i].index) and np.array_equal(a[i].values, b[i].values), i
+        assert a[5] == b[5]
+    a = runs["1"]
     assert a[4].iloc[5, 7] == raw.iloc[5, 7] + 3.0                     # the edited count was restored, not the stale resident one
     # not counts: the upload declines, the host path runs
     monkeypatch.setenv("DIMN_RESIDENT_COUNTS", "1")
