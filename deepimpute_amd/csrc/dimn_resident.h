@@ -61,7 +61,10 @@
 #endif
 #define DIMN_RES_W2S 27104        // LDS float offset of the W2 state
 #define DIMN_RES_LDS_FLOATS (DIMN_RES_W2S + 3 * 16 * 256)
-#define DIMN_RES_SLOTS 2          // slots per exchange buffer (step parity)
+#define DIMN_RES_SLOTS 2
+#ifndef DIMN_RES_M2WIN
+#define DIMN_RES_M2WIN 8        // dD partial requests in flight per thread in M2 (16: tried)
+#endif          // slots per exchange buffer (step parity)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -646,6 +649,16 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                     const int o0 = half * (OT >> 1), o1 = half ? OT : (OT >> 1);
                     const uint32_t base = dcur + (uint32_t)((ht * 1024 + 4 * (tid & 255)) * 4);
                     int o = o0;
+#if DIMN_RES_M2WIN == 16
+                    if (o + 16 <= o1) {                              // all 16 producers of this half requested at once: one round trip
+                        f32x4 tq[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) tq[i] = res_ld(rD, base + (uint32_t)((o + i) * 65536));
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { res_fix(tq[i], rD, base + (uint32_t)((o + i) * 65536), abort_w); d += tq[i]; }
+                        o += 16;
+                    }
+#else
                     if (o + 16 <= o1) {                              // rolling window of 8 requests over 16 producers
                         f32x4 tq[8];
 #pragma unroll
@@ -660,6 +673,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                         for (int i = 0; i < 8; ++i) { res_fix(tq[i], rD, base + (uint32_t)((o + 8 + i) * 65536), abort_w); d += tq[i]; }
                         o += 16;
                     }
+#endif
                     for (; o + 4 <= o1; o += 4) {
                         f32x4 tq[4];
 #pragma unroll

@@ -617,11 +617,10 @@ class MultiNet:
             return dev
         return wait
 
-    def _start_counts_upload(self, raw, pool_box=None, pool_ready=None):
+    def _start_counts_upload(self, raw):
         """Begin uploading raw's counts to the GPU on a helper thread (ctypes releases the GIL) and return a function that waits
-        for it and gives the _counts.DeviceCounts, or None where the fast path does not apply / the values are not counts.
-        With `pool_ready` (a threading.Event) the helper goes on, once the event is set, to the |corr| matrix of the columns
-        pool_box["pool"] -- the caller sets it when the first sweep of its gene statistics has named the candidate pool."""
+        for it and gives the _counts.DeviceCounts, or None where the fast path does not apply / the values are not counts
+        (predict() of a frame that is not the fitted one: the upload runs beside load())."""
         self._drop_resident()
         values = getattr(raw, "values", None)
         if not self._counts_path_applies(raw):
@@ -633,12 +632,6 @@ class MultiNet:
         def work():
             try:
                 box["counts"] = DeviceCounts.try_create(values, self.device_id)
-                if pool_ready is not None:
-                    pool_ready.wait(600.0)                   # (bounded: a caller that failed before naming the pool must not pin this thread)
-                    corr_pool = pool_box.get("pool")
-                    if box["counts"] is not None and corr_pool is not None and len(corr_pool) >= 2 and values.shape[0] >= 2:
-                        box["counts"].corr(corr_pool)
-                        box["counts"].corr_ready = True
             except Exception as exc:                          # the host path takes over; a real failure shows up there
                 box["error"] = exc
         thread = threading.Thread(target=work, name="dimn-counts-upload", daemon=True)
