@@ -62,6 +62,9 @@
 #define DIMN_RES_W2S 27104        // LDS float offset of the W2 state
 #define DIMN_RES_LDS_FLOATS (DIMN_RES_W2S + 3 * 16 * 256)
 #define DIMN_RES_SLOTS 2
+#ifndef DIMN_RES_ABL
+#define DIMN_RES_ABL 0          // timing ablations of the tile loop (tools/r03_res_abl.sh): 1 = no Adam, 2 = no LDS staging of the X tiles (loads kept), 4 = no X tile loads (staging kept); WRONG results
+#endif
 #ifndef DIMN_RES_M2WIN
 #define DIMN_RES_M2WIN 8        // dD partial requests in flight per thread in M2 (16: tried)
 #endif          // slots per exchange buffer (step parity)
@@ -206,6 +209,16 @@ __global__ __launch_bounds__(512) void k_res_masks(const SubnetDev* __restrict__
     maskw[(size_t)blockIdx.x * 512 + ww] = word;
 }
 
+// Order of the tile loop's "virtual tiles" (role1): gradient tile j and forward tile j alternate (g0 f0 g1 f1 ..); without GRAD (the
+// epoch's first forward) there are forward tiles only.  DIMN_RES_BF_SPLIT=1 (experiment, bf16 operands only): all gradient tiles
+// first, then the forward tiles -- every request then has two tile-times of lead from the same two register sets; measured on
+// one box 20.0 vs 19.7 us per step at K = 5 and 38.6 vs 38.0 at configs[4]'s 8 sub-nets: the rows are not what the loop waits for
+// (tools/r03_res_bfsplit.sh; fp32 operands in that order: 24.1 vs 23.8).
+#ifndef DIMN_RES_BF_SPLIT
+#define DIMN_RES_BF_SPLIT 0
+#endif
+template <bool GRAD, bool BF, int T1> __device__ __forceinline__ constexpr bool res_vfwd(int v) { return !GRAD ? true : ((BF && DIMN_RES_BF_SPLIT) ? v >= T1 : (v & 1) != 0); }
+template <bool GRAD, bool BF, int T1> __device__ __forceinline__ constexpr int res_vtile(int v) { return !GRAD ? v : ((BF && DIMN_RES_BF_SPLIT) ? (v >= T1 ? v - T1 : v) : (v >> 1)); }
 // c += sum_r a[r] (x) b[r] over the four k-slots a lane owns: four exact-fp32 matrix instructions, or (BF) ONE bf16 instruction
 // whose four-element operands are those k-slots rounded to nearest even
 template <bool BF>
@@ -334,48 +347,61 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
 #pragma unroll
         for (int i = 0; i < 4; ++i) xo[i] = (uint32_t)rr[i] * (uint32_t)s.Dp;
     };
-    // The body of role 1: W1 gradient of batch t + Adam in registers (do_grad; bfr = dA[b = 4kb+lj][h = li]), then the
-    // forward partial of batch t+1 with the fresh W1 (do_fwd).  xa/xb: the X_t / X_{t+1} tiles of the wave's first
-    // chunk, requested by the caller (before its wait); xot/xon from xrows().  The partial goes to the manager of the hidden
-    // tile: a sibling publishes it (slot_out), the manager keeps its own in LDS (yl) until it sums the tile (M1).
-    auto role1 = [&](const int tid, const uint32_t (&xot)[4], const uint32_t (&xon)[4], XRaw<XT> (&xa)[4], XRaw<XT> (&xb)[4], bool do_grad, bool do_fwd,
+    // The body of role 1: W1 gradient of batch t + Adam in registers (GRAD; bfr = dA[b = 4kb+lj][h = li]) and the forward
+    // partial of batch t+1 with the fresh W1 (do_fwd) -- as ONE sequence of "virtual tiles" (res_vfwd / res_vtile say which
+    // tile a position is): a gradient tile reads the rows of X_t, a forward tile those of X_{t+1}, each needs ONE X tile
+    // (16 bytes per lane and row group), and two register sets hold the X tiles of positions v+1 and v+2.
+    // xr[0] / xr[1]: virtual tiles 0 and 1, requested by the caller (before its wait);
+    // xot / xon from xrows().  The partial goes to the manager of the hidden tile: a sibling publishes it (slot_out), the manager
+    // keeps its own in LDS (yl) until it sums the tile (M1).
+    auto role1 = [&](auto grad_c, const int tid, const uint32_t (&xot)[4], const uint32_t (&xon)[4], XRaw<XT> (&xr)[2][4], bool do_fwd,
                      const float (&bfr)[16], const AdamP ap, uint32_t slot_out) {
+        constexpr bool GRAD = decltype(grad_c)::value;
+        constexpr int NV = GRAD ? 2 * T1 : T1;
         const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lj = lane >> 4;
         const XT* xk = (const XT*)p.X + s.xoff + 4 * (lane & 3);
-        float* xt = xst + wave * 2048;
-        float* xn = xt + 1024;
+        float* xs = xst + wave * 2048;                           // two wave-private staging tiles, alternating
         f32x4 pT[4] = {zero4, zero4, zero4, zero4};
+        float abl_sink = 0.f;
 #pragma unroll
-        for (int j = 0; j < T1; ++j) {
-            if (j > 0 && !tv[j]) break;                          // wave-uniform: a wave's tiles are its first ones (tile 0 always runs: it may be a clamped one)
+        for (int v = 0; v < NV; ++v) {
+            const bool fwd = res_vfwd<GRAD, BF, T1>(v);
+            const int j = res_vtile<GRAD, BF, T1>(v);
+            const bool live = tv[j] || j == 0;                   // wave-uniform: a wave's tiles are its first ones (tile 0 always runs: it may be a clamped one)
+            float* xv = xs + (v & 1) * 1024;
+            if (live && (!(DIMN_RES_ABL & 2) || !GRAD)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {                        // wave-private staging (in-order LDS, no barrier)
-                *(f32x4*)(xt + 256 * i + 4 * lane) = xa[i].get();
-                *(f32x4*)(xn + 256 * i + 4 * lane) = xb[i].get();
+                for (int i = 0; i < 4; ++i) *(f32x4*)(xv + 256 * i + 4 * lane) = xr[v & 1][i].get();   // wave-private staging (in-order LDS, no barrier)
+            } else if (DIMN_RES_ABL & 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) abl_sink += xr[v & 1][i].get()[0];                         // (ablation: the loads stay live)
             }
-            if (j + 1 < T1) {
+            if (v + 2 < NV && (!(DIMN_RES_ABL & 4) || !GRAD)) {
+                const bool f2 = res_vfwd<GRAD, BF, T1>(v + 2);
+                const int j2 = res_vtile<GRAD, BF, T1>(v + 2);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { xa[i].load(xk + xot[i] + 16 * tc[j + 1]); xb[i].load(xk + xon[i] + 16 * tc[j + 1]); }
+                for (int i = 0; i < 4; ++i) xr[v & 1][i].load(xk + (f2 ? xon[i] : xot[i]) + 16 * tc[j2]);
             }
-            __builtin_amdgcn_sched_barrier(0);                   // the requests of the next tile leave before this tile's MFMAs
-            if (do_grad) {
+            __builtin_amdgcn_sched_barrier(0);                   // the requests leave before this tile's MFMAs
+            if (!fwd) {
                 f32x4 g = zero4;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {                    // A = X_t^T[d = li][b = 4kb+lj], B = dA[b = 4kb+lj][h = li], kb = 4q + r
-                    const f32x4 xq = (f32x4){xt[64 * (4 * q) + lane], xt[64 * (4 * q + 1) + lane], xt[64 * (4 * q + 2) + lane], xt[64 * (4 * q + 3) + lane]};
+                    const f32x4 xq = (f32x4){xv[64 * (4 * q) + lane], xv[64 * (4 * q + 1) + lane], xv[64 * (4 * q + 2) + lane], xv[64 * (4 * q + 3) + lane]};
                     const f32x4 bq = (f32x4){bfr[4 * q], bfr[4 * q + 1], bfr[4 * q + 2], bfr[4 * q + 3]};
                     g = res_mfma4<BF>(xq, bq, g);
                 }
-                if (tv[j]) adam4(w1[j], m1[j], v1[j], g, ap);
-            }
-            if (do_fwd && tv[j]) {                               // wave-uniform
+                if (tv[j] && !(DIMN_RES_ABL & 1)) adam4(w1[j], m1[j], v1[j], g, ap);
+                if (DIMN_RES_ABL & 1) w1[j] += g * 1e-30f;             // (ablation: the gradient stays live)
+            } else if (do_fwd && tv[j]) {                        // wave-uniform
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
-                    const f32x4 x4 = *(const f32x4*)(xn + (16 * n + li) * 16 + 4 * lj);         // X_next[b = 16n+li][d = 4lj+r]
+                    const f32x4 x4 = *(const f32x4*)(xv + (16 * n + li) * 16 + 4 * lj);         // X_next[b = 16n+li][d = 4lj+r]
                     pT[n] = res_mfma4<BF>(w1[j], x4, pT[n]);                                    // P^T[h][b] += W1^T X^T
                 }
             }
         }
+        if ((DIMN_RES_ABL & 2) && abl_sink == 12345.678f) pT[0][0] += 1.f;
         RES_STAMP(8)
         if (do_fwd) {
 #pragma unroll
@@ -421,12 +447,12 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
         const int b0 = p.n_tr < B ? p.n_tr : B;
         AdamP ap0; ap0.alpha = 0.f; ap0.omb1 = p.omb1; ap0.omb2 = p.omb2; ap0.eps = p.eps;
         xrows(tid, 0, b0, xo0);
-        XRaw<XT> xa[4], xb[4];
+        XRaw<XT> xr[2][4];
         const XT* xk = (const XT*)p.X + s.xoff + 4 * (lane & 3);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { xa[i].load(xk + xo0[i] + 16 * tc[0]); xb[i] = xa[i]; }
+        for (int i = 0; i < 4; ++i) { xr[0][i].load(xk + xo0[i] + 16 * tc[0]); xr[1][i].load(xk + xo0[i] + 16 * tc[T1 > 1 ? 1 : 0]); }
         __syncthreads();                                         // b1l written
-        role1(tid, xo0, xo0, xa, xb, false, true, nob, ap0, 0u);
+        role1(std::false_type{}, tid, xo0, xo0, xr, true, nob, ap0, 0u);
         y_a = targets(tid, target_row(tid, 0));
     }
 
@@ -630,11 +656,14 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             uint32_t xon[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) xon[i] = b_next > 0 ? (uint32_t)rn[i] * (uint32_t)s.Dp : xo0[i];
-            XRaw<XT> xa[4], xb[4];
-            {
+            XRaw<XT> xr[2][4];
+            {   // virtual tiles 0 and 1 of the step's tile loop
                 const XT* xk = (const XT*)p.X + s.xoff + 4 * (lane & 3);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { xa[i].load(xk + xo0[i] + 16 * tc[0]); xb[i].load(xk + xon[i] + 16 * tc[0]); }
+                for (int i = 0; i < 4; ++i) {
+                    xr[0][i].load(xk + xo0[i] + 16 * tc[0]);
+                    xr[1][i].load(xk + (res_vfwd<true, BF, T1>(1) ? xon[i] : xo0[i]) + 16 * tc[res_vtile<true, BF, T1>(1)]);
+                }
             }
             if (t + 1 < p.steps) y_a = targets(tid, yrow_n);     // every thread (unconditional load); role 2 uses the first 256
             RES_STAMP(5)
@@ -728,7 +757,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
 #pragma unroll
             for (int kb = 0; kb < 16; ++kb) bfr[kb] = dzl[64 * kb + lane];                                        // dA[b = 4kb+lj][h = li]
             RES_STAMP(7)
-            role1(tid, xo0, xon, xa, xb, true, b_next > 0, bfr, ap, pnext);     // its first barrier orders b1l / dzl
+            role1(std::true_type{}, tid, xo0, xon, xr, b_next > 0, bfr, ap, pnext);     // its first barrier orders b1l / dzl
             if (b_next == 0) __syncthreads();
 #pragma unroll
             for (int i = 0; i < 4; ++i) xo0[i] = xon[i];         // the next batch becomes the current one
