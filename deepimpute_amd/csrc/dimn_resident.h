@@ -209,6 +209,29 @@ __global__ __launch_bounds__(512) void k_res_masks(const SubnetDev* __restrict__
     maskw[(size_t)blockIdx.x * 512 + ww] = word;
 }
 
+// One X tile of a virtual tile of role1, as raw register words.  A forward tile is four row-major 16-byte pieces (row16); with
+// DIMN_RES_GDIRECT a gradient tile is SIXTEEN single elements X[b = 4kb+lj][d = li] (elem): exactly the A operand of the matrix
+// instruction X_t^T dA -- one coalesced 64-byte run per four rows and request, no transposition through LDS.
+#ifndef DIMN_RES_GDIRECT
+#define DIMN_RES_GDIRECT 0
+#endif
+template <typename XT> struct XSlot;
+template <> struct XSlot<float> {
+    uint32_t w[16];
+    __device__ __forceinline__ void load_row16(int i, const float* q) { const f32x4 t = *(const f32x4*)q; for (int r = 0; r < 4; ++r) w[4 * i + r] = __float_as_uint(t[r]); }
+    __device__ __forceinline__ f32x4 row16(int i) const { return (f32x4){__uint_as_float(w[4 * i]), __uint_as_float(w[4 * i + 1]), __uint_as_float(w[4 * i + 2]), __uint_as_float(w[4 * i + 3])}; }
+    __device__ __forceinline__ void load_elem(int kb, const float* q) { w[kb] = __float_as_uint(*q); }
+    __device__ __forceinline__ float elem(int kb) const { return __uint_as_float(w[kb]); }
+};
+template <> struct XSlot<bf16_t> {
+    uint32_t w[16];
+    __device__ __forceinline__ void load_row16(int i, const bf16_t* q) { const uint2 t = *(const uint2*)q; w[2 * i] = t.x; w[2 * i + 1] = t.y; }
+    __device__ __forceinline__ f32x4 row16(int i) const {
+        return (f32x4){__uint_as_float(w[2 * i] << 16), __uint_as_float(w[2 * i] & 0xffff0000u), __uint_as_float(w[2 * i + 1] << 16), __uint_as_float(w[2 * i + 1] & 0xffff0000u)};
+    }
+    __device__ __forceinline__ void load_elem(int kb, const bf16_t* q) { w[kb] = (uint32_t)*q; }
+    __device__ __forceinline__ float elem(int kb) const { return __uint_as_float(w[kb] << 16); }
+};
 // Order of the tile loop's "virtual tiles" (role1): gradient tile j and forward tile j alternate (g0 f0 g1 f1 ..); without GRAD (the
 // epoch's first forward) there are forward tiles only.  DIMN_RES_BF_SPLIT=1 (experiment, bf16 operands only): all gradient tiles
 // first, then the forward tiles -- every request then has two tile-times of lead from the same two register sets; measured on
@@ -354,12 +377,13 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
     // xr[0] / xr[1]: virtual tiles 0 and 1, requested by the caller (before its wait);
     // xot / xon from xrows().  The partial goes to the manager of the hidden tile: a sibling publishes it (slot_out), the manager
     // keeps its own in LDS (yl) until it sums the tile (M1).
-    auto role1 = [&](auto grad_c, const int tid, const uint32_t (&xot)[4], const uint32_t (&xon)[4], XRaw<XT> (&xr)[2][4], bool do_fwd,
+    auto role1 = [&](auto grad_c, const int tid, const uint32_t (&xot)[4], const uint32_t (&xon)[4], const uint32_t (&xog)[16], XSlot<XT> (&xr)[2], bool do_fwd,
                      const float (&bfr)[16], const AdamP ap, uint32_t slot_out) {
         constexpr bool GRAD = decltype(grad_c)::value;
         constexpr int NV = GRAD ? 2 * T1 : T1;
         const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lj = lane >> 4;
         const XT* xk = (const XT*)p.X + s.xoff + 4 * (lane & 3);
+        const XT* xg = (const XT*)p.X + s.xoff + li;              // (DIMN_RES_GDIRECT) element d = li of a row
         float* xs = xst + wave * 2048;                           // two wave-private staging tiles, alternating
         f32x4 pT[4] = {zero4, zero4, zero4, zero4};
         float abl_sink = 0.f;
@@ -369,27 +393,45 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             const int j = res_vtile<GRAD, BF, T1>(v);
             const bool live = tv[j] || j == 0;                   // wave-uniform: a wave's tiles are its first ones (tile 0 always runs: it may be a clamped one)
             float* xv = xs + (v & 1) * 1024;
-            if (live && (!(DIMN_RES_ABL & 2) || !GRAD)) {
+            auto request = [&]() {                               // the X tile of position v + 2 into the register set of position v
+                if (v + 2 < NV && (!(DIMN_RES_ABL & 4) || !GRAD)) {
+                    const bool f2 = res_vfwd<GRAD, BF, T1>(v + 2);
+                    const int j2 = res_vtile<GRAD, BF, T1>(v + 2);
+                    if (DIMN_RES_GDIRECT && !f2) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) *(f32x4*)(xv + 256 * i + 4 * lane) = xr[v & 1][i].get();   // wave-private staging (in-order LDS, no barrier)
+                        for (int kb = 0; kb < 16; ++kb) xr[v & 1].load_elem(kb, xg + xog[kb] + 16 * tc[j2]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) xr[v & 1].load_row16(i, xk + (f2 ? xon[i] : xot[i]) + 16 * tc[j2]);
+                    }
+                }
+            };
+            if (DIMN_RES_GDIRECT && !fwd) {
+                // operands straight from the registers: the request for position v + 2 follows the matrix instructions that read them
+            } else if (live && (!(DIMN_RES_ABL & 2) || !GRAD)) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(f32x4*)(xv + 256 * i + 4 * lane) = xr[v & 1].row16(i);   // wave-private staging (in-order LDS, no barrier)
             } else if (DIMN_RES_ABL & 2) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) abl_sink += xr[v & 1][i].get()[0];                         // (ablation: the loads stay live)
+                for (int i = 0; i < 4; ++i) abl_sink += xr[v & 1].row16(i)[0];                         // (ablation: the loads stay live)
             }
-            if (v + 2 < NV && (!(DIMN_RES_ABL & 4) || !GRAD)) {
-                const bool f2 = res_vfwd<GRAD, BF, T1>(v + 2);
-                const int j2 = res_vtile<GRAD, BF, T1>(v + 2);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) xr[v & 1][i].load(xk + (f2 ? xon[i] : xot[i]) + 16 * tc[j2]);
+            if (!(DIMN_RES_GDIRECT && !fwd)) {
+                request();
+                __builtin_amdgcn_sched_barrier(0);               // the requests leave before this tile's MFMAs
             }
-            __builtin_amdgcn_sched_barrier(0);                   // the requests leave before this tile's MFMAs
             if (!fwd) {
                 f32x4 g = zero4;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {                    // A = X_t^T[d = li][b = 4kb+lj], B = dA[b = 4kb+lj][h = li], kb = 4q + r
-                    const f32x4 xq = (f32x4){xv[64 * (4 * q) + lane], xv[64 * (4 * q + 1) + lane], xv[64 * (4 * q + 2) + lane], xv[64 * (4 * q + 3) + lane]};
+                    const f32x4 xq = DIMN_RES_GDIRECT ? (f32x4){xr[v & 1].elem(4 * q), xr[v & 1].elem(4 * q + 1), xr[v & 1].elem(4 * q + 2), xr[v & 1].elem(4 * q + 3)}
+                                                      : (f32x4){xv[64 * (4 * q) + lane], xv[64 * (4 * q + 1) + lane], xv[64 * (4 * q + 2) + lane], xv[64 * (4 * q + 3) + lane]};
                     const f32x4 bq = (f32x4){bfr[4 * q], bfr[4 * q + 1], bfr[4 * q + 2], bfr[4 * q + 3]};
                     g = res_mfma4<BF>(xq, bq, g);
+                }
+                if (DIMN_RES_GDIRECT) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    request();
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (tv[j] && !(DIMN_RES_ABL & 1)) adam4(w1[j], m1[j], v1[j], g, ap);
                 if (DIMN_RES_ABL & 1) w1[j] += g * 1e-30f;             // (ablation: the gradient stays live)
@@ -447,12 +489,13 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
         const int b0 = p.n_tr < B ? p.n_tr : B;
         AdamP ap0; ap0.alpha = 0.f; ap0.omb1 = p.omb1; ap0.omb2 = p.omb2; ap0.eps = p.eps;
         xrows(tid, 0, b0, xo0);
-        XRaw<XT> xr[2][4];
+        XSlot<XT> xr[2];
         const XT* xk = (const XT*)p.X + s.xoff + 4 * (lane & 3);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { xr[0][i].load(xk + xo0[i] + 16 * tc[0]); xr[1][i].load(xk + xo0[i] + 16 * tc[T1 > 1 ? 1 : 0]); }
+        for (int i = 0; i < 4; ++i) { xr[0].load_row16(i, xk + xo0[i] + 16 * tc[0]); xr[1].load_row16(i, xk + xo0[i] + 16 * tc[T1 > 1 ? 1 : 0]); }
         __syncthreads();                                         // b1l written
-        role1(std::false_type{}, tid, xo0, xo0, xr, true, nob, ap0, 0u);
+        const uint32_t nog[16] = {0u};
+        role1(std::false_type{}, tid, xo0, xo0, nog, xr, true, nob, ap0, 0u);
         y_a = targets(tid, target_row(tid, 0));
     }
 
@@ -656,13 +699,34 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             uint32_t xon[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) xon[i] = b_next > 0 ? (uint32_t)rn[i] * (uint32_t)s.Dp : xo0[i];
-            XRaw<XT> xr[2][4];
+            XSlot<XT> xr[2];
+            int32_t rg[16];                                                              // (DIMN_RES_GDIRECT) rows 4kb + lj of the CURRENT batch
+                if (DIMN_RES_GDIRECT) {
+#pragma unroll
+                    for (int kb = 0; kb < 16; ++kb) {
+                            const int b = 4 * kb + (lane >> 4);
+                            int pos = t * B + (b < b_act ? b : 0);
+                            pos = pos < p.n_tr ? pos : p.n_tr - 1;
+                            rg[kb] = p.rows[pos];
+                    }
+                }
+            uint32_t xog[16];                                    // (DIMN_RES_GDIRECT) rows b = 4kb + lj of the CURRENT batch, element offsets
+#pragma unroll
+            for (int kb = 0; kb < 16; ++kb) xog[kb] = DIMN_RES_GDIRECT ? (uint32_t)rg[kb] * (uint32_t)s.Dp : 0u;
             {   // virtual tiles 0 and 1 of the step's tile loop
                 const XT* xk = (const XT*)p.X + s.xoff + 4 * (lane & 3);
+                const XT* xg = (const XT*)p.X + s.xoff + (lane & 15);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    xr[0][i].load(xk + xo0[i] + 16 * tc[0]);
-                    xr[1][i].load(xk + (res_vfwd<true, BF, T1>(1) ? xon[i] : xo0[i]) + 16 * tc[res_vtile<true, BF, T1>(1)]);
+                for (int vv = 0; vv < 2; ++vv) {
+                    const bool f = res_vfwd<true, BF, T1>(vv);
+                    const int jj = res_vtile<true, BF, T1>(vv);
+                    if (DIMN_RES_GDIRECT && !f) {
+#pragma unroll
+                        for (int kb = 0; kb < 16; ++kb) xr[vv].load_elem(kb, xg + xog[kb] + 16 * tc[jj]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) xr[vv].load_row16(i, xk + (f ? xon[i] : xo0[i]) + 16 * tc[jj]);
+                    }
                 }
             }
             if (t + 1 < p.steps) y_a = targets(tid, yrow_n);     // every thread (unconditional load); role 2 uses the first 256
@@ -757,7 +821,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
 #pragma unroll
             for (int kb = 0; kb < 16; ++kb) bfr[kb] = dzl[64 * kb + lane];                                        // dA[b = 4kb+lj][h = li]
             RES_STAMP(7)
-            role1(std::true_type{}, tid, xo0, xon, xr, b_next > 0, bfr, ap, pnext);     // its first barrier orders b1l / dzl
+            role1(std::true_type{}, tid, xo0, xon, xog, xr, b_next > 0, bfr, ap, pnext);     // its first barrier orders b1l / dzl
             if (b_next == 0) __syncthreads();
 #pragma unroll
             for (int i = 0; i < 4; ++i) xo0[i] = xon[i];         // the next batch becomes the current one
