@@ -1311,10 +1311,14 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
         hipLaunchKernelGGL(k_res_masks, dim3((unsigned)(steps * h->K)), dim3(512), 0, h->stream, h->d_sn, (unsigned*)h->d_res_b1, h->K, h->H,
                            (uint64_t)h->cfg.seed, (uint32_t)epoch, h->cfg.dropout_rate);
 #define RES_LAUNCH(T, S)                                                                                                           \
-    do { if (h->res_bf16) RES_LAUNCH_X(T, S, bf16_t, true) else WITH_XT(h, RES_LAUNCH_X(T, S, XT, false)); } while (0)
-#define RES_LAUNCH_X(T, S, XT, BFV)                                                                                                \
+    do {                                                                                                                         \
+        if (h->res_bf16) { if (split) RES_LAUNCH_X(T, S, bf16_t, true, true) else RES_LAUNCH_X(T, S, bf16_t, true, false) }       \
+        else if (split) WITH_XT(h, RES_LAUNCH_X(T, S, XT, false, true));                                                         \
+        else WITH_XT(h, RES_LAUNCH_X(T, S, XT, false, false));                                                                   \
+    } while (0)
+#define RES_LAUNCH_X(T, S, XT, BFV, SPV)                                                                                           \
     {                                                                                                                            \
-        const void* fn_ = (const void*)k_epoch_resident<T, S, XT, BFV>;                                                          \
+        const void* fn_ = (const void*)k_epoch_resident<T, S, XT, BFV, SPV>;                                                     \
         (void)hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
         if (!h->res_checked) {                                                                                                   \
             int per_cu_ = 0;                                                                                                     \
@@ -1324,10 +1328,13 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
         if (!not_resident) {                                                                                                     \
             void* args_[1] = {(void*)&p};                                                                                        \
             if (coop) { if (hipLaunchCooperativeKernel(fn_, grid, dim3(DIMN_RES_THREADS), args_, (unsigned)lds, h->stream) != hipSuccess) not_resident = true; } \
-            else hipLaunchKernelGGL((k_epoch_resident<T, S, XT, BFV>), grid, dim3(DIMN_RES_THREADS), lds, h->stream, p);         \
+            else hipLaunchKernelGGL((k_epoch_resident<T, S, XT, BFV, SPV>), grid, dim3(DIMN_RES_THREADS), lds, h->stream, p);    \
         }                                                                                                                        \
     }
     bool not_resident = false;
+    // tile order of the kernel's loop: rows of a large arena are far away (TLB reach), so their requests get two tile-times of lead
+    bool split = (double)h->x_total * XBYTES(h) > 16.0 * 1073741824.0;
+    if (const char* e = getenv("DIMN_RES_SPLIT")) split = atoi(e) != 0;
     // one launch per group of res_Kg sub-nets (all of them when they fit at once), one after the other on the stream
     for (int k0 = 0; k0 < h->K && !not_resident; k0 += h->res_Kg) {
         p.k0 = k0;

@@ -232,16 +232,15 @@ template <> struct XSlot<bf16_t> {
     __device__ __forceinline__ void load_elem(int kb, const bf16_t* q) { w[kb] = (uint32_t)*q; }
     __device__ __forceinline__ float elem(int kb) const { return __uint_as_float(w[kb] << 16); }
 };
-// Order of the tile loop's "virtual tiles" (role1): gradient tile j and forward tile j alternate (g0 f0 g1 f1 ..); without GRAD (the
-// epoch's first forward) there are forward tiles only.  DIMN_RES_BF_SPLIT=1 (experiment, bf16 operands only): all gradient tiles
-// first, then the forward tiles -- every request then has two tile-times of lead from the same two register sets; measured on
-// one box 20.0 vs 19.7 us per step at K = 5 and 38.6 vs 38.0 at configs[4]'s 8 sub-nets: the rows are not what the loop waits for
-// (tools/r03_res_bfsplit.sh; fp32 operands in that order: 24.1 vs 23.8).
-#ifndef DIMN_RES_BF_SPLIT
-#define DIMN_RES_BF_SPLIT 0
-#endif
-template <bool GRAD, bool BF, int T1> __device__ __forceinline__ constexpr bool res_vfwd(int v) { return !GRAD ? true : ((BF && DIMN_RES_BF_SPLIT) ? v >= T1 : (v & 1) != 0); }
-template <bool GRAD, bool BF, int T1> __device__ __forceinline__ constexpr int res_vtile(int v) { return !GRAD ? v : ((BF && DIMN_RES_BF_SPLIT) ? (v >= T1 ? v - T1 : v) : (v >> 1)); }
+// Order of the tile loop's "virtual tiles" (role1).  Alternating (g0 f0 g1 f1 ..: gradient tile j, forward tile j): every row
+// request has ONE tile-time of lead.  SPLIT (all gradient tiles, then the forward tiles: g0 g1 .. f0 f1 ..): TWO tile-times from
+// the same two register sets.  Which one wins depends on how far away the rows are: with a small X arena the alternating order
+// (K = 5 of configs[3], 1.2 GB: 19.7 vs 20.0 us per step with bf16 operands, 23.8 vs 24.1 with fp32; configs[4]'s 8 sub-nets at
+// 200k cells, 7.8 GB: 38.0 vs 38.6), with a large one the split order (the same 8 sub-nets at the full 1M cells, 39 GB of rows
+// gathered at random: 44.8 vs 52.6 us per step) -- the host picks SPLIT above 16 GB of arena (DIMN_RES_SPLIT=0/1 forces).
+// Without GRAD (the epoch's first forward) there are forward tiles only.
+template <bool GRAD, bool SPLIT, int T1> __device__ __forceinline__ constexpr bool res_vfwd(int v) { return !GRAD ? true : (SPLIT ? v >= T1 : (v & 1) != 0); }
+template <bool GRAD, bool SPLIT, int T1> __device__ __forceinline__ constexpr int res_vtile(int v) { return !GRAD ? v : (SPLIT ? (v >= T1 ? v - T1 : v) : (v >> 1)); }
 // c += sum_r a[r] (x) b[r] over the four k-slots a lane owns: four exact-fp32 matrix instructions, or (BF) ONE bf16 instruction
 // whose four-element operands are those k-slots rounded to nearest even
 template <bool BF>
@@ -252,7 +251,7 @@ __device__ __forceinline__ f32x4 res_mfma4(const f32x4 a, const f32x4 b, f32x4 c
     return c;
 }
 
-template <int T1, int S1C, typename XT = float, bool BF = false>   // W1 tiles per wave; D-splits (0: run-time p.S1); element type of the X arena; bf16 matrix cores
+template <int T1, int S1C, typename XT = float, bool BF = false, bool SPLIT = false>   // W1 tiles per wave; D-splits (0: run-time p.S1); element type of the X arena; bf16 matrix cores; tile order (res_vfwd)
 __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int ldd = DIMN_RES_LDD;
@@ -389,14 +388,14 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
         float abl_sink = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const bool fwd = res_vfwd<GRAD, BF, T1>(v);
-            const int j = res_vtile<GRAD, BF, T1>(v);
+            const bool fwd = res_vfwd<GRAD, SPLIT, T1>(v);
+            const int j = res_vtile<GRAD, SPLIT, T1>(v);
             const bool live = tv[j] || j == 0;                   // wave-uniform: a wave's tiles are its first ones (tile 0 always runs: it may be a clamped one)
             float* xv = xs + (v & 1) * 1024;
             auto request = [&]() {                               // the X tile of position v + 2 into the register set of position v
                 if (v + 2 < NV && (!(DIMN_RES_ABL & 4) || !GRAD)) {
-                    const bool f2 = res_vfwd<GRAD, BF, T1>(v + 2);
-                    const int j2 = res_vtile<GRAD, BF, T1>(v + 2);
+                    const bool f2 = res_vfwd<GRAD, SPLIT, T1>(v + 2);
+                    const int j2 = res_vtile<GRAD, SPLIT, T1>(v + 2);
                     if (DIMN_RES_GDIRECT && !f2) {
 #pragma unroll
                         for (int kb = 0; kb < 16; ++kb) xr[v & 1].load_elem(kb, xg + xog[kb] + 16 * tc[j2]);
@@ -718,8 +717,8 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 const XT* xg = (const XT*)p.X + s.xoff + (lane & 15);
 #pragma unroll
                 for (int vv = 0; vv < 2; ++vv) {
-                    const bool f = res_vfwd<true, BF, T1>(vv);
-                    const int jj = res_vtile<true, BF, T1>(vv);
+                    const bool f = res_vfwd<true, SPLIT, T1>(vv);
+                    const int jj = res_vtile<true, SPLIT, T1>(vv);
                     if (DIMN_RES_GDIRECT && !f) {
 #pragma unroll
                         for (int kb = 0; kb < 16; ++kb) xr[vv].load_elem(kb, xg + xog[kb] + 16 * tc[jj]);
