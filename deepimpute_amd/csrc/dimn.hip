@@ -202,6 +202,7 @@ struct dimn_handle_s {
     float *d_res_P = nullptr, *d_res_D = nullptr, *d_res_T = nullptr, *d_res_A = nullptr, *d_res_b1 = nullptr, *d_res_alpha = nullptr;
     unsigned* d_res_flags = nullptr; double* d_res_loss = nullptr; int64_t res_alpha_cap = 0;
     float* d_res_snap = nullptr;           // the optimiser state before the running epoch launch (restored if the launch aborts)
+    float *d_res_Xe = nullptr, *d_res_Ye = nullptr; int32_t* d_res_iota = nullptr; int64_t res_iota_n = 0;   // epoch-ordered copies of the training rows (large arenas)
     int res_checked = 0;                   // 1: co-residency of a launch's workgroups verified against the occupancy of the kernel
     int res_bf16 = 0;                      // 1: precision bf16 -> the resident kernel runs EVERY training GEMM on the bf16 matrix cores (template BF)
     double tm_res_ms = 0; int64_t tm_res_steps = 0;
@@ -649,7 +650,7 @@ extern "C" int dimn_destroy(dimn_handle h) {
     DEV_FREE(h->d_epoch_rows); DEV_FREE(h->d_val_rows); DEV_FREE(h->d_pred_rows); DEV_FREE(h->d_out);
     DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage); DEV_FREE(h->d_red);
     DEV_FREE(h->d_W1b); DEV_FREE(h->d_W2t); DEV_FREE(h->d_W2tf);
-    DEV_FREE(h->d_res_P); DEV_FREE(h->d_res_D); DEV_FREE(h->d_res_T); DEV_FREE(h->d_res_A); DEV_FREE(h->d_res_b1); DEV_FREE(h->d_res_alpha); DEV_FREE(h->d_res_flags); DEV_FREE(h->d_res_loss); DEV_FREE(h->d_res_snap);
+    DEV_FREE(h->d_res_P); DEV_FREE(h->d_res_D); DEV_FREE(h->d_res_T); DEV_FREE(h->d_res_A); DEV_FREE(h->d_res_b1); DEV_FREE(h->d_res_alpha); DEV_FREE(h->d_res_flags); DEV_FREE(h->d_res_loss); DEV_FREE(h->d_res_snap); DEV_FREE(h->d_res_Xe); DEV_FREE(h->d_res_Ye); DEV_FREE(h->d_res_iota);
     for (auto& ln : h->lanes) {
         (void)hipStreamDestroy(ln.stream);
         for (int i = 0; i < 8; ++i) { if (ln.ev_m[i]) (void)hipEventDestroy(ln.ev_m[i]); if (ln.ev_w[i]) (void)hipEventDestroy(ln.ev_w[i]); }
@@ -731,13 +732,13 @@ static int gather_prepare(dimn_handle h, int32_t with_targets) {
     }
     // the arenas are re-used across calls (19.5 GB at cfg3: a hipFree/hipMalloc pair costs up to a second)
     if (!h->d_X || h->x_total != x) {
-        DEV_FREE(h->d_X);
+        DEV_FREE(h->d_X); DEV_FREE(h->d_res_Xe);
         HIPCHK(hipMalloc((void**)&h->d_X, std::max<size_t>(1, (size_t)x * XBYTES(h))));
         h->x_total = x;
     }
     const int64_t y_need = (int64_t)h->K * h->n * h->dm.Op;
     if (with_targets && (!h->d_Y || h->y_total != y_need)) {
-        DEV_FREE(h->d_Y);
+        DEV_FREE(h->d_Y); DEV_FREE(h->d_res_Ye);
         CHK(dev_alloc(&h->d_Y, (size_t)y_need));
         h->y_total = y_need;
     }
@@ -1252,6 +1253,32 @@ extern "C" int dimn_epoch_permutation(uint64_t seed, int32_t epoch, int64_t n, i
 }
 
 // One epoch as ONE persistent launch with the optimiser state in registers (dimn_resident.h); d_epoch_rows is uploaded.
+// The training rows of one epoch in the order the epoch visits them: Xe / Ye row `pos` of sub-net k = X / Y row rows[pos] (the arenas'
+// own layout, the first n_tr rows of every sub-net used).  One wave per row and sub-net, 16-byte pieces.  For LARGE arenas: the
+// resident kernel gathers 64 rows per step at random, and beyond ~16 GB those rows are beyond the TLB's reach -- every request of
+// its tile loop then waits for a page walk (configs[4]'s share at 1M cells: 45 us per step against 38 at 200k cells).  Copying the
+// epoch's rows once (2 x the arena at HBM rate: ~25 ms for 55 GB) makes every step read 64 CONSECUTIVE rows.
+template <typename XT>
+__global__ __launch_bounds__(256) void k_res_epoch_rows(const SubnetDev* __restrict__ sn, const XT* __restrict__ X, const float* __restrict__ Y, const int32_t* __restrict__ rows,
+                                                        int64_t n_tr, int64_t n_cells, int Op, XT* __restrict__ Xe, float* __restrict__ Ye) {
+    const int k = blockIdx.y;
+    const SubnetDev s = sn[k];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int xp = (int)((int64_t)s.Dp * (int64_t)sizeof(XT) / 16), yp = Op / 4;
+    for (int64_t pos = (int64_t)blockIdx.x * 4 + wave; pos < n_tr; pos += (int64_t)gridDim.x * 4) {
+        const int64_t r = rows[pos];
+        const uint4* xs = (const uint4*)(X + s.xoff + r * s.Dp);
+        uint4* xd = (uint4*)(Xe + s.xoff + pos * s.Dp);
+        for (int i = lane; i < xp; i += 64) xd[i] = xs[i];
+        const uint4* ys = (const uint4*)(Y + ((int64_t)k * n_cells + r) * Op);
+        uint4* yd = (uint4*)(Ye + ((int64_t)k * n_cells + pos) * Op);
+        for (int i = lane; i < yp; i += 64) yd[i] = ys[i];
+    }
+}
+__global__ __launch_bounds__(256) void k_res_iota(int32_t* __restrict__ v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] = (int32_t)i;
+}
 static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss) {
     const Dims& dm = h->dm;
     const int steps = (int)((h->n_tr + h->B - 1) / h->B);
@@ -1331,10 +1358,33 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
             else hipLaunchKernelGGL((k_epoch_resident<T, S, XT, BFV, SPV>), grid, dim3(DIMN_RES_THREADS), lds, h->stream, p);    \
         }                                                                                                                        \
     }
+    // large arenas: the epoch's rows copied into visiting order first (k_res_epoch_rows), the kernel then walks rows 0 .. n_tr-1
+    bool erows = false;
+    {
+        erows = ((double)h->x_total * XBYTES(h) + (double)h->y_total * 4.0) > 16.0 * 1073741824.0;
+        if (const char* e = getenv("DIMN_RES_EPOCH_ROWS")) erows = atoi(e) != 0;
+        if (erows) {
+            if (!h->d_res_Xe) HIPCHK(hipMalloc((void**)&h->d_res_Xe, std::max<size_t>(1, (size_t)h->x_total * XBYTES(h))));
+            if (!h->d_res_Ye) CHK(dev_alloc(&h->d_res_Ye, (size_t)h->y_total));
+            if (!h->d_res_iota || h->res_iota_n != h->n_tr) {
+                DEV_FREE(h->d_res_iota);
+                HIPCHK(hipMalloc((void**)&h->d_res_iota, std::max<size_t>(1, (size_t)h->n_tr * 4)));
+                h->res_iota_n = h->n_tr;
+                hipLaunchKernelGGL(k_res_iota, dim3((unsigned)((h->n_tr + 255) / 256)), dim3(256), 0, h->stream, h->d_res_iota, (int64_t)h->n_tr);
+            }
+            const unsigned gx = (unsigned)std::min<int64_t>((h->n_tr + 3) / 4, 4096);
+            WITH_XT(h, hipLaunchKernelGGL((k_res_epoch_rows<XT>), dim3(gx, (unsigned)h->K), dim3(256), 0, h->stream, h->d_sn, (const XT*)h->d_X, h->d_Y, h->d_epoch_rows,
+                                          (int64_t)h->n_tr, (int64_t)h->n, dm.Op, (XT*)h->d_res_Xe, h->d_res_Ye));
+            HIPCHK(hipGetLastError());
+            p.X = h->d_res_Xe; p.Y = h->d_res_Ye; p.rows = h->d_res_iota;
+        }
+    }
     bool not_resident = false;
     // tile order of the kernel's loop: rows of a large arena are far away (TLB reach), so their requests get two tile-times of lead
-    bool split = (double)h->x_total * XBYTES(h) > 16.0 * 1073741824.0;
+    // (only when the rows stay where they are: with the epoch-ordered copies the alternating order is the better one again, 39.1 vs 39.8 us)
+    bool split = !erows && (double)h->x_total * XBYTES(h) > 16.0 * 1073741824.0;
     if (const char* e = getenv("DIMN_RES_SPLIT")) split = atoi(e) != 0;
+    if (getenv("DIMN_TRACE") && atoi(getenv("DIMN_TRACE")) && epoch == 0) fprintf(stderr, "[dimn] resident epoch: arena %.1f GB, epoch-ordered rows %d, split tile order %d\n", ((double)h->x_total * XBYTES(h) + (double)h->y_total * 4.0) / 1073741824.0, (int)erows, (int)split);
     // one launch per group of res_Kg sub-nets (all of them when they fit at once), one after the other on the stream
     for (int k0 = 0; k0 < h->K && !not_resident; k0 += h->res_Kg) {
         p.k0 = k0;

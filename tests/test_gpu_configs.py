@@ -166,12 +166,15 @@ def test_cfg3_shapes_match_oracle():
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("split", ["0", "1"])         # tile order of the kernel's loop: alternating / all gradient tiles first (DIMN_RES_SPLIT; picked by arena size)
-def test_cfg4_8gpu_share_resident_matches_oracle(split, monkeypatch):
+@pytest.mark.parametrize("split,erows", [("0", "0"), ("1", "0"), ("0", "1")])
+# split: tile order of the kernel's loop, alternating / all gradient tiles first (DIMN_RES_SPLIT); erows: the epoch's rows copied into
+# visiting order before the launch (DIMN_RES_EPOCH_ROWS; what the library does for large arenas)
+def test_cfg4_8gpu_share_resident_matches_oracle(split, erows, monkeypatch):
     """BASELINE configs[3], one rank's share of the 8-GPU job (sub-nets 10-14 of the 40, global Philox keys) on the path the
     library picks for it -- the register-resident epoch kernel -- against the ORACLE (not against the streaming kernels): 5 full
     + 1 partial optimiser step, validation, predict; two epochs' worth of hand-off slots (t % 3, t % 2) are cycled."""
     monkeypatch.setenv("DIMN_RES_SPLIT", split)
+    monkeypatch.setenv("DIMN_RES_EPOCH_ROWS", erows)
     cfg, norm, targets, preds = _cfg3_sample(2048)
     ks = list(range(10, 15))
     train = (np.arange(0, 5 * 64 + 33, dtype=np.int32) * 5) % 1800
@@ -186,14 +189,15 @@ def test_cfg4_8gpu_share_resident_matches_oracle(split, monkeypatch):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("split", ["0", "1"])         # (at the full 1M cells the library picks 1: 39 GB of rows)
-def test_cfg5_share_shapes_match_oracle(split, monkeypatch):
+@pytest.mark.parametrize("split,erows", [("0", "0"), ("1", "0"), ("0", "1")])         # (at the full 1M cells the library picks 0 / 1: 55 GB of rows)
+def test_cfg5_share_shapes_match_oracle(split, erows, monkeypatch):
     """BASELINE configs[4], one rank's share at its real shapes: g = 30 000 genes, 8 of the K = 59 sub-nets (D_k ~ 2 450 from
     bench.synth_indices(30000, 512)), precision bf16 (bf16 X arena, bf16 matrix cores), the matrix STREAMED from host memory
     (three ~128 MB row blocks), on the path the library picks; 3 full + 1 partial step, validation, predict against the oracle
     in the matching rounding modes at the tolerances DESIGN section 3b states for them."""
     import bench
     monkeypatch.setenv("DIMN_RES_SPLIT", split)
+    monkeypatch.setenv("DIMN_RES_EPOCH_ROWS", erows)
     cfg = dict(bench.CONFIGS["cfg5"])
     n = 3072
     norm = bench.synth_counts(n, cfg["g"], seed=0)                       # 369 MB -> 3 streamed blocks
