@@ -202,7 +202,7 @@ struct dimn_handle_s {
     float *d_res_P = nullptr, *d_res_D = nullptr, *d_res_T = nullptr, *d_res_A = nullptr, *d_res_b1 = nullptr, *d_res_alpha = nullptr;
     unsigned* d_res_flags = nullptr; double* d_res_loss = nullptr; int64_t res_alpha_cap = 0;
     float* d_res_snap = nullptr;           // the optimiser state before the running epoch launch (restored if the launch aborts)
-    float *d_res_Xe = nullptr, *d_res_Ye = nullptr; int32_t* d_res_iota = nullptr; int64_t res_iota_n = 0;   // epoch-ordered copies of the training rows (large arenas)
+    float *d_res_Xe = nullptr, *d_res_Ye = nullptr; int32_t* d_res_iota = nullptr; int64_t res_iota_n = 0; bool res_erows_off = false;   // epoch-ordered copies of the training rows (large arenas)
     int res_checked = 0;                   // 1: co-residency of a launch's workgroups verified against the occupancy of the kernel
     int res_bf16 = 0;                      // 1: precision bf16 -> the resident kernel runs EVERY training GEMM on the bf16 matrix cores (template BF)
     double tm_res_ms = 0; int64_t tm_res_steps = 0;
@@ -1363,9 +1363,13 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
     {
         erows = ((double)h->x_total * XBYTES(h) + (double)h->y_total * 4.0) > 16.0 * 1073741824.0;
         if (const char* e = getenv("DIMN_RES_EPOCH_ROWS")) erows = atoi(e) != 0;
+        if (erows && h->res_erows_off) erows = false;
+        if (erows) {     // (no room for the copies: the kernel gathers its rows where they are, as for small arenas)
+            if (!h->d_res_Xe && hipMalloc((void**)&h->d_res_Xe, std::max<size_t>(1, (size_t)h->x_total * XBYTES(h))) != hipSuccess) { h->d_res_Xe = nullptr; erows = false; }
+            if (erows && !h->d_res_Ye && hipMalloc((void**)&h->d_res_Ye, std::max<size_t>(1, (size_t)h->y_total * 4)) != hipSuccess) { h->d_res_Ye = nullptr; erows = false; }
+            if (!erows) { (void)hipGetLastError(); DEV_FREE(h->d_res_Xe); DEV_FREE(h->d_res_Ye); h->res_erows_off = true; }
+        }
         if (erows) {
-            if (!h->d_res_Xe) HIPCHK(hipMalloc((void**)&h->d_res_Xe, std::max<size_t>(1, (size_t)h->x_total * XBYTES(h))));
-            if (!h->d_res_Ye) CHK(dev_alloc(&h->d_res_Ye, (size_t)h->y_total));
             if (!h->d_res_iota || h->res_iota_n != h->n_tr) {
                 DEV_FREE(h->d_res_iota);
                 HIPCHK(hipMalloc((void**)&h->d_res_iota, std::max<size_t>(1, (size_t)h->n_tr * 4)));
