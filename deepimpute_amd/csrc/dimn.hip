@@ -704,6 +704,26 @@ static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
     for (auto& t : th) t.join();
 }
 
+// dst[r][j] = src[r][cols[j]], r < nr: the columns a handle needs of a row block, packed (host threads over rows; a row is walked
+// front to back, so the reads stream)
+static void parallel_pack_columns(float* dst, const float* src, int64_t nr, int64_t g, const int32_t* cols, int64_t gc) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    unsigned cap = 48;
+    if (const char* e = getenv("DIMN_STREAM_THREADS")) cap = (unsigned)std::max(1, atoi(e));      // (diagnostic)
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw ? hw / 2 : 8, cap), nr * g / (1 << 20)));
+    auto work = [=](int t) {
+        for (int64_t r = nr * t / nt; r < nr * (t + 1) / nt; ++r) {
+            const float* in = src + r * g;
+            float* out = dst + r * gc;
+            for (int64_t j = 0; j < gc; ++j) out[j] = in[cols[j]];
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+}
+
 // Index lists and arenas of the device gather for a matrix of h->n cells (validated against h->g columns).
 static int gather_prepare(dimn_handle h, int32_t with_targets) {
     for (int k = 0; k < h->K; ++k) {
@@ -746,17 +766,22 @@ static int gather_prepare(dimn_handle h, int32_t with_targets) {
     return DIMN_OK;
 }
 // X_k / Y_k rows [row0, row0 + nrows) from a device block of the matrix (the whole matrix, or one streamed block)
-static int gather_block(dimn_handle h, const float* d_block, int64_t nrows, int64_t row0, int32_t with_targets, hipStream_t st) {
-    if ((size_t)h->g * sizeof(float) <= 150 * 1024) {      // the row fits in LDS: read `norm` once, serve all sub-nets from LDS
-        const size_t lds = (size_t)h->g * sizeof(float);
+// (g_eff / pred / targ: a block whose rows hold only SOME columns of the matrix, with index lists that address those -- the streamed hand-over)
+static int gather_block(dimn_handle h, const float* d_block, int64_t nrows, int64_t row0, int32_t with_targets, hipStream_t st,
+                        int64_t g_eff = 0, const int32_t* pred = nullptr, const int32_t* targ = nullptr) {
+    if (g_eff <= 0) g_eff = h->g;
+    if (!pred) pred = h->d_pred;
+    if (!targ) targ = h->d_targ;
+    if ((size_t)g_eff * sizeof(float) <= 150 * 1024) {      // the row fits in LDS: read `norm` once, serve all sub-nets from LDS
+        const size_t lds = (size_t)g_eff * sizeof(float);
         WITH_XT(h, {
             if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_gather_lds<XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_gather_lds<XT>, dim3((unsigned)std::min<int64_t>(nrows, 2048)), dim3(512), lds, st, h->d_sn, d_block, nrows, h->g, h->d_pred,
-                               h->d_pred_off, h->d_targ, (XT*)h->d_X, h->d_Y, h->dm, with_targets ? 1 : 0, row0, h->n);
+            hipLaunchKernelGGL(k_gather_lds<XT>, dim3((unsigned)std::min<int64_t>(nrows, 2048)), dim3(512), lds, st, h->d_sn, d_block, nrows, g_eff, pred,
+                               h->d_pred_off, targ, (XT*)h->d_X, h->d_Y, h->dm, with_targets ? 1 : 0, row0, h->n);
         });
     } else {
         const dim3 grid((unsigned)h->K, (unsigned)std::min<int64_t>(nrows, 8192));
-        WITH_XT(h, hipLaunchKernelGGL(k_gather<XT>, grid, dim3(256), 0, st, h->d_sn, d_block, nrows, h->g, h->d_pred, h->d_pred_off, h->d_targ,
+        WITH_XT(h, hipLaunchKernelGGL(k_gather<XT>, grid, dim3(256), 0, st, h->d_sn, d_block, nrows, g_eff, pred, h->d_pred_off, targ,
                                       (XT*)h->d_X, h->d_Y, h->dm, with_targets ? 1 : 0, row0, h->n));
     }
     HIPCHK(hipGetLastError());
@@ -787,32 +812,68 @@ extern "C" int dimn_set_matrix_streamed(dimn_handle h, const float* norm, int64_
     if (n != h->n) { h->n_tr = 0; h->n_val = 0; h->train_rows.clear(); h->val_rows.clear(); }
     h->n = n; h->g = g; h->gathered = false; h->streamed = true;
     CHK(gather_prepare(h, with_targets));
-    const int64_t blk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(128u << 20) / (g * 4)));
-    float *pin[2] = {nullptr, nullptr}, *dev[2] = {nullptr, nullptr};
-    hipStream_t st[2] = {nullptr, nullptr};
+    // Only the columns this handle's sub-nets read cross PCIe: a rank of a sharded job needs the predictors and targets of ITS sub-nets
+    // (configs[4], 8 of 59 sub-nets: ~55 % of the genes), so the host threads pack those columns of every row block into the bounce
+    // buffer and the device gather runs on index lists that address the packed rows.  (DIMN_STREAM_PACK=0, or more than 85 % of the
+    // columns needed: the rows go over as they are.)
+    std::vector<int32_t> cols;
+    int32_t *d_pred_c = nullptr, *d_targ_c = nullptr;
+    {
+        std::vector<int32_t> where((size_t)g, -1);
+        for (int k = 0; k < h->K; ++k) {
+            for (int32_t c : h->pred[k]) where[(size_t)c] = 0;
+            if (with_targets) for (int32_t c : h->targ[k]) where[(size_t)c] = 0;
+        }
+        for (int64_t c = 0; c < g; ++c) if (where[(size_t)c] == 0) { where[(size_t)c] = (int32_t)cols.size(); cols.push_back((int32_t)c); }
+        const char* e = getenv("DIMN_STREAM_PACK");
+        if ((e && atoi(e) == 0) || (double)cols.size() > 0.85 * (double)g) cols.clear();
+        if (!cols.empty()) {
+            std::vector<int32_t> pflat, tflat;
+            for (int k = 0; k < h->K; ++k) {
+                for (int32_t c : h->pred[k]) pflat.push_back(where[(size_t)c]);
+                for (int32_t c : h->targ[k]) tflat.push_back(with_targets ? where[(size_t)c] : 0);
+            }
+            CHK(dev_alloc(&d_pred_c, pflat.size()));
+            if (dev_alloc(&d_targ_c, tflat.size()) != DIMN_OK) { (void)hipFree(d_pred_c); return DIMN_ERR_HIP; }
+            if (hipMemcpy(d_pred_c, pflat.data(), pflat.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(d_targ_c, tflat.data(), tflat.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipFree(d_pred_c); (void)hipFree(d_targ_c);
+                return fail(DIMN_ERR_HIP, "dimn_set_matrix_streamed: index upload failed");
+            }
+        }
+    }
+    const int64_t gc = cols.empty() ? g : (int64_t)cols.size();
+    const int64_t blk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(128u << 20) / (gc * 4)));
+    int NBUF = 2;                // blocks in flight (host packing | PCIe copy | device gather); DIMN_STREAM_BUFS = 2 .. 4
+    if (const char* e = getenv("DIMN_STREAM_BUFS")) NBUF = std::max(2, std::min(4, atoi(e)));
+    float *pin[4] = {nullptr, nullptr, nullptr, nullptr}, *dev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
     int rc = DIMN_OK;
 #define STR_TRY(expr) do { hipError_t e_ = (expr); if (rc == DIMN_OK && e_ != hipSuccess) rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
-    for (int b = 0; b < 2; ++b) {
-        STR_TRY(hipHostMalloc((void**)&pin[b], (size_t)blk * g * 4, hipHostMallocDefault));
-        STR_TRY(hipMalloc((void**)&dev[b], (size_t)blk * g * 4));
+    for (int b = 0; b < NBUF; ++b) {
+        STR_TRY(hipHostMalloc((void**)&pin[b], (size_t)blk * gc * 4, hipHostMallocDefault));
+        STR_TRY(hipMalloc((void**)&dev[b], (size_t)blk * gc * 4));
         STR_TRY(hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking));
     }
     int64_t bi = 0;
     for (int64_t r0 = 0; r0 < n && rc == DIMN_OK; r0 += blk, ++bi) {
-        const int b = (int)(bi & 1);
+        const int b = (int)(bi % NBUF);
         const int64_t nr = std::min(blk, n - r0);
-        STR_TRY(hipStreamSynchronize(st[b]));               // block bi-2 has left this pair of buffers
+        STR_TRY(hipStreamSynchronize(st[b]));               // block bi-NBUF has left these buffers
         if (rc != DIMN_OK) break;
-        parallel_memcpy(pin[b], norm + r0 * g, (size_t)nr * g * 4);
-        STR_TRY(hipMemcpyAsync(dev[b], pin[b], (size_t)nr * g * 4, hipMemcpyHostToDevice, st[b]));
-        if (rc == DIMN_OK) rc = gather_block(h, dev[b], nr, r0, with_targets, st[b]);
+        if (cols.empty()) parallel_memcpy(pin[b], norm + r0 * g, (size_t)nr * g * 4);
+        else parallel_pack_columns(pin[b], norm + r0 * g, nr, g, cols.data(), gc);
+        STR_TRY(hipMemcpyAsync(dev[b], pin[b], (size_t)nr * gc * 4, hipMemcpyHostToDevice, st[b]));
+        if (rc == DIMN_OK) rc = gather_block(h, dev[b], nr, r0, with_targets, st[b], gc, d_pred_c, d_targ_c);
     }
 #undef STR_TRY
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < NBUF; ++b) {
         if (st[b]) { (void)hipStreamSynchronize(st[b]); (void)hipStreamDestroy(st[b]); }
         if (pin[b]) (void)hipHostFree(pin[b]);
         if (dev[b]) (void)hipFree(dev[b]);
     }
+    if (d_pred_c) (void)hipFree(d_pred_c);
+    if (d_targ_c) (void)hipFree(d_targ_c);
     if (rc != DIMN_OK) return rc;
     h->gathered = true;
     h->gathered_targets = with_targets != 0;
