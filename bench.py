@@ -213,6 +213,23 @@ def bring_up_rccl(eng, rdzv, rank, world):
     return None, err or "RCCL failed on %d other rank(s)" % int(failed)
 
 
+def bring_up_job(factory, rdzv, rank, world):
+    """(engine, RcclBenchComm, None), or (engine or None, None, error string) on EVERY rank.  Anything that can go wrong before the
+    first collective belongs here: a rank whose engine cannot be built (dimn_create on a device that does not exist: --gpus 2 on a
+    one-GPU box) must not leave the others waiting inside ncclCommInitRank, so the ranks first agree through files that every
+    engine exists, and only then bring RCCL up (bring_up_rccl, which votes again)."""
+    eng, err = None, None
+    try:
+        eng = factory()
+    except Exception as e:
+        err = "engine: %r" % (e,)
+    failed = file_vote(rdzv, "engine_vote", 0.0 if err is None else 1.0)
+    if failed:
+        return eng, None, err or "the engine could not be built on %d other rank(s)" % int(failed)
+    comm, rccl_error = bring_up_rccl(eng, rdzv, rank, world)
+    return eng, comm, rccl_error
+
+
 def rccl_failure_line(args, world, label, error):
     """The line of an N > 1 run whose RCCL communicator did not come up: the contract's keys with value null, so that nothing
     downstream can mistake it for a measurement."""
@@ -502,21 +519,25 @@ def main():
         engine_cls = general_factory
     else:
         engine_cls = HipEngine
-    eng = make_engine(engine_cls, cfg, targets, preds, norm, train, val, counts, offs, rank, local_rank, args.lr, stream=args.stream,
-                      **({"precision": "bf16"} if args.precision == "bf16" else {}))
+    def build_engine():
+        return make_engine(engine_cls, cfg, targets, preds, norm, train, val, counts, offs, rank, local_rank, args.lr, stream=args.stream,
+                           **({"precision": "bf16"} if args.precision == "bf16" else {}))
     comm = None
     if world > 1:
         rdzv = FileRendezvous(rank, world)
-        comm, rccl_error = bring_up_rccl(eng, rdzv, rank, world)
+        eng, comm, rccl_error = bring_up_job(build_engine, rdzv, rank, world)
         if comm is None:
-            sys.stderr.write("bench.py rank %d: RCCL did not come up (%s): no measurement\n" % (rank, rccl_error))
+            sys.stderr.write("bench.py rank %d: the %d-rank job did not come up (%s): no measurement\n" % (rank, world, rccl_error))
             if rank == 0:
                 print(json.dumps(rccl_failure_line(args, world, cfg["label"], rccl_error)))
                 sys.stdout.flush()
             file_vote(rdzv, "bye", 0.0, timeout=60.0)            # nobody removes the directory under a rank still reading it
             rdzv.cleanup()
-            eng.close()
+            if eng is not None:
+                eng.close()
             sys.exit(3)
+    else:
+        eng = build_engine()
 
     def barrier():
         eng.synchronize()

@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_BATCH = 64
 COMM_ID_BYTES = 128
 # hidden-layer activations the kernels implement (ids = DIMN_ACT_* of include/dimn.h; Keras names)
@@ -86,6 +86,7 @@ GENERAL = {
 GPU_ONLY = {
     "abi_version": [],
     "device_count": [C.POINTER(C.c_int32)],
+    "release_cached_memory": [],
     "set_matrix_streamed": [_H, _pf, _i64, _i64, _i32],
     "predict_device": [_H, _pi, _i64, C.POINTER(C.c_void_p)],
     "synchronize": [_H],
@@ -99,6 +100,7 @@ GPU_ONLY = {
     "comm_allreduce_sum": [_H, _pd, _i32],
     "comm_gather_predictions": [_H, _i64, _pi, _i32, _pf],
     "comm_destroy": [_H],
+    "comm_gather_loopback": [C.POINTER(_H), _i32, _i64, _pi, _i32, _pf],
     "abs_corrcoef": [_i32, _pd, _i64, _i64, _pd],
     "val_metrics": [_H, _pd],
     "impute_finish": [_H, _pd, _i64, _i64, _pi, _pi, _i32, C.c_double, _i32, _pd],
@@ -112,6 +114,7 @@ GPU_ONLY = {
     "counts_corr": [_H, _pi, _i64],
     "counts_topk": [_H, _pi, _i32, _i32, _pi, _i32, _pi],
     "counts_corr_read": [_H, _pd, _i64],
+    "counts_corr_drop": [_H],
     "counts_gene_stats": [_H, _pd, _pd, _pd, _pd],
     "set_matrix_counts": [_H, _H, _pf, _i64],
     "col_stats_first": [_pd, _i64, _i64, _i64, _pd, _pd, _pd, _pd, _pd, _pi, _i32],
@@ -162,28 +165,3 @@ def p_i32(a):
 
 def p_u8(a):
     return None if a is None else a.ctypes.data_as(_pu8)
-
-
-def bind_general_oracle(lib):
-    """Function table of the general CPU oracle (prefix dimog_; `create` there is the general constructor)."""
-    names = ["destroy", "set_matrix", "set_indices", "set_split", "init_weights", "get_step_count", "train_step_general",
-             "train_epoch", "val_loss", "fit", "predict", "epoch_permutation"]
-    fns = {}
-    for name in names:
-        real = "train_step" if name == "train_step_general" else name
-        fn = getattr(lib, "dimog_" + real)
-        fn.argtypes = [_H, _pi, _i32, _i32, _i32, _pf] if name == "train_step_general" else SIGNATURES[name]
-        fn.restype = C.c_int
-        fns[name] = fn
-    for name, args in (("create", GENERAL["create_general"]), ("set_layer_weights", GENERAL["set_layer_weights"]),
-                       ("get_layer_weights", GENERAL["get_layer_weights"])):
-        fn = getattr(lib, "dimog_" + name)
-        fn.argtypes = args
-        fn.restype = C.c_int
-        fns["create_general" if name == "create" else name] = fn
-    fns["gather"] = lambda h, w: 0
-    le = lib.dimog_last_error
-    le.argtypes = []
-    le.restype = C.c_char_p
-    fns["last_error"] = le
-    return fns

@@ -69,6 +69,13 @@ class DeviceCounts:
         if fns["counts_corr"](self.handle, _cabi.p_i32(pool_cols), pool_cols.size) != 0:
             raise RuntimeError("dimn_counts_corr: " + fns["last_error"]().decode("utf-8", "replace"))
 
+    def corr_drop(self):
+        """Free what corr() left on the device when the selection takes another path (pool^2 * 8 bytes)."""
+        if self.handle is not None and self.handle:
+            from . import _lib
+            _lib.load()["counts_corr_drop"](self.handle)
+        self.corr_ready = False
+
     def corr_read(self, pool_n):
         """(tests / diagnostics) the |corr| matrix corr() left on the device."""
         from . import _lib

@@ -42,10 +42,37 @@ def _block_for(frame_or_shape, axis, target_bytes=32 << 20):
     return max(16, int(target_bytes // max(1, 8 * other)))
 
 
+_pandas_order_ok = None
+
+
+def pandas_order_holds():
+    """One-time self-check of what the native gene statistics (host: dimn_col_stats*, device: dimn_counts_gene_stats) assume about
+    THIS pandas / numpy: DataFrame.mean() a running sum down the column, DataFrame.var() numpy's pairwise reduction over 8192-element
+    buffer chunks (no bottleneck, csrc/dimn_hoststats.h).  A small count matrix crossing one chunk boundary must come out of the
+    native routine equal to pandas TO THE BIT; otherwise the native paths are switched off for the process (pandas computes the
+    statistics: the gene ranking of fit() then follows the installed library, as the reference's does) and a warning says so."""
+    global _pandas_order_ok
+    if _pandas_order_ok is None:
+        _pandas_order_ok = True                      # (re-entrancy: the probe below calls _native_col_stats)
+        rng = np.random.default_rng(20240607)
+        probe = pd.DataFrame(rng.poisson(rng.gamma(2.0, 3.0, size=(8200, 6))).astype(np.float64))
+        got = _native_col_stats(probe.values)
+        if got is not None:
+            same = np.array_equal(got[0], probe.mean().values) and np.array_equal(got[1], probe.var().values)
+            if not same:
+                import warnings
+                warnings.warn("deepimpute_amd: the native gene statistics differ from this pandas' DataFrame.mean()/var() at ulp level "
+                              "(pandas %s, numpy %s); using pandas' own reductions" % (pd.__version__, np.__version__), RuntimeWarning)
+            _pandas_order_ok = bool(same)
+    return _pandas_order_ok
+
+
 def _native_col_stats(values, want_var=True):
     """(mean, var, max) of the columns of a C-ordered float64 matrix through libdimn's host routine (dimn_col_stats:
     pandas' order of operations, multi-threaded), or None when the library is not built / a NaN is present."""
     if values.dtype != np.float64 or values.ndim != 2 or not values.flags.c_contiguous or values.shape[0] < 2 or values.shape[1] < 1:
+        return None
+    if not pandas_order_holds():
         return None
     try:
         from . import _cabi, _lib
@@ -67,7 +94,7 @@ def col_stats_first(values):
     """First sweep of the gene statistics (dimn_col_stats_first): dict(mean, avg, cmin, cmax, vmax) of a NaN-free C-ordered
     float64 matrix, or None (library missing, NaN present, another dtype / layout)."""
     if os.environ.get("DIMN_HOST_STATS", "1") == "0" or not isinstance(values, np.ndarray) or values.dtype != np.float64 or values.ndim != 2 \
-            or not values.flags.c_contiguous or values.shape[0] < 2 or values.shape[1] < 1:
+            or not values.flags.c_contiguous or values.shape[0] < 2 or values.shape[1] < 1 or not pandas_order_holds():
         return None
     try:
         from . import _cabi, _lib

@@ -24,7 +24,7 @@
 #include "dimn_hoststats.h"
 #include "dimn_counts_dev.h"
 
-#define DIMN_ABI_VERSION 6
+#define DIMN_ABI_VERSION 7
 
 // DIMN_TRACE=1: stage times of the host-heavy entry points on stderr (diagnostic)
 struct Trace {
@@ -161,9 +161,6 @@ struct dimn_handle_s {
     dimn_config cfg;
     Dims dm;
     int K, H, O, B, NT, NT2, OTW, HS;   // NT/NT2 hidden tiles per wave (4-/8-wave kernels); OTW out tiles per wave; HS = ceil(HT/2)
-    int wg_per_cu = 1;
-    int variant = 1;
-    int mf_variant = 16, mb_waves = 4;   // DIMN_MF=16 hoists all W2 operands (162 VGPRs); DIMN_MB=8: 8-wave middle backward
     int ncu = 256;
     std::vector<SubnetDev> sn;
     std::vector<Work> work;
@@ -209,13 +206,8 @@ struct dimn_handle_s {
     hipStream_t stream = nullptr;          // lane 0's stream; also used by every non-training call
     struct Lane {                          // sub-nets [k0,k1), work items [w0,w1)
         hipStream_t stream; int k0, k1, w0, w1;
-        hipStream_t stream_w = nullptr;    // partitioned mode: the weight-update stream (its own CUs); nullptr: everything on `stream`
-        hipEvent_t ev_m[8] = {nullptr}, ev_w[8] = {nullptr};   // partitioned mode: "second layer of step t done" / "weight update of step t done" (rings)
-        int ev_i = 0;
     };
-    int part = 0, part_cm = 0;             // DIMN_PART=<groups>: sub-net groups pipelined over two CU-masked streams (experiment)
-    hipStream_t st_part_m = nullptr, st_part_w = nullptr;
-    std::vector<Lane> lanes;               // independent sub-net groups trained on concurrent streams
+    std::vector<Lane> lanes;               // sub-net groups with a stream each (one lane: all sub-nets on the handle's stream)
     int64_t t = 0;
     // profiling
     bool profiling = false;
@@ -249,39 +241,113 @@ static int use_device(dimn_handle h) {
     return DIMN_OK;
 }
 
+// ---- process-wide cache of the LARGE device allocations ------------------------------------
+// A fresh process gets 28 GB from hipMalloc in a few milliseconds, but memory that was hipFree'd earlier in the SAME process comes
+// back slowly (the driver wipes freed VRAM before it hands it out again): the hand-over of a drop-in fit() that followed another
+// engine's life in the process took 0.19-0.62 s instead of 0.02 s (BENCH_r03 config.dropin.stages_s).  Blocks of >= 32 MB (the
+// matrix, the gathered X / Y arenas, the resident counts, predictions, correlation temporaries) are therefore never given back
+// while the process lives: a freed block waits here for the next request it fits (at most 25 % larger than asked for), oldest
+// first.  dimn_release_cached_memory() empties the cache; an allocation that fails empties it and tries once more; the cache never
+// holds more than DIMN_ARENA_CACHE_GB (default 96, 0 = no cache).
+static const size_t kArenaMin = (size_t)32 << 20;
+struct ArenaPool {
+    struct Blk { void* p; size_t bytes; int dev; };
+    std::mutex mu;
+    std::vector<Blk> idle, live;
+    size_t idle_bytes = 0;
+    double cap_gb() { const char* e = getenv("DIMN_ARENA_CACHE_GB"); return e ? atof(e) : 96.0; }
+    hipError_t get(void** out, size_t bytes) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            size_t best = idle.size();
+            for (size_t i = 0; i < idle.size(); ++i)
+                if (idle[i].dev == dev && idle[i].bytes >= bytes && idle[i].bytes <= bytes + bytes / 4 && (best == idle.size() || idle[i].bytes < idle[best].bytes)) best = i;
+            if (best < idle.size()) {
+                *out = idle[best].p;
+                live.push_back(idle[best]);
+                idle_bytes -= idle[best].bytes;
+                idle.erase(idle.begin() + (long)best);
+                return hipSuccess;
+            }
+        }
+        hipError_t e = hipMalloc(out, bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); trim(0); e = hipMalloc(out, bytes); }
+        if (e == hipSuccess) { std::lock_guard<std::mutex> lk(mu); live.push_back({*out, bytes, dev}); }
+        return e;
+    }
+    // true: p was one of ours (now idle, or freed when the cache is full / off)
+    bool put(void* p) {
+        Blk b{nullptr, 0, 0};
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < live.size(); ++i)
+                if (live[i].p == p) { b = live[i]; live.erase(live.begin() + (long)i); break; }
+            if (!b.p) return false;
+            if ((double)(idle_bytes + b.bytes) <= cap_gb() * 1073741824.0) { idle.push_back(b); idle_bytes += b.bytes; return true; }
+        }
+        (void)hipFree(p);
+        return true;
+    }
+    void trim(size_t keep_bytes) {
+        std::vector<Blk> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            while (!idle.empty() && idle_bytes > keep_bytes) { drop.push_back(idle.front()); idle_bytes -= idle.front().bytes; idle.erase(idle.begin()); }
+        }
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        for (auto& b : drop) { (void)hipSetDevice(b.dev); (void)hipFree(b.p); }
+        if (!drop.empty()) (void)hipSetDevice(cur);
+    }
+};
+static ArenaPool g_arena;
+static hipError_t dev_malloc_bytes(void** p, size_t bytes) {
+    if (bytes >= kArenaMin) return g_arena.get(p, bytes);
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); g_arena.trim(0); e = hipMalloc(p, bytes); }
+    return e;
+}
+static void dev_free_any(void* p) {
+    if (p && !g_arena.put(p)) (void)hipFree(p);
+}
+extern "C" int dimn_release_cached_memory(void) {
+    g_arena.trim(0);
+    return DIMN_OK;
+}
+
 template <typename T>
 static int dev_alloc(T** p, size_t count) {
     *p = nullptr;
     if (count == 0) count = 1;
-    HIPCHK(hipMalloc((void**)p, count * sizeof(T)));
+    HIPCHK(dev_malloc_bytes((void**)p, count * sizeof(T)));
     return DIMN_OK;
 }
 #define DEV_FREE(p)            \
     do {                       \
-        if (p) (void)hipFree(p); \
+        if (p) dev_free_any(p); \
         p = nullptr;           \
     } while (0)
 
 #include "dimn_general_host.inc"
 
-static void build_work(dimn_handle h, int groups = 1, int64_t group_target = 0) {
+static void build_work(dimn_handle h) {
     // Split every sub-net's chunk range into slices = workgroups of the W1 kernels.  The total is made
-    // EXACTLY ncu * wg_per_cu (a partially filled last round of workgroups costs a whole round), shared
+    // EXACTLY ncu (a partially filled last round of workgroups costs a whole round), shared
     // out in proportion to the chunk counts (largest remainder), subject to a minimum slice length: every
     // workgroup writes a 64-row split-K partial, so very fine slicing would drown the step in partials.
-    // (groups > 1: every contiguous group of sub-nets gets group_target workgroups of its own -- one launch per group.)
     std::vector<int> ns((size_t)h->K);
-    for (int gi = 0; gi < groups; ++gi) {
-        const int k0 = (int)((int64_t)h->K * gi / groups), k1 = (int)((int64_t)h->K * (gi + 1) / groups);
+    {
+        const int k0 = 0, k1 = h->K;
         int64_t total_chunks = 0;
         for (int k = k0; k < k1; ++k) total_chunks += h->sn[k].nchunk;
-        const int64_t target = groups > 1 ? group_target : (int64_t)h->ncu * h->wg_per_cu;
+        const int64_t target = (int64_t)h->ncu;
         std::vector<std::pair<double, int>> frac;
         int64_t assigned = 0;
         // minimum chunks per slice: 8 when there is plenty of work per CU; down to 2 when a GPU owns only a
         // few sub-nets (8-GPU sharding): the step is then latency-bound and parallelism beats partial traffic
-        int min_chunks = (int)std::min<int64_t>(8, std::max<int64_t>(2, total_chunks / std::max<int64_t>(1, target)));
-        if (const char* e = getenv("DIMN_MIN_CHUNKS")) min_chunks = std::max(1, atoi(e));
+        const int min_chunks = (int)std::min<int64_t>(8, std::max<int64_t>(2, total_chunks / std::max<int64_t>(1, target)));
         for (int k = k0; k < k1; ++k) {
             const double share = (double)target * h->sn[k].nchunk / (double)total_chunks;
             const int cap = std::max(1, h->sn[k].nchunk / min_chunks);
@@ -347,7 +413,7 @@ static void build_mid(dimn_handle h) {
     h->mid_fused = 1;
     int tmax = 0;
     for (auto& m : h->midwork) tmax = std::max(tmax, m.ot1 - m.ot0);
-    h->mid_keep = tmax <= 6 && !(getenv("DIMN_MID_KEEP") && atoi(getenv("DIMN_MID_KEEP")) == 0);
+    h->mid_keep = tmax <= 6;
     h->train_bf16 = h->mid_keep && h->prec == DIMN_PREC_BF16 && !(getenv("DIMN_TRAIN_BF16") && atoi(getenv("DIMN_TRAIN_BF16")) == 0);
 }
 
@@ -389,13 +455,13 @@ static void build_resident(dimn_handle h) {
     const Dims& dm = h->dm;
     if (const char* e = getenv("DIMN_RESIDENT")) if (atoi(e) == 0) return;
     if (dm.HT != 16 || (dm.H & 3) != 0 || h->B > DIMN_TB) return;
-    int max_groups = 3, min_groups = 1;
-    if (const char* e = getenv("DIMN_RES_GROUPS")) max_groups = std::max(1, atoi(e));
+    const int max_groups = 3;
+    int min_groups = 1;
     if (const char* e = getenv("DIMN_RES_MIN_GROUPS")) min_groups = std::max(1, atoi(e));      // tests: groups on small problems
     min_groups = std::min(min_groups, h->K);
     // (round 3: with the manager protocol a launch of five sub-nets costs 23.7 us per step, so FOUR groups of five -- the 2-GPU share of the
     //  50k x 20k job -- take 94 us against 104 us for the streaming kernels; four groups of four (K = 16) only draw: 86 vs 84-88 us)
-    const bool four_of_five = !getenv("DIMN_RES_GROUPS") && max_groups == 3 && ceil_div(h->K, 4) == 5;
+    const bool four_of_five = ceil_div(h->K, 4) == 5;
     for (int groups = min_groups; groups <= std::min(std::max(four_of_five ? 4 : max_groups, min_groups), h->K); ++groups) {
         const int Kg = ceil_div(h->K, groups);
         int S1 = 0, T1c = 0;
@@ -433,7 +499,7 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
     // the shared-staging B1F1 kernel can run it as 10 waves x 2 whole tiles with no predicated memory op: 165 vs 204 us
     // per launch, step 0.276 vs 0.298 ms at 50k x 20k (DIMN_HT20=0: off).  The three-set ring needs 168 VGPRs + 50
     // spilled at 10 waves x 2 tiles, and two co-resident 10 x 1 workgroups spill 16: both no faster than the generic kernel
-    if (dm.HT == 19 && !(getenv("DIMN_HT20") && atoi(getenv("DIMN_HT20")) == 0)) { dm.Hp = 320; dm.HT = 20; }
+    if (dm.HT == 19) { dm.Hp = 320; dm.HT = 20; }
     dm.Op = ceil_div(h->O, 16) * 16; dm.OT = dm.Op / 16;
     dm.ldd = dm.Hp + ((dm.Hp % 32 == 0) ? 2 : 18);   // LDS row stride = 2 (mod 32) words: conflict-free b32 column reads
     dm.ldp = dm.Hp + ((dm.Hp % 32 == 0) ? 4 : 20);   // k_predict: 4 (mod 32) words, rows 16-byte aligned: conflict-free b128 row reads
@@ -441,7 +507,7 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
     dm.LS = dm.OS;
     h->NT = ceil_div(dm.HT, 4);
     h->NT2 = ceil_div(dm.HT, 8);
-    h->OTW = ceil_div(dm.OT, 4);   // output tiles per wave of the 4-wave middle-backward kernel
+    h->OTW = ceil_div(dm.OT, 4);   // output tiles per wave of the 4-wave middle-backward kernel (k_mid_bwd)
     h->HS = ceil_div(dm.HT, 2);
     if (!general && h->NT > 6) {
         delete h;
@@ -457,11 +523,6 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
         return fail(DIMN_ERR_HIP, "dimn_create: cannot select device %d", cfg->device_id);
     }
     h->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char* e = getenv("DIMN_WG_PER_CU")) h->wg_per_cu = std::max(1, atoi(e));
-    if (const char* e = getenv("DIMN_B1F1")) h->variant = atoi(e);
-    if (const char* e = getenv("DIMN_MF")) h->mf_variant = atoi(e);
-    if (const char* e = getenv("DIMN_MB")) h->mb_waves = atoi(e) == 8 ? 8 : 4;
-    h->OTW = ceil_div(dm.OT, h->mb_waves);
 
     h->sn.resize(h->K);
     h->pred.resize(h->K); h->targ.resize(h->K);
@@ -480,33 +541,9 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
     h->w1_total = w1;
     build_work(h);
     if (!general) { build_mid(h); build_resident(h); }
-    // Experiment (DIMN_PART=<groups>, DIMN_PART_CM=<CUs of the second layer>): a FIXED CU partition.  The sub-nets are cut into
-    // groups; the HBM-bound weight update (B1F1) of group g runs on one stream whose queue is masked to the "W" CUs while the
-    // latency-bound second-layer chain (RED -> MFB -> RED2) of another group runs on a stream masked to the "M" CUs; events order
-    // the two streams per group and step.  Only for handles on the streaming kernels with the fused second layer.
-    if (!general && !h->res_G && h->mid_fused && getenv("DIMN_PART") && atoi(getenv("DIMN_PART")) >= 2 && h->K >= 2 * atoi(getenv("DIMN_PART"))) {
-        h->part = atoi(getenv("DIMN_PART"));
-        h->part_cm = getenv("DIMN_PART_CM") ? std::max(8, std::min(h->ncu - 8, atoi(getenv("DIMN_PART_CM")))) : 96;
-        uint32_t mm[16] = {0}, mw[16] = {0};
-        for (int cu = 0; cu < h->ncu; ++cu) { if (cu < h->part_cm) mm[cu >> 5] |= 1u << (cu & 31); else mw[cu >> 5] |= 1u << (cu & 31); }
-        const uint32_t words = (uint32_t)((h->ncu + 31) / 32);
-        if (hipExtStreamCreateWithCUMask(&h->st_part_m, words, mm) != hipSuccess || hipExtStreamCreateWithCUMask(&h->st_part_w, words, mw) != hipSuccess) {
-            (void)hipGetLastError();
-            fprintf(stderr, "libdimn: DIMN_PART: hipExtStreamCreateWithCUMask failed; partitioned mode off\n");
-            if (h->st_part_m) (void)hipStreamDestroy(h->st_part_m);
-            h->st_part_m = h->st_part_w = nullptr; h->part = 0;
-        } else {
-            build_work(h, h->part, h->ncu - h->part_cm);       // every group's weight update: one workgroup per "W" CU
-        }
-    }
-    // Sub-net lanes: independent sub-net groups on concurrent streams.  Default 1: with 2 lanes the
-    // end-to-end rate is ~9 % higher on cfg3 (one lane's latency-bound kernels hide under the other's
-    // weight update) but the two HBM-bound weight updates then share the bandwidth, which halves the
-    // per-launch figure the roofline is quoted on; opt in with DIMN_LANES=2.
-    int n_lanes = 1;
-    if (const char* e = getenv("DIMN_LANES")) n_lanes = std::max(1, atoi(e));
-    n_lanes = std::min(n_lanes, h->K);
-    if (h->part) n_lanes = h->part;
+    // One lane: every sub-net on the handle's stream.  (Two free-running lanes on two streams, a "W token" ring between them and a fixed
+    // CU partition with CU-masked streams were all measured and lost to the serial step: DESIGN.md section 2, profiles/r03_cu_partition_sweep.txt.)
+    const int n_lanes = 1;
 
     const size_t w2n = (size_t)h->K * dm.Hp * dm.Op;
 #define TRY(expr) do { int rc_ = (expr); if (rc_) { dimn_destroy(h); return rc_; } } while (0)
@@ -520,14 +557,6 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
         ln.k1 = (int)((int64_t)h->K * (l + 1) / n_lanes);
         ln.w0 = h->sn[ln.k0].slot0;
         ln.w1 = ln.k1 < h->K ? h->sn[ln.k1].slot0 : h->nslots;
-        if (h->part) {
-            ln.stream_w = h->st_part_w;
-            for (int i = 0; i < 8; ++i)
-                if (hipEventCreateWithFlags(&ln.ev_m[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ln.ev_w[i], hipEventDisableTiming) != hipSuccess) {
-                    delete h;
-                    return fail(DIMN_ERR_HIP, "dimn_create: hipEventCreate failed");
-                }
-        }
         h->lanes.push_back(ln);
     }
     h->stream = h->lanes[0].stream;
@@ -636,8 +665,6 @@ extern "C" int dimn_destroy(dimn_handle h) {
     if (!h) return DIMN_OK;
     (void)hipSetDevice(h->cfg.device_id);
     for (auto& ln : h->lanes) (void)hipStreamSynchronize(ln.stream);
-    if (h->st_part_m) (void)hipStreamSynchronize(h->st_part_m);
-    if (h->st_part_w) (void)hipStreamSynchronize(h->st_part_w);
     gen_free(h->gen); h->gen = nullptr;
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (auto e : h->ev) (void)hipEventDestroy(e);
@@ -651,12 +678,7 @@ extern "C" int dimn_destroy(dimn_handle h) {
     DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage); DEV_FREE(h->d_red);
     DEV_FREE(h->d_W1b); DEV_FREE(h->d_W2t); DEV_FREE(h->d_W2tf);
     DEV_FREE(h->d_res_P); DEV_FREE(h->d_res_D); DEV_FREE(h->d_res_T); DEV_FREE(h->d_res_A); DEV_FREE(h->d_res_b1); DEV_FREE(h->d_res_alpha); DEV_FREE(h->d_res_flags); DEV_FREE(h->d_res_loss); DEV_FREE(h->d_res_snap); DEV_FREE(h->d_res_Xe); DEV_FREE(h->d_res_Ye); DEV_FREE(h->d_res_iota);
-    for (auto& ln : h->lanes) {
-        (void)hipStreamDestroy(ln.stream);
-        for (int i = 0; i < 8; ++i) { if (ln.ev_m[i]) (void)hipEventDestroy(ln.ev_m[i]); if (ln.ev_w[i]) (void)hipEventDestroy(ln.ev_w[i]); }
-    }
-    if (h->st_part_m) (void)hipStreamDestroy(h->st_part_m);
-    if (h->st_part_w) (void)hipStreamDestroy(h->st_part_w);
+    for (auto& ln : h->lanes) (void)hipStreamDestroy(ln.stream);
     delete h;
     return DIMN_OK;
 }
@@ -708,8 +730,7 @@ static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
 // front to back, so the reads stream)
 static void parallel_pack_columns(float* dst, const float* src, int64_t nr, int64_t g, const int32_t* cols, int64_t gc) {
     const unsigned hw = std::thread::hardware_concurrency();
-    unsigned cap = 48;
-    if (const char* e = getenv("DIMN_STREAM_THREADS")) cap = (unsigned)std::max(1, atoi(e));      // (diagnostic)
+    const unsigned cap = 48;      // (16 .. 128 threads measured the same: the host reads its matrix at ~70 GB/s)
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw ? hw / 2 : 8, cap), nr * g / (1 << 20)));
     auto work = [=](int t) {
         for (int64_t r = nr * t / nt; r < nr * (t + 1) / nt; ++r) {
@@ -733,6 +754,7 @@ static int gather_prepare(dimn_handle h, int32_t with_targets) {
     }
     CHK(use_device(h));
     HIPCHK(hipStreamSynchronize(h->stream));
+    Trace tr;
     std::vector<int32_t> pflat, tflat;
     std::vector<int64_t> poff(h->K);
     for (int k = 0; k < h->K; ++k) {
@@ -744,6 +766,7 @@ static int gather_prepare(dimn_handle h, int32_t with_targets) {
     HIPCHK(hipMemcpy(h->d_pred, pflat.data(), pflat.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_targ, tflat.data(), tflat.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_pred_off, poff.data(), poff.size() * 8, hipMemcpyHostToDevice));
+    tr.lap("gather: index lists");
     int64_t x = 0;
     for (int k = 0; k < h->K; ++k) {
         if ((int64_t)h->n * h->sn[k].Dp > 0xffffffffLL) return fail(DIMN_ERR_UNSUP, "dimn_gather: n*Dp exceeds 32-bit row offsets");
@@ -753,7 +776,7 @@ static int gather_prepare(dimn_handle h, int32_t with_targets) {
     // the arenas are re-used across calls (19.5 GB at cfg3: a hipFree/hipMalloc pair costs up to a second)
     if (!h->d_X || h->x_total != x) {
         DEV_FREE(h->d_X); DEV_FREE(h->d_res_Xe);
-        HIPCHK(hipMalloc((void**)&h->d_X, std::max<size_t>(1, (size_t)x * XBYTES(h))));
+        HIPCHK(dev_malloc_bytes((void**)&h->d_X, std::max<size_t>(1, (size_t)x * XBYTES(h))));
         h->x_total = x;
     }
     const int64_t y_need = (int64_t)h->K * h->n * h->dm.Op;
@@ -762,6 +785,7 @@ static int gather_prepare(dimn_handle h, int32_t with_targets) {
         CHK(dev_alloc(&h->d_Y, (size_t)y_need));
         h->y_total = y_need;
     }
+    tr.lap("gather: X / Y arenas");
     HIPCHK(hipMemcpy(h->d_sn, h->sn.data(), h->sn.size() * sizeof(SubnetDev), hipMemcpyHostToDevice));
     return DIMN_OK;
 }
@@ -792,8 +816,10 @@ extern "C" int dimn_gather(dimn_handle h, int32_t with_targets) {
     if (!h) return fail(DIMN_ERR_ARG, "dimn_gather: null handle");
     if (!h->d_norm) return fail(DIMN_ERR_STATE, h->streamed ? "dimn_gather: the matrix was streamed (dimn_set_matrix_streamed gathers itself)" : "dimn_gather: call dimn_set_matrix first");
     CHK(gather_prepare(h, with_targets));
+    Trace tr;
     CHK(gather_block(h, h->d_norm, h->n, 0, with_targets, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    tr.lap("gather: kernel");
     h->gathered = true;
     h->gathered_targets = with_targets != 0;
     return DIMN_OK;
@@ -834,25 +860,24 @@ extern "C" int dimn_set_matrix_streamed(dimn_handle h, const float* norm, int64_
                 for (int32_t c : h->targ[k]) tflat.push_back(with_targets ? where[(size_t)c] : 0);
             }
             CHK(dev_alloc(&d_pred_c, pflat.size()));
-            if (dev_alloc(&d_targ_c, tflat.size()) != DIMN_OK) { (void)hipFree(d_pred_c); return DIMN_ERR_HIP; }
+            if (dev_alloc(&d_targ_c, tflat.size()) != DIMN_OK) { (void)dev_free_any(d_pred_c); return DIMN_ERR_HIP; }
             if (hipMemcpy(d_pred_c, pflat.data(), pflat.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
                 hipMemcpy(d_targ_c, tflat.data(), tflat.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-                (void)hipFree(d_pred_c); (void)hipFree(d_targ_c);
+                (void)dev_free_any(d_pred_c); (void)dev_free_any(d_targ_c);
                 return fail(DIMN_ERR_HIP, "dimn_set_matrix_streamed: index upload failed");
             }
         }
     }
     const int64_t gc = cols.empty() ? g : (int64_t)cols.size();
     const int64_t blk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(128u << 20) / (gc * 4)));
-    int NBUF = 2;                // blocks in flight (host packing | PCIe copy | device gather); DIMN_STREAM_BUFS = 2 .. 4
-    if (const char* e = getenv("DIMN_STREAM_BUFS")) NBUF = std::max(2, std::min(4, atoi(e)));
+    const int NBUF = 2;          // blocks in flight (host packing | PCIe copy | device gather); 3 and 4 measured the same
     float *pin[4] = {nullptr, nullptr, nullptr, nullptr}, *dev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
     int rc = DIMN_OK;
 #define STR_TRY(expr) do { hipError_t e_ = (expr); if (rc == DIMN_OK && e_ != hipSuccess) rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
     for (int b = 0; b < NBUF; ++b) {
         STR_TRY(hipHostMalloc((void**)&pin[b], (size_t)blk * gc * 4, hipHostMallocDefault));
-        STR_TRY(hipMalloc((void**)&dev[b], (size_t)blk * gc * 4));
+        STR_TRY(dev_malloc_bytes((void**)&dev[b], (size_t)blk * gc * 4));
         STR_TRY(hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking));
     }
     int64_t bi = 0;
@@ -870,10 +895,10 @@ extern "C" int dimn_set_matrix_streamed(dimn_handle h, const float* norm, int64_
     for (int b = 0; b < NBUF; ++b) {
         if (st[b]) { (void)hipStreamSynchronize(st[b]); (void)hipStreamDestroy(st[b]); }
         if (pin[b]) (void)hipHostFree(pin[b]);
-        if (dev[b]) (void)hipFree(dev[b]);
+        if (dev[b]) (void)dev_free_any(dev[b]);
     }
-    if (d_pred_c) (void)hipFree(d_pred_c);
-    if (d_targ_c) (void)hipFree(d_targ_c);
+    if (d_pred_c) (void)dev_free_any(d_pred_c);
+    if (d_targ_c) (void)dev_free_any(d_targ_c);
     if (rc != DIMN_OK) return rc;
     h->gathered = true;
     h->gathered_targets = with_targets != 0;
@@ -1065,12 +1090,10 @@ static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, hipStream_t 
                                                          (const XT*)h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, \
                                                          (const float*)h->d_dA, h->d_P, h->dm, ap)
     WITH_XT(h, {
-        if (h->dm.HT == 20 && h->variant == 1)        // H = 300 (padded to 320): 10 waves x 2 hidden tiles, two-set shared-staging variant
+        if (h->dm.HT == 20)                           // H = 300 (padded to 320): 10 waves x 2 hidden tiles, two-set shared-staging variant
             W1_LAUNCH((k_w1_update_fwd_sh<10, 2, 1, XT>), 640);
-        else if (h->dm.HT == 16 && h->variant == 1)   // H = 256: 16 waves x 1 hidden tile, X tiles staged once per workgroup, 3-set register ring
+        else if (h->dm.HT == 16)                      // H = 256: 16 waves x 1 hidden tile, X tiles staged once per workgroup, 3-set register ring
             W1_LAUNCH((k_w1_update_fwd_ring<16, 1, 3, 1, XT>), 1024);
-        else if (h->dm.HT == 16 && h->variant == 2)
-            W1_LAUNCH((k_w1_update_fwd_sh<16, 1, 1, XT>), 1024);
         else if (h->dm.HT == 8 * NT2)
             W1_LAUNCH((k_w1_update_fwd<NT2, true, XT>), 512);
         else
@@ -1084,7 +1107,7 @@ static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, f
     if (h->predict_bf16) {                         // bf16 matrix cores (precision bf16): fresh bf16 images of the weights, then the forward
         hipLaunchKernelGGL(k_prep_bf16, dim3(256, (unsigned)h->K), dim3(256), 0, h->stream, h->d_sn, (const float*)h->d_W1, (const float*)h->d_W2,
                            h->d_W1b, h->d_W2t, h->dm);
-        if (h->dm.Hp <= 256 && !(getenv("DIMN_PREDICT_R2") && atoi(getenv("DIMN_PREDICT_R2")) != 0)) {
+        if (h->dm.Hp <= 256) {
             // 128 rows per workgroup, 32-deep bf16 matrix instructions, X staged through LDS (dimn_kernels.h); loss slots stay 64-row tiles
             const unsigned tiles128 = (unsigned)((n_rows + DIMN_PB_M - 1) / DIMN_PB_M);
             const int hq = (h->dm.Hp + 31) & ~31;
@@ -1146,15 +1169,7 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     const float inv_n = (float)(1.0 / ((double)b_act * h->O));
     const size_t kh = (size_t)h->K * dm.Hp, ko = (size_t)h->K * dm.Op;
     const unsigned nk = (unsigned)(ln.k1 - ln.k0);
-    // partitioned mode: the second-layer chain on the "M" stream, the weight update on the "W" stream, ordered per group by events
-    dimn_handle_s::Lane& lnm = const_cast<dimn_handle_s::Lane&>(ln);
-    hipStream_t st = ln.stream_w ? h->st_part_m : ln.stream;
-    hipStream_t stw = ln.stream_w ? ln.stream_w : ln.stream;
-    const int evi = lnm.ev_i;
-    if (ln.stream_w) {
-        lnm.ev_i = (evi + 1) & 7;
-        if (!need_fwd) HIPCHK(hipStreamWaitEvent(st, ln.ev_w[(evi + 7) & 7], 0));      // this step's forward partials come from the group's last weight update
-    }
+    hipStream_t st = ln.stream, stw = ln.stream;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     // one step in eight is timed, on every lane, with HIP events on the lane's own stream: enough samples
     // for a mean, and the event traffic stays out of the way of the other seven
@@ -1198,27 +1213,21 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
         const size_t lds = (size_t)DIMN_TB * dm.ldd * sizeof(float);
 #define LAUNCH_MF(HTC) hipLaunchKernelGGL(k_mid_fwd<HTC>, grid, dim3(512), lds, st, h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, \
                                           h->n, d_rows, b_act, h->d_Dd, h->d_dZ, h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary, ln.k0)
-        if (h->mf_variant == 16 && dm.HT == 16) LAUNCH_MF(16);                      // all W2 operands hoisted, 162 VGPRs
-        else if (h->mf_variant == 16 && dm.HT == 20) LAUNCH_MF(20);                 // hidden = 300 (padded to 320)
+        if (dm.HT == 16) LAUNCH_MF(16);                                             // all W2 operands hoisted, 162 VGPRs
+        else if (dm.HT == 20) LAUNCH_MF(20);                                        // hidden = 300 (padded to 320)
         else LAUNCH_MF(0);                                                          // generic: 78 VGPRs
 #undef LAUNCH_MF
     }
     // one hidden tile (16 rows of W2) per workgroup; 4 or 8 waves split the output tiles
 #define LAUNCH_MB(FULLV, WV) hipLaunchKernelGGL((k_mid_bwd<FULLV, 1, WV>), dim3((unsigned)dm.HT, nk), dim3(WV * 64), 0, st, h->d_Dd, h->d_dZ, \
                                                 h->d_W2, h->d_M2, h->d_V2, h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0, (const float*)h->d_G)
-    if (h->mb_waves == 8) { if (dm.OT == 8 * h->OTW) LAUNCH_MB(true, 8); else LAUNCH_MB(false, 8); }
-    else if (dm.OT == 4 * h->OTW && (int64_t)dm.HT * nk <= 2 * (int64_t)h->ncu)   // few workgroups (a GPU that owns few sub-nets):
+    if (dm.OT == 4 * h->OTW && (int64_t)dm.HT * nk <= 2 * (int64_t)h->ncu)   // few workgroups (a GPU that owns few sub-nets):
         hipLaunchKernelGGL((k_mid_bwd<true, 1, 4, 2>), dim3((unsigned)dm.HT, nk), dim3(256), 0, st, h->d_Dd, h->d_dZ,   // 2 per CU fit anyway -> no register cap, no spills
                            h->d_W2, h->d_M2, h->d_V2, h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0, (const float*)h->d_G);
     else { if (dm.OT == 4 * h->OTW) LAUNCH_MB(true, 4); else LAUNCH_MB(false, 4); }
 #undef LAUNCH_MB
     }
-    if (ln.stream_w) {
-        HIPCHK(hipEventRecord(ln.ev_m[evi], st));
-        HIPCHK(hipStreamWaitEvent(stw, ln.ev_m[evi], 0));
-    }
     DISPATCH_NT2(launch_w1, h, ln, stw, d_rows, b_act, d_rows_n, b_next, ap, e1, e2);   // e1/e2 (timed steps): the kernel's own begin/end
-    if (ln.stream_w) HIPCHK(hipEventRecord(ln.ev_w[evi], stw));
     HIPCHK(hipGetLastError());
     return DIMN_OK;
 }
@@ -1227,8 +1236,6 @@ static int sync_lanes(dimn_handle h);
 static int sync_lanes_fwd(dimn_handle h) { return sync_lanes(h); }
 static int sync_lanes(dimn_handle h) {
     for (auto& ln : h->lanes) HIPCHK(hipStreamSynchronize(ln.stream));
-    if (h->st_part_m) HIPCHK(hipStreamSynchronize(h->st_part_m));
-    if (h->st_part_w) HIPCHK(hipStreamSynchronize(h->st_part_w));
     return DIMN_OK;
 }
 
@@ -1238,7 +1245,7 @@ static int collect_timers(dimn_handle h) {
         float a = 0, b = 0;
         if (hipEventElapsedTime(&a, h->ev[i], h->ev[i + 2]) == hipSuccess &&
             hipEventElapsedTime(&b, h->ev[i + 1], h->ev[i + 2]) == hipSuccess) {
-            if (!h->part) { h->tm_step_ms += a; h->tm_steps++; }      // (partitioned mode: steps of different groups overlap -- the epoch's wall time counts, dimn_train_epoch)
+            h->tm_step_ms += a; h->tm_steps++;
             h->tm_w1_ms += b; h->tm_w1++;
             h->tm_w1_bytes += h->ev_bytes[i / 3];
         }
@@ -1375,7 +1382,7 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
     const size_t lds = (size_t)DIMN_RES_LDS_FLOATS * sizeof(float);
     // The workgroups of a launch wait for each other, so all of them must be resident at once.  (1) the grid is checked against
     // the kernel's occupancy on this device, and the launch is a COOPERATIVE one (the runtime refuses it unless the whole grid
-    // fits the device; DIMN_RES_COOP=0: plain launch); (2) the state the launch will overwrite is snapshotted first, so that a
+    // fits the device; measured: no cost, 26.09 vs 26.00 us per step); (2) the state the launch will overwrite is snapshotted first, so that a
     // launch that still times out (a GPU shared with another process) is undone and the epoch re-run on the streaming kernels.
     const size_t w2n = (size_t)h->K * dm.Hp * dm.Op, nb1 = (size_t)3 * h->K * dm.Hp, nb2 = (size_t)3 * h->K * dm.Op;
     const size_t snap_floats = 3 * (size_t)h->w1_total + 3 * w2n + nb1 + nb2;
@@ -1386,7 +1393,7 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
         const size_t cnt[8] = {(size_t)h->w1_total, (size_t)h->w1_total, (size_t)h->w1_total, w2n, w2n, w2n, nb1, nb2};
         for (int i = 0; i < 8; ++i) { HIPCHK(hipMemcpyAsync(d, src[i], cnt[i] * 4, hipMemcpyDeviceToDevice, h->stream)); d += cnt[i]; }
     }
-    const bool coop = !(getenv("DIMN_RES_COOP") && atoi(getenv("DIMN_RES_COOP")) == 0);
+    const bool coop = true;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) { e0 = next_event(h); e1 = next_event(h); next_event(h); }
     if (e0 && e1) (void)hipEventRecord(e0, h->stream);
@@ -1426,14 +1433,14 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
         if (const char* e = getenv("DIMN_RES_EPOCH_ROWS")) erows = atoi(e) != 0;
         if (erows && h->res_erows_off) erows = false;
         if (erows) {     // (no room for the copies: the kernel gathers its rows where they are, as for small arenas)
-            if (!h->d_res_Xe && hipMalloc((void**)&h->d_res_Xe, std::max<size_t>(1, (size_t)h->x_total * XBYTES(h))) != hipSuccess) { h->d_res_Xe = nullptr; erows = false; }
-            if (erows && !h->d_res_Ye && hipMalloc((void**)&h->d_res_Ye, std::max<size_t>(1, (size_t)h->y_total * 4)) != hipSuccess) { h->d_res_Ye = nullptr; erows = false; }
+            if (!h->d_res_Xe && dev_malloc_bytes((void**)&h->d_res_Xe, std::max<size_t>(1, (size_t)h->x_total * XBYTES(h))) != hipSuccess) { h->d_res_Xe = nullptr; erows = false; }
+            if (erows && !h->d_res_Ye && dev_malloc_bytes((void**)&h->d_res_Ye, std::max<size_t>(1, (size_t)h->y_total * 4)) != hipSuccess) { h->d_res_Ye = nullptr; erows = false; }
             if (!erows) { (void)hipGetLastError(); DEV_FREE(h->d_res_Xe); DEV_FREE(h->d_res_Ye); h->res_erows_off = true; }
         }
         if (erows) {
             if (!h->d_res_iota || h->res_iota_n != h->n_tr) {
                 DEV_FREE(h->d_res_iota);
-                HIPCHK(hipMalloc((void**)&h->d_res_iota, std::max<size_t>(1, (size_t)h->n_tr * 4)));
+                HIPCHK(dev_malloc_bytes((void**)&h->d_res_iota, std::max<size_t>(1, (size_t)h->n_tr * 4)));
                 h->res_iota_n = h->n_tr;
                 hipLaunchKernelGGL(k_res_iota, dim3((unsigned)((h->n_tr + 255) / 256)), dim3(256), 0, h->stream, h->d_res_iota, (int64_t)h->n_tr);
             }
@@ -1542,7 +1549,6 @@ extern "C" int dimn_train_epoch(dimn_handle h, int32_t epoch, const int32_t* per
     // d_loss_acc accumulates sum(w e^2) per step; the per-step means are weighted by b_act,
     // i.e. sum_steps (sum/(b_act*O))*b_act / n_tr = total / (O*n_tr)
     int step = 0;
-    const auto wall0 = std::chrono::steady_clock::now();
     for (int64_t i0 = 0; i0 < h->n_tr; i0 += h->B, ++step) {
         const int b_act = (int)std::min<int64_t>(h->B, h->n_tr - i0);
         const int64_t i1 = i0 + h->B;
@@ -1555,10 +1561,6 @@ extern "C" int dimn_train_epoch(dimn_handle h, int32_t epoch, const int32_t* per
         h->t += 1;
     }
     CHK(sync_lanes(h));
-    if (h->profiling && h->part) {
-        h->tm_step_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-        h->tm_steps += step;
-    }
     if (h->profiling) collect_timers(h);
     if (train_loss) {
         std::vector<double> acc((size_t)h->K * dm.LS);
@@ -1681,7 +1683,7 @@ extern "C" int dimn_val_metrics(dimn_handle h, double* out7) {
             hipStreamSynchronize(h->stream) != hipSuccess)
             rc = fail(DIMN_ERR_HIP, "dimn_val_metrics: kernel or copy failed");
     }
-    (void)hipFree(d);
+    (void)dev_free_any(d);
     return rc;
 }
 
@@ -1720,11 +1722,11 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
         if (!pins.take(4, std::max<size_t>((size_t)(128u << 20), (size_t)blk * g * 8), &why)) return fail(DIMN_ERR_HIP, "dimn_impute_finish: pinning the bounce buffers failed: %s", why);
     }
 #define FIN_TRY(expr) do { hipError_t e_ = (expr); if (rc == DIMN_OK && e_ != hipSuccess) rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
-    FIN_TRY(hipMalloc((void**)&dOff, (size_t)(g + 1) * 4));
-    FIN_TRY(hipMalloc((void**)&dSlot, (size_t)std::max<int64_t>(S, 1) * 4));
+    FIN_TRY(dev_malloc_bytes((void**)&dOff, (size_t)(g + 1) * 4));
+    FIN_TRY(dev_malloc_bytes((void**)&dSlot, (size_t)std::max<int64_t>(S, 1) * 4));
     for (int b = 0; b < 2; ++b) {
-        if (!resident) FIN_TRY(hipMalloc((void**)&dRaw[b], (size_t)blk * g * 8));
-        FIN_TRY(hipMalloc((void**)&dRes[b], (size_t)blk * g * 8));
+        if (!resident) FIN_TRY(dev_malloc_bytes((void**)&dRaw[b], (size_t)blk * g * 8));
+        FIN_TRY(dev_malloc_bytes((void**)&dRes[b], (size_t)blk * g * 8));
         pIn[b] = (double*)pins.buf[b]; pOut[b] = (double*)pins.buf[2 + b];
         FIN_TRY(hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking));
         FIN_TRY(hipEventCreateWithFlags(&evOut[b], hipEventDisableTiming));
@@ -1774,11 +1776,11 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
     for (int b = 0; b < 2; ++b) {
         if (st[b]) { (void)hipStreamSynchronize(st[b]); (void)hipStreamDestroy(st[b]); }
         if (evOut[b]) (void)hipEventDestroy(evOut[b]);
-        if (dRaw[b]) (void)hipFree(dRaw[b]);
-        if (dRes[b]) (void)hipFree(dRes[b]);
+        if (dRaw[b]) (void)dev_free_any(dRaw[b]);
+        if (dRes[b]) (void)dev_free_any(dRes[b]);
     }
-    if (dOff) (void)hipFree(dOff);
-    if (dSlot) (void)hipFree(dSlot);
+    if (dOff) (void)dev_free_any(dOff);
+    if (dSlot) (void)dev_free_any(dSlot);
     tr.lap("finish: frees");
     return rc;
 }
@@ -1868,9 +1870,44 @@ extern "C" int dimn_comm_allreduce_sum(dimn_handle h, double* v, int32_t n) {
     HIPCHK(hipStreamSynchronize(h->stream));
     return DIMN_OK;
 }
+// Root's side of the gather, after the peers' blocks have landed contiguously in the staging arena (block of rank r at
+// n_rows * koff[r] * O floats): every [n_rows][K_r*O] block is placed into its column range of the full [n_rows][K_global*O]
+// matrix in HBM by a strided D2D copy (root's own block straight from d_out); host copy only if out != NULL.
+static int gather_arenas(dimn_handle h, int64_t n_rows, const int32_t* counts, int n_ranks, std::vector<int64_t>& koff, int64_t& ktot) {
+    ktot = 0;
+    koff.assign((size_t)n_ranks, 0);
+    for (int r = 0; r < n_ranks; ++r) {
+        if (counts[r] < 0) return fail(DIMN_ERR_ARG, "gather: counts[%d] < 0", r);
+        koff[(size_t)r] = ktot; ktot += counts[r];
+    }
+    const int64_t need = n_rows * ktot * h->O;
+    if (h->full_cap < need) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        DEV_FREE(h->d_full); DEV_FREE(h->d_stage);
+        CHK(dev_alloc(&h->d_full, (size_t)need));
+        CHK(dev_alloc(&h->d_stage, (size_t)need));
+        h->full_cap = need;
+    }
+    return DIMN_OK;
+}
+static int gather_place(dimn_handle h, int64_t n_rows, const int32_t* counts, int n_ranks, int root, const std::vector<int64_t>& koff, int64_t ktot, float* out) {
+    const int O = h->O;
+    for (int r = 0; r < n_ranks; ++r) {
+        const float* src = (r == root) ? h->d_out : h->d_stage + (size_t)n_rows * koff[(size_t)r] * O;
+        if (n_rows > 0 && counts[r] > 0)
+            HIPCHK(hipMemcpy2DAsync(h->d_full + koff[(size_t)r] * O, (size_t)ktot * O * 4, src, (size_t)counts[r] * O * 4,
+                                    (size_t)counts[r] * O * 4, (size_t)n_rows, hipMemcpyDeviceToDevice, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->full_rows = n_rows; h->full_width = ktot * O;
+    const int64_t need = n_rows * ktot * O;
+    if (out && need > 0) HIPCHK(hipMemcpy(out, h->d_full, (size_t)need * 4, hipMemcpyDeviceToHost));
+    return DIMN_OK;
+}
 extern "C" int dimn_comm_gather_predictions(dimn_handle h, int64_t n_rows, const int32_t* counts, int32_t root, float* out) {
     if (!h || !counts || n_rows < 0) return fail(DIMN_ERR_ARG, "dimn_comm_gather_predictions: bad argument");
     if (!h->comm) return fail(DIMN_ERR_STATE, "dimn_comm_gather_predictions: dimn_comm_init first");
+    if (root < 0 || root >= h->n_ranks) return fail(DIMN_ERR_ARG, "dimn_comm_gather_predictions: root out of range");
     if (h->out_rows != n_rows) return fail(DIMN_ERR_STATE, "dimn_comm_gather_predictions: last dimn_predict_device had %lld rows", (long long)h->out_rows);
     if (counts[h->rank] != h->K) return fail(DIMN_ERR_ARG, "dimn_comm_gather_predictions: counts[rank] != n_subnets");
     CHK(use_device(h));
@@ -1882,37 +1919,43 @@ extern "C" int dimn_comm_gather_predictions(dimn_handle h, int64_t n_rows, const
         HIPCHK(hipStreamSynchronize(h->stream));
         return DIMN_OK;
     }
-    // root: every peer sends over its own xGMI link; blocks land contiguously in a staging
-    // arena, then each [n_rows][K_r*O] block is placed into its column range of the full
-    // [n_rows][K_global*O] matrix in HBM (strided D2D copy); host copy only if out != NULL.
+    // root: every peer sends over its own xGMI link; the blocks land contiguously in the staging arena, then gather_place
     int64_t ktot = 0;
-    std::vector<int64_t> koff((size_t)h->n_ranks);
-    for (int r = 0; r < h->n_ranks; ++r) { koff[(size_t)r] = ktot; ktot += counts[r]; }
-    const int64_t need = n_rows * ktot * O;
-    if (h->full_cap < need) {
-        HIPCHK(hipStreamSynchronize(h->stream));
-        DEV_FREE(h->d_full); DEV_FREE(h->d_stage);
-        CHK(dev_alloc(&h->d_full, (size_t)need));
-        CHK(dev_alloc(&h->d_stage, (size_t)need));
-        h->full_cap = need;
-    }
-    float* stage = h->d_stage;
+    std::vector<int64_t> koff;
+    CHK(gather_arenas(h, n_rows, counts, h->n_ranks, koff, ktot));
     NCCLCHK(g_rccl.GroupStart());
     for (int r = 0; r < h->n_ranks; ++r) {
         if (r == root) continue;
-        NCCLCHK(g_rccl.Recv(stage + (size_t)n_rows * koff[(size_t)r] * O, (size_t)n_rows * counts[r] * O, kNcclFloat32, r, h->comm, h->stream));
+        NCCLCHK(g_rccl.Recv(h->d_stage + (size_t)n_rows * koff[(size_t)r] * O, (size_t)n_rows * counts[r] * O, kNcclFloat32, r, h->comm, h->stream));
     }
     NCCLCHK(g_rccl.GroupEnd());
-    for (int r = 0; r < h->n_ranks; ++r) {
-        const float* src = (r == root) ? h->d_out : stage + (size_t)n_rows * koff[(size_t)r] * O;
-        if (n_rows > 0)
-            HIPCHK(hipMemcpy2DAsync(h->d_full + koff[(size_t)r] * O, (size_t)ktot * O * 4, src, (size_t)counts[r] * O * 4,
-                                    (size_t)counts[r] * O * 4, (size_t)n_rows, hipMemcpyDeviceToDevice, h->stream));
+    return gather_place(h, n_rows, counts, h->n_ranks, root, koff, ktot, out);
+}
+// The same gather with the transport replaced by device-to-device copies on ONE GPU: handles[r] plays rank r (handles[root] is the
+// root; every handle on the root's device, each with a dimn_predict_device result over the same n_rows).  Everything behind the
+// ncclRecv -- arena sizing, block offsets, the strided placement, full_rows / full_width for dimn_impute_finish(from_gathered) -- is
+// the code of dimn_comm_gather_predictions; only RCCL itself is not exercised.  For the single-GPU boxes the tests run on.
+extern "C" int dimn_comm_gather_loopback(const dimn_handle* handles, int32_t n_ranks, int64_t n_rows, const int32_t* counts, int32_t root, float* out) {
+    if (!handles || !counts || n_ranks < 1 || n_rows < 0 || root < 0 || root >= n_ranks) return fail(DIMN_ERR_ARG, "dimn_comm_gather_loopback: bad argument");
+    dimn_handle h = handles[root];
+    if (!h) return fail(DIMN_ERR_ARG, "dimn_comm_gather_loopback: null root handle");
+    for (int r = 0; r < n_ranks; ++r) {
+        dimn_handle p = handles[r];
+        if (!p || p->cfg.device_id != h->cfg.device_id || p->O != h->O) return fail(DIMN_ERR_ARG, "dimn_comm_gather_loopback: handle %d is null, on another device or of another out_dim", r);
+        if (p->out_rows != n_rows || !p->d_out) return fail(DIMN_ERR_STATE, "dimn_comm_gather_loopback: handle %d has no dimn_predict_device result over %lld rows", r, (long long)n_rows);
+        if (counts[r] != p->K) return fail(DIMN_ERR_ARG, "dimn_comm_gather_loopback: counts[%d] != n_subnets of handle %d", r, r);
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->full_rows = n_rows; h->full_width = ktot * O;
-    if (out && need > 0) HIPCHK(hipMemcpy(out, h->d_full, (size_t)need * 4, hipMemcpyDeviceToHost));
-    return DIMN_OK;
+    CHK(use_device(h));
+    int64_t ktot = 0;
+    std::vector<int64_t> koff;
+    CHK(gather_arenas(h, n_rows, counts, n_ranks, koff, ktot));
+    for (int r = 0; r < n_ranks; ++r) {
+        if (r == root) continue;
+        HIPCHK(hipStreamSynchronize(handles[r]->stream));        // (the "send": the peer's forward has finished)
+        if (n_rows > 0)
+            HIPCHK(hipMemcpyAsync(h->d_stage + (size_t)n_rows * koff[(size_t)r] * h->O, handles[r]->d_out, (size_t)n_rows * counts[r] * h->O * 4, hipMemcpyDeviceToDevice, h->stream));
+    }
+    return gather_place(h, n_rows, counts, n_ranks, root, koff, ktot, out);
 }
 extern "C" int dimn_comm_destroy(dimn_handle h) {
     if (!h) return fail(DIMN_ERR_ARG, "null handle");
@@ -2005,14 +2048,14 @@ static int corr_on_device_streamed(const double* X, int64_t n, int64_t g, hipStr
         for (int j = i; j < nb; ++j) pairs.push_back(make_int2(i, j));
 #define CORR_TRY(expr) do { hipError_t e_ = (expr); if (rc == DIMN_OK && e_ != hipSuccess) rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
     for (int b = 0; b < 2; ++b) {
-        CORR_TRY(hipMalloc((void**)&dZ[b], (size_t)blk * gp * 8));
+        CORR_TRY(dev_malloc_bytes((void**)&dZ[b], (size_t)blk * gp * 8));
         CORR_TRY(hipHostMalloc((void**)&pin[b], (size_t)blk * g * 8, hipHostMallocDefault));
         CORR_TRY(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
     }
-    CORR_TRY(hipMalloc((void**)&dC, (size_t)gp * gp * 8));
-    CORR_TRY(hipMalloc((void**)&dOut, (size_t)g * g * 8));
-    CORR_TRY(hipMalloc((void**)&dMean, (size_t)gp * 8));
-    CORR_TRY(hipMalloc((void**)&dPairs, pairs.size() * sizeof(int2)));
+    CORR_TRY(dev_malloc_bytes((void**)&dC, (size_t)gp * gp * 8));
+    CORR_TRY(dev_malloc_bytes((void**)&dOut, (size_t)g * g * 8));
+    CORR_TRY(dev_malloc_bytes((void**)&dMean, (size_t)gp * 8));
+    CORR_TRY(dev_malloc_bytes((void**)&dPairs, pairs.size() * sizeof(int2)));
     if (rc == DIMN_OK) {
         CORR_TRY(hipMemsetAsync(dMean, 0, (size_t)gp * 8, st));
         CORR_TRY(hipMemcpyAsync(dPairs, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
@@ -2047,14 +2090,14 @@ static int corr_on_device_streamed(const double* X, int64_t n, int64_t g, hipStr
     CORR_TRY(hipStreamSynchronize(st));
 #undef CORR_TRY
     for (int b = 0; b < 2; ++b) {
-        if (dZ[b]) (void)hipFree(dZ[b]);
+        if (dZ[b]) (void)dev_free_any(dZ[b]);
         if (pin[b]) (void)hipHostFree(pin[b]);
         if (ev[b]) (void)hipEventDestroy(ev[b]);
     }
-    if (dC) (void)hipFree(dC);
-    if (dMean) (void)hipFree(dMean);
-    if (dPairs) (void)hipFree(dPairs);
-    if (rc != DIMN_OK && dOut) { (void)hipFree(dOut); dOut = nullptr; }
+    if (dC) (void)dev_free_any(dC);
+    if (dMean) (void)dev_free_any(dMean);
+    if (dPairs) (void)dev_free_any(dPairs);
+    if (rc != DIMN_OK && dOut) { (void)dev_free_any(dOut); dOut = nullptr; }
     *dOutp = dOut;
     return rc;
 }
@@ -2090,12 +2133,12 @@ static int corr_on_device(const double* X, int64_t n, int64_t g, hipStream_t st,
     const int64_t rows_per_block = (n + nparts - 1) / nparts;
 #define CORR_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
     Trace tr;
-    CORR_TRY(hipMalloc((void**)&dZ, (size_t)np_ * gp * 8));
-    CORR_TRY(hipMalloc((void**)&dC, (size_t)gp * gp * 8));
-    CORR_TRY(hipMalloc((void**)&dOut, (size_t)g * g * 8));
-    CORR_TRY(hipMalloc((void**)&dMean, (size_t)gp * 8));
-    CORR_TRY(hipMalloc((void**)&dPart, (size_t)nparts * gp * 8));
-    CORR_TRY(hipMalloc((void**)&dPairs, pairs.size() * sizeof(int2)));
+    CORR_TRY(dev_malloc_bytes((void**)&dZ, (size_t)np_ * gp * 8));
+    CORR_TRY(dev_malloc_bytes((void**)&dC, (size_t)gp * gp * 8));
+    CORR_TRY(dev_malloc_bytes((void**)&dOut, (size_t)g * g * 8));
+    CORR_TRY(dev_malloc_bytes((void**)&dMean, (size_t)gp * 8));
+    CORR_TRY(dev_malloc_bytes((void**)&dPart, (size_t)nparts * gp * 8));
+    CORR_TRY(dev_malloc_bytes((void**)&dPairs, pairs.size() * sizeof(int2)));
     CORR_TRY(hipMemsetAsync(dZ, 0, (size_t)np_ * gp * 8, st));
     tr.lap("corr: device allocations");
     if (src) {      // the candidate columns are already on the device (dimn_counts): one conversion kernel instead of an 8 GB upload
@@ -2138,12 +2181,12 @@ static int corr_on_device(const double* X, int64_t n, int64_t g, hipStream_t st,
     tr.lap("corr: kernels");
 #undef CORR_TRY
 done:
-    if (dZ) (void)hipFree(dZ);
-    if (dC) (void)hipFree(dC);
-    if (dMean) (void)hipFree(dMean);
-    if (dPart) (void)hipFree(dPart);
-    if (dPairs) (void)hipFree(dPairs);
-    if (rc != DIMN_OK && dOut) { (void)hipFree(dOut); dOut = nullptr; }
+    if (dZ) (void)dev_free_any(dZ);
+    if (dC) (void)dev_free_any(dC);
+    if (dMean) (void)dev_free_any(dMean);
+    if (dPart) (void)dev_free_any(dPart);
+    if (dPairs) (void)dev_free_any(dPairs);
+    if (rc != DIMN_OK && dOut) { (void)dev_free_any(dOut); dOut = nullptr; }
     tr.lap("corr: free temporaries");
     *dOutp = dOut;
     return rc;
@@ -2165,7 +2208,7 @@ extern "C" int dimn_abs_corrcoef(int32_t device_id, const double* X, int64_t n, 
     int rc = corr_on_device(X, n, g, st, &dOut);
     if (rc == DIMN_OK && hipMemcpy(out, dOut, (size_t)g * g * 8, hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(DIMN_ERR_HIP, "dimn_abs_corrcoef: device-to-host copy failed");
-    if (dOut) (void)hipFree(dOut);
+    if (dOut) (void)dev_free_any(dOut);
     (void)hipStreamDestroy(st);
     return rc;
 }
@@ -2183,9 +2226,9 @@ static int topk_core(const char* who, const double* dCorr, int64_t g, const int3
     int32_t *dT = nullptr, *dR = nullptr, *dI = nullptr;
     int rc = DIMN_OK;
 #define SEL_TRY(expr) do { hipError_t e_ = (expr); if (rc == DIMN_OK && e_ != hipSuccess) rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
-    SEL_TRY(hipMalloc((void**)&dT, (size_t)K * O * 4));
-    SEL_TRY(hipMalloc((void**)&dR, (size_t)g * 4));
-    SEL_TRY(hipMalloc((void**)&dI, (size_t)K * O * ntop * 4));
+    SEL_TRY(dev_malloc_bytes((void**)&dT, (size_t)K * O * 4));
+    SEL_TRY(dev_malloc_bytes((void**)&dR, (size_t)g * 4));
+    SEL_TRY(dev_malloc_bytes((void**)&dI, (size_t)K * O * ntop * 4));
     if (rc == DIMN_OK) {
         SEL_TRY(hipMemcpyAsync(dT, targ_pos, (size_t)K * O * 4, hipMemcpyHostToDevice, st));
         SEL_TRY(hipMemcpyAsync(dR, col_rank, (size_t)g * 4, hipMemcpyHostToDevice, st));
@@ -2205,9 +2248,9 @@ static int topk_core(const char* who, const double* dCorr, int64_t g, const int3
         SEL_TRY(hipStreamSynchronize(st));
     }
 #undef SEL_TRY
-    if (dT) (void)hipFree(dT);
-    if (dR) (void)hipFree(dR);
-    if (dI) (void)hipFree(dI);
+    if (dT) (void)dev_free_any(dT);
+    if (dR) (void)dev_free_any(dR);
+    if (dI) (void)dev_free_any(dI);
     return rc;
 }
 static int select_predictors_core(const char* who, int32_t device_id, const double* X, const CorrDevSrc* src, int64_t n, int64_t g, const int32_t* targ_pos,
@@ -2216,7 +2259,7 @@ static int select_predictors_core(const char* who, int32_t device_id, const doub
     double* dOut = nullptr;
     int rc = corr_on_device(X, n, g, st, &dOut, src);
     if (rc == DIMN_OK) rc = topk_core(who, dOut, g, targ_pos, K, O, col_rank, ntop, out_idx, st);
-    if (dOut) (void)hipFree(dOut);
+    if (dOut) (void)dev_free_any(dOut);
     return rc;
 }
 
@@ -2247,9 +2290,7 @@ static inline uint64_t counts_mix(uint64_t x) {      // splitmix64 finaliser
 static void counts_scan(const double* raw, int64_t g, int64_t r0, int64_t r1, float* dst, double* vmax, uint64_t* sum, int* ok) {
     const unsigned hw = std::thread::hardware_concurrency();
     const int64_t rows = r1 - r0;
-    const char* want_s = getenv("DIMN_COUNTS_THREADS");                                     // (diagnostic override)
-    const int want = want_s ? atoi(want_s) : 0;
-    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(want > 0 ? (unsigned)want : std::min<unsigned>(hw ? hw / 2 : 8, 32), rows * g / (1 << 20)));
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw ? hw / 2 : 8, 32), rows * g / (1 << 20)));
     std::vector<double> mx((size_t)nt, -INFINITY);
     std::vector<uint64_t> cs((size_t)nt, 0);
     std::vector<int> good((size_t)nt, 1);
@@ -2266,7 +2307,7 @@ static void counts_scan(const double* raw, int64_t g, int64_t r0, int64_t r1, fl
                 memcpy(&bits, &x, 8);
                 h += counts_mix(bits + 0x9e3779b97f4a7c15ull * (base + (uint64_t)j + 1));
                 m = x > m ? x : m;
-                fine &= (x >= 0.0) & (x <= 4194304.0) & (x == (double)(int64_t)x);
+                fine &= x >= 0.0 && x <= 4194304.0 && x == trunc(x) && !signbit(x);      // (range first: no float-to-int conversion of NaN / Inf / huge values; -0.0 is not a count)
                 if (out) out[j] = (float)x;
             }
         }
@@ -2288,8 +2329,8 @@ extern "C" int dimn_counts_checksum(const double* raw, int64_t n, int64_t g, uin
 extern "C" int dimn_counts_destroy(dimn_counts c) {
     if (!c) return DIMN_OK;
     (void)hipSetDevice(c->device);
-    if (c->d) (void)hipFree(c->d);
-    if (c->d_corr) (void)hipFree(c->d_corr);
+    if (c->d) (void)dev_free_any(c->d);
+    if (c->d_corr) (void)dev_free_any(c->d_corr);
     delete c;
     return DIMN_OK;
 }
@@ -2305,7 +2346,7 @@ extern "C" int dimn_counts_create(int32_t device_id, const double* raw, int64_t 
     PinLease pins;
     const int64_t blk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(128u << 20) / (g * 4)));
 #define CNT_TRY(expr) do { hipError_t e_ = (expr); if (rc == DIMN_OK && e_ != hipSuccess) rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
-    CNT_TRY(hipMalloc((void**)&c->d, (size_t)n * g * 4));
+    CNT_TRY(dev_malloc_bytes((void**)&c->d, (size_t)n * g * 4));
     CNT_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     {
         const char* why = "";
@@ -2352,11 +2393,11 @@ static int corr_counts_i8(dimn_counts c, const int32_t* dCols, int64_t pool_n, h
     const size_t lds = (size_t)CI8_NBUF * 16 * P * 1024;
 #define CI8_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
     Trace tr;
-    CI8_TRY(hipMalloc((void**)&dPlanes, (size_t)P * plane_bytes));
-    CI8_TRY(hipMalloc((void**)&dC, (size_t)pool_n * pool_n * 8));
-    CI8_TRY(hipMalloc((void**)&dSums, (size_t)gp * 8));
-    CI8_TRY(hipMalloc((void**)&dRoot, (size_t)gp * 8));
-    CI8_TRY(hipMalloc((void**)&dPairs, pairs.size() * sizeof(int2)));
+    CI8_TRY(dev_malloc_bytes((void**)&dPlanes, (size_t)P * plane_bytes));
+    CI8_TRY(dev_malloc_bytes((void**)&dC, (size_t)pool_n * pool_n * 8));
+    CI8_TRY(dev_malloc_bytes((void**)&dSums, (size_t)gp * 8));
+    CI8_TRY(dev_malloc_bytes((void**)&dRoot, (size_t)gp * 8));
+    CI8_TRY(dev_malloc_bytes((void**)&dPairs, pairs.size() * sizeof(int2)));
     CI8_TRY(hipMemsetAsync(dSums, 0, (size_t)gp * 8, st));
     CI8_TRY(hipMemcpyAsync(dPairs, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
     tr.lap("corr i8: device allocations");
@@ -2378,11 +2419,11 @@ static int corr_counts_i8(dimn_counts c, const int32_t* dCols, int64_t pool_n, h
     tr.lap("corr i8: kernels");
 #undef CI8_TRY
 done:
-    if (dPlanes) (void)hipFree(dPlanes);
-    if (dSums) (void)hipFree(dSums);
-    if (dRoot) (void)hipFree(dRoot);
-    if (dPairs) (void)hipFree(dPairs);
-    if (rc != DIMN_OK) { if (dC) (void)hipFree(dC); return rc; }
+    if (dPlanes) (void)dev_free_any(dPlanes);
+    if (dSums) (void)dev_free_any(dSums);
+    if (dRoot) (void)dev_free_any(dRoot);
+    if (dPairs) (void)dev_free_any(dPairs);
+    if (rc != DIMN_OK) { if (dC) (void)dev_free_any(dC); return rc; }
     *dOutp = (double*)dC;
     return DIMN_OK;
 }
@@ -2397,9 +2438,9 @@ extern "C" int dimn_counts_gene_stats(dimn_counts c, double* mean, double* var, 
     int rc = DIMN_OK;
 #define GS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
     GS_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    GS_TRY(hipMalloc((void**)&dSum, (size_t)g * 8 * 5));
+    GS_TRY(dev_malloc_bytes((void**)&dSum, (size_t)g * 8 * 5));
     dMin = dSum + g; dMax = dMin + g; dAvg = dMax + g; dVar = dAvg + g;
-    GS_TRY(hipMalloc((void**)&dPart, (size_t)chunks * g * 8));
+    GS_TRY(dev_malloc_bytes((void**)&dPart, (size_t)chunks * g * 8));
     hipLaunchKernelGGL(k_cnt_seqsum, dim3((unsigned)((g + 63) / 64)), dim3(64), 0, st, c->d, n, g, dSum, dMin, dMax);
     hipLaunchKernelGGL(k_cnt_div, dim3((unsigned)((g + 255) / 256)), dim3(256), 0, st, dSum, g, (double)n);
     if (var) {
@@ -2416,8 +2457,8 @@ extern "C" int dimn_counts_gene_stats(dimn_counts c, double* mean, double* var, 
     GS_TRY(hipStreamSynchronize(st));
 #undef GS_TRY
 done:
-    if (dSum) (void)hipFree(dSum);
-    if (dPart) (void)hipFree(dPart);
+    if (dSum) (void)dev_free_any(dSum);
+    if (dPart) (void)dev_free_any(dPart);
     if (st) (void)hipStreamDestroy(st);
     return rc;
 }
@@ -2428,12 +2469,12 @@ extern "C" int dimn_counts_corr(dimn_counts c, const int32_t* pool_cols, int64_t
     if (pool_n > 65535) return fail(DIMN_ERR_UNSUP, "dimn_counts_corr: more than 65535 candidate genes");
     for (int64_t j = 0; j < pool_n; ++j) if (pool_cols[j] < 0 || pool_cols[j] >= c->g) return fail(DIMN_ERR_ARG, "dimn_counts_corr: pool column out of range");
     CHK(corr_device_ok("dimn_counts_corr", c->device));
-    if (c->d_corr) { (void)hipFree(c->d_corr); c->d_corr = nullptr; c->corr_g = 0; }
+    if (c->d_corr) { (void)dev_free_any(c->d_corr); c->d_corr = nullptr; c->corr_g = 0; }
     hipStream_t st = nullptr;
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     int32_t* dCols = nullptr;
     int rc = DIMN_OK;
-    if (hipMalloc((void**)&dCols, (size_t)pool_n * 4) != hipSuccess || hipMemcpyAsync(dCols, pool_cols, (size_t)pool_n * 4, hipMemcpyHostToDevice, st) != hipSuccess)
+    if (dev_malloc_bytes((void**)&dCols, (size_t)pool_n * 4) != hipSuccess || hipMemcpyAsync(dCols, pool_cols, (size_t)pool_n * 4, hipMemcpyHostToDevice, st) != hipSuccess)
         rc = fail(DIMN_ERR_HIP, "dimn_counts_corr: pool upload failed");
     if (rc == DIMN_OK) {
         // integer counts below 65536: exactly, on the int8 matrix cores (dimn_counts_dev.h); anything else in float64 (dimn_corr.h)
@@ -2445,7 +2486,7 @@ extern "C" int dimn_counts_corr(dimn_counts c, const int32_t* pool_cols, int64_t
         }
         if (rc == DIMN_OK) c->corr_g = pool_n;
     }
-    if (dCols) (void)hipFree(dCols);
+    if (dCols) (void)dev_free_any(dCols);
     (void)hipStreamDestroy(st);
     return rc;
 }
@@ -2457,8 +2498,17 @@ extern "C" int dimn_counts_topk(dimn_counts c, const int32_t* targ_pos, int32_t 
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     const int rc = topk_core("dimn_counts_topk", c->d_corr, c->corr_g, targ_pos, K, O, col_rank, ntop, out_idx, st);
     (void)hipStreamDestroy(st);
-    (void)hipFree(c->d_corr); c->d_corr = nullptr; c->corr_g = 0;
+    (void)dev_free_any(c->d_corr); c->d_corr = nullptr; c->corr_g = 0;
     return rc;
+}
+// Give the |corr| matrix of dimn_counts_corr back without selecting from it (the caller's selection took another path).
+extern "C" int dimn_counts_corr_drop(dimn_counts c) {
+    if (!c) return fail(DIMN_ERR_ARG, "dimn_counts_corr_drop: null argument");
+    if (c->d_corr) {
+        (void)hipSetDevice(c->device);
+        dev_free_any(c->d_corr); c->d_corr = nullptr; c->corr_g = 0;
+    }
+    return DIMN_OK;
 }
 // setPredictors over the resident counts: the candidate pool = columns pool_cols[pool_n] of the count matrix
 extern "C" int dimn_counts_select_predictors(dimn_counts c, const int32_t* pool_cols, int64_t pool_n, const int32_t* targ_pos, int32_t K, int32_t O,
@@ -2485,24 +2535,27 @@ __global__ __launch_bounds__(256) void k_counts_lut(const float* __restrict__ co
             const f32x4 v = *(const f32x4*)(counts + e);
             f32x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const int64_t i = (int64_t)v[r]; o[r] = lut[i < lut_n ? i : lut_n - 1]; }
+            for (int r = 0; r < 4; ++r) { const int64_t i = (int64_t)v[r]; o[r] = lut[i < 0 ? 0 : (i < lut_n ? i : lut_n - 1)]; }
             *(f32x4*)(norm + e) = o;
         } else {
-            for (int64_t q = e; q < total; ++q) { const int64_t i = (int64_t)counts[q]; norm[q] = lut[i < lut_n ? i : lut_n - 1]; }
+            for (int64_t q = e; q < total; ++q) { const int64_t i = (int64_t)counts[q]; norm[q] = lut[i < 0 ? 0 : (i < lut_n ? i : lut_n - 1)]; }
         }
     }
 }
 extern "C" int dimn_set_matrix_counts(dimn_handle h, dimn_counts c, const float* lut, int64_t lut_n) {
+    if (h) h->counts = nullptr;                    // (a failed rebind must not leave the handle pointing at the previous counts object)
     if (!h || !c || !lut || lut_n < 1) return fail(DIMN_ERR_ARG, "dimn_set_matrix_counts: bad argument");
     if (c->device != h->cfg.device_id) return fail(DIMN_ERR_ARG, "dimn_set_matrix_counts: the counts live on another device");
     if ((double)lut_n <= c->vmax) return fail(DIMN_ERR_ARG, "dimn_set_matrix_counts: the table has %lld entries, the largest count is %.0f", (long long)lut_n, c->vmax);
     if (c->n > 0x7fffffffLL || c->g > 0x7fffffffLL) return fail(DIMN_ERR_UNSUP, "dimn_set_matrix_counts: dimension exceeds int32");
     CHK(use_device(h));
     HIPCHK(hipStreamSynchronize(h->stream));
+    Trace tr;
     if (!h->d_norm || h->n != c->n || h->g != c->g) {
         DEV_FREE(h->d_norm);
         CHK(dev_alloc(&h->d_norm, (size_t)c->n * c->g));
     }
+    tr.lap("set_matrix_counts: matrix allocation");
     if (c->n != h->n) { h->n_tr = 0; h->n_val = 0; h->train_rows.clear(); h->val_rows.clear(); }
     h->n = c->n; h->g = c->g; h->gathered = false; h->streamed = false;
     float* dLut = nullptr;
@@ -2513,7 +2566,8 @@ extern "C" int dimn_set_matrix_counts(dimn_handle h, dimn_counts c, const float*
         hipLaunchKernelGGL(k_counts_lut, dim3(4096), dim3(256), 0, h->stream, (const float*)c->d, (const float*)dLut, lut_n, c->n * c->g, h->d_norm);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(DIMN_ERR_HIP, "dimn_set_matrix_counts: table kernel failed");
     }
-    (void)hipFree(dLut);
+    (void)dev_free_any(dLut);
+    tr.lap("set_matrix_counts: log1p table kernel");
     if (rc == DIMN_OK) h->counts = c;
     return rc;
 }

@@ -362,6 +362,16 @@ class HipEngine(Engine):
     def comm_destroy(self):
         self._check(self._f["comm_destroy"](self._h))
 
+    @staticmethod
+    def gather_loopback(engines, n_rows, root=0, want_host=True):
+        """dimn_comm_gather_loopback: the engines (all on one GPU, each after predict_device() over n_rows) play the ranks of a
+        sharded job; returns root's gathered [n_rows, sum(K_r) * O] matrix (it also stays in root's HBM for impute_finish)."""
+        handles = (C.c_void_p * len(engines))(*[e._h for e in engines])
+        counts = i32([e.K for e in engines])
+        out = np.empty((n_rows, int(counts.sum()) * engines[root].O), np.float32) if want_host else None
+        engines[root]._check(engines[root]._f["comm_gather_loopback"](handles, len(engines), int(n_rows), p_i32(counts), int(root), p_f32(out)))
+        return out
+
 
 class HipGeneralEngine(GeneralEngine, HipEngine):
     """GeneralEngine on libdimn.so (dimn_create_general: batched fp32-MFMA GEMMs per layer, dimn_general.h)."""

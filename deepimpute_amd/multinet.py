@@ -210,9 +210,13 @@ def _shard_rank(path):
 
 # ------------------------------------------------------------------------------- the estimator
 class MultiNet:
+    # planning on the device from ONE upload of the raw counts (fit(): gene statistics, correlation, predictor selection; predict():
+    # restore / max against the resident counts); needs the HIP engine's dimn_set_matrix_counts
+    _device_planning = True
+
     def __init__(self, learning_rate=1e-4, batch_size=64, max_epochs=500, patience=5, ncores=-1,
                  loss="wMSE", output_prefix=_SCRATCH, sub_outputdim=512, verbose=1, seed=1234,
-                 architecture=None, device_id=0, engine_factory=None, comm=None, precision="fp32", stream_matrix=None):
+                 architecture=None, device_id=0, comm=None, precision="fp32", stream_matrix=None):
         self.NN_parameters = dict(learning_rate=learning_rate, batch_size=batch_size, loss=loss,
                                   architecture=architecture, max_epochs=max_epochs, patience=patience)
         self.sub_outputdim = sub_outputdim
@@ -228,7 +232,6 @@ class MultiNet:
         # (None: automatically, for matrices above 32 GB)
         self.precision = precision
         self.stream_matrix = stream_matrix
-        self._engine_factory = engine_factory      # extension (tests): None -> HipEngine, no fallback
         self._engine = None
         # extension: a deepimpute_amd.sharded Comm (one process per GPU); the string "rccl" builds
         # an RcclComm from RANK/WORLD_SIZE/LOCAL_RANK at fit time.  None = single process.
@@ -252,6 +255,12 @@ class MultiNet:
             {"type": "dense", "neurons": self.sub_outputdim // 2, "activation": "relu"},
             {"type": "dropout", "rate": 0.2}]
 
+    def _engine_classes(self):
+        """(engine of the tuned kernels, engine of the general path): the two constructors build() chooses between.  The product
+        binds libdimn.so (hand-written HIP) and has no other implementation behind this seam."""
+        from .engine import HipEngine, HipGeneralEngine
+        return HipEngine, HipGeneralEngine
+
     # -- the seam: where the reference builds/compiles the Keras model (multinet.py:126-167) --
     def build(self, inputdims, subnet_offset=0):
         if self.NN_parameters['architecture'] is None:
@@ -264,26 +273,20 @@ class MultiNet:
                       device_id=self.device_id, subnet_offset=subnet_offset)
         if str(self.precision).lower() not in ("fp32", "f32", "float32"):
             common["precision"] = self.precision
-        make = self._engine_factory
+        tuned_cls, general_cls = self._engine_classes()
         # the tuned kernels take the reference's default shape family: one hidden layer of <= 384 units (+ dropout),
         # batch <= 64, wMSE -- loadDefaultArchitecture(), the CLI defaults; everything else build() accepts runs on the
         # general path (dimn_create_general)
         tuned = len(layers) == 1 and layers[0][0] <= 384 and batch <= 64 and loss in ("wmse", "wmse_binary")
         if tuned:
-            if make is None:
-                from .engine import HipEngine as make
             hidden, act, rate = layers[0]
             extra = {} if act == "relu" else {"activation": act}
             if loss == "wmse_binary":
                 extra["loss_binary"] = True
-            return make(list(inputdims), hidden, self.sub_outputdim, dropout_rate=rate, **common, **extra)
-        if make is None:
-            from .engine import HipGeneralEngine as make
-        elif hasattr(make, "general"):
-            make = make.general                  # tests: an injected factory may offer a general constructor
-        else:
-            raise NotImplementedError("the injected engine factory has no general constructor for %r" % (self.NN_parameters['architecture'],))
-        return make(list(inputdims), layers, self.sub_outputdim, loss=loss, **common)
+            return tuned_cls(list(inputdims), hidden, self.sub_outputdim, dropout_rate=rate, **common, **extra)
+        if general_cls is None:
+            raise NotImplementedError("no general engine for %r" % (self.NN_parameters['architecture'],))
+        return general_cls(list(inputdims), layers, self.sub_outputdim, loss=loss, **common)
 
     # -- persistence (reference: model.json + model.h5, multinet.py:105-124) --
     def _model_format(self):
@@ -301,9 +304,22 @@ class MultiNet:
         with more than one rank it is replaced by a directory named after the job (launcher pid + start time + MASTER_PORT:
         the same string on every rank, sharded._job_tag) -- an explicit output_prefix is used as given."""
         if comm is not None and comm.world > 1 and self.outputdir == _SCRATCH:
-            from .sharded import _job_tag
-            self.outputdir = os.path.join(tempfile.gettempdir(), "dimn_model_%d_%s" % (os.getuid(), _job_tag()))
+            self.outputdir = self._job_directory(create=True)
         return self.outputdir
+
+    @staticmethod
+    def _job_directory(create):
+        """The per-job default directory of a sharded fit: a predictable name under the shared temporary directory, so it is
+        created private (0700) and refused unless it is a real directory (no symlink) owned by this user."""
+        import stat
+        from .sharded import _job_tag
+        path = os.path.join(tempfile.gettempdir(), "dimn_model_%d_%s" % (os.getuid(), _job_tag()))
+        if create:
+            os.makedirs(path, mode=0o700, exist_ok=True)
+        info = os.lstat(path)                        # (FileNotFoundError when a load() finds nothing: the caller's message)
+        if not stat.S_ISDIR(info.st_mode) or stat.S_ISLNK(info.st_mode) or info.st_uid != os.getuid():
+            raise PermissionError("MultiNet: %s is not a directory owned by uid %d; pass output_prefix explicitly" % (path, os.getuid()))
+        return path
 
     def save(self, model):
         """model.json (rank 0; the Keras functional-model JSON of build()'s network, our own metadata under the extra key
@@ -387,8 +403,7 @@ class MultiNet:
         if self._engine is None:
             from . import keras_io
             if isinstance(self._comm_spec, str) and self.outputdir == _SCRATCH and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-                from .sharded import _job_tag                 # the directory a sharded fit of this job wrote to (_sharded_outputdir)
-                self.outputdir = os.path.join(tempfile.gettempdir(), "dimn_model_%d_%s" % (os.getuid(), _job_tag()))
+                self.outputdir = self._job_directory(create=False)      # the directory a sharded fit of this job wrote to (_sharded_outputdir)
             with open(os.path.join(self.outputdir, "model.json")) as fh:
                 doc = json.load(fh)
             dense_names = None
@@ -470,8 +485,8 @@ class MultiNet:
                 dev_early = DeviceCounts.try_create(raw.values, self.device_id)
             if dev_early is not None:
                 with tm.stage("fit.gene_statistics"):
-                    if raw.shape[0] < 2:
-                        first = None                         # (pandas' var of one row: the plain sequence below says what that is)
+                    if raw.shape[0] < 2 or not _hostpar.pandas_order_holds():
+                        first = None                         # (pandas' var of one row / another pandas: the plain sequence below computes what that gives)
                     elif os.environ.get("DIMN_DEVICE_STATS", "1") != "0":
                         first = dev_early.gene_stats()
                     else:                                    # the host routines (same numbers; dimn_hoststats.h)
@@ -479,11 +494,11 @@ class MultiNet:
                         if first is not None:
                             first["var"] = _hostpar.col_stats_var(raw.values, first["avg"])
         if first is not None:
-            if n_pred is None:
+            with tm.stage("fit.inspect_data"):           # (before any helper thread has work in flight: inspect_data() may exit(1))
+                inspect_data(raw, _max=first["vmax"])
+            if n_pred is None and ntop <= 16:            # (the device selection takes ntop <= 16: nothing is computed ahead that it would not use)
                 spec_pool = np.flatnonzero((first["cmax"] > first["cmin"]) & (first["mean"] > 0)).astype(np.int32)
             upload = self._start_correlation(dev_early, spec_pool, raw.shape[0])
-            with tm.stage("fit.inspect_data"):
-                inspect_data(raw, _max=first["vmax"])
             if self.seed is not None:
                 np.random.seed(self.seed)
             var = pd.Series(first["var"], index=raw.columns)
@@ -521,7 +536,10 @@ class MultiNet:
         with tm.stage("fit.correlation_wait"):
             dev_counts = upload()
         with tm.stage("fit.correlation+predictors"):
-            if not (_gpu_visible() and self._set_predictors_device(raw, n_pred, ntop, (var, mean), counts=dev_counts, corr_pool=spec_pool)):
+            on_device = _gpu_visible() and self._set_predictors_device(raw, n_pred, ntop, (var, mean), counts=dev_counts, corr_pool=spec_pool)
+            if dev_counts is not None:
+                dev_counts.corr_drop()                   # whatever the helper thread left that the selection did not consume (pool^2 * 8 bytes)
+            if not on_device:
                 correlations = get_distance_matrix(raw, n_pred=n_pred, device_id=self.device_id, _var_mean=(var, mean))
                 self.setPredictors(correlations, ntop=ntop)
 
@@ -592,7 +610,7 @@ class MultiNet:
         """The resident-counts path is for: one GPU (no sharded / streamed job), the product engine, a C-ordered float64 frame
         that fits the device (DIMN_RESIDENT_COUNTS=0 switches it off).  Whether the VALUES are counts is decided by the upload."""
         values = getattr(raw, "values", None)
-        return not (os.environ.get("DIMN_RESIDENT_COUNTS", "1") == "0" or self._comm_spec is not None or self._engine_factory is not None or self.stream_matrix
+        return not (os.environ.get("DIMN_RESIDENT_COUNTS", "1") == "0" or self._comm_spec is not None or not self._device_planning or self.stream_matrix
                     or not isinstance(values, np.ndarray) or values.dtype != np.float64 or not values.flags.c_contiguous
                     or values.size * 4 > (32 << 30) or not _gpu_visible())
 
@@ -614,6 +632,8 @@ class MultiNet:
 
         def wait():
             thread.join()
+            if "error" in box:                               # not fatal: the selection runs the product itself and raises a real failure there
+                warnings.warn("deepimpute_amd: the correlation computed ahead of the gene selection failed (%r); recomputing" % (box["error"],), RuntimeWarning)
             return dev
         return wait
 
@@ -663,8 +683,10 @@ class MultiNet:
         """Extension: release the GPU (and, in a sharded job, the RCCL communicator) now instead of at exit."""
         self._release_engine()
 
-    def _shard_plan(self, K):
-        """(rank, world, counts) of this process for K sub-networks under the caller's comm spec."""
+    def _shard_plan(self, inputdims):
+        """(rank, world, counts) of this process for the sub-networks of `inputdims` under the caller's comm spec (contiguous blocks
+        balanced by predictor count D_k: sharded.shard_subnets)."""
+        K = len(inputdims)
         from .sharded import shard_subnets
         spec = self._comm_spec
         if spec is None:
@@ -675,7 +697,7 @@ class MultiNet:
             rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
         else:
             rank, world = spec.rank, spec.world
-        counts, _ = shard_subnets(K, world)
+        counts, _ = shard_subnets(K, world, weights=inputdims if world > 1 and K > world else None)
         if min(counts) < 1:
             raise ValueError("more ranks (%d) than sub-networks (%d)" % (world, K))
         return rank, world, counts
@@ -683,7 +705,7 @@ class MultiNet:
     def _build_shard(self, inputdims):
         """The engine of this rank's contiguous block of sub-nets + the communicator bound to it."""
         from .sharded import RcclComm, SingleComm
-        rank, world, counts = self._shard_plan(len(inputdims))
+        rank, world, counts = self._shard_plan(list(inputdims))
         self._first_subnet = sum(counts[:rank])
         mine = range(self._first_subnet, self._first_subnet + counts[rank])
         engine = self.build([inputdims[k] for k in mine], subnet_offset=self._first_subnet)

@@ -24,10 +24,39 @@ import time
 import numpy as np
 
 
-def shard_subnets(K, world):
-    """Contiguous balanced split: (counts[r], offsets[r]).  Ranks beyond K get zero sub-nets
-    (callers must have K >= world for a useful job)."""
-    counts = [K // world + (1 if r < K % world else 0) for r in range(world)]
+def shard_subnets(K, world, weights=None):
+    """Contiguous split of K sub-nets over `world` ranks: (counts[r], offsets[r]).  Contiguous because Philox keys and the
+    np.hstack order of the predictions use the global sub-net index.  Without weights: balanced by count.  With weights[k]
+    (the predictor count D_k: a rank's step time and its X arena grow with its sum of D_k): the contiguous
+    partition with the smallest maximum rank load (linear-partition dynamic programme); when the by-count split is within
+    2 % of that optimum it is kept, so the common case of near-equal D_k shards exactly as before.  Ranks beyond K get zero
+    sub-nets (callers must have K >= world for a useful job)."""
+    by_count = [K // world + (1 if r < K % world else 0) for r in range(world)]
+    counts = by_count
+    if weights is not None and world > 1 and K > world:
+        w = np.asarray(weights, np.float64)
+        if w.shape != (K,) or not np.all(w > 0):
+            raise ValueError("shard_subnets: weights must be K positive numbers")
+        pre = np.concatenate([[0.0], np.cumsum(w)])
+        load = lambda i, j: pre[j] - pre[i]                      # sub-nets [i, j)
+        best = np.full((world + 1, K + 1), np.inf)
+        cut = np.zeros((world + 1, K + 1), np.int64)
+        best[0, 0] = 0.0
+        for r in range(1, world + 1):
+            for j in range(r, K - (world - r) + 1):             # every rank keeps at least one sub-net
+                for i in range(r - 1, j):
+                    cost = max(best[r - 1, i], load(i, j))
+                    if cost < best[r, j]:                        # strict: ties keep the earliest cut (reproducible on every rank)
+                        best[r, j], cut[r, j] = cost, i
+        ends, j = [], K
+        for r in range(world, 0, -1):
+            ends.append(j)
+            j = int(cut[r, j])
+        ends = ends[::-1]
+        optimal = [ends[0]] + [ends[r] - ends[r - 1] for r in range(1, world)]
+        offs = np.concatenate([[0], np.cumsum(by_count)])
+        worst_by_count = max(load(int(offs[r]), int(offs[r + 1])) for r in range(world))
+        counts = by_count if worst_by_count <= 1.02 * best[world, K] else optimal
     offsets = [sum(counts[:r]) for r in range(world)]
     return counts, offsets
 

@@ -105,6 +105,13 @@ int dimn_create_general(const dimn_config* cfg, const int32_t* D, const dimn_lay
 int dimn_set_layer_weights(dimn_handle h, int32_t k, int32_t layer, const float* W, const float* b);
 int dimn_get_layer_weights(dimn_handle h, int32_t k, int32_t layer, int32_t which, float* W, float* b);
 int dimn_destroy(dimn_handle h);
+/* Device memory policy (no reference analogue: Keras/TF own their allocator).  Blocks of >= 32 MB -- the matrix, the gathered
+ * X_k / Y_k arenas (multinet.py:231-235), the resident counts, predictions, correlation temporaries -- are kept by the PROCESS
+ * when a handle / counts object releases them and are handed to the next request they fit: memory that was hipFree'd earlier
+ * in the same process comes back from hipMalloc slowly (the driver wipes it first), which made the hand-over of a second fit()
+ * cost 0.2-0.6 s instead of 0.02 s.  dimn_release_cached_memory() gives every idle block back to the driver;
+ * DIMN_ARENA_CACHE_GB caps what is kept (default 96, 0: nothing).  ABI 7. */
+int dimn_release_cached_memory(void);
 
 /*
  * The shared log1p matrix (multinet.py:217 `norm_data`, :271 `norm_raw`), row-major
@@ -259,6 +266,11 @@ int dimn_comm_allreduce_sum(dimn_handle h, double* v, int32_t n);
 int dimn_comm_gather_predictions(dimn_handle h, int64_t n_rows, const int32_t* counts,
                                  int32_t root, float* out);
 int dimn_comm_destroy(dimn_handle h);
+/* The same gather on ONE GPU, with device-to-device copies where ncclSend / ncclRecv would run: handles[r] plays rank r (all on the
+ * root's device, each holding a dimn_predict_device result over n_rows).  Sizing, offsets, the strided placement into
+ * [n_rows][K_global*O] and the hand-over to dimn_impute_finish(from_gathered) are dimn_comm_gather_predictions' own code; RCCL
+ * itself is not exercised.  Test / bring-up aid for single-GPU machines.  ABI 7. */
+int dimn_comm_gather_loopback(const dimn_handle* handles, int32_t n_ranks, int64_t n_rows, const int32_t* counts, int32_t root, float* out);
 
 /* ---- next row: get_distance_matrix (multinet.py:20-34) ------------------------
  * out[g][g] = np.abs(np.corrcoef(X.T)) with NaN -> 0, X host row-major fp64 [n][g] (the candidate
@@ -311,6 +323,8 @@ int dimn_counts_select_predictors(dimn_counts c, const int32_t* pool_cols, int64
  * genes): dimn_counts_corr leaves |corr| of the pool on the device, dimn_counts_topk selects from it and frees it */
 int dimn_counts_corr(dimn_counts c, const int32_t* pool_cols, int64_t pool_n);
 int dimn_counts_topk(dimn_counts c, const int32_t* targ_pos, int32_t K, int32_t O, const int32_t* col_rank, int32_t ntop, int32_t* out_idx);
+/* frees what dimn_counts_corr left when the caller's selection takes another path after all (pool_n^2 * 8 bytes).  ABI 7. */
+int dimn_counts_corr_drop(dimn_counts c);
 int dimn_set_matrix_counts(dimn_handle h, dimn_counts c, const float* lut, int64_t lut_n);
 /* ABI 6.  The correlation of resident counts below 65536 runs EXACTLY on the int8 matrix cores (integer numerator and radicands,
  * one rounding each into float64; csrc/dimn_counts_dev.h), larger counts on the float64 kernel; DIMN_CORR_I8=0 forces the latter.

@@ -458,6 +458,16 @@ int dimo_train_step(dimo_handle h, const int32_t* rows, int32_t b_act, const uin
     return DIMN_OK;
 }
 
+/* Test instrument: dL/dz and z of sub-net k, [b_act][O], as the LAST dimo_train_step left them (multinet.py:36-41 under
+ * model.fit: dL/dz = dwMSE/dyhat * sigmoid(z)); tests/test_oracle_kat.py divides the two and compares with central differences of
+ * the REFERENCE's own wMSE (tests/golden/make_wmse.py). */
+int dimo_debug_last_dz(dimo_handle h, int32_t k, int32_t b_act, double* dz_out, double* z_out) {
+    if (!h || k < 0 || k >= h->K || b_act < 1 || b_act > h->B || !dz_out || !z_out) return fail(DIMN_ERR_ARG, "debug_last_dz: bad argument");
+    const subnet* s = &h->s[k];
+    for (size_t i = 0; i < (size_t)b_act * h->O; ++i) { dz_out[i] = (double)s->dz[i]; z_out[i] = (double)s->z[i]; }
+    return DIMN_OK;
+}
+
 int dimo_epoch_permutation(uint64_t seed, int32_t epoch, int64_t n, int32_t* perm) {
     dimn_fill_permutation(seed, (uint32_t)epoch, n, perm);
     return DIMN_OK;

@@ -45,6 +45,16 @@ class OracleEngine(Engine):
             lib.dimo_set_training_bf16(self._h, int(train_bf16))
 
 
+    def last_dz(self, k, b_act):
+        """Test instrument (dimo_debug_last_dz): (dL/dz, z) of sub-net k over the last train_step's batch, float64 [b_act, O]."""
+        import numpy as np
+        lib = C.CDLL(self._lib_name)
+        lib.dimo_debug_last_dz.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        dz, z = np.empty((b_act, self.O), np.float64), np.empty((b_act, self.O), np.float64)
+        if lib.dimo_debug_last_dz(self._h, int(k), int(b_act), dz.ctypes.data_as(C.POINTER(C.c_double)), z.ctypes.data_as(C.POINTER(C.c_double))) != 0:
+            raise ValueError("last_dz: bad argument")
+        return dz, z
+
     def invert_gate(self, k, epoch, step, b, unit):
         """Test instrument (oracle/dimo.c dimo_invert_gate): take the relu gate of (sub-net k, epoch, step, batch position b,
         hidden unit) on the other side of zero -- for pre-activations the fp64 replay shows to be at fp32 noise level."""
@@ -52,6 +62,31 @@ class OracleEngine(Engine):
         lib.dimo_invert_gate.argtypes = [C.c_void_p] + [C.c_int32] * 5
         if lib.dimo_invert_gate(self._h, int(k), int(epoch), int(step), int(b), int(unit)) != 0:
             raise ValueError("invert_gate: bad argument or more than 8 inversions")
+
+
+def _bind_general_oracle(lib):
+    """Function table of the general CPU oracle (prefix dimog_; `create` there is the general constructor)."""
+    names = ["destroy", "set_matrix", "set_indices", "set_split", "init_weights", "get_step_count", "train_step_general",
+             "train_epoch", "val_loss", "fit", "predict", "epoch_permutation"]
+    fns = {}
+    for name in names:
+        real = "train_step" if name == "train_step_general" else name
+        fn = getattr(lib, "dimog_" + real)
+        fn.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float)] if name == "train_step_general" else _cabi.SIGNATURES[name]
+        fn.restype = C.c_int
+        fns[name] = fn
+    for name, args in (("create", _cabi.GENERAL["create_general"]), ("set_layer_weights", _cabi.GENERAL["set_layer_weights"]),
+                       ("get_layer_weights", _cabi.GENERAL["get_layer_weights"])):
+        fn = getattr(lib, "dimog_" + name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+        fns["create_general" if name == "create" else name] = fn
+    fns["gather"] = lambda h, w: 0
+    le = lib.dimog_last_error
+    le.argtypes = []
+    le.restype = C.c_char_p
+    fns["last_error"] = le
+    return fns
 
 
 def _load_general(fp64=False):
@@ -62,7 +97,7 @@ def _load_general(fp64=False):
         lib = C.CDLL(name)
         lib.dimog_real_bytes.restype = C.c_int
         assert lib.dimog_real_bytes() == (8 if fp64 else 4)
-        _cache[name] = _cabi.bind_general_oracle(lib)
+        _cache[name] = _bind_general_oracle(lib)
     return _cache[name]
 
 

@@ -22,7 +22,32 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def main():
+def main_oracle(out_path):
+    """The SAME file layout from the CPU oracle: a stand-in that lets the consumer (tests/helpers.check_against_keras_file) run end
+    to end without TensorFlow.  It pins nothing -- the oracle is compared with itself -- and says so in `source`."""
+    import sys
+    root = os.path.dirname(os.path.dirname(HERE))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from helpers import kat_engine, load_kat
+    from oracle.dimo import OracleEngine
+    kat = load_kat()
+    K, O = len(kat["Ds"]), int(kat["O"])
+    eng = kat_engine(OracleEngine, kat, dropout_rate=0.0)
+    out = {"source": np.array("oracle/dimo.c stand-in (plumbing check, NOT Keras)")}
+    out["loss"] = np.array([eng.train_step(kat["rows_%d" % t]) for t in range(3)], np.float64)
+    pred = eng.predict()
+    for k in range(K):
+        W1, b1, W2, b2 = eng.get_weights(k)
+        out.update({"W1_%d" % k: W1, "b1_%d" % k: b1, "W2_%d" % k: W2, "b2_%d" % k: b2, "predict_%d" % k: pred[:, k * O:(k + 1) * O]})
+    eng.close()
+    np.savez_compressed(out_path, **out)
+
+
+def main(backend="keras", out_path=None):
+    if backend == "oracle":
+        return main_oracle(out_path)
     import tensorflow as tf
     from tensorflow import keras
     from tensorflow.keras import backend as Kb
@@ -67,7 +92,7 @@ def main():
         W1, b1 = firsts[k].get_weights()
         W2, b2 = lasts[k].get_weights()
         out.update({"W1_%d" % k: W1, "b1_%d" % k: b1, "W2_%d" % k: W2, "b2_%d" % k: b2, "predict_%d" % k: pred[k]})
-    np.savez_compressed(os.path.join(HERE, "kat_keras.npz"), **out)
+    np.savez_compressed(out_path or os.path.join(HERE, "kat_keras.npz"), **out)
     print("wrote kat_keras.npz (tensorflow %s)" % tf.__version__)
 
 

@@ -10,7 +10,10 @@ INPUTS and OBSERVED OUTPUTS in tests/golden/kat_wmse.npz:
   * a small one-sub-net problem (matrix, predictor / target columns, batch rows incl. a partial batch, Glorot seed);
     y_true = the targets of the batch rows, y_pred = the sub-net's predictions at its initial weights as the CPU oracle
     computes them (the tests check that the engine under test reproduces y_pred before they compare losses);
-  * two free-standing (y_true, y_pred) pairs with their losses.
+  * two free-standing (y_true, y_pred) pairs with their losses;
+  * (round 4) dwMSE/dy_pred of the two batches, [b][O] float64, by CENTRAL DIFFERENCES OF THE REFERENCE'S FUNCTION evaluated in
+    float64 (the same stub, which then keeps float64: the loss is quadratic in y_pred, so the difference quotient is exact up
+    to ~1e-12) -- the gradient the optimiser step starts from, pinned to reference-held code rather than to a restatement.
 Nothing of the reference's source is stored; the reference never travels to the GPU box.
 """
 import os
@@ -29,7 +32,8 @@ def install_tf_stub():
     tf.float32 = np.float32
     tf.cast = lambda x, dtype: np.asarray(x).astype(dtype)
     tf.square = lambda x: np.square(np.asarray(x))
-    tf.reduce_mean = lambda x: np.mean(np.asarray(x), dtype=np.float64).astype(np.float32)   # exact mean, rounded once
+    # exact mean, rounded once into the dtype of the operand (float32 tensors -> float32, as TF; float64 stays float64)
+    tf.reduce_mean = lambda x: np.mean(np.asarray(x), dtype=np.float64).astype(np.asarray(x).dtype if np.asarray(x).dtype == np.float32 else np.float64)
     tf.random = types.SimpleNamespace(set_seed=lambda s: None)
     tf.config = types.SimpleNamespace(threading=types.SimpleNamespace(set_inter_op_parallelism_threads=lambda n: None,
                                                                       set_intra_op_parallelism_threads=lambda n: None))
@@ -74,6 +78,15 @@ def main():
         out["rows_%d" % i], out["y_pred_%d" % i] = rows, y_pred
         out["wmse_%d" % i] = np.float32(wMSE(y_true, y_pred))
         out["wmse_binary_%d" % i] = np.float32(wMSE(y_true, y_pred, binary=True))
+        yt64, yp64, step = y_true.astype(np.float64), y_pred.astype(np.float64), 1e-4
+        for tag, binary in (("dwmse_%d", False), ("dwmse_binary_%d", True)):
+            grad = np.empty(yp64.shape, np.float64)
+            for idx in np.ndindex(*yp64.shape):
+                up, dn = yp64.copy(), yp64.copy()
+                up[idx] += step
+                dn[idx] -= step
+                grad[idx] = (float(wMSE(yt64, up, binary=binary)) - float(wMSE(yt64, dn, binary=binary))) / (2 * step)
+            out[tag % i] = grad
     eng.close()
     for i in range(2):                            # free-standing pairs (any restatement of the loss can be checked on these)
         yt = np.log1p(rng.poisson(1.3, size=(37, 29))).astype(np.float32)

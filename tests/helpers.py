@@ -6,6 +6,20 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def multinet_with(engine_factory, **kw):
+    """A MultiNet whose build() seam constructs `engine_factory` engines (and `engine_factory.general` ones for what the tuned
+    kernels do not take) -- test infrastructure: the product class binds libdimn.so and has no such hook.  Planning on the
+    device from the resident counts is a feature of the HIP engine, so it is off here."""
+    from deepimpute_amd.multinet import MultiNet
+
+    class Injected(MultiNet):
+        _device_planning = False
+
+        def _engine_classes(self):
+            return engine_factory, getattr(engine_factory, "general", None)
+    return Injected(**kw)
+
+
 def load_kat():
     return np.load(os.path.join(GOLDEN, "kat_steps.npz"))
 
@@ -271,3 +285,47 @@ def check_reference_wmse(cls, rtol, **kw):
             np.testing.assert_allclose(loss[0], want, rtol=rtol, err_msg="wMSE(binary=%s) batch %d" % (binary, i))
             np.testing.assert_allclose(eng.predict(rows), z["y_pred_%d" % i], rtol=1e-5, atol=1e-6)      # lr = 0: nothing moved
         eng.close()
+
+
+def check_reference_wmse_gradient(cls, rtol, atol, **kw):
+    """dL/dy_hat of an optimiser step (lr = 0, no dropout) against central differences of the REFERENCE's own wMSE in float64
+    (tests/golden/make_wmse.py, `dwmse_*`): the engine's dL/dz divided by sigmoid(z) (softplus' derivative)."""
+    z = np.load(os.path.join(GOLDEN, "kat_wmse.npz"))
+    D = int(z["pred"].size)
+    for binary in (False, True):
+        eng = cls([D], int(z["H"]), int(z["O"]), batch_size=64, dropout_rate=0.0, learning_rate=0.0, seed=int(z["seed"]), loss_binary=binary, **kw)
+        eng.set_matrix(z["norm"])
+        eng.set_indices(0, z["pred"], z["targ"])
+        eng.gather(True)
+        n = z["norm"].shape[0]
+        eng.set_split(np.arange(n - 10, dtype=np.int32), np.arange(n - 10, n, dtype=np.int32))
+        eng.init_weights()
+        for i in range(2):
+            rows = z["rows_%d" % i]
+            eng.train_step(rows, epoch_key=0, step_key=i)
+            dz, pre = eng.last_dz(0, rows.size)
+            got = dz * (1.0 + np.exp(-pre))                      # / sigmoid(z)
+            want = z["dwmse_binary_%d" % i] if binary else z["dwmse_%d" % i]
+            assert want.shape == got.shape and np.abs(want).max() > 0
+            np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg="d wMSE(binary=%s) / d y_hat, batch %d" % (binary, i))
+        eng.close()
+
+
+def check_against_keras_file(path, cls, require_real=True):
+    """The consumer of tests/golden/make_keras.py's output: three train_on_batch steps (dropout rate 0) + predict of the kat_steps
+    problem.  require_real: refuse a file that does not say which TensorFlow wrote it (the plumbing check feeds one made from
+    the oracle itself, which pins nothing)."""
+    ker, kat = np.load(path), load_kat()
+    if require_real:
+        assert "tf_version" in ker.files and "source" not in ker.files, "kat_keras.npz must come from real Keras (make_keras.py)"
+    K, O = len(kat["Ds"]), int(kat["O"])
+    eng = kat_engine(cls, kat, dropout_rate=0.0)       # Dropout(0): identity, no 1/(1-p) scale
+    for t in range(3):
+        loss = eng.train_step(kat["rows_%d" % t])
+        np.testing.assert_allclose(loss, ker["loss"][t], rtol=2e-5)
+    pred = eng.predict()
+    for k in range(K):
+        for got, name in zip(eng.get_weights(k), ("W1", "b1", "W2", "b2")):
+            np.testing.assert_allclose(got, ker["%s_%d" % (name, k)], rtol=1e-4, atol=1e-6, err_msg="%s k=%d" % (name, k))
+        np.testing.assert_allclose(pred[:, k * O:(k + 1) * O], ker["predict_%d" % k], rtol=1e-4, atol=1e-6)
+    eng.close()

@@ -1,5 +1,5 @@
 """Worker of tests/test_sharded.py: one rank of a world_size-N gloo job (CPU).  The engine is
-the CPU oracle injected through MultiNet's engine_factory hook (test infrastructure); what is
+the CPU oracle injected into MultiNet's build() seam (helpers.multinet_with, test infrastructure); what is
 under test is the sharding / early-stopping all-reduce / gather logic of deepimpute_amd.sharded
 and MultiNet's comm path."""
 import os
@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main(out_path):
     import torch.distributed as dist
-    from deepimpute_amd.multinet import MultiNet
+    from helpers import multinet_with
     from torch_comm import TorchComm
     from oracle.dimo import OracleEngine
 
@@ -31,15 +31,15 @@ def main(out_path):
                        index=["c%d" % i for i in range(n)], columns=["g%d" % j for j in range(g)])
     default_dir = os.environ.get("SHARDED_WORKER_MODE") == "default_dir"      # no output_prefix: the per-process temporary default
     where = {} if default_dir else {"output_prefix": out_path + ".dir"}
-    kw = dict(engine_factory=OracleEngine, comm=comm, seed=17, sub_outputdim=64, ncores=1, verbose=0,
+    kw = dict(comm=comm, seed=17, sub_outputdim=64, ncores=1, verbose=0,
               architecture=[{"type": "dense", "neurons": 32, "activation": "relu"}, {"type": "dropout", "rate": 0.2}])
-    net = MultiNet(max_epochs=6, patience=2, learning_rate=2e-3, **where, **kw)
+    net = multinet_with(OracleEngine, max_epochs=6, patience=2, learning_rate=2e-3, **where, **kw)
     net.fit(raw, NN_lim=300)
     imputed = net.predict(raw)
     rank = 0 if comm is None else comm.rank
     if default_dir:
         # a FRESH object of the same job finds the shards the fit wrote (every rank resolved the same shared directory)
-        again = MultiNet(**({"output_prefix": net.outputdir}), **kw)
+        again = multinet_with(OracleEngine, **({"output_prefix": net.outputdir}), **kw)
         again.predictors, again.targets = net.predictors, net.targets
         reloaded = again.predict(raw)
         if rank == 0:

@@ -101,6 +101,33 @@ def test_rccl_failure_yields_a_null_value_line_on_every_rank(monkeypatch):
         else:
             assert all(got[r][0] is None and got[r][1] for r in range(3))
             assert "ncclCommInitRank" in got[1][1] and "other rank" in got[0][1]
+    # a rank whose ENGINE cannot be built (dimn_create on a missing device: --gpus 2 on a one-GPU box) ends the same way, and no
+    # rank reaches ncclCommInitRank (FakeEngine.comm_init would raise AssertionError through `reached`)
+    reached = []
+
+    class Untouched(FakeEngine):
+        def comm_unique_id(self):
+            reached.append(self.rank)
+            return super().comm_unique_id()
+
+    def factory(r):
+        if r == 2:
+            raise RuntimeError("libdimn error -1: dimn_create: device_id 2 out of range (1 devices)")
+        return Untouched(r, False)
+    rd = [bench.FileRendezvous(r, 3) for r in range(3)]
+    got = {}
+
+    def run_job(r):
+        got[r] = bench.bring_up_job(lambda: factory(r), rd[r], r, 3)
+    th = [threading.Thread(target=run_job, args=(r,)) for r in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    rd[0].cleanup()
+    assert not reached
+    assert all(got[r][1] is None and got[r][2] for r in range(3))
+    assert got[2][0] is None and "device_id 2 out of range" in got[2][2] and "other rank" in got[0][2] and got[0][0] is not None
     args = argparse.Namespace(steps=2, warmup=1, precision="fp32")
     line = bench.rccl_failure_line(args, 8, "50k x 20k", "boom")
     assert line["value"] is None and line["ms_per_step"] is None and line["rccl_error"] == "boom" and line["n_gpus"] == 8

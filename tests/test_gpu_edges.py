@@ -99,3 +99,78 @@ def test_general_and_bf16_paths_on_degenerate_sizes():
     np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-3 if mode else 5e-4)
     np.testing.assert_allclose(a.predict(), b.predict(), rtol=5e-3 if mode else 2e-3, atol=5e-4 if mode else 2e-4)
     a.close(); b.close()
+
+
+def test_loopback_gather_places_blocks_like_hstack():
+    """dimn_comm_gather_loopback: the root-side code of dimn_comm_gather_predictions (arena sizing, block offsets, the strided
+    placement into [n][K_global * O]) with device-to-device copies where ncclRecv would run -- 59 sub-nets over 8 "ranks"
+    (8 + 8 + 8 + 7 + 7 + 7 + 7 + 7: configs[4]'s split) on one GPU, against np.hstack of the per-rank predictions; then
+    dimn_impute_finish(from_gathered) over the gathered matrix against the same epilogue over one handle that owns all 59."""
+    from deepimpute_amd.sharded import shard_subnets
+    HipEngine = _hip()
+    K, world, n, g, H, O = 59, 8, 333, 400, 32, 16
+    rng = np.random.default_rng(11)
+    prob = make_problem(n=n, g=g, Ds=[int(d) for d in rng.integers(9, 40, size=K)], H=H, O=O, seed=8)
+    counts, offs = shard_subnets(K, world)
+    assert counts == [8, 8, 8, 7, 7, 7, 7, 7]
+    whole = load_problem(HipEngine, prob, batch_size=32, learning_rate=1e-3, seed=21)
+    whole.init_weights()
+    engines = []
+    for r in range(world):
+        ks = range(offs[r], offs[r] + counts[r])
+        e = HipEngine([prob["Ds"][k] for k in ks], H, O, batch_size=32, learning_rate=1e-3, seed=21, subnet_offset=offs[r])
+        e.set_matrix(prob["norm"])
+        for i, k in enumerate(ks):
+            e.set_indices(i, prob["pred"][k], prob["targ"][k])
+        e.gather(True)
+        e.set_split(prob["train"], prob["val"])
+        e.init_weights()                                        # keyed by the GLOBAL sub-net index: the same weights as `whole`
+        engines.append(e)
+    full = whole.predict()
+    for root in (0, 3):
+        for e in engines:
+            e.predict_device()
+        got = HipEngine.gather_loopback(engines, n, root=root)
+        assert got.shape == (n, K * O)
+        np.testing.assert_array_equal(got, np.hstack([e.predict() for e in engines]))
+        np.testing.assert_allclose(got, full, rtol=1e-5, atol=1e-6)      # (split-K partition differs with the sub-nets per handle)
+    # the epilogue of predict() over root's gathered matrix == over one handle's own predictions
+    raw = np.rint(np.expm1(prob["norm"].astype(np.float64)))
+    slots = np.concatenate([prob["targ"][k] for k in range(K)])
+    order = np.lexsort((np.arange(slots.size), slots))
+    gene_off = np.zeros(g + 1, np.int64)
+    np.cumsum(np.bincount(slots, minlength=g), out=gene_off[1:])
+    ceiling = 2 * np.log1p(raw.max())
+    for e in engines:
+        e.predict_device()
+    HipEngine.gather_loopback(engines, n, root=0, want_host=False)
+    a = engines[0].impute_finish(raw, gene_off, order, "restore", ceiling, from_gathered=True)
+    whole.predict_device()
+    b = whole.impute_finish(raw, gene_off, order, "restore", ceiling)
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+    for e in engines + [whole]:
+        e.close()
+
+
+def test_arena_cache_hands_blocks_back_and_can_be_emptied(monkeypatch):
+    """Large device blocks outlive their handle inside the process (include/dimn.h: dimn_release_cached_memory): a second engine of
+    the same shapes trains to the same bits on recycled arenas, with the cache emptied in between, and with the cache off."""
+    from deepimpute_amd import _lib
+    prob = make_problem(n=9000, g=1500, Ds=[700, 650], H=64, O=32, seed=12)      # X arena 2 x 9000 x ~700 x 4 B = 50 MB: above the 32 MB threshold
+
+    def run():
+        e = load_problem(_hip(), prob, batch_size=64, learning_rate=1e-3, seed=4)
+        e.init_weights()
+        loss = e.train_epoch(0)
+        out = e.predict(np.arange(50, dtype=np.int32))
+        e.close()
+        return loss, out
+    first = run()
+    again = run()                                                # matrix and arenas come from the cache (stale contents of the first life)
+    assert _lib.load()["release_cached_memory"]() == 0
+    fresh = run()
+    monkeypatch.setenv("DIMN_ARENA_CACHE_GB", "0")
+    uncached = run()
+    for other in (again, fresh, uncached):
+        np.testing.assert_array_equal(first[0], other[0])
+        np.testing.assert_array_equal(first[1], other[1])

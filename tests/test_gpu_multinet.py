@@ -10,6 +10,8 @@ import numpy as np
 import pandas as pd
 import pytest
 
+from helpers import multinet_with
+
 pytestmark = pytest.mark.gpu
 
 
@@ -56,7 +58,7 @@ def test_shell_on_hip_matches_shell_on_oracle(tmp_path):
     kw = dict(sub_outputdim=64, seed=7, ncores=1, verbose=0, max_epochs=5, patience=2, learning_rate=1e-3,
               architecture=[{"type": "dense", "neurons": 48, "activation": "relu"}, {"type": "dropout", "rate": 0.25}])
     a = MultiNet(output_prefix=str(tmp_path / "a"), **kw).fit(raw, NN_lim=128)
-    b = MultiNet(output_prefix=str(tmp_path / "b"), engine_factory=OracleEngine, **kw).fit(raw, NN_lim=128)
+    b = multinet_with(OracleEngine, output_prefix=str(tmp_path / "b"), **kw).fit(raw, NN_lim=128)
     assert a.trained_epochs == b.trained_epochs
     np.testing.assert_allclose(a.history["val_loss"], b.history["val_loss"], rtol=2e-4)
     pa, pb = a.predict(raw, imputed_only=True), b.predict(raw, imputed_only=True)
@@ -72,7 +74,7 @@ def test_shell_with_tanh_architecture_on_hip_matches_oracle(tmp_path):
     kw = dict(sub_outputdim=64, seed=11, ncores=1, verbose=0, max_epochs=3, patience=3, learning_rate=1e-3,
               architecture=[{"type": "dense", "neurons": 40, "activation": "tanh"}, {"type": "dropout", "rate": 0.2}])
     a = MultiNet(output_prefix=str(tmp_path / "a"), **kw).fit(raw, NN_lim=128)
-    b = MultiNet(output_prefix=str(tmp_path / "b"), engine_factory=OracleEngine, **kw).fit(raw, NN_lim=128)
+    b = multinet_with(OracleEngine, output_prefix=str(tmp_path / "b"), **kw).fit(raw, NN_lim=128)
     np.testing.assert_allclose(a.history["val_loss"], b.history["val_loss"], rtol=1e-4)
     np.testing.assert_allclose(a.predict(raw).values, b.predict(raw).values, rtol=1e-4, atol=1e-6)
     fresh = MultiNet(output_prefix=str(tmp_path / "a"), sub_outputdim=64, seed=11, ncores=1, verbose=0)   # reload: model.json carries the architecture
@@ -134,7 +136,7 @@ def test_general_architecture_through_the_shell_matches_oracle(tmp_path):
               architecture=[{"type": "dense", "neurons": 48, "activation": "relu"}, {"type": "dropout", "rate": 0.2},
                             {"type": "dense", "neurons": 32, "activation": "tanh"}, {"type": "dropout", "rate": 0.1}])
     a = MultiNet(output_prefix=str(tmp_path / "a"), **kw).fit(raw, NN_lim=128)
-    b = MultiNet(output_prefix=str(tmp_path / "b"), engine_factory=Oracles, **kw).fit(raw, NN_lim=128)
+    b = multinet_with(Oracles, output_prefix=str(tmp_path / "b"), **kw).fit(raw, NN_lim=128)
     assert type(a._engine).__name__ == "HipGeneralEngine" and a.trained_epochs == b.trained_epochs == 3
     np.testing.assert_allclose(a.history["val_loss"], b.history["val_loss"], rtol=1e-4)
     np.testing.assert_allclose(a.predict(raw).values, b.predict(raw).values, rtol=1e-4, atol=1e-6)

@@ -3,7 +3,7 @@ the committed torch-fp64 known answers.  Run on the MI355X box: pytest -m gpu.""
 import numpy as np
 import pytest
 
-from helpers import check_kat, kat_engine, load_kat, make_problem, load_problem
+from helpers import check_kat, kat_engine, load_kat, make_problem, load_problem, multinet_with
 
 pytestmark = pytest.mark.gpu
 
@@ -264,7 +264,7 @@ def test_abs_corrcoef_matches_numpy_and_selects_same_predictors():
     # predictor selection consumes the matrix: identical lists from either backend
     nets = []
     for m in (a, b):
-        net = MultiNet(sub_outputdim=64, ncores=1, engine_factory=lambda *x, **k: None)
+        net = multinet_with(lambda *x, **k: None, sub_outputdim=64, ncores=1)
         np.random.seed(5)
         net.setTargets(raw.reindex(columns=list(a.columns[:256])), mode="random")
         net.setPredictors(m, ntop=5)

@@ -5,6 +5,8 @@ import numpy as np
 import pandas as pd
 import pytest
 
+from helpers import multinet_with
+
 import test_shell as shell                     # FakeEngine, fixtures (CPU module; importing it runs nothing)
 from deepimpute_amd.multinet import MultiNet, get_distance_matrix
 
@@ -18,7 +20,7 @@ def test_device_predictor_selection_matches_reference_capture(name, tmp_path, mo
     used = []
     real = MultiNet._set_predictors_device
     monkeypatch.setattr(MultiNet, "_set_predictors_device", lambda self, *a, **k: used.append(real(self, *a, **k)) or used[-1])
-    net = MultiNet(output_prefix=str(tmp_path), engine_factory=shell.FakeEngine, **meta["ctor"])
+    net = multinet_with(shell.FakeEngine, output_prefix=str(tmp_path), **meta["ctor"])
     net.fit(raw, **dict(meta["fit"]))
     assert used == [True], "the fused device selection did not run"
     col = {c: i for i, c in enumerate(raw.columns)}

@@ -9,6 +9,8 @@ import numpy as np
 import pandas as pd
 import pytest
 
+from helpers import multinet_with
+
 from deepimpute_amd import keras_io
 from deepimpute_amd.multinet import MultiNet
 
@@ -172,7 +174,7 @@ def test_multinet_save_load(tmp_path, monkeypatch, fmt, arch):
         pytest.skip("no HDF5 library")
     monkeypatch.setenv("DIMN_MODEL_FORMAT", fmt)
     dims = [6, 9, 4]
-    net = MultiNet(engine_factory=_HoldEngine, sub_outputdim=20, output_prefix=str(tmp_path), architecture=arch, verbose=0,
+    net = multinet_with(_HoldEngine, sub_outputdim=20, output_prefix=str(tmp_path), architecture=arch, verbose=0,
                    loss="mean_squared_error" if arch else "wMSE", batch_size=32)
     net.predictors = [["g%d" % j for j in range(d)] for d in dims]
     eng = net.build(dims)
@@ -187,7 +189,7 @@ def test_multinet_save_load(tmp_path, monkeypatch, fmt, arch):
     doc = json.load(open(str(tmp_path / "model.json")))
     assert doc["class_name"] == "Functional" and doc["deepimpute_amd"]["weights"] == fmt       # model_from_json ignores the extra key
 
-    fresh = MultiNet(engine_factory=_HoldEngine, output_prefix=str(tmp_path), verbose=0)
+    fresh = multinet_with(_HoldEngine, output_prefix=str(tmp_path), verbose=0)
     got = fresh.load()
     assert fresh.sub_outputdim == 20 and fresh.NN_parameters["batch_size"] == 32
     assert got.D == dims and [tuple(l) for l in got.layers] == [tuple(l) for l in layers]
@@ -200,7 +202,7 @@ def test_multinet_save_load(tmp_path, monkeypatch, fmt, arch):
         # the reference's own pair: a Keras model.json WITHOUT our metadata + model.h5
         del doc["deepimpute_amd"]
         json.dump(doc, open(str(tmp_path / "model.json"), "w"))
-        plain = MultiNet(engine_factory=_HoldEngine, output_prefix=str(tmp_path), verbose=0, batch_size=32,
+        plain = multinet_with(_HoldEngine, output_prefix=str(tmp_path), verbose=0, batch_size=32,
                          loss="mean_squared_error" if arch else "wMSE")
         got = plain.load()
         assert plain.sub_outputdim == 20 and got.D == dims
@@ -215,7 +217,7 @@ def test_stale_weights_of_an_older_fit_are_removed(tmp_path, monkeypatch):
     dims = [5, 5]
     for fmt in ("npz", "h5"):
         monkeypatch.setenv("DIMN_MODEL_FORMAT", fmt)
-        net = MultiNet(engine_factory=_HoldEngine, sub_outputdim=8, output_prefix=str(tmp_path), verbose=0)
+        net = multinet_with(_HoldEngine, sub_outputdim=8, output_prefix=str(tmp_path), verbose=0)
         net.predictors = [list(range(d)) for d in dims]
         eng = net.build(dims)
         _, weights = _weights(dims, eng.layers, 8, seed=1)

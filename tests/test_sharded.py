@@ -40,6 +40,26 @@ def test_shard_subnets():
     assert shard_subnets(3, 1) == ([3], [0])
 
 
+def test_shard_subnets_balances_by_predictor_count():
+    """ranks are balanced by sum of D_k (a rank's step time and arena follow it), in contiguous blocks; near-equal D_k
+    -- the 50k x 20k job, configs[4]'s 59 sub-nets -- keep the by-count split."""
+    assert shard_subnets(40, 8, [2390 + (7 * k) % 30 for k in range(40)])[0] == [5] * 8
+    assert shard_subnets(59, 8, [2400 + (k % 7) for k in range(59)])[0] == [8, 8, 8, 7, 7, 7, 7, 7]
+    # a user-supplied gene list with two heavy sub-nets at the end: by count [3, 3, 2, 2] would give the last rank 1800
+    counts, offs = shard_subnets(10, 4, [100] * 8 + [900, 900])
+    assert counts == [4, 4, 1, 1] and offs == [0, 4, 8, 9]
+    w = [50, 700, 60, 40, 30, 650, 45, 55, 35]
+    counts, offs = shard_subnets(9, 3, w)
+    loads = [sum(w[offs[r]:offs[r] + counts[r]]) for r in range(3)]
+    assert sum(counts) == 9 and min(counts) >= 1
+    best = min(max(sum(w[:i]), sum(w[i:j]), sum(w[j:])) for i in range(1, 8) for j in range(i + 1, 9))
+    assert max(loads) == best                                  # the optimum of the contiguous partitions
+    assert shard_subnets(5, 5, [1, 2, 3, 4, 5])[0] == [1] * 5   # every rank keeps one sub-net
+    assert shard_subnets(4, 6)[0] == [1, 1, 1, 1, 0, 0]         # (more ranks than sub-nets: the caller refuses)
+    with pytest.raises(ValueError):
+        shard_subnets(3, 2, [1.0, 0.0, 2.0])
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_gloo_sharded_equals_single_process(tmp_path, world):
     single = _run(1, str(tmp_path / "single.npz"))

@@ -10,7 +10,7 @@ import numpy as np
 import pandas as pd
 import pytest
 
-from helpers import GOLDEN
+from helpers import GOLDEN, multinet_with
 sys.path.insert(0, GOLDEN)
 from make_shell import fake_prediction  # noqa: E402  (pure function shared with the capture script)
 
@@ -72,7 +72,7 @@ def test_shell_matches_reference_capture(name, tmp_path, capsys):
     meta = CASES[name]
     raw = _raw(name)
     fitkw = dict(meta["fit"])
-    net = MultiNet(output_prefix=str(tmp_path), engine_factory=FakeEngine, **meta["ctor"])
+    net = multinet_with(FakeEngine, output_prefix=str(tmp_path), **meta["ctor"])
     net.fit(raw, **fitkw)
     eng = FakeEngine.instances[-1]
     col = {c: i for i, c in enumerate(raw.columns)}
@@ -126,7 +126,7 @@ def test_shell_matches_reference_capture(name, tmp_path, capsys):
 
 def test_restore_policy_invariants():
     raw = _raw("default64")
-    net = MultiNet(engine_factory=FakeEngine, seed=123, sub_outputdim=64, ncores=1, verbose=0)
+    net = multinet_with(FakeEngine, seed=123, sub_outputdim=64, ncores=1, verbose=0)
     net.fit(raw)
     out = net.predict(raw, policy="restore")
     pos = raw.values > 0
@@ -153,21 +153,21 @@ def test_module_functions():
 
 
 def test_unsupported_architecture_is_loud():
-    net = MultiNet(engine_factory=FakeEngine, ncores=1,
+    net = multinet_with(FakeEngine, ncores=1,
                    architecture=[{"type": "dense", "neurons": 8, "activation": "swish"}])
     with pytest.raises(NotImplementedError):
         net.build([10])
     with pytest.raises(NotImplementedError):           # two hidden layers: the general path, which this injected factory lacks
-        MultiNet(engine_factory=FakeEngine, ncores=1, architecture=[{"type": "dense", "neurons": 8, "activation": "relu"},
+        multinet_with(FakeEngine, ncores=1, architecture=[{"type": "dense", "neurons": 8, "activation": "relu"},
                                                                     {"type": "dense", "neurons": 8, "activation": "relu"}]).build([10])
     with pytest.raises(NotImplementedError):           # dropout on the inputs
-        MultiNet(engine_factory=FakeEngine, ncores=1, architecture=[{"type": "dropout", "rate": 0.1},
+        multinet_with(FakeEngine, ncores=1, architecture=[{"type": "dropout", "rate": 0.1},
                                                                     {"type": "dense", "neurons": 8, "activation": "relu"}]).build([10])
-    eng = MultiNet(engine_factory=FakeEngine, ncores=1,
+    eng = multinet_with(FakeEngine, ncores=1,
                    architecture=[{"type": "dense", "neurons": 8, "activation": "tanh"}, {"type": "dropout", "rate": 0.1}]).build([10])
     assert eng.kw["activation"] == "tanh" and eng.H == 8 and abs(eng.kw["dropout_rate"] - 0.1) < 1e-12
     with pytest.raises(SystemExit):                    # the reference's "Unknown loss ... Aborting." (multinet.py:160-161)
-        MultiNet(engine_factory=FakeEngine, ncores=1, loss="not_a_loss").build([10])
+        multinet_with(FakeEngine, ncores=1, loss="not_a_loss").build([10])
 
 
 def test_general_architectures_reach_the_general_engine():
@@ -182,15 +182,15 @@ def test_general_architectures_reach_the_general_engine():
             return "general"
     arch = [{"type": "dense", "neurons": 600, "activation": "relu"}, {"type": "dropout", "rate": 0.3},
             {"type": "dense", "neurons": 64, "activation": "tanh"}]
-    assert MultiNet(engine_factory=Factory, ncores=1, architecture=arch, batch_size=128, loss="mean_squared_error", seed=7).build([10, 12]) == "general"
+    assert multinet_with(Factory, ncores=1, architecture=arch, batch_size=128, loss="mean_squared_error", seed=7).build([10, 12]) == "general"
     D, layers, out_dim, kw = calls[-1]
     assert D == [10, 12] and layers == [(600, "relu", 0.3), (64, "tanh", 0.0)] and out_dim == 512
     assert kw["batch_size"] == 128 and kw["loss"] == "mean_squared_error" and kw["seed"] == 7
     # each of the three limits of the tuned kernels alone is enough
     for extra in (dict(batch_size=65), dict(architecture=[{"type": "dense", "neurons": 400, "activation": "relu"}]), dict(loss="mae")):
-        assert MultiNet(engine_factory=Factory, ncores=1, **extra).build([10]) == "general"
+        assert multinet_with(Factory, ncores=1, **extra).build([10]) == "general"
     # and the default family stays on the tuned kernels
-    eng = MultiNet(engine_factory=Factory, ncores=1).build([10])
+    eng = multinet_with(Factory, ncores=1).build([10])
     assert isinstance(eng, FakeEngine) and eng.H == 256
 
 
@@ -208,7 +208,7 @@ def test_cli_digit_limit_and_subset_are_coerced(tmp_path, monkeypatch):
     """`--limit 64` arrives as a str and `--subset 90` as a float (parser.py:26,38); the reference
     crashes on both, the drop-in coerces them."""
     raw = _raw("progressive")
-    net = MultiNet(engine_factory=FakeEngine, seed=99, sub_outputdim=32, ncores=1, verbose=0, output_prefix=str(tmp_path))
+    net = multinet_with(FakeEngine, seed=99, sub_outputdim=32, ncores=1, verbose=0, output_prefix=str(tmp_path))
     net.fit(raw, NN_lim="64", cell_subset=90.0)
     assert net.targets.shape[1] == 32 and FakeEngine.instances[-1].norm.shape[0] == 90
 
@@ -260,7 +260,7 @@ def test_host_pool_blocks_are_bit_identical(monkeypatch):
 def test_predict_row_blocks_do_not_change_the_result(monkeypatch):
     from deepimpute_amd import multinet as mn
     raw = _raw("default64")
-    net = MultiNet(engine_factory=FakeEngine, seed=123, sub_outputdim=64, ncores=1, verbose=0)
+    net = multinet_with(FakeEngine, seed=123, sub_outputdim=64, ncores=1, verbose=0)
     net.fit(raw)
     whole = {p: net.predict(raw, policy=p).values for p in ("restore", "max", None)}
     monkeypatch.setattr(mn, "_POST_ROWS", 7)
