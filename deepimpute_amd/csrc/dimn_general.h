@@ -3,7 +3,7 @@
 // :150-162: other losses; parser.py:50-66: any batch size, any hidden width).  Same arithmetic definitions (Keras-form
 // Adam, Philox dropout streams, softplus output, wMSE), plain structure: per layer one batched fp32-MFMA GEMM over the
 // sub-nets (64 x 64 output tile per workgroup, operands staged through LDS, transposes resolved while staging) with the
-// layer's epilogue fused, an element-wise loss kernel, and one Adam pass over the flat parameter array.  Correct and
+// layer's epilogue fused, an element-wise loss kernel, and Keras-Adam fused behind the weight-gradient GEMM and the bias column sums.  Correct and
 // reasonably fast, not roofline-tuned: the default architecture (one hidden layer <= 384, batch <= 64) never comes here.
 #pragma once
 #include "dimn_kernels.h"
@@ -18,10 +18,14 @@ struct GDesc {                 // one GEMM of one sub-net:  C[M][N] = op(A)[M][K
 };
 
 struct GEpi {
-    int32_t mode;              // 0 store; 1 hidden forward (bias, activation, dropout -> C = H, G = gate); 2 bias only; 3 C = acc * G
+    int32_t mode;              // 0 store; 1 hidden forward (bias, activation, dropout -> C = H, G = gate); 2 bias only; 3 C = acc * G;
+                               // 4 (weight gradients): Keras-Adam on the parameters the tile belongs to -- C addresses the tile inside the flat
+                               //   PARAMETER array P, whose offsets the m / v arrays share: the gradient itself never goes to memory
     int32_t act, train;        // mode 1
     float rate, scale;
     uint64_t seed; uint32_t epoch, step;   // step already carries the dropout layer in its top byte
+    float *P, *Mo, *Vo;                    // mode 4: flat parameter array and Adam moments (same offsets)
+    AdamP ap;                              // mode 4
 };
 
 // dropout key of layer `dl` (0 = first Dropout layer, the stream of the tuned kernels): the layer ordinal rides in the
@@ -33,6 +37,7 @@ __host__ __device__ static inline uint32_t gen_step_key(uint32_t step, int dl) {
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ descs, int Mo, int Ko, GEpi ep) {
     __shared__ __attribute__((aligned(16))) float As[16][68], Bs[16][68];   // [k][m], [k][n]; 68: conflict-free column reads by 16-lane groups, rows 16-byte aligned
+    __shared__ __attribute__((aligned(16))) float Cs[TA ? 64 : 1][68];       // mode 4 (the weight-gradient instance): the output tile, re-read row-wise
     GDesc d = descs[blockIdx.z];
     const int M = Mo >= 0 ? Mo : d.K;
     if (Ko >= 0) d.K = Ko;
@@ -95,6 +100,43 @@ __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ desc
                 for (int j = 0; j < 2; ++j) acc[i][j] = MFMA16(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
+    }
+    if constexpr (TA) {
+        if (ep.mode == 4) {
+            // Round 4: Adam fused behind the weight-gradient GEMM (round 3 wrote the gradient -- 4 B per parameter -- and a separate
+            // pass over the flat arrays read it back with w, m, v: 36 B per parameter and step, now 24).  The tile goes through LDS
+            // so that every thread owns float4 pieces of a ROW: 256-byte runs per row and wave on each of the six streams, instead
+            // of the accumulator layout's 64-byte ones.  Same gradient bits, same adam1 per element as the separate pass.
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Cs[wm + 16 * i + 4 * lj + r][wn + 16 * j + li] = acc[i][j][r];
+            __syncthreads();
+            const int64_t base = d.C - ep.P;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int piece = tid + 256 * q, rr = piece >> 4, c4 = (piece & 15) * 4;
+                const int row = m0 + rr, col = n0 + c4;
+                if (row >= M || col >= d.N) continue;
+                const int64_t o = base + (int64_t)row * d.ldc + col;
+                if (col + 3 < d.N && ((o | d.ldc) & 3) == 0) {
+                    f32x4 w = *(const f32x4*)(ep.P + o), m = *(const f32x4*)(ep.Mo + o), v = *(const f32x4*)(ep.Vo + o);
+                    const f32x4 g = *(const f32x4*)&Cs[rr][c4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { float w1 = w[r], m1 = m[r], v1 = v[r]; adam1(w1, m1, v1, g[r], ep.ap); w[r] = w1; m[r] = m1; v[r] = v1; }
+                    *(f32x4*)(ep.P + o) = w; *(f32x4*)(ep.Mo + o) = m; *(f32x4*)(ep.Vo + o) = v;
+                } else {
+                    for (int r = 0; r < 4 && col + r < d.N; ++r) {
+                        float w = ep.P[o + r], m = ep.Mo[o + r], v = ep.Vo[o + r];
+                        adam1(w, m, v, Cs[rr][c4 + r], ep.ap);
+                        ep.P[o + r] = w; ep.Mo[o + r] = m; ep.Vo[o + r] = v;
+                    }
+                }
+            }
+            return;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -186,23 +228,17 @@ __global__ __launch_bounds__(256) void k_gen_output(float* __restrict__ Z, int l
     if (threadIdx.x == 0) loss_sum[(int64_t)k * GEN_OUT_CH + blockIdx.y] += red[0] + red[1] + red[2] + red[3];
 }
 
-// bias gradients: gb[n] = sum_b dZ[b][n]   (one workgroup per (sub-net, layer) entry of `descs`: C = gb, A = dZ, N, lda)
-__global__ __launch_bounds__(256) void k_gen_colsum(const GDesc* __restrict__ descs, int M) {
+// bias gradients: gb[n] = sum_b dZ[b][n] -> Keras-Adam on the bias (one workgroup per (sub-net, layer) entry of `descs`: A = dZ, N, lda;
+// C addresses the bias inside the flat parameter array, whose offsets the m / v arrays share: ep as in k_gen_gemm's mode 4)
+__global__ __launch_bounds__(256) void k_gen_colsum_adam(const GDesc* __restrict__ descs, int M, GEpi ep) {
     const GDesc d = descs[blockIdx.x];
+    const int64_t base = d.C - ep.P;
     for (int n = threadIdx.x; n < d.N; n += 256) {
         float s = 0.f;
         for (int b = 0; b < M; ++b) s += d.A[(int64_t)b * d.lda + n];
-        d.C[n] = s;
-    }
-}
-
-// Keras-form Adam over the flat parameter array (every kernel and bias of every sub-net of the handle)
-__global__ __launch_bounds__(256) void k_gen_adam(float* __restrict__ P, float* __restrict__ Mo, float* __restrict__ Vo, const float* __restrict__ Gr,
-                                                  int64_t n, AdamP ap) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float w = P[i], m = Mo[i], v = Vo[i];
-        adam1(w, m, v, Gr[i], ap);
-        P[i] = w; Mo[i] = m; Vo[i] = v;
+        float w = ep.P[base + n], m = ep.Mo[base + n], v = ep.Vo[base + n];
+        adam1(w, m, v, s, ep.ap);
+        ep.P[base + n] = w; ep.Mo[base + n] = m; ep.Vo[base + n] = v;
     }
 }
 

@@ -551,11 +551,15 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 gate |= g1 << r;
                 dd[r] = g1 ? a[r] * p.scale : 0.f;
             }
-            // P(t) of every sibling is in, so each of them has run the tile loop of step t-1, i.e. consumed dA(t-1): its slot is
-            // free -- marked "not written" for dA(t+1), and acknowledged before the Dd tile (which lets everybody move on) leaves
-            if (S1 > 1) res_st(rA, tnext + (uint32_t)(ht * 4096 + 16 * tid), sent4);
+            // Round 4: no store round trip on the critical path.  The drain below waits for the re-arm of the Dd slot that M2 of the
+            // step before issued BEHIND its dA store, i.e. a whole tile loop ago: it is in place long since, so the Dd tile leaves at
+            // once (round 3 issued a re-arm right here and waited ~1 us for its acknowledgement before the tile everybody waits for).
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             res_st(rT, tcur + (uint32_t)(ht * 4096 + 16 * tid), dd);
+            // P(t) of every sibling is in, so each of them has run the tile loop of step t-1, i.e. consumed dA(t-1): its slot is
+            // free -- marked "not written" for dA(t+1) BEHIND the Dd tile; M2's drain (a role-2 phase later) acknowledges it before
+            // dA(t) -- which is what lets a sibling get as far as polling that slot -- leaves
+            if (S1 > 1) res_st(rA, tnext + (uint32_t)(ht * 4096 + 16 * tid), sent4);
         }
         RES_STAMP(0)
 
@@ -775,9 +779,6 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                     }
                     for (; o < o1; ++o) { f32x4 t1 = res_ld(rD, base + (uint32_t)(o * 65536)); res_fix(t1, rD, base + (uint32_t)(o * 65536), abort_w); d += t1; }
                 }
-                // every dD partial of this step was out, so every role-2 workgroup has read the Dd tiles of this step: that slot is
-                // free -- marked "not written" for step t+2 (acknowledged before the dA tile / the next Dd tile leaves: vmcnt(0) there)
-                if (tid < 256) res_st(rT, tcur + (uint32_t)(ht * 4096 + 16 * tid), sent4);
                 if (half) *(f32x4*)(yl + 4 * (tid & 255)) = d;
                 __syncthreads();
                 if (half == 0) {
@@ -787,9 +788,13 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                     for (int r = 0; r < 4; ++r) da[r] = ((gate >> r) & 1u) ? d[r] * p.scale : 0.f;
                     *(f32x4*)(dzl + 4 * tid) = da;               // dA tile [64][16]
                     if (S1 > 1) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the re-arm of this dA slot's sibling, issued behind the Dd tile in M1: long in place)
                         res_st(rA, tcur + (uint32_t)(ht * 4096 + 16 * tid), da);
                     }
+                    // every dD partial of this step was out, so every role-2 workgroup has read the Dd tiles of this step: that slot is
+                    // free -- marked "not written" for step t+2, BEHIND the dA tile; acknowledged by M1's drain of the next step, a tile
+                    // loop from here, before Dd(t+1) leaves
+                    res_st(rT, tcur + (uint32_t)(ht * 4096 + 16 * tid), sent4);
                     col4(da);
                 }
             } else {
