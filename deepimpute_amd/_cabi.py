@@ -87,6 +87,7 @@ GPU_ONLY = {
     "abi_version": [],
     "device_count": [C.POINTER(C.c_int32)],
     "release_cached_memory": [],
+    "warm_up": [_i32],
     "set_matrix_streamed": [_H, _pf, _i64, _i64, _i32],
     "predict_device": [_H, _pi, _i64, C.POINTER(C.c_void_p)],
     "synchronize": [_H],

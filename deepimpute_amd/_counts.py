@@ -33,6 +33,11 @@ class DeviceCounts:
             return None
         return DeviceCounts(h, values.shape[0], values.shape[1], vmax.value, cs.value, device_id)
 
+    def shape_matches(self, values):
+        """The cheap half of matches(): a C-ordered float64 frame of the uploaded shape."""
+        return (self.handle is not None and isinstance(values, np.ndarray) and values.dtype == np.float64 and values.shape == (self.n, self.g)
+                and values.flags.c_contiguous)
+
     def matches(self, values):
         """True when `values` is, bit for bit, the matrix that was uploaded (one threaded host pass: a position-dependent
         checksum of the float64 bit patterns)."""

@@ -45,3 +45,24 @@ def device_count():
     n = C.c_int32(0)
     load()["device_count"](C.byref(n))
     return n.value
+
+
+_warm = {}
+
+
+def warm_up_async(device_id=0):
+    """Bring the GPU up on a helper thread (dimn_warm_up: HIP context + the pinned bounce buffers, ~0.1 s) while the caller still
+    parses arguments / reads its matrix; returns at once.  Once per (process, device); silent when there is no library or GPU --
+    the first real call then reports that."""
+    import threading
+    device_id = int(device_id)
+    if device_id in _warm:
+        return
+    _warm[device_id] = True
+
+    def work():
+        try:
+            load()["warm_up"](device_id)
+        except Exception:
+            pass
+    threading.Thread(target=work, name="dimn-warm-up", daemon=True).start()

@@ -11,6 +11,11 @@ def deepImpute(**kwargs):
     for name, value in kwargs.items():
         setattr(args, name, value)
 
+    try:                                                # the GPU comes up (HIP context, pinned buffers) while the CSV is parsed
+        from . import _lib
+        _lib.warm_up_async(0)
+    except (ImportError, OSError):
+        pass                                            # no library / no GPU: MultiNet.fit says so
     counts = csvio.read_csv(args.inputFile)             # pd.read_csv(inputFile, index_col=0), multi-threaded for count matrices
     if args.cell_axis == "columns":
         counts = counts.T

@@ -242,6 +242,12 @@ class MultiNet:
             # one process per GPU: the rank's device is known before any planning touches a GPU
             self.device_id = int(os.environ.get("LOCAL_RANK", str(device_id)))
         self.setCores(ncores)
+        if self._device_planning and comm is None:     # the GPU comes up (context, pinned bounce buffers) while the caller still prepares its frame
+            try:
+                from . import _lib
+                _lib.warm_up_async(self.device_id)
+            except (ImportError, OSError):
+                pass                                   # no library: fit() says so
 
     def setCores(self, ncores):
         # the reference only sizes TensorFlow's CPU thread pools with this (multinet.py:222-223);
@@ -341,8 +347,10 @@ class MultiNet:
             with open(os.path.join(self.outputdir, "model.json"), "w") as fh:
                 json.dump(keras_io.model_json(dims, layers, self.sub_outputdim, self.seed, meta), fh)
         blobs = {}
+        # (the K device-to-host copies + re-layouts are independent reads of the handle: fetched on the host pool)
+        fetched = _hostpar.pmap(model.get_weights, range(model.K)) if hasattr(model, "predict_device") else [model.get_weights(k) for k in range(model.K)]
         for k in range(model.K):                         # dense layer l (1-based, the last one is the output layer): Wl_<k>, bl_<k>
-            arrays = model.get_weights(k)
+            arrays = fetched[k]
             for i, arr in enumerate(arrays):
                 blobs["%s%d_%d" % ("Wb"[i % 2], i // 2 + 1, self._first_subnet + k)] = arr
         # never leave weights of an older fit beside the new ones: the other format's file, and the shards of ranks this job
@@ -662,6 +670,24 @@ class MultiNet:
             return box.get("counts")
         return wait
 
+    def _start_checksum(self, counts, values):
+        """counts.matches(values) on a helper thread (ctypes releases the GIL); returns a function that waits for the answer."""
+        import threading
+        box = {}
+
+        def work():
+            try:
+                box["same"] = counts.matches(values)
+            except Exception:
+                box["same"] = False
+        thread = threading.Thread(target=work, name="dimn-checksum", daemon=True)
+        thread.start()
+
+        def wait():
+            thread.join()
+            return bool(box.get("same"))
+        return wait
+
     def _drop_resident(self):
         held = getattr(self, "_resident", None)
         self._resident = None
@@ -777,8 +803,13 @@ class MultiNet:
         with tm.stage("predict.counts"):
             held = getattr(self, "_resident", None)
             values = getattr(raw, "values", None)
-            if held is not None and getattr(engine, "_dev_counts", None) is held[0] and raw.columns.equals(held[1]) and held[0].matches(values):
-                resident = held[0]                       # same cells, same columns, same numbers: X_k is already gathered
+            verdict = None
+            if held is not None and getattr(engine, "_dev_counts", None) is held[0] and raw.columns.equals(held[1]) and held[0].shape_matches(values):
+                # same cells and columns; whether they are the same NUMBERS is one pass over the frame (a checksum of its bit patterns),
+                # which runs on a helper thread beside the forward pass and the epilogue: a frame that turns out to differ costs a second,
+                # ordinary predict below -- the result of the speculative one is dropped
+                resident = held[0]
+                verdict = self._start_checksum(resident, values)
             else:
                 wait = self._start_counts_upload(raw) if hasattr(engine, "set_matrix_counts") else (lambda: None)
                 fresh = wait()
@@ -815,6 +846,22 @@ class MultiNet:
 
         with tm.stage("predict.forward+finish"):
             values = self._finish_on_device(engine, observed, where[slot_gene], policy, ceiling, resident=resident is not None)
+            if resident is not None and verdict is not None and not verdict():
+                # the frame is not the one that was fitted: upload it and run the ordinary sequence
+                values = None
+                fresh = self._start_counts_upload(raw)()
+                if fresh is not None:
+                    self._bind_columns(engine, raw.columns)
+                    engine.set_matrix_counts(fresh)
+                    engine.gather(False)
+                    self._resident = (fresh, raw.columns)
+                    top = fresh.vmax
+                else:
+                    self._bind_columns(engine, raw.columns)
+                    self._hand_over(engine, _hostpar.log1p_float32(raw).values, False)
+                    top = _hostpar.matrix_max(observed)
+                ceiling = 2 * np.log1p(top)
+                values = self._finish_on_device(engine, observed, where[slot_gene], policy, ceiling, resident=fresh is not None)
         if values is False:
             return None                                  # sharded job: rank 0 returns the frame
         if values is None:                               # engines without the device epilogue (tests: oracle / fake engines)

@@ -112,6 +112,9 @@ int dimn_destroy(dimn_handle h);
  * cost 0.2-0.6 s instead of 0.02 s.  dimn_release_cached_memory() gives every idle block back to the driver;
  * DIMN_ARENA_CACHE_GB caps what is kept (default 96, 0: nothing).  ABI 7. */
 int dimn_release_cached_memory(void);
+/* Start-up cost moved out of fit(): creates the HIP context of the device and pins the process-wide bounce buffers (~0.1 s).
+ * Idempotent, thread-safe; host code calls it from a helper thread as soon as it knows which GPU it will use.  ABI 7. */
+int dimn_warm_up(int32_t device_id);
 
 /*
  * The shared log1p matrix (multinet.py:217 `norm_data`, :271 `norm_raw`), row-major
