@@ -34,74 +34,90 @@ __host__ __device__ static inline uint32_t gen_step_key(uint32_t step, int dl) {
 
 // Mo >= 0: the row count of every sub-net (batch rows); Mo < 0: the descriptor's K field is the row count (weight
 // gradients: rows = inputs of the layer, which differ per sub-net) and Ko is the inner dimension (the batch).
-template <bool TA, bool TB>
+// Round 4: 64-deep k-steps (round 3: 16-deep -- the first layer's forward, K = D ~ 2 400 on 4 workgroups per sub-net, spent 150
+// dependent load -> LDS -> barrier rounds of ~1.3 us each: 0.2 ms of a 0.46 ms step, rocprofv3) and a 64 x 32 output tile (BN = 32)
+// for the batch-row GEMMs, whose grids were 160 workgroups on 256 CUs.
+template <bool TA, bool TB, int BN>
 __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ descs, int Mo, int Ko, GEpi ep) {
-    __shared__ __attribute__((aligned(16))) float As[16][68], Bs[16][68];   // [k][m], [k][n]; 68: conflict-free column reads by 16-lane groups, rows 16-byte aligned
-    __shared__ __attribute__((aligned(16))) float Cs[TA ? 64 : 1][68];       // mode 4 (the weight-gradient instance): the output tile, re-read row-wise
+    constexpr int BK = 64, NJ = BN / 32;                         // k-depth of a step; 16-column tiles per wave
+    __shared__ __attribute__((aligned(16))) float As[BK][68], Bs[BK][BN + 4];   // [k][m], [k][n]; rows 16-byte aligned, stride 4 mod 32 words
+    __shared__ __attribute__((aligned(16))) float Cs[TA ? 64 : 1][68];          // mode 4 (the weight-gradient instance): the output tile, re-read row-wise
     GDesc d = descs[blockIdx.z];
     const int M = Mo >= 0 ? Mo : d.K;
     if (Ko >= 0) d.K = Ko;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BN;
     if (n0 >= d.N || m0 >= M) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    f32x4 acc[2][2];
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * (BN / 2);
+    f32x4 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // Staging (round 3): every thread moves ONE 16-byte piece of each operand per 16-deep tile -- four elements along the operand's
-    // memory-contiguous index (k for a row-major A / a transposed B, m or n otherwise) -- requested for the NEXT tile before the
-    // current one is multiplied (round 2: four scalar loads per operand, no overlap).  Pieces that cross an edge, or operands whose
-    // rows are not 16-byte aligned, fall back to four guarded scalar loads.
-    const bool a_k = !TA, b_k = TB;                              // the operand's contiguous index is k
-    const int a_maj = a_k ? tid >> 2 : tid >> 4, a_min = a_k ? (tid & 3) * 4 : (tid & 15) * 4;      // (m, k4) or (k, m4)
-    const int b_maj = b_k ? tid >> 2 : tid >> 4, b_min = b_k ? (tid & 3) * 4 : (tid & 15) * 4;      // (n, k4) or (k, n4)
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Staging: every thread moves 16-byte pieces -- four elements along the operand's memory-contiguous index (k for a row-major A /
+    // a transposed B, m or n otherwise) -- requested for the NEXT step before the current one is multiplied.  Pieces that cross an
+    // edge, or operands whose rows are not 16-byte aligned, fall back to guarded scalar loads.
+    constexpr bool a_k = !TA, b_k = TB;                          // the operand's contiguous index is k
+    constexpr int NA = 4, NB = BN / 16;                          // pieces per thread: A 64 x 64, B 64 x BN
     const bool a_vec = (d.lda & 3) == 0 && ((uintptr_t)d.A & 15) == 0, b_vec = (d.ldb & 3) == 0 && ((uintptr_t)d.B & 15) == 0;
-    auto load_a = [&](int k0) -> f32x4 {
-        const int gmaj = a_k ? m0 + a_maj : k0 + a_maj, gmin = a_k ? k0 + a_min : m0 + a_min;
-        const int lim_maj = a_k ? M : d.K, lim_min = a_k ? d.K : M;
+    auto piece = [&](const float* base, int64_t ld, int gmaj, int gmin, int lim_maj, int lim_min, bool vec) -> f32x4 {
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (gmaj < lim_maj) {
-            const float* p = d.A + (int64_t)gmaj * d.lda + gmin;
-            if (a_vec && gmin + 3 < lim_min) v = *(const f32x4*)p;
+            const float* p = base + (int64_t)gmaj * ld + gmin;
+            if (vec && gmin + 3 < lim_min) v = *(const f32x4*)p;
             else
                 for (int r = 0; r < 4; ++r) if (gmin + r < lim_min) v[r] = p[r];
         }
         return v;
     };
-    auto load_b = [&](int k0) -> f32x4 {
-        const int gmaj = b_k ? n0 + b_maj : k0 + b_maj, gmin = b_k ? k0 + b_min : n0 + b_min;
-        const int lim_maj = b_k ? d.N : d.K, lim_min = b_k ? d.K : d.N;
-        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (gmaj < lim_maj) {
-            const float* p = d.B + (int64_t)gmaj * d.ldb + gmin;
-            if (b_vec && gmin + 3 < lim_min) v = *(const f32x4*)p;
-            else
-                for (int r = 0; r < 4; ++r) if (gmin + r < lim_min) v[r] = p[r];
+    // piece q of this thread: (major, minor) inside the tile; the minor index runs over 16 pieces of four
+    auto load_a = [&](int k0, f32x4 (&ra)[NA]) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int p = tid + 256 * q, maj = p >> 4, mn = (p & 15) * 4;
+            ra[q] = a_k ? piece(d.A, d.lda, m0 + maj, k0 + mn, M, d.K, a_vec) : piece(d.A, d.lda, k0 + maj, m0 + mn, d.K, M, a_vec);
         }
-        return v;
     };
-    f32x4 ra = load_a(0), rb = load_b(0);
-    for (int k0 = 0; k0 < d.K; k0 += 16) {
-        if (a_k) { for (int r = 0; r < 4; ++r) As[a_min + r][a_maj] = ra[r]; } else *(f32x4*)&As[a_maj][a_min] = ra;
-        if (b_k) { for (int r = 0; r < 4; ++r) Bs[b_min + r][b_maj] = rb[r]; } else *(f32x4*)&Bs[b_maj][b_min] = rb;
+    auto load_b = [&](int k0, f32x4 (&rb)[NB]) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int p = tid + 256 * q;
+            if (b_k) { const int maj = p >> 4, mn = (p & 15) * 4; rb[q] = piece(d.B, d.ldb, n0 + maj, k0 + mn, d.N, d.K, b_vec); }
+            else { const int maj = p / (BN / 4), mn = (p % (BN / 4)) * 4; rb[q] = piece(d.B, d.ldb, k0 + maj, n0 + mn, d.K, d.N, b_vec); }
+        }
+    };
+    f32x4 ra[NA], rb[NB];
+    load_a(0, ra); load_b(0, rb);
+    for (int k0 = 0; k0 < d.K; k0 += BK) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int p = tid + 256 * q, maj = p >> 4, mn = (p & 15) * 4;
+            if (a_k) { for (int r = 0; r < 4; ++r) As[mn + r][maj] = ra[q][r]; } else *(f32x4*)&As[maj][mn] = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int p = tid + 256 * q;
+            if (b_k) { const int maj = p >> 4, mn = (p & 15) * 4; for (int r = 0; r < 4; ++r) Bs[mn + r][maj] = rb[q][r]; }
+            else { const int maj = p / (BN / 4), mn = (p % (BN / 4)) * 4; *(f32x4*)&Bs[maj][mn] = rb[q]; }
+        }
         __syncthreads();
-        if (k0 + 16 < d.K) { ra = load_a(k0 + 16); rb = load_b(k0 + 16); }
+        if (k0 + BK < d.K) { load_a(k0 + BK, ra); load_b(k0 + BK, rb); }
+        const int kend = d.K - k0 < BK ? ((d.K - k0 + 3) & ~3) : BK;      // (the tile beyond K is zero-filled: whole 4-deep instructions only)
+        for (int kk = 0; kk < kend; kk += 4) {
+            float a[2], b[NJ];
 #pragma unroll
-        for (int kk = 0; kk < 16; kk += 4) {
-            float a[2], b[2];
+            for (int i = 0; i < 2; ++i) a[i] = As[kk + lj][wm + 16 * i + li];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { a[i] = As[kk + lj][wm + 16 * i + li]; b[i] = Bs[kk + lj][wn + 16 * i + li]; }
+            for (int j = 0; j < NJ; ++j) b[j] = Bs[kk + lj][wn + 16 * j + li];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = MFMA16(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = MFMA16(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
     }
-    if constexpr (TA) {
+    if constexpr (TA && BN == 64) {
         if (ep.mode == 4) {
             // Round 4: Adam fused behind the weight-gradient GEMM (round 3 wrote the gradient -- 4 B per parameter -- and a separate
             // pass over the flat arrays read it back with w, m, v: 36 B per parameter and step, now 24).  The tile goes through LDS
@@ -110,14 +126,14 @@ __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ desc
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Cs[wm + 16 * i + 4 * lj + r][wn + 16 * j + li] = acc[i][j][r];
             __syncthreads();
             const int64_t base = d.C - ep.P;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int piece = tid + 256 * q, rr = piece >> 4, c4 = (piece & 15) * 4;
+                const int pc = tid + 256 * q, rr = pc >> 4, c4 = (pc & 15) * 4;
                 const int row = m0 + rr, col = n0 + c4;
                 if (row >= M || col >= d.N) continue;
                 const int64_t o = base + (int64_t)row * d.ldc + col;
@@ -141,7 +157,7 @@ __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ desc
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int col = n0 + wn + 16 * j + li;
             if (col >= d.N) continue;
 #pragma unroll
@@ -228,17 +244,25 @@ __global__ __launch_bounds__(256) void k_gen_output(float* __restrict__ Z, int l
     if (threadIdx.x == 0) loss_sum[(int64_t)k * GEN_OUT_CH + blockIdx.y] += red[0] + red[1] + red[2] + red[3];
 }
 
-// bias gradients: gb[n] = sum_b dZ[b][n] -> Keras-Adam on the bias (one workgroup per (sub-net, layer) entry of `descs`: A = dZ, N, lda;
-// C addresses the bias inside the flat parameter array, whose offsets the m / v arrays share: ep as in k_gen_gemm's mode 4)
+// bias gradients: gb[n] = sum_b dZ[b][n] -> Keras-Adam on the bias.  grid (ceil(N / 64), entries of `descs` = sub-net x layer), 256
+// threads = 64 columns x 4 row groups (round 3: ONE workgroup per entry with a serial loop over the batch: 28 us per launch on 40 of
+// 256 CUs); the four partial sums of a column are added in row-group order.  A = dZ, N, lda; C addresses the bias inside the flat
+// parameter array, whose offsets the m / v arrays share (ep as in k_gen_gemm's mode 4).
 __global__ __launch_bounds__(256) void k_gen_colsum_adam(const GDesc* __restrict__ descs, int M, GEpi ep) {
-    const GDesc d = descs[blockIdx.x];
-    const int64_t base = d.C - ep.P;
-    for (int n = threadIdx.x; n < d.N; n += 256) {
-        float s = 0.f;
-        for (int b = 0; b < M; ++b) s += d.A[(int64_t)b * d.lda + n];
-        float w = ep.P[base + n], m = ep.Mo[base + n], v = ep.Vo[base + n];
-        adam1(w, m, v, s, ep.ap);
-        ep.P[base + n] = w; ep.Mo[base + n] = m; ep.Vo[base + n] = v;
+    __shared__ float part[4][64];
+    const GDesc d = descs[blockIdx.y];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6, n = blockIdx.x * 64 + c;
+    float s = 0.f;
+    if (n < d.N)
+        for (int b = rg; b < M; b += 4) s += d.A[(int64_t)b * d.lda + n];
+    part[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && n < d.N) {
+        const float g = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+        const int64_t o = (d.C - ep.P) + n;
+        float w = ep.P[o], m = ep.Mo[o], v = ep.Vo[o];
+        adam1(w, m, v, g, ep.ap);
+        ep.P[o] = w; ep.Mo[o] = m; ep.Vo[o] = v;
     }
 }
 
