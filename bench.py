@@ -487,6 +487,9 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     from deepimpute_amd.engine import HipEngine
+    if world == 1:                                  # what a long-lived process does at start-up: HIP context + pinned bounce buffers, on a helper thread
+        from deepimpute_amd import _lib
+        _lib.warm_up_async(local_rank)
     cfg = dict(CONFIGS[args.config])
     if args.hidden:
         cfg["H"] = args.hidden

@@ -333,7 +333,13 @@ extern "C" int dimn_warm_up(int32_t device_id) {
             if (!pb && e == hipSuccess) { e = hipHostMalloc(&pb, bytes, hipHostMallocDefault); if (e != hipSuccess) pb = nullptr; }
     }
     g_pin_warming = 0;
+    lock.unlock();
     if (e != hipSuccess) return fail(DIMN_ERR_HIP, "dimn_warm_up: pinning the bounce buffers failed: %s", hipGetErrorString(e));
+    // ... and the two 128 MB device blocks the row-block pipelines (dimn_impute_finish) take per call: the first hipMalloc of that
+    // size class in a process was measured at ~40 ms each (DIMN_TRACE, "finish: allocations" 81 ms on the first predict(), 9 ms after)
+    void* blk[2] = {nullptr, nullptr};
+    for (auto& p : blk) if (dev_malloc_bytes(&p, bytes) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    for (auto& p : blk) if (p) dev_free_any(p);                   // (they wait in the arena cache)
     return DIMN_OK;
 }
 

@@ -26,7 +26,32 @@ struct GEpi {
     uint64_t seed; uint32_t epoch, step;   // step already carries the dropout layer in its top byte
     float *P, *Mo, *Vo;                    // mode 4: flat parameter array and Adam moments (same offsets)
     AdamP ap;                              // mode 4
+    int32_t ksplit;                        // > 1: split-K -- grid.z = descriptors x ksplit, every workgroup multiplies one k-range and stores its raw
+    float* part; int64_t part_stride;      //   partial tile into part[(desc * ksplit + s) * part_stride + row * N + col]; k_gen_splitk_fin applies `mode`
 };
+
+// the per-element epilogue of modes 0 .. 3 (k_gen_gemm without split-K, k_gen_splitk_fin with it)
+__device__ __forceinline__ void gen_epilogue(const GEpi& ep, const GDesc& d, int row, int col, float v) {
+    const int64_t o = (int64_t)row * d.ldc + col;
+    if (ep.mode == 1) {
+        v += d.bias[col];
+        float f, df;
+        hidden_act(ep.act, v, f, df);
+        if (ep.train) {
+            const bool keep = !(ep.rate > 0.f) || dimn_dropout_keep(ep.seed, (uint32_t)d.kg, ep.epoch, ep.step, (uint32_t)(row * d.N + col), ep.rate);
+            d.C[o] = keep ? f * ep.scale : 0.f;
+            d.G[o] = keep ? df * ep.scale : 0.f;
+        } else {
+            d.C[o] = f;
+        }
+    } else if (ep.mode == 2) {
+        d.C[o] = v + d.bias[col];
+    } else if (ep.mode == 3) {
+        d.C[o] = v * d.G[o];
+    } else {
+        d.C[o] = v;
+    }
+}
 
 // dropout key of layer `dl` (0 = first Dropout layer, the stream of the tuned kernels): the layer ordinal rides in the
 // top byte of the step word, so dl = 0 reproduces dimn_dropout_block(seed, kg, epoch, step, ...) exactly
@@ -37,16 +62,35 @@ __host__ __device__ static inline uint32_t gen_step_key(uint32_t step, int dl) {
 // Round 4: 64-deep k-steps (round 3: 16-deep -- the first layer's forward, K = D ~ 2 400 on 4 workgroups per sub-net, spent 150
 // dependent load -> LDS -> barrier rounds of ~1.3 us each: 0.2 ms of a 0.46 ms step, rocprofv3) and a 64 x 32 output tile (BN = 32)
 // for the batch-row GEMMs, whose grids were 160 workgroups on 256 CUs.
-template <bool TA, bool TB, int BN>
+// The weight-gradient instance (TA: K = the batch, one or two steps) takes 32-deep steps and lets its output tile alias the
+// operand tiles: 17 KB of LDS, eight workgroups per CU -- with 64-deep steps and a tile of its own (52 KB, three per CU) the
+// 6 080 workgroups of the first layer's gradient ran 139 instead of 120 us.
+template <bool TA, bool TB, int BN, int BK = 64>
 __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ descs, int Mo, int Ko, GEpi ep) {
-    constexpr int BK = 64, NJ = BN / 32;                         // k-depth of a step; 16-column tiles per wave
-    __shared__ __attribute__((aligned(16))) float As[BK][68], Bs[BK][BN + 4];   // [k][m], [k][n]; rows 16-byte aligned, stride 4 mod 32 words
-    __shared__ __attribute__((aligned(16))) float Cs[TA ? 64 : 1][68];          // mode 4 (the weight-gradient instance): the output tile, re-read row-wise
-    GDesc d = descs[blockIdx.z];
+    constexpr int NJ = BN / 32;                                  // 16-column tiles per wave
+    constexpr int LDB = BN + 4;
+    static_assert(!TA || BK * 68 + BK * LDB >= 64 * 68, "the output tile of mode 4 aliases the operand tiles");
+    __shared__ __attribute__((aligned(16))) float smem[BK * 68 + BK * LDB];
+    float (*As)[68] = (float (*)[68])smem;                       // [k][m]; rows 16-byte aligned, stride 4 mod 32 words
+    float (*Bs)[LDB] = (float (*)[LDB])(smem + BK * 68);         // [k][n]
+    float (*Cs)[68] = (float (*)[68])smem;                       // mode 4 (the weight-gradient instance): the output tile, re-read row-wise
+    // split-K (ep.ksplit > 1; batch-row GEMMs with a long inner dimension -- the first layer's forward: K = D ~ 2 400 against 64 rows):
+    // workgroup z multiplies k-range z % ksplit of descriptor z / ksplit and stores its raw partial tile; k_gen_splitk_fin adds the
+    // ranges in order and applies the epilogue.  Without it that GEMM is 4 workgroups per sub-net walking 38 dependent
+    // load -> LDS -> barrier steps: 146 us for 98 MB of weights (rocprofv3, 40 sub-nets).
+    const int S = ep.ksplit > 1 ? ep.ksplit : 1;
+    const int zi = (int)blockIdx.z / S, sp = (int)blockIdx.z - zi * S;
+    GDesc d = descs[zi];
     const int M = Mo >= 0 ? Mo : d.K;
     if (Ko >= 0) d.K = Ko;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BN;
     if (n0 >= d.N || m0 >= M) return;
+    int kbeg = 0;
+    if (S > 1) {
+        const int kc = ((d.K + S - 1) / S + BK - 1) / BK * BK;   // whole 64-deep steps per range (a late range may be empty: it stores zeros)
+        kbeg = sp * kc;
+        d.K = d.K < kbeg + kc ? d.K : kbeg + kc;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * (BN / 2);
@@ -59,7 +103,8 @@ __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ desc
     // a transposed B, m or n otherwise) -- requested for the NEXT step before the current one is multiplied.  Pieces that cross an
     // edge, or operands whose rows are not 16-byte aligned, fall back to guarded scalar loads.
     constexpr bool a_k = !TA, b_k = TB;                          // the operand's contiguous index is k
-    constexpr int NA = 4, NB = BN / 16;                          // pieces per thread: A 64 x 64, B 64 x BN
+    constexpr int NA = BK / 16, NB = BK * BN / 1024;             // 16-byte pieces per thread: A 64 x BK, B BK x BN
+    constexpr int KQ = BK / 4, NQ = BN / 4;                      // pieces along k / along n
     const bool a_vec = (d.lda & 3) == 0 && ((uintptr_t)d.A & 15) == 0, b_vec = (d.ldb & 3) == 0 && ((uintptr_t)d.B & 15) == 0;
     auto piece = [&](const float* base, int64_t ld, int gmaj, int gmin, int lim_maj, int lim_min, bool vec) -> f32x4 {
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -71,35 +116,37 @@ __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ desc
         }
         return v;
     };
-    // piece q of this thread: (major, minor) inside the tile; the minor index runs over 16 pieces of four
+    // piece q of this thread: (major, minor) inside the tile
     auto load_a = [&](int k0, f32x4 (&ra)[NA]) {
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
-            const int p = tid + 256 * q, maj = p >> 4, mn = (p & 15) * 4;
-            ra[q] = a_k ? piece(d.A, d.lda, m0 + maj, k0 + mn, M, d.K, a_vec) : piece(d.A, d.lda, k0 + maj, m0 + mn, d.K, M, a_vec);
+            const int p = tid + 256 * q;
+            if (a_k) { const int maj = p / KQ, mn = (p % KQ) * 4; ra[q] = piece(d.A, d.lda, m0 + maj, k0 + mn, M, d.K, a_vec); }
+            else { const int maj = p >> 4, mn = (p & 15) * 4; ra[q] = piece(d.A, d.lda, k0 + maj, m0 + mn, d.K, M, a_vec); }
         }
     };
     auto load_b = [&](int k0, f32x4 (&rb)[NB]) {
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const int p = tid + 256 * q;
-            if (b_k) { const int maj = p >> 4, mn = (p & 15) * 4; rb[q] = piece(d.B, d.ldb, n0 + maj, k0 + mn, d.N, d.K, b_vec); }
-            else { const int maj = p / (BN / 4), mn = (p % (BN / 4)) * 4; rb[q] = piece(d.B, d.ldb, k0 + maj, n0 + mn, d.K, d.N, b_vec); }
+            if (b_k) { const int maj = p / KQ, mn = (p % KQ) * 4; rb[q] = piece(d.B, d.ldb, n0 + maj, k0 + mn, d.N, d.K, b_vec); }
+            else { const int maj = p / NQ, mn = (p % NQ) * 4; rb[q] = piece(d.B, d.ldb, k0 + maj, n0 + mn, d.K, d.N, b_vec); }
         }
     };
     f32x4 ra[NA], rb[NB];
-    load_a(0, ra); load_b(0, rb);
-    for (int k0 = 0; k0 < d.K; k0 += BK) {
+    load_a(kbeg, ra); load_b(kbeg, rb);
+    for (int k0 = kbeg; k0 < d.K; k0 += BK) {
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
-            const int p = tid + 256 * q, maj = p >> 4, mn = (p & 15) * 4;
-            if (a_k) { for (int r = 0; r < 4; ++r) As[mn + r][maj] = ra[q][r]; } else *(f32x4*)&As[maj][mn] = ra[q];
+            const int p = tid + 256 * q;
+            if (a_k) { const int maj = p / KQ, mn = (p % KQ) * 4; for (int r = 0; r < 4; ++r) As[mn + r][maj] = ra[q][r]; }
+            else { const int maj = p >> 4, mn = (p & 15) * 4; *(f32x4*)&As[maj][mn] = ra[q]; }
         }
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const int p = tid + 256 * q;
-            if (b_k) { const int maj = p >> 4, mn = (p & 15) * 4; for (int r = 0; r < 4; ++r) Bs[mn + r][maj] = rb[q][r]; }
-            else { const int maj = p / (BN / 4), mn = (p % (BN / 4)) * 4; *(f32x4*)&Bs[maj][mn] = rb[q]; }
+            if (b_k) { const int maj = p / KQ, mn = (p % KQ) * 4; for (int r = 0; r < 4; ++r) Bs[mn + r][maj] = rb[q][r]; }
+            else { const int maj = p / NQ, mn = (p % NQ) * 4; *(f32x4*)&Bs[maj][mn] = rb[q]; }
         }
         __syncthreads();
         if (k0 + BK < d.K) { load_a(k0 + BK, ra); load_b(k0 + BK, rb); }
@@ -164,28 +211,26 @@ __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ desc
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm + 16 * i + 4 * lj + r;
                 if (row >= M) continue;
-                const int64_t o = (int64_t)row * d.ldc + col;
-                float v = acc[i][j][r];
-                if (ep.mode == 1) {
-                    v += d.bias[col];
-                    float f, df;
-                    hidden_act(ep.act, v, f, df);
-                    if (ep.train) {
-                        const bool keep = !(ep.rate > 0.f) || dimn_dropout_keep(ep.seed, (uint32_t)d.kg, ep.epoch, ep.step, (uint32_t)(row * d.N + col), ep.rate);
-                        d.C[o] = keep ? f * ep.scale : 0.f;
-                        d.G[o] = keep ? df * ep.scale : 0.f;
-                    } else {
-                        d.C[o] = f;
-                    }
-                } else if (ep.mode == 2) {
-                    d.C[o] = v + d.bias[col];
-                } else if (ep.mode == 3) {
-                    d.C[o] = v * d.G[o];
-                } else {
-                    d.C[o] = v;
-                }
+                if (S > 1) ep.part[((int64_t)zi * S + sp) * ep.part_stride + (int64_t)row * d.N + col] = acc[i][j][r];
+                else gen_epilogue(ep, d, row, col, acc[i][j][r]);
             }
         }
+}
+
+// second half of a split-K GEMM: element (row, col) = sum over the k-ranges of the partial tiles, in range order, then the epilogue.
+// grid (ceil(M * Nmax / 1024), descriptors), 256 threads x 4 elements.
+__global__ __launch_bounds__(256) void k_gen_splitk_fin(const GDesc* __restrict__ descs, int M, GEpi ep) {
+    const GDesc d = descs[blockIdx.y];
+    const int S = ep.ksplit;
+    const float* p0 = ep.part + (int64_t)blockIdx.y * S * ep.part_stride;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t e = ((int64_t)blockIdx.x * 4 + q) * 256 + threadIdx.x;
+        if (e >= (int64_t)M * d.N) continue;
+        const int row = (int)(e / d.N), col = (int)(e - (int64_t)row * d.N);
+        float v = 0.f;
+        for (int s2 = 0; s2 < S; ++s2) v += p0[(int64_t)s2 * ep.part_stride + e];
+        gen_epilogue(ep, d, row, col, v);
+    }
 }
 
 // Xb[k][b][Dp_k] = X_k[rows[b]][:]  (the batch rows of every sub-net, dense, so that every GEMM operand is a plain matrix)
