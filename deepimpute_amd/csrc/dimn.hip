@@ -244,13 +244,15 @@ static int use_device(dimn_handle h) {
 }
 
 // ---- process-wide cache of the LARGE device allocations ------------------------------------
-// A fresh process gets 28 GB from hipMalloc in a few milliseconds, but memory that was hipFree'd earlier in the SAME process comes
-// back slowly (the driver wipes freed VRAM before it hands it out again): the hand-over of a drop-in fit() that followed another
-// engine's life in the process took 0.19-0.62 s instead of 0.02 s (BENCH_r03 config.dropin.stages_s).  Blocks of >= 32 MB (the
-// matrix, the gathered X / Y arenas, the resident counts, predictions, correlation temporaries) are therefore never given back
-// while the process lives: a freed block waits here for the next request it fits (at most 25 % larger than asked for), oldest
-// first.  dimn_release_cached_memory() empties the cache; an allocation that fails empties it and tries once more; the cache never
-// holds more than DIMN_ARENA_CACHE_GB (default 96, 0 = no cache).
+// hipMalloc of a multi-GB block usually returns in 0.3 ms and SOMETIMES in 0.5-3.4 s -- whenever the driver has to wipe the VRAM it
+// hands out, which depends on what earlier processes left behind, not on this process's history (tools/malloc_probe.py,
+// profiles/r04_malloc_probe.txt: 19.6 GB in 0.3 ms / 483 ms / 1 071 ms / 2 295 ms in one process).  That is the 0.02 / 0.19 / 0.62 s
+// of the drop-in fit()'s hand-over (BENCH_r03 config.dropin.stages_s).  Blocks of >= 32 MB (the matrix, the gathered X / Y arenas,
+// the resident counts, predictions, correlation temporaries) are therefore never given back while the process lives: a freed
+// block waits here for the next request it fits (at most 25 % larger than asked for), and requests are rounded up to an eighth of
+// their power of two (19.49 and 19.55 GB both take a 20 GiB block: the arena of the next fit(), whose predictor lists differ by
+// a few columns, fits the previous one's).  dimn_release_cached_memory() empties the cache; an allocation that fails empties it
+// and tries once more; the cache never holds more than DIMN_ARENA_CACHE_GB (default 96, 0 = no cache, no rounding).
 static const size_t kArenaMin = (size_t)32 << 20;
 struct ArenaPool {
     struct Blk { void* p; size_t bytes; int dev; };
@@ -261,6 +263,12 @@ struct ArenaPool {
     hipError_t get(void** out, size_t bytes) {
         int dev = 0;
         (void)hipGetDevice(&dev);
+        if (cap_gb() > 0.0) {                                    // size classes: multiples of 2^floor(log2(bytes)) / 8
+            size_t p2 = (size_t)1 << 25;
+            while ((p2 << 1) <= bytes) p2 <<= 1;
+            const size_t gran = p2 >> 3;
+            bytes = (bytes + gran - 1) / gran * gran;
+        }
         {
             std::lock_guard<std::mutex> lk(mu);
             size_t best = idle.size();

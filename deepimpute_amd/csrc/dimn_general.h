@@ -218,19 +218,47 @@ __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ desc
 }
 
 // second half of a split-K GEMM: element (row, col) = sum over the k-ranges of the partial tiles, in range order, then the epilogue.
-// grid (ceil(M * Nmax / 1024), descriptors), 256 threads x 4 elements.
+// grid (ceil(M * N / 1024), descriptors), 256 threads x FOUR CONSECUTIVE elements: one 16-byte load per partial tile, and (hidden
+// layers in training) ONE Philox block for the four keep decisions -- element e draws word e & 3 of block e >> 2, so four aligned
+// elements share a block (the first version took one element per thread and computed the block four times: 25 us per launch).
 __global__ __launch_bounds__(256) void k_gen_splitk_fin(const GDesc* __restrict__ descs, int M, GEpi ep) {
     const GDesc d = descs[blockIdx.y];
     const int S = ep.ksplit;
     const float* p0 = ep.part + (int64_t)blockIdx.y * S * ep.part_stride;
-    for (int q = 0; q < 4; ++q) {
-        const int64_t e = ((int64_t)blockIdx.x * 4 + q) * 256 + threadIdx.x;
-        if (e >= (int64_t)M * d.N) continue;
-        const int row = (int)(e / d.N), col = (int)(e - (int64_t)row * d.N);
-        float v = 0.f;
-        for (int s2 = 0; s2 < S; ++s2) v += p0[(int64_t)s2 * ep.part_stride + e];
-        gen_epilogue(ep, d, row, col, v);
+    const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4, total = (int64_t)M * d.N;
+    if (e0 >= total) return;
+    const bool fast = (d.N & 3) == 0 && (ep.part_stride & 3) == 0 && (d.ldc & 3) == 0 && ep.mode == 1 && e0 + 3 < total;
+    if (!fast) {
+        for (int q = 0; q < 4 && e0 + q < total; ++q) {
+            const int64_t e = e0 + q;
+            const int row = (int)(e / d.N), col = (int)(e - (int64_t)row * d.N);
+            float v = 0.f;
+            for (int s2 = 0; s2 < S; ++s2) v += p0[(int64_t)s2 * ep.part_stride + e];
+            gen_epilogue(ep, d, row, col, v);
+        }
+        return;
     }
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s2 = 0; s2 < S; ++s2) v += *(const f32x4*)(p0 + (int64_t)s2 * ep.part_stride + e0);
+    const int row = (int)(e0 / d.N), col = (int)(e0 - (int64_t)row * d.N);      // N % 4 == 0: the four elements share the row
+    const int64_t o = (int64_t)row * d.ldc + col;
+    const f32x4 bias = *(const f32x4*)(d.bias + col);
+    dimn_u32x4 rnd;
+    const bool drop = ep.train && ep.rate > 0.f;
+    if (drop) rnd = dimn_dropout_block(ep.seed, (uint32_t)d.kg, ep.epoch, ep.step, (uint32_t)(e0 >> 2));     // (row * N + col == e0)
+    f32x4 c, g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float f, df;
+        hidden_act(ep.act, v[r] + bias[r], f, df);
+        if (ep.train) {
+            const bool keep = !drop || dimn_u01(rnd.v[r]) >= ep.rate;
+            c[r] = keep ? f * ep.scale : 0.f;
+            g[r] = keep ? df * ep.scale : 0.f;
+        } else c[r] = f;
+    }
+    *(f32x4*)(d.C + o) = c;
+    if (ep.train) *(f32x4*)(d.G + o) = g;
 }
 
 // Xb[k][b][Dp_k] = X_k[rows[b]][:]  (the batch rows of every sub-net, dense, so that every GEMM operand is a plain matrix)
@@ -249,10 +277,11 @@ __global__ __launch_bounds__(256) void k_gen_gather_batch(const SubnetDev* __res
 
 // Output layer: yhat = softplus(Z); the loss of build()'s `loss` (multinet.py:150-162) and dZ = dL/dZ in place.
 // grid (K, GEN_OUT_CH), block 256: workgroup (k, c) takes every GEN_OUT_CH-th stripe of 256 elements of sub-net k (round 2
-// launched ONE workgroup per sub-net: 40 of 256 CUs busy, 28 % of a general-path step).  out != NULL (predict):
+// launched ONE workgroup per sub-net: 40 of 256 CUs busy, 28 % of a general-path step; round 3 sixteen, each walking eight dependent
+// load -> softplus -> store rounds: 20 us; now 64).  out != NULL (predict):
 // out[(row0 + b)][k*O + o] = yhat, no loss.  loss_sum[k][c] += sum of the per-element loss terms of the workgroup's stripes (one
 // owner per slot: deterministic; the host adds the slots and divides by the element count); train != 0 writes dZ over Z.
-#define GEN_OUT_CH 16
+#define GEN_OUT_CH 64
 __global__ __launch_bounds__(256) void k_gen_output(float* __restrict__ Z, int ldz, int64_t z_stride, const float* __restrict__ Y, int64_t n_cells,
                                                     const int32_t* __restrict__ rows, int64_t row0, int b_cnt, Dims dm, int loss, int train,
                                                     float inv_n, double* __restrict__ loss_sum, float* __restrict__ out, int64_t out_row0, int k_off) {
