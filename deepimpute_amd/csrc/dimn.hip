@@ -124,6 +124,9 @@ enum { kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0 };
 static std::mutex g_pin_mu;
 static void* g_pin_buf[4] = {nullptr, nullptr, nullptr, nullptr};
 static size_t g_pin_cap = 0;
+static void* g_fin_res[2] = {nullptr, nullptr};   // the two device result blocks of dimn_impute_finish's pipeline: they belong to whoever holds the shared lease
+static int g_fin_dev = -1;                         // the device they live on
+static size_t g_fin_cap = 0;                       // (the first hipMalloc of that size in a process cost 17-86 ms inside predict(); dimn_warm_up makes them)
 static volatile int g_pin_warming = 0;         // dimn_warm_up holds the lock while it pins the shared set: a pipeline that arrives meanwhile waits for it
 struct PinLease {
     std::unique_lock<std::mutex> lock;
@@ -340,14 +343,17 @@ extern "C" int dimn_warm_up(int32_t device_id) {
         for (auto& pb : g_pin_buf)
             if (!pb && e == hipSuccess) { e = hipHostMalloc(&pb, bytes, hipHostMallocDefault); if (e != hipSuccess) pb = nullptr; }
     }
+    // ... and the two 128 MB device blocks of dimn_impute_finish's row-block pipeline (DIMN_TRACE, "finish: allocations": 17-86 ms on
+    // the first predict() of a process, the hipMalloc lottery of tools/malloc_probe.py)
+    if (e == hipSuccess && g_fin_cap < bytes && (g_fin_dev < 0 || g_fin_dev == device_id)) {
+        for (auto& p : g_fin_res) { if (p) (void)hipFree(p); p = nullptr; }
+        g_fin_cap = 0;
+        if (hipMalloc(&g_fin_res[0], bytes) == hipSuccess && hipMalloc(&g_fin_res[1], bytes) == hipSuccess) { g_fin_cap = bytes; g_fin_dev = device_id; }
+        else { (void)hipGetLastError(); for (auto& p : g_fin_res) { if (p) (void)hipFree(p); p = nullptr; } }
+    }
     g_pin_warming = 0;
     lock.unlock();
     if (e != hipSuccess) return fail(DIMN_ERR_HIP, "dimn_warm_up: pinning the bounce buffers failed: %s", hipGetErrorString(e));
-    // ... and the two 128 MB device blocks the row-block pipelines (dimn_impute_finish) take per call: the first hipMalloc of that
-    // size class in a process was measured at ~40 ms each (DIMN_TRACE, "finish: allocations" 81 ms on the first predict(), 9 ms after)
-    void* blk[2] = {nullptr, nullptr};
-    for (auto& p : blk) if (dev_malloc_bytes(&p, bytes) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
-    for (auto& p : blk) if (p) dev_free_any(p);                   // (they wait in the arena cache)
     return DIMN_OK;
 }
 
@@ -1763,9 +1769,21 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
 #define FIN_TRY(expr) do { hipError_t e_ = (expr); if (rc == DIMN_OK && e_ != hipSuccess) rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
     FIN_TRY(dev_malloc_bytes((void**)&dOff, (size_t)(g + 1) * 4));
     FIN_TRY(dev_malloc_bytes((void**)&dSlot, (size_t)std::max<int64_t>(S, 1) * 4));
+    // the result blocks: the process-wide pair when this call holds the shared lease (made once, by dimn_warm_up or here), else its own
+    const size_t res_bytes = (size_t)blk * g * 8;
+    const bool shared_res = !pins.own && (g_fin_dev < 0 || g_fin_dev == h->cfg.device_id);      // (one process = one GPU in every supported layout)
+    if (shared_res && g_fin_cap < res_bytes) {
+        for (auto& p : g_fin_res) { if (p) (void)hipFree(p); p = nullptr; }
+        g_fin_cap = 0;
+        const size_t want = std::max<size_t>(res_bytes, (size_t)128u << 20);
+        if (hipMalloc(&g_fin_res[0], want) == hipSuccess && hipMalloc(&g_fin_res[1], want) == hipSuccess) { g_fin_cap = want; g_fin_dev = h->cfg.device_id; }
+        else { (void)hipGetLastError(); for (auto& p : g_fin_res) { if (p) (void)hipFree(p); p = nullptr; } }
+    }
+    const bool use_shared = shared_res && g_fin_cap >= res_bytes;
     for (int b = 0; b < 2; ++b) {
         if (!resident) FIN_TRY(dev_malloc_bytes((void**)&dRaw[b], (size_t)blk * g * 8));
-        FIN_TRY(dev_malloc_bytes((void**)&dRes[b], (size_t)blk * g * 8));
+        if (use_shared) dRes[b] = (double*)g_fin_res[b];
+        else FIN_TRY(dev_malloc_bytes((void**)&dRes[b], res_bytes));
         pIn[b] = (double*)pins.buf[b]; pOut[b] = (double*)pins.buf[2 + b];
         FIN_TRY(hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking));
         FIN_TRY(hipEventCreateWithFlags(&evOut[b], hipEventDisableTiming));
@@ -1816,7 +1834,7 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
         if (st[b]) { (void)hipStreamSynchronize(st[b]); (void)hipStreamDestroy(st[b]); }
         if (evOut[b]) (void)hipEventDestroy(evOut[b]);
         if (dRaw[b]) (void)dev_free_any(dRaw[b]);
-        if (dRes[b]) (void)dev_free_any(dRes[b]);
+        if (dRes[b] && !use_shared) (void)dev_free_any(dRes[b]);
     }
     if (dOff) (void)dev_free_any(dOff);
     if (dSlot) (void)dev_free_any(dSlot);

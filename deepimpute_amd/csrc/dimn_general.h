@@ -15,6 +15,8 @@ struct GDesc {                 // one GEMM of one sub-net:  C[M][N] = op(A)[M][K
     const float* bias;         // epilogue 1, 2: [N]
     float* G;                  // epilogue 1: gate out [M][N] (ldc); epilogue 3: gate in
     int32_t N, K, lda, ldb, ldc, kg;
+    int32_t agather;           // 1: A is not a dense matrix but the batch rows of this sub-net's block of the X arena (GEpi.xbase / arows): the
+                               //    first layer's forward and weight-gradient GEMMs read the gathered predictors in place (fp32 arenas)
 };
 
 struct GEpi {
@@ -26,6 +28,8 @@ struct GEpi {
     uint64_t seed; uint32_t epoch, step;   // step already carries the dropout layer in its top byte
     float *P, *Mo, *Vo;                    // mode 4: flat parameter array and Adam moments (same offsets)
     AdamP ap;                              // mode 4
+    const float* xbase; const SubnetDev* sn;   // agather descriptors: the X arena and the sub-nets' blocks in it (xoff, Dp), descriptor i <-> sub-net i
+    const int32_t* arows; int64_t arow0;       //   batch row b = arows[b] (device row list) or arow0 + b
     int32_t ksplit;                        // > 1: split-K -- grid.z = descriptors x ksplit, every workgroup multiplies one k-range and stores its raw
     float* part; int64_t part_stride;      //   partial tile into part[(desc * ksplit + s) * part_stride + row * N + col]; k_gen_splitk_fin applies `mode`
 };
@@ -102,14 +106,20 @@ __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ desc
     // Staging: every thread moves 16-byte pieces -- four elements along the operand's memory-contiguous index (k for a row-major A /
     // a transposed B, m or n otherwise) -- requested for the NEXT step before the current one is multiplied.  Pieces that cross an
     // edge, or operands whose rows are not 16-byte aligned, fall back to guarded scalar loads.
+    // Round 4: the first layer reads its batch rows straight from the gathered X arena (row b of the operand = arena row arows[b]):
+    // the dense copy k_gen_gather_batch made of them every step -- 24.6 MB out and in again, 18.5 us -- is gone for fp32 arenas.
+    const float* Abase = d.A;
+    int64_t a_ld = d.lda;
+    if (d.agather) { const SubnetDev sd = ep.sn[zi]; Abase = ep.xbase + sd.xoff; a_ld = sd.Dp; }
     constexpr bool a_k = !TA, b_k = TB;                          // the operand's contiguous index is k
     constexpr int NA = BK / 16, NB = BK * BN / 1024;             // 16-byte pieces per thread: A 64 x BK, B BK x BN
     constexpr int KQ = BK / 4, NQ = BN / 4;                      // pieces along k / along n
-    const bool a_vec = (d.lda & 3) == 0 && ((uintptr_t)d.A & 15) == 0, b_vec = (d.ldb & 3) == 0 && ((uintptr_t)d.B & 15) == 0;
-    auto piece = [&](const float* base, int64_t ld, int gmaj, int gmin, int lim_maj, int lim_min, bool vec) -> f32x4 {
+    const bool a_vec = (a_ld & 3) == 0 && ((uintptr_t)Abase & 15) == 0, b_vec = (d.ldb & 3) == 0 && ((uintptr_t)d.B & 15) == 0;
+    auto piece = [&](const float* base, int64_t ld, int gmaj, int gmin, int lim_maj, int lim_min, bool vec, bool rows = false) -> f32x4 {
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (gmaj < lim_maj) {
-            const float* p = base + (int64_t)gmaj * ld + gmin;
+            const int64_t r = rows ? (ep.arows ? (int64_t)ep.arows[gmaj] : ep.arow0 + gmaj) : (int64_t)gmaj;    // (the major index of A is the batch row in both forms)
+            const float* p = base + r * ld + gmin;
             if (vec && gmin + 3 < lim_min) v = *(const f32x4*)p;
             else
                 for (int r = 0; r < 4; ++r) if (gmin + r < lim_min) v[r] = p[r];
@@ -121,8 +131,8 @@ __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ desc
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
             const int p = tid + 256 * q;
-            if (a_k) { const int maj = p / KQ, mn = (p % KQ) * 4; ra[q] = piece(d.A, d.lda, m0 + maj, k0 + mn, M, d.K, a_vec); }
-            else { const int maj = p >> 4, mn = (p & 15) * 4; ra[q] = piece(d.A, d.lda, k0 + maj, m0 + mn, d.K, M, a_vec); }
+            if (a_k) { const int maj = p / KQ, mn = (p % KQ) * 4; ra[q] = piece(Abase, a_ld, m0 + maj, k0 + mn, M, d.K, a_vec, d.agather != 0); }
+            else { const int maj = p >> 4, mn = (p & 15) * 4; ra[q] = piece(Abase, a_ld, k0 + maj, m0 + mn, d.K, M, a_vec, d.agather != 0); }
         }
     };
     auto load_b = [&](int k0, f32x4 (&rb)[NB]) {
