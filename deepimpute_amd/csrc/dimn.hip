@@ -126,6 +126,8 @@ static void* g_pin_buf[4] = {nullptr, nullptr, nullptr, nullptr};
 static size_t g_pin_cap = 0;
 static void* g_fin_res[2] = {nullptr, nullptr};   // the two device result blocks of dimn_impute_finish's pipeline: they belong to whoever holds the shared lease
 static int g_fin_dev = -1;                         // the device they live on
+static hipStream_t g_fin_st[2] = {nullptr, nullptr};     // ... and the pipeline's two streams / events (an HSA queue per stream: ~10-25 ms to create)
+static hipEvent_t g_fin_ev[2] = {nullptr, nullptr};
 static size_t g_fin_cap = 0;                       // (the first hipMalloc of that size in a process cost 17-86 ms inside predict(); dimn_warm_up makes them)
 static volatile int g_pin_warming = 0;         // dimn_warm_up holds the lock while it pins the shared set: a pipeline that arrives meanwhile waits for it
 struct PinLease {
@@ -351,6 +353,11 @@ extern "C" int dimn_warm_up(int32_t device_id) {
         if (hipMalloc(&g_fin_res[0], bytes) == hipSuccess && hipMalloc(&g_fin_res[1], bytes) == hipSuccess) { g_fin_cap = bytes; g_fin_dev = device_id; }
         else { (void)hipGetLastError(); for (auto& p : g_fin_res) { if (p) (void)hipFree(p); p = nullptr; } }
     }
+    if (e == hipSuccess && g_fin_dev == device_id)
+        for (int b = 0; b < 2; ++b) {
+            if (!g_fin_st[b] && hipStreamCreateWithFlags(&g_fin_st[b], hipStreamNonBlocking) != hipSuccess) { g_fin_st[b] = nullptr; (void)hipGetLastError(); }
+            if (!g_fin_ev[b] && hipEventCreateWithFlags(&g_fin_ev[b], hipEventDisableTiming) != hipSuccess) { g_fin_ev[b] = nullptr; (void)hipGetLastError(); }
+        }
     g_pin_warming = 0;
     lock.unlock();
     if (e != hipSuccess) return fail(DIMN_ERR_HIP, "dimn_warm_up: pinning the bounce buffers failed: %s", hipGetErrorString(e));
@@ -1785,8 +1792,14 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
         if (use_shared) dRes[b] = (double*)g_fin_res[b];
         else FIN_TRY(dev_malloc_bytes((void**)&dRes[b], res_bytes));
         pIn[b] = (double*)pins.buf[b]; pOut[b] = (double*)pins.buf[2 + b];
-        FIN_TRY(hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking));
-        FIN_TRY(hipEventCreateWithFlags(&evOut[b], hipEventDisableTiming));
+        if (use_shared) {
+            if (!g_fin_st[b]) FIN_TRY(hipStreamCreateWithFlags(&g_fin_st[b], hipStreamNonBlocking));
+            if (!g_fin_ev[b]) FIN_TRY(hipEventCreateWithFlags(&g_fin_ev[b], hipEventDisableTiming));
+            st[b] = g_fin_st[b]; evOut[b] = g_fin_ev[b];
+        } else {
+            FIN_TRY(hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking));
+            FIN_TRY(hipEventCreateWithFlags(&evOut[b], hipEventDisableTiming));
+        }
     }
     if (rc == DIMN_OK) {
         FIN_TRY(hipMemcpy(dOff, gene_off, (size_t)(g + 1) * 4, hipMemcpyHostToDevice));
@@ -1831,8 +1844,8 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
 #undef FIN_TRY
     tr.lap("finish: pipeline");
     for (int b = 0; b < 2; ++b) {
-        if (st[b]) { (void)hipStreamSynchronize(st[b]); (void)hipStreamDestroy(st[b]); }
-        if (evOut[b]) (void)hipEventDestroy(evOut[b]);
+        if (st[b]) { (void)hipStreamSynchronize(st[b]); if (!use_shared) (void)hipStreamDestroy(st[b]); }
+        if (evOut[b] && !use_shared) (void)hipEventDestroy(evOut[b]);
         if (dRaw[b]) (void)dev_free_any(dRaw[b]);
         if (dRes[b] && !use_shared) (void)dev_free_any(dRes[b]);
     }
