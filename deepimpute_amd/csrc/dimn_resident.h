@@ -62,12 +62,8 @@
 #define DIMN_RES_W2S 27104        // LDS float offset of the W2 state
 #define DIMN_RES_LDS_FLOATS (DIMN_RES_W2S + 3 * 16 * 256)
 #define DIMN_RES_SLOTS 2
-#ifndef DIMN_RES_ABL
-#define DIMN_RES_ABL 0          // timing ablations of the tile loop (tools/r03_res_abl.sh): 1 = no Adam, 2 = no LDS staging of the X tiles (loads kept), 4 = no X tile loads (staging kept); WRONG results
-#endif
-#ifndef DIMN_RES_M2WIN
-#define DIMN_RES_M2WIN 8        // dD partial requests in flight per thread in M2 (16: tried)
-#endif          // slots per exchange buffer (step parity)
+// (round 3's experiment switches -- DIMN_RES_EVEN / _DIRECT / _XCD / _GDIRECT / _M2WIN / _ABL -- are gone from the source; what each
+//  measured is in DESIGN.md section 2b and profiles/r03_resident_*.txt)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -84,19 +80,10 @@ __device__ unsigned long long g_res_tl[1024 * 16];
 
 // The D-chunks [cb, ce) of sub-net chunks 0..nchunk-1 that D-split `sp` of S1 owns: the even split.  A workgroup's tile loop
 // is bound by the matrix pipe of its busiest SIMD (waves w and w + 4 share one): ceil(c / 4) tile-times for c chunks, so the
-// even split is also the fastest one for the manager, whose loop every step waits for.  Measured (DIMN_RES_EVEN=0): giving the
-// siblings whole tiles and the manager the rest (150 chunks: 48 / 48 / 54, so that both hand-offs around the manager travel
-// under its last tile) puts 14 instead of 13 tiles on two of the manager's SIMDs: 24.3 vs 23.7 us per step.
-#ifndef DIMN_RES_EVEN
-#define DIMN_RES_EVEN 1
-#endif
+// even split is also the fastest one for the manager, whose loop every step waits for.  (Measured in round 3: giving the
+// siblings whole tiles and the manager the rest -- 150 chunks: 48 / 48 / 54, so that both hand-offs around the manager travel
+// under its last tile -- puts 14 instead of 13 tiles on two of the manager's SIMDs: 24.3 vs 23.7 us per step.)
 __host__ __device__ static inline void res_chunk_range(int nchunk, int S1, int sp, int& cb, int& ce) {
-    const int tiles_even = ((nchunk + S1 - 1) / S1 + 7) / 8;
-    const int cs = 8 * (tiles_even - 1), cm = nchunk - (S1 - 1) * cs;
-    if (!DIMN_RES_EVEN && S1 > 1 && cs >= 1 && cm >= 1 && cm <= 8 * tiles_even) {
-        cb = sp * cs; ce = sp == S1 - 1 ? nchunk : cb + cs;
-        return;
-    }
     cb = (int)((int64_t)nchunk * sp / S1); ce = (int)((int64_t)nchunk * (sp + 1) / S1);
 }
 
@@ -173,26 +160,6 @@ __device__ __forceinline__ void res_fix(f32x4& x, __amdgpu_buffer_rsrc_t r, uint
         if (++spins > DIMN_RES_SPIN_LIMIT) { __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
 }
-// DIMN_RES_DIRECT=1: a SMALL payload (one 16-byte piece per lane: the P tiles of the siblings, the dA tile) is waited for on the
-// data itself, no canary round trip in front of it -- every lane re-requests its piece until the whole wave has seen written
-// data (s_sleep between rounds); wall-clock bounded.  Measured: 23.4 / 24.0 vs 23.9 / 23.7 us per step with the canary (two
-// runs each, one box): no difference, so the canary form (less polling traffic) ships.
-#ifndef DIMN_RES_DIRECT
-#define DIMN_RES_DIRECT 0
-#endif
-__device__ __forceinline__ void res_spin(f32x4& x, __amdgpu_buffer_rsrc_t r, uint32_t off, unsigned* abort_w) {
-    unsigned spins = 0;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_ballot_w64(res_unwritten(x)) != 0) {
-        __builtin_amdgcn_s_sleep(2);
-        asm volatile("" ::: "memory");
-        x = res_ld(r, off);
-        if ((++spins & 63u) == 0u) {
-            if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > DIMN_RES_WAIT_TICKS) { __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-    }
-}
 // The dropout keep words of a whole epoch (they depend on no data): maskw[t][k][row b][word h/32], bit h%32 = keep(b, h);
 // Philox block (b*H)/4 + h/4 of step t gives four units.  grid (steps * K), 512 threads: one word per thread.
 __global__ __launch_bounds__(512) void k_res_masks(const SubnetDev* __restrict__ sn, unsigned* __restrict__ maskw, int K, int H,
@@ -209,19 +176,14 @@ __global__ __launch_bounds__(512) void k_res_masks(const SubnetDev* __restrict__
     maskw[(size_t)blockIdx.x * 512 + ww] = word;
 }
 
-// One X tile of a virtual tile of role1, as raw register words.  A forward tile is four row-major 16-byte pieces (row16); with
-// DIMN_RES_GDIRECT a gradient tile is SIXTEEN single elements X[b = 4kb+lj][d = li] (elem): exactly the A operand of the matrix
-// instruction X_t^T dA -- one coalesced 64-byte run per four rows and request, no transposition through LDS.
-#ifndef DIMN_RES_GDIRECT
-#define DIMN_RES_GDIRECT 0
-#endif
+// One X tile of a virtual tile of role1, as raw register words: four row-major 16-byte pieces (row16).  (Round 3 also tried taking
+// a gradient tile as SIXTEEN single elements X[b = 4kb+lj][d = li] -- exactly the A operand of X_t^T dA, no transposition through
+// LDS: 27.7 vs 23.5 us per step, sixteen vector-memory instructions per tile cost more than four plus the LDS round trip.)
 template <typename XT> struct XSlot;
 template <> struct XSlot<float> {
     uint32_t w[16];
     __device__ __forceinline__ void load_row16(int i, const float* q) { const f32x4 t = *(const f32x4*)q; for (int r = 0; r < 4; ++r) w[4 * i + r] = __float_as_uint(t[r]); }
     __device__ __forceinline__ f32x4 row16(int i) const { return (f32x4){__uint_as_float(w[4 * i]), __uint_as_float(w[4 * i + 1]), __uint_as_float(w[4 * i + 2]), __uint_as_float(w[4 * i + 3])}; }
-    __device__ __forceinline__ void load_elem(int kb, const float* q) { w[kb] = __float_as_uint(*q); }
-    __device__ __forceinline__ float elem(int kb) const { return __uint_as_float(w[kb]); }
 };
 template <> struct XSlot<bf16_t> {
     uint32_t w[16];
@@ -229,8 +191,6 @@ template <> struct XSlot<bf16_t> {
     __device__ __forceinline__ f32x4 row16(int i) const {
         return (f32x4){__uint_as_float(w[2 * i] << 16), __uint_as_float(w[2 * i] & 0xffff0000u), __uint_as_float(w[2 * i + 1] << 16), __uint_as_float(w[2 * i + 1] & 0xffff0000u)};
     }
-    __device__ __forceinline__ void load_elem(int kb, const bf16_t* q) { w[kb] = (uint32_t)*q; }
-    __device__ __forceinline__ float elem(int kb) const { return __uint_as_float(w[kb] << 16); }
 };
 // Order of the tile loop's "virtual tiles" (role1).  Alternating (g0 f0 g1 f1 ..: gradient tile j, forward tile j): every row
 // request has ONE tile-time of lead.  SPLIT (all gradient tiles, then the forward tiles: g0 g1 .. f0 f1 ..): TWO tile-times from
@@ -274,18 +234,10 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
     const int G = p.G, S1 = S1C > 0 ? S1C : p.S1;
     // Workgroup -> (sub-net, D-split, hidden tile): the plain order.  Observed (MI355X guide: "for speed only"): block b runs on XCD
     // b % 8, so the sixteen hidden-tile workgroups of one (sub-net, D-split) -- which read the SAME batch rows of X -- sit on all
-    // eight XCDs and X reaches every L2 separately (PMC: ~49 of the 92 MB per step at 5 sub-nets).  Tried (DIMN_RES_XCD=1): blocks
-    // of one XCD for each such group (consecutive slots of the list "XCD 0's blocks, XCD 1's blocks, ...", a bijection).  The tile
-    // loop got ~9 % shorter, but a sub-net's 32 role-2 workgroups then read their 64 KB of Dd tiles through two XCDs' fabric ports
-    // instead of eight at the same moment: 24.7 vs 23.8 us per step (two A/B pairs, one box).  The plain order ships.
-#ifndef DIMN_RES_XCD
-#define DIMN_RES_XCD 0
-#endif
-    int slot = (int)blockIdx.x;
-    if (DIMN_RES_XCD) {
-        const int nb = (int)gridDim.x, x = slot & 7, j = slot >> 3, q = nb >> 3, r = nb & 7;      // XCD x holds q + 1 blocks if x < r, else q
-        slot = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-    }
+    // eight XCDs and X reaches every L2 separately (PMC: ~49 of the 92 MB per step at 5 sub-nets).  Round 3 tried blocks of one XCD
+    // for each such group: the tile loop got ~9 % shorter, but a sub-net's 32 role-2 workgroups then read their 64 KB of Dd tiles
+    // through two XCDs' fabric ports instead of eight at the same moment: 24.7 vs 23.8 us per step.  The plain order ships.
+    const int slot = (int)blockIdx.x;
     const int kl = slot / G, wi = slot - kl * G;
     const int k = p.k0 + kl;                                 // sub-net of the handle (every array below is indexed by it)
     const int ht = wi & 15, sp = wi >> 4;
@@ -376,64 +328,40 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
     // xr[0] / xr[1]: virtual tiles 0 and 1, requested by the caller (before its wait);
     // xot / xon from xrows().  The partial goes to the manager of the hidden tile: a sibling publishes it (slot_out), the manager
     // keeps its own in LDS (yl) until it sums the tile (M1).
-    auto role1 = [&](auto grad_c, const int tid, const uint32_t (&xot)[4], const uint32_t (&xon)[4], const uint32_t (&xog)[16], XSlot<XT> (&xr)[2], bool do_fwd,
+    auto role1 = [&](auto grad_c, const int tid, const uint32_t (&xot)[4], const uint32_t (&xon)[4], XSlot<XT> (&xr)[2], bool do_fwd,
                      const float (&bfr)[16], const AdamP ap, uint32_t slot_out) {
         constexpr bool GRAD = decltype(grad_c)::value;
         constexpr int NV = GRAD ? 2 * T1 : T1;
         const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lj = lane >> 4;
         const XT* xk = (const XT*)p.X + s.xoff + 4 * (lane & 3);
-        const XT* xg = (const XT*)p.X + s.xoff + li;              // (DIMN_RES_GDIRECT) element d = li of a row
         float* xs = xst + wave * 2048;                           // two wave-private staging tiles, alternating
         f32x4 pT[4] = {zero4, zero4, zero4, zero4};
-        float abl_sink = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const bool fwd = res_vfwd<GRAD, SPLIT, T1>(v);
             const int j = res_vtile<GRAD, SPLIT, T1>(v);
             const bool live = tv[j] || j == 0;                   // wave-uniform: a wave's tiles are its first ones (tile 0 always runs: it may be a clamped one)
             float* xv = xs + (v & 1) * 1024;
-            auto request = [&]() {                               // the X tile of position v + 2 into the register set of position v
-                if (v + 2 < NV && (!(DIMN_RES_ABL & 4) || !GRAD)) {
-                    const bool f2 = res_vfwd<GRAD, SPLIT, T1>(v + 2);
-                    const int j2 = res_vtile<GRAD, SPLIT, T1>(v + 2);
-                    if (DIMN_RES_GDIRECT && !f2) {
-#pragma unroll
-                        for (int kb = 0; kb < 16; ++kb) xr[v & 1].load_elem(kb, xg + xog[kb] + 16 * tc[j2]);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) xr[v & 1].load_row16(i, xk + (f2 ? xon[i] : xot[i]) + 16 * tc[j2]);
-                    }
-                }
-            };
-            if (DIMN_RES_GDIRECT && !fwd) {
-                // operands straight from the registers: the request for position v + 2 follows the matrix instructions that read them
-            } else if (live && (!(DIMN_RES_ABL & 2) || !GRAD)) {
+            if (live) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) *(f32x4*)(xv + 256 * i + 4 * lane) = xr[v & 1].row16(i);   // wave-private staging (in-order LDS, no barrier)
-            } else if (DIMN_RES_ABL & 2) {
+            }
+            if (v + 2 < NV) {                                    // the X tile of position v + 2 into the register set of position v
+                const bool f2 = res_vfwd<GRAD, SPLIT, T1>(v + 2);
+                const int j2 = res_vtile<GRAD, SPLIT, T1>(v + 2);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) abl_sink += xr[v & 1].row16(i)[0];                         // (ablation: the loads stay live)
+                for (int i = 0; i < 4; ++i) xr[v & 1].load_row16(i, xk + (f2 ? xon[i] : xot[i]) + 16 * tc[j2]);
             }
-            if (!(DIMN_RES_GDIRECT && !fwd)) {
-                request();
-                __builtin_amdgcn_sched_barrier(0);               // the requests leave before this tile's MFMAs
-            }
+            __builtin_amdgcn_sched_barrier(0);                   // the requests leave before this tile's MFMAs
             if (!fwd) {
                 f32x4 g = zero4;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {                    // A = X_t^T[d = li][b = 4kb+lj], B = dA[b = 4kb+lj][h = li], kb = 4q + r
-                    const f32x4 xq = DIMN_RES_GDIRECT ? (f32x4){xr[v & 1].elem(4 * q), xr[v & 1].elem(4 * q + 1), xr[v & 1].elem(4 * q + 2), xr[v & 1].elem(4 * q + 3)}
-                                                      : (f32x4){xv[64 * (4 * q) + lane], xv[64 * (4 * q + 1) + lane], xv[64 * (4 * q + 2) + lane], xv[64 * (4 * q + 3) + lane]};
+                    const f32x4 xq = (f32x4){xv[64 * (4 * q) + lane], xv[64 * (4 * q + 1) + lane], xv[64 * (4 * q + 2) + lane], xv[64 * (4 * q + 3) + lane]};
                     const f32x4 bq = (f32x4){bfr[4 * q], bfr[4 * q + 1], bfr[4 * q + 2], bfr[4 * q + 3]};
                     g = res_mfma4<BF>(xq, bq, g);
                 }
-                if (DIMN_RES_GDIRECT) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    request();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (tv[j] && !(DIMN_RES_ABL & 1)) adam4(w1[j], m1[j], v1[j], g, ap);
-                if (DIMN_RES_ABL & 1) w1[j] += g * 1e-30f;             // (ablation: the gradient stays live)
+                if (tv[j]) adam4(w1[j], m1[j], v1[j], g, ap);
             } else if (do_fwd && tv[j]) {                        // wave-uniform
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
@@ -442,7 +370,6 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 }
             }
         }
-        if ((DIMN_RES_ABL & 2) && abl_sink == 12345.678f) pT[0][0] += 1.f;
         RES_STAMP(8)
         if (do_fwd) {
 #pragma unroll
@@ -493,8 +420,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
 #pragma unroll
         for (int i = 0; i < 4; ++i) { xr[0].load_row16(i, xk + xo0[i] + 16 * tc[0]); xr[1].load_row16(i, xk + xo0[i] + 16 * tc[T1 > 1 ? 1 : 0]); }
         __syncthreads();                                         // b1l written
-        const uint32_t nog[16] = {0u};
-        role1(std::false_type{}, tid, xo0, xo0, nog, xr, true, nob, ap0, 0u);
+        role1(std::false_type{}, tid, xo0, xo0, xr, true, nob, ap0, 0u);
         y_a = targets(tid, target_row(tid, 0));
     }
 
@@ -529,14 +455,13 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             constexpr int NS = S1C > 0 ? S1C - 1 : 7;            // siblings (run-time S1: up to 7, clamped requests)
             f32x4 a = *(const f32x4*)(yl + 4 * tid);
             if (S1 > 1) {
-                if (!DIMN_RES_DIRECT) (void)res_poll(rP, pcur + (uint32_t)(ht * 4096), S1 - 1, 65536u, abort_w);      // (abort: the next workgroup-wide wait leaves)
+                (void)res_poll(rP, pcur + (uint32_t)(ht * 4096), S1 - 1, 65536u, abort_w);      // (abort: the next workgroup-wide wait leaves)
                 f32x4 pv[NS > 0 ? NS : 1];
 #pragma unroll
                 for (int ss = 0; ss < NS; ++ss) pv[ss] = res_ld(rP, pcur + (uint32_t)(((ss < S1 - 1 ? ss : 0) * 16 + ht) * 4096 + 16 * tid));
 #pragma unroll
                 for (int ss = 0; ss < NS; ++ss) {
-                    if (DIMN_RES_DIRECT) res_spin(pv[ss], rP, pcur + (uint32_t)(((ss < S1 - 1 ? ss : 0) * 16 + ht) * 4096 + 16 * tid), abort_w);
-                    else res_fix(pv[ss], rP, pcur + (uint32_t)(((ss < S1 - 1 ? ss : 0) * 16 + ht) * 4096 + 16 * tid), abort_w);
+                    res_fix(pv[ss], rP, pcur + (uint32_t)(((ss < S1 - 1 ? ss : 0) * 16 + ht) * 4096 + 16 * tid), abort_w);
                     if (ss < S1 - 1) a += pv[ss];
                 }
             }
@@ -703,33 +628,14 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
 #pragma unroll
             for (int i = 0; i < 4; ++i) xon[i] = b_next > 0 ? (uint32_t)rn[i] * (uint32_t)s.Dp : xo0[i];
             XSlot<XT> xr[2];
-            int32_t rg[16];                                                              // (DIMN_RES_GDIRECT) rows 4kb + lj of the CURRENT batch
-                if (DIMN_RES_GDIRECT) {
-#pragma unroll
-                    for (int kb = 0; kb < 16; ++kb) {
-                            const int b = 4 * kb + (lane >> 4);
-                            int pos = t * B + (b < b_act ? b : 0);
-                            pos = pos < p.n_tr ? pos : p.n_tr - 1;
-                            rg[kb] = p.rows[pos];
-                    }
-                }
-            uint32_t xog[16];                                    // (DIMN_RES_GDIRECT) rows b = 4kb + lj of the CURRENT batch, element offsets
-#pragma unroll
-            for (int kb = 0; kb < 16; ++kb) xog[kb] = DIMN_RES_GDIRECT ? (uint32_t)rg[kb] * (uint32_t)s.Dp : 0u;
             {   // virtual tiles 0 and 1 of the step's tile loop
                 const XT* xk = (const XT*)p.X + s.xoff + 4 * (lane & 3);
-                const XT* xg = (const XT*)p.X + s.xoff + (lane & 15);
 #pragma unroll
                 for (int vv = 0; vv < 2; ++vv) {
                     const bool f = res_vfwd<true, SPLIT, T1>(vv);
                     const int jj = res_vtile<true, SPLIT, T1>(vv);
-                    if (DIMN_RES_GDIRECT && !f) {
 #pragma unroll
-                        for (int kb = 0; kb < 16; ++kb) xr[vv].load_elem(kb, xg + xog[kb] + 16 * tc[jj]);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) xr[vv].load_row16(i, xk + (f ? xon[i] : xo0[i]) + 16 * tc[jj]);
-                    }
+                    for (int i = 0; i < 4; ++i) xr[vv].load_row16(i, xk + (f ? xon[i] : xo0[i]) + 16 * tc[jj]);
                 }
             }
             if (t + 1 < p.steps) y_a = targets(tid, yrow_n);     // every thread (unconditional load); role 2 uses the first 256
@@ -745,16 +651,6 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                     const int o0 = half * (OT >> 1), o1 = half ? OT : (OT >> 1);
                     const uint32_t base = dcur + (uint32_t)((ht * 1024 + 4 * (tid & 255)) * 4);
                     int o = o0;
-#if DIMN_RES_M2WIN == 16
-                    if (o + 16 <= o1) {                              // all 16 producers of this half requested at once: one round trip
-                        f32x4 tq[16];
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) tq[i] = res_ld(rD, base + (uint32_t)((o + i) * 65536));
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) { res_fix(tq[i], rD, base + (uint32_t)((o + i) * 65536), abort_w); d += tq[i]; }
-                        o += 16;
-                    }
-#else
                     if (o + 16 <= o1) {                              // rolling window of 8 requests over 16 producers
                         f32x4 tq[8];
 #pragma unroll
@@ -769,7 +665,6 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                         for (int i = 0; i < 8; ++i) { res_fix(tq[i], rD, base + (uint32_t)((o + 8 + i) * 65536), abort_w); d += tq[i]; }
                         o += 16;
                     }
-#endif
                     for (; o + 4 <= o1; o += 4) {
                         f32x4 tq[4];
 #pragma unroll
@@ -798,16 +693,13 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                     col4(da);
                 }
             } else {
-                if (!DIMN_RES_DIRECT) {
-                    if (wave == 0) { const bool ok = res_poll(rA, tcur + (uint32_t)(ht * 4096), 1, 4096u, abort_w); if (lane == 0) flagl[1] = ok ? 1 : 0; }
-                    __syncthreads();
-                    if (!flagl[1]) return;
-                }
+                if (wave == 0) { const bool ok = res_poll(rA, tcur + (uint32_t)(ht * 4096), 1, 4096u, abort_w); if (lane == 0) flagl[1] = ok ? 1 : 0; }
+                __syncthreads();
+                if (!flagl[1]) return;
                 RES_STAMP(6)
                 if (tid < 256) {
                     f32x4 da = res_ld(rA, tcur + (uint32_t)(ht * 4096 + 16 * tid));
-                    if (DIMN_RES_DIRECT) res_spin(da, rA, tcur + (uint32_t)(ht * 4096 + 16 * tid), abort_w);
-                    else res_fix(da, rA, tcur + (uint32_t)(ht * 4096 + 16 * tid), abort_w);
+                    res_fix(da, rA, tcur + (uint32_t)(ht * 4096 + 16 * tid), abort_w);
                     *(f32x4*)(dzl + 4 * tid) = da;
                     // dA(t) exists, so the manager has summed P(t): this workgroup's P slot of step t is free -- marked "not
                     // written" for P(t+2); acknowledged before P(t+1) leaves (vmcnt(0) in role1)
@@ -825,7 +717,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
 #pragma unroll
             for (int kb = 0; kb < 16; ++kb) bfr[kb] = dzl[64 * kb + lane];                                        // dA[b = 4kb+lj][h = li]
             RES_STAMP(7)
-            role1(std::true_type{}, tid, xo0, xon, xog, xr, b_next > 0, bfr, ap, pnext);     // its first barrier orders b1l / dzl
+            role1(std::true_type{}, tid, xo0, xon, xr, b_next > 0, bfr, ap, pnext);     // its first barrier orders b1l / dzl
             if (b_next == 0) __syncthreads();
 #pragma unroll
             for (int i = 0; i < 4; ++i) xo0[i] = xon[i];         // the next batch becomes the current one

@@ -32,12 +32,12 @@ for rep in range(2):
           % (t1, t3, t7, t4, t5, t2, t6, np.array_equal(st["mean"], f["mean"]), np.array_equal(st["var"], v)), flush=True)
     c.close()
 for threads in (8, 16, 32, 64, 128):
-    os.environ["DIMN_COUNTS_THREADS"] = str(threads)
+    os.environ["DIMN_COUNTS_THREADS_REMOVED"] = str(threads)
     t1, c = clock(lambda: DeviceCounts.try_create(counts, 0))
     t2, ok = clock(lambda: c.matches(counts))
-    print("DIMN_COUNTS_THREADS=%d: create %.3f checksum-only scan %.3f" % (threads, t1, t2), flush=True)
+    print("DIMN_COUNTS_THREADS_REMOVED=%d: create %.3f checksum-only scan %.3f" % (threads, t1, t2), flush=True)
     c.close()
-os.environ.pop("DIMN_COUNTS_THREADS")
+os.environ.pop("DIMN_COUNTS_THREADS_REMOVED")
 # concurrent: create || first
 box = {}
 th = threading.Thread(target=lambda: box.__setitem__("c", clock(lambda: DeviceCounts.try_create(counts, 0))))
