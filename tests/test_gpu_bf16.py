@@ -2,6 +2,8 @@
 (set_matrix(streamed=True): row blocks through pinned buffers, the matrix never resident).  Parity definition of the
 bf16 arena: fp32 arithmetic on predictor values rounded to bfloat16 (nearest even) when they are stored; targets,
 weights, Adam state and accumulation are fp32 -- so the oracle in the same mode must agree at the fp32 tolerances."""
+import os
+
 import numpy as np
 import pytest
 
@@ -67,7 +69,13 @@ def test_streamed_matrix_equals_resident_matrix(precision):
     targ = [rng.choice(g, 64, replace=False).astype(np.int32) for _ in Ds]
     train, val = np.arange(0, 1000, dtype=np.int32), np.arange(4000, 4200, dtype=np.int32)
     outs = []
-    for streamed in (False, True):
+    # resident; streamed with only the columns the sub-nets read packed into the bounce buffer (the default: 2 % of the genes here);
+    # streamed as whole rows (DIMN_STREAM_PACK=0)
+    for streamed, pack in ((False, None), (True, None), (True, "0")):
+        if pack is None:
+            os.environ.pop("DIMN_STREAM_PACK", None)
+        else:
+            os.environ["DIMN_STREAM_PACK"] = pack
         e = _hip()(Ds, 64, 64, batch_size=64, dropout_rate=0.2, learning_rate=1e-3, seed=5, precision=precision)
         for k in range(2):
             e.set_indices(k, pred[k], targ[k])
@@ -77,8 +85,10 @@ def test_streamed_matrix_equals_resident_matrix(precision):
         e.init_weights()
         outs.append((e.train_epoch(0), e.val_loss(), e.predict(np.arange(0, n, 7, dtype=np.int32))))
         e.close()
-    for x, y in zip(*outs):
-        assert np.array_equal(x, y)
+    os.environ.pop("DIMN_STREAM_PACK", None)
+    for other in outs[1:]:
+        for x, y in zip(outs[0], other):
+            assert np.array_equal(x, y)
 
 
 def test_general_path_on_bf16_arena_matches_general_oracle_rounded():
