@@ -174,3 +174,68 @@ def test_arena_cache_hands_blocks_back_and_can_be_emptied(monkeypatch):
     for other in (again, fresh, uncached):
         np.testing.assert_array_equal(first[0], other[0])
         np.testing.assert_array_equal(first[1], other[1])
+
+
+def test_sharded_fit_and_gather_on_hip_engines_as_threads_of_one_gpu():
+    """The N > 1 leg of configs[3] as far as one GPU can carry it: 8 HIP handles, one per "rank" (threads), run sharded.fit_sharded --
+    one all-reduce of the two loss sums per epoch, the GLOBAL early-stopping decision of multinet.py:242-243 -- and sharded.predict_sharded
+    with the device gather (dimn_comm_gather_loopback: everything of the RCCL gather but RCCL).  Against ONE handle that owns all the
+    sub-nets: the same stopping epoch, the same loss curves and predictions to fp32 rounding (the first layer's split-K partition
+    depends on how many sub-nets share a handle), and against the oracle at the usual tolerance."""
+    import threading
+    from deepimpute_amd.sharded import fit_sharded, predict_sharded, shard_subnets
+    from loopback_comm import LoopbackComm, LoopbackWorld
+    HipEngine = _hip()
+    K, world, H, O = 19, 8, 48, 32
+    rng = np.random.default_rng(5)
+    prob = make_problem(n=700, g=500, Ds=[int(d) for d in rng.integers(20, 90, size=K)], H=H, O=O, seed=14)
+    kw = dict(batch_size=64, dropout_rate=0.2, learning_rate=2e-3, seed=31)
+    whole = load_problem(HipEngine, prob, **kw)
+    whole.init_weights()
+    ref_epochs, ref_loss, ref_val = whole.fit(40, 2)
+    ref_pred = whole.predict()
+    assert 2 < ref_epochs < 40                                 # early stopping decides, not the epoch limit
+    counts, offs = shard_subnets(K, world, weights=prob["Ds"])
+    assert sum(counts) == K and min(counts) >= 1
+    shared = LoopbackWorld(world)
+    engines, results, errors = [], [None] * world, []
+    for r in range(world):
+        ks = range(offs[r], offs[r] + counts[r])
+        e = HipEngine([prob["Ds"][k] for k in ks], H, O, subnet_offset=offs[r], **kw)
+        e.set_matrix(prob["norm"])
+        for i, k in enumerate(ks):
+            e.set_indices(i, prob["pred"][k], prob["targ"][k])
+        e.gather(True)
+        e.set_split(prob["train"], prob["val"])
+        e.init_weights()
+        engines.append(e)
+
+    def rank_main(r):
+        try:
+            comm = LoopbackComm(shared, r)
+            epochs, loss, val = fit_sharded(engines[r], comm, 40, 2)
+            block = predict_sharded(engines[r], comm, counts)
+            results[r] = (epochs, loss, val, block)
+        except Exception as exc:                                # a dead rank would leave the others at the barrier
+            errors.append((r, exc))
+            shared.barrier.abort()
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    for r in range(world):
+        epochs, loss, val, block = results[r]
+        assert epochs == ref_epochs                              # every rank took the single-process stop decision
+        np.testing.assert_allclose(loss, ref_loss, rtol=2e-5)
+        np.testing.assert_allclose(val, ref_val, rtol=2e-5)
+        assert (block is not None) == (r == 0)
+    np.testing.assert_allclose(results[0][3], ref_pred, rtol=2e-4, atol=2e-6)
+    ora = load_problem(_oracle(), prob, **kw)
+    ora.init_weights()
+    o_epochs, o_loss, o_val = ora.fit(40, 2)
+    assert o_epochs == ref_epochs
+    np.testing.assert_allclose(results[0][3], ora.predict(), rtol=1e-4, atol=1e-6)
+    for e in engines + [whole, ora]:
+        e.close()
