@@ -75,3 +75,28 @@ def test_general_path_equals_tuned_kernels_on_default_architecture():
         np.testing.assert_allclose(a.train_epoch(e), b.train_epoch(e), rtol=1e-4)
     np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
     np.testing.assert_allclose(a.predict(), b.predict(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("layers,B", [
+    ([(256, "relu", 0.2)], 64),                      # the default shapes on the general path (bench.py --general)
+    ([(512, "relu", 0.2)], 128),                     # deepImpute --hidden-neurons 512 --batch-size 128
+    ([(300, "relu", 0.2), (128, "tanh", 0.1)], 100),
+])
+def test_general_path_at_configs2_widths_matches_general_oracle(layers, B):
+    """The general path at the predictor widths of BASELINE configs[2] (D ~ 2 400, ragged; O = 512): the first layer's forward runs
+    split-K over the long inner dimension (k-ranges summed by k_gen_splitk_fin, dropout from one Philox block per four elements) and
+    both first-layer GEMMs read their batch rows in place from the X arena -- code the small-shape tests above never reach (their D is
+    below one k-range).  Two epochs incl. a partial batch, against oracle/dimo_general.c."""
+    prob = make_problem(n=2 * B + B // 3 + 60, g=3000, Ds=[2400, 2391, 700], H=layers[0][0], O=512, seed=23)
+    a, b = _pair(prob, layers, batch_size=B, learning_rate=1e-3, seed=99, loss="wmse")
+    for epoch in range(2):
+        np.testing.assert_allclose(a.train_epoch(epoch), b.train_epoch(epoch), rtol=1e-4)
+        np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
+    assert a.step_count() == b.step_count()
+    for k in range(a.K):
+        for x, y in zip(a.get_weights(k), b.get_weights(k)):
+            np.testing.assert_allclose(x, y, rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=1e-4, atol=1e-6)
+    rows = prob["val"][:7]
+    np.testing.assert_allclose(a.predict(rows), b.predict(rows), rtol=1e-4, atol=1e-6)
+    a.close(); b.close()
