@@ -11,6 +11,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -762,20 +765,64 @@ extern "C" int dimn_set_indices(dimn_handle h, int32_t k, const int32_t* pred_id
     return DIMN_OK;
 }
 
+// Host worker threads of the row-block pipelines (counts upload, streamed hand-over, predict()'s epilogue), made once per process.  Every
+// pipeline stage used to create and join its own threads -- 24 to 64 of them per ~128 MB block, 31-62 blocks per call: ~1-2 ms of
+// pthread_create / join per block beside 2-5 ms of useful work.  run(n, fn) executes fn(0 .. n-1), fn(0) on the caller; calls from
+// several threads at once (a retiring block beside the next copy-in) share the workers.  The pool is never destroyed (its threads
+// end with the process).
+class HostPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    void loop() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !q.empty(); });
+                job = std::move(q.front());
+                q.pop_front();
+            }
+            job();
+        }
+    }
+public:
+    explicit HostPool(unsigned n) { for (unsigned i = 0; i < n; ++i) std::thread([this] { loop(); }).detach(); }
+    void run(int n, const std::function<void(int)>& fn) {
+        if (n <= 1) { if (n == 1) fn(0); return; }
+        struct Ctx { std::mutex m; std::condition_variable c; int left; } ctx;
+        ctx.left = n - 1;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (int t = 1; t < n; ++t)
+                q.emplace_back([&ctx, &fn, t] {
+                    fn(t);
+                    std::lock_guard<std::mutex> l2(ctx.m);
+                    if (--ctx.left == 0) ctx.c.notify_one();
+                });
+        }
+        cv.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> l3(ctx.m);
+        ctx.c.wait(l3, [&] { return ctx.left == 0; });
+    }
+};
+static HostPool& host_pool() {
+    static HostPool* pool = new HostPool(std::min<unsigned>(64, std::max(4u, std::thread::hardware_concurrency() / 2)));
+    return *pool;
+}
+
 // memcpy of a large block on several host threads (one pageable <-> pinned copy per pipeline stage: a single thread
 // moves ~10 GB/s, the PCIe link five times that)
 static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
     const unsigned hw = std::thread::hardware_concurrency();
     const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(hw ? hw / 2 : 8, 24), bytes / (4u << 20)));
     if (nt <= 1) { memcpy(dst, src, bytes); return; }
-    std::vector<std::thread> th;
     const size_t chunk = ((bytes + nt - 1) / nt + 63) & ~(size_t)63;
-    for (size_t i = 0; i < nt; ++i) {
-        const size_t a = i * chunk, b = std::min(bytes, a + chunk);
-        if (a >= b) break;
-        th.emplace_back([=] { memcpy((char*)dst + a, (const char*)src + a, b - a); });
-    }
-    for (auto& t : th) t.join();
+    host_pool().run((int)nt, [=](int i) {
+        const size_t a = (size_t)i * chunk, b = std::min(bytes, a + chunk);
+        if (a < b) memcpy((char*)dst + a, (const char*)src + a, b - a);
+    });
 }
 
 // dst[r][j] = src[r][cols[j]], r < nr: the columns a handle needs of a row block, packed (host threads over rows; a row is walked
@@ -791,10 +838,7 @@ static void parallel_pack_columns(float* dst, const float* src, int64_t nr, int6
             for (int64_t j = 0; j < gc; ++j) out[j] = in[cols[j]];
         }
     };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto& x : th) x.join();
+    host_pool().run(nt, work);
 }
 
 // Index lists and arenas of the device gather for a matrix of h->n cells (validated against h->g columns).
@@ -2379,16 +2423,17 @@ static void counts_scan(const double* raw, int64_t g, int64_t r0, int64_t r1, fl
                 memcpy(&bits, &x, 8);
                 h += counts_mix(bits + 0x9e3779b97f4a7c15ull * (base + (uint64_t)j + 1));
                 m = x > m ? x : m;
-                fine &= x >= 0.0 && x <= 4194304.0 && x == trunc(x) && !signbit(x);      // (range first: no float-to-int conversion of NaN / Inf / huge values; -0.0 is not a count)
+                // a count: in [0, 2^22], integral, not -0.0.  The range test comes first, so the conversion below only ever sees values it is
+                // defined for (NaN / Inf / huge values take the 0.5 and fail); no libm call per element (trunc() was one on plain x86-64)
+                const bool in_range = x >= 0.0 && x <= 4194304.0;
+                const double xr = in_range ? x : 0.5;
+                fine &= in_range & ((double)(int32_t)xr == xr) & ((bits >> 63) == 0);
                 if (out) out[j] = (float)x;
             }
         }
         mx[(size_t)t] = m; cs[(size_t)t] = h; good[(size_t)t] = fine ? 1 : 0;
     };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto& th : pool) th.join();
+    host_pool().run(nt, work);
     for (int t = 0; t < nt; ++t) { *vmax = mx[(size_t)t] > *vmax ? mx[(size_t)t] : *vmax; *sum += cs[(size_t)t]; *ok &= good[(size_t)t]; }
 }
 extern "C" int dimn_counts_checksum(const double* raw, int64_t n, int64_t g, uint64_t* checksum) {
