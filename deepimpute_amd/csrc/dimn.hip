@@ -1317,7 +1317,13 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     // one hidden tile (16 rows of W2) per workgroup; 4 or 8 waves split the output tiles
 #define LAUNCH_MB(FULLV, WV) hipLaunchKernelGGL((k_mid_bwd<FULLV, 1, WV>), dim3((unsigned)dm.HT, nk), dim3(WV * 64), 0, st, h->d_Dd, h->d_dZ, \
                                                 h->d_W2, h->d_M2, h->d_V2, h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0, (const float*)h->d_G)
-    if (dm.OT == 4 * h->OTW && (int64_t)dm.HT * nk <= 2 * (int64_t)h->ncu)   // few workgroups (a GPU that owns few sub-nets):
+    // TWO hidden tiles per workgroup where that still leaves a workgroup per CU (round 4): every workgroup reads the whole dZ block of its
+    // sub-net (128 KB from L2), so half as many workgroups halve that traffic -- hidden 300 at 40 sub-nets: step 0.228 -> 0.221 ms, same box
+    // (with the three-waves-per-SIMD register cap of the one-tile form it spills: 0.27)
+    if (dm.OT == 4 * h->OTW && dm.HT % 2 == 0 && (int64_t)(dm.HT / 2) * nk >= (int64_t)h->ncu)
+        hipLaunchKernelGGL((k_mid_bwd<true, 2, 4, 2>), dim3((unsigned)(dm.HT / 2), nk), dim3(256), 0, st, h->d_Dd, h->d_dZ,
+                           h->d_W2, h->d_M2, h->d_V2, h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0, (const float*)h->d_G);
+    else if (dm.OT == 4 * h->OTW && (int64_t)dm.HT * nk <= 2 * (int64_t)h->ncu)   // few workgroups (a GPU that owns few sub-nets):
         hipLaunchKernelGGL((k_mid_bwd<true, 1, 4, 2>), dim3((unsigned)dm.HT, nk), dim3(256), 0, st, h->d_Dd, h->d_dZ,   // 2 per CU fit anyway -> no register cap, no spills
                            h->d_W2, h->d_M2, h->d_V2, h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0, (const float*)h->d_G);
     else { if (dm.OT == 4 * h->OTW) LAUNCH_MB(true, 4); else LAUNCH_MB(false, 4); }
