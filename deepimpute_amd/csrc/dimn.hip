@@ -1198,7 +1198,7 @@ static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, hipStream_t 
 #undef W1_LAUNCH
 }
 template <int NT>
-static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out, float* loss_part) {
+static void launch_predict_impl(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out, float* loss_part) {
     const unsigned tiles = (unsigned)((n_rows + DIMN_TB - 1) / DIMN_TB);
     if (h->predict_bf16) {                         // bf16 matrix cores (precision bf16): fresh bf16 images of the weights, then the forward
         hipLaunchKernelGGL(k_prep_bf16, dim3(256, (unsigned)h->K), dim3(256), 0, h->stream, h->d_sn, (const float*)h->d_W1, (const float*)h->d_W2,
@@ -1208,10 +1208,17 @@ static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, f
             const unsigned tiles128 = (unsigned)((n_rows + DIMN_PB_M - 1) / DIMN_PB_M);
             const int hq = (h->dm.Hp + 31) & ~31;
             const size_t ldsb = std::max<size_t>((size_t)2 * DIMN_PB_M * DIMN_PB_XLD * 2, (size_t)DIMN_PB_M * (hq + 8) * 2) + 64;
-            (void)hipFuncSetAttribute((const void*)k_predict_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-            hipLaunchKernelGGL(k_predict_bf16, dim3(tiles128, (unsigned)h->K), dim3(256), ldsb, h->stream, h->d_sn, (const bf16_t*)h->d_X, (const bf16_t*)h->d_W1b,
-                               (const float*)h->d_b1, (const bf16_t*)h->d_W2t, (const float*)h->d_b2, rows, n_rows, out, (const float*)h->d_Y, h->n, loss_part,
-                               (int64_t)tiles, h->dm, h->cfg.loss_binary, h->act);
+            const bool fast = h->act == 0 && (h->dm.O & 3) == 0;            // (the instantiation without the activation switch and the scalar stores)
+#define PB_LAUNCH(F, L)                                                                                                                                          \
+            {                                                                                                                                                    \
+                (void)hipFuncSetAttribute((const void*)k_predict_bf16<F, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);                             \
+                hipLaunchKernelGGL((k_predict_bf16<F, L>), dim3(tiles128, (unsigned)h->K), dim3(256), ldsb, h->stream, h->d_sn, (const bf16_t*)h->d_X,           \
+                                   (const bf16_t*)h->d_W1b, (const float*)h->d_b1, (const bf16_t*)h->d_W2t, (const float*)h->d_b2, rows, n_rows, out,            \
+                                   (const float*)h->d_Y, h->n, loss_part, (int64_t)tiles, h->dm, h->cfg.loss_binary, h->act);                                    \
+            }
+            if (fast) { if (loss_part) PB_LAUNCH(true, true) else PB_LAUNCH(true, false) }
+            else { if (loss_part) PB_LAUNCH(false, true) else PB_LAUNCH(false, false) }
+#undef PB_LAUNCH
             return;
         }
         const size_t ldsb = (size_t)DIMN_TB * (h->dm.Hp + 4) * 2 + 16;
@@ -1228,6 +1235,29 @@ static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, f
         hipLaunchKernelGGL((k_predict<NT, XT>), dim3(tiles, (unsigned)h->K), dim3(256), lds, h->stream, h->d_sn, (const XT*)h->d_X, h->d_W1, h->d_b1,
                            h->d_W2tf, h->d_b2, rows, n_rows, out, h->d_Y, h->n, loss_part, h->dm, h->cfg.loss_binary, h->act);
     });
+}
+template <int NT>
+static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out, float* loss_part) {
+#if DIMN_PB_TRACE                                  // diagnostic build only (dimn_kernels.h, PB_STAMP; tools/pb_trace.sh)
+    const char* tp = getenv("DIMN_PREDICT_TRACE");
+    if (tp && h->predict_bf16 && out && h->dm.Hp <= 256) {
+        const size_t nwg = (size_t)((n_rows + DIMN_PB_M - 1) / DIMN_PB_M) * h->K;
+        unsigned long long* d_tr = nullptr;
+        (void)hipMalloc(&d_tr, nwg * 64);
+        (void)hipMemset(d_tr, 0, nwg * 64);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pb_trace), &d_tr, sizeof(d_tr));
+        launch_predict_impl<NT>(h, rows, n_rows, out, loss_part);
+        (void)hipStreamSynchronize(h->stream);
+        std::vector<unsigned long long> host(nwg * 8);
+        (void)hipMemcpy(host.data(), d_tr, nwg * 64, hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(tp, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+        (void)hipFree(d_tr);
+        d_tr = nullptr;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pb_trace), &d_tr, sizeof(d_tr));
+        return;
+    }
+#endif
+    launch_predict_impl<NT>(h, rows, n_rows, out, loss_part);
 }
 #define DISPATCH_NT(fn, ...)                          \
     switch (h->NT) {                                  \

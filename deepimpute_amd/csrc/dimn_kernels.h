@@ -209,6 +209,13 @@ __device__ __forceinline__ void hidden_act(int act, float a, float& f, float& df
     }
 }
 
+// One out-of-line copy for kernels that unroll an activation many times (see k_predict_bf16).
+__device__ __attribute__((noinline)) float hidden_act_call(int act, float a) {
+    float f, df;
+    hidden_act(act, a, f, df);
+    return f;
+}
+
 // Training-path versions on the hardware exp2/log2/rcp units (v_exp_f32, v_log_f32, v_rcp_f32):
 // t = exp(-|x|) in (0,1];  softplus = max(x,0) + log1p(t);  sigmoid = x>=0 ? 1/(1+t) : t/(1+t).
 // log1p(t) switches to its series below 2^-12 so tiny outputs keep their relative accuracy.  They feed
@@ -1747,8 +1754,8 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = acc[mt][nt][r] + bias;
-                    float f = v > 0.f ? v : 0.f, df;
-                    if (act != 0) { hidden_act(act, v, f, df); if (h >= dm.H) f = 0.f; }
+                    float f = v > 0.f ? v : 0.f;
+                    if (act != 0) { f = hidden_act_call(act, v); if (h >= dm.H) f = 0.f; }     // (out of line: 64 inlined switches were 100 KB of code)
                     lds[(16 * mt + 4 * lj + r) * ldp + h] = f;
                 }
         }
@@ -1962,6 +1969,19 @@ typedef __bf16 bf16x8n __attribute__((ext_vector_type(8)));
 #ifndef DIMN_PB_WPS
 #define DIMN_PB_WPS 2
 #endif
+// Diagnostic build (-DDIMN_PB_TRACE=1, tools/pb_trace.sh): thread 0 of every workgroup stamps the 100 MHz clock at its phase boundaries
+// (0 start, 1 first layer done, 2 activations in LDS, 3 / 5 second-layer MFMAs of pass 0 / 1 done, 4 epilogue of pass 0 done, 6 end);
+// launch_predict writes the stamps to the file DIMN_PREDICT_TRACE names.  This is how the instruction-cache problem above was found.
+#ifndef DIMN_PB_TRACE
+#define DIMN_PB_TRACE 0
+#endif
+#if DIMN_PB_TRACE
+__device__ unsigned long long* g_pb_trace = nullptr;
+#define PB_STAMP(j) do { if (g_pb_trace && threadIdx.x == 0) g_pb_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (j)] = wall_clock64(); } while (0)
+#else
+#define PB_STAMP(j) do { } while (0)
+#endif
+template <bool FAST, bool LOSS>
 __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetDev* __restrict__ sn, const bf16_t* __restrict__ X,
                                                          const bf16_t* __restrict__ W1b, const float* __restrict__ b1,
                                                          const bf16_t* __restrict__ W2t, const float* __restrict__ b2,
@@ -1982,6 +2002,7 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
+    PB_STAMP(0);
     // ---- first layer: A = X W1 over 32-deep steps ----
     f32x4 acc[8][4];
 #pragma unroll
@@ -2040,7 +2061,9 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
         for (int rt = 0; rt < 8; ++rt) {
             const bf16x8n a = *(const bf16x8n*)(xt + (16 * rt + li) * DIMN_PB_XLD + 8 * lj);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8n, b[ct]), acc[rt][ct], 0, 0, 0);
+            // A^T tile = W1b (16 hidden units x 32 d) x X^T (32 d x 16 rows): a lane's accumulator is then four CONSECUTIVE HIDDEN UNITS of one
+            // row (acc[rt][ct][r] = A[16 rt + li][64 wave + 16 ct + 4 lj + r]) -- one packed conversion and one 8-byte LDS store per tile below
+            for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8n, b[ct]), a, acc[rt][ct], 0, 0, 0);
         }
     };
     {
@@ -2076,31 +2099,39 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
 #undef PB_STEP
         // (every PB_STEP ends with a barrier: every wave is done with the ring -- the activations take its place)
     }
-    // bias + activation, rounded to bf16 into LDS; columns [Hp, Hq) zero
+    PB_STAMP(1);
+    // bias + activation, rounded to bf16 into LDS (four hidden units of a row at a time); columns [Hp, Hq) zero.
+    // CODE SIZE matters here: this block is unrolled 32 x 4 times.  With the activation switch inlined at every element (tanhf, expm1f,
+    // log1pf(expf)) the kernel was 250 KB of code against a 64 KB instruction cache, and a workgroup spent 36 us in this block --
+    // one instruction-cache miss per skipped switch -- and 57 + 28 us in the two output epilogues below (round 4, per-workgroup
+    // phase stamps).  FAST (relu, O % 4 == 0) holds no switch at all; the other instantiation calls one out-of-line copy.
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
-        const int h = 64 * wave + 16 * ct + li;
-        if (h < Hq) {
-            const float bias = h < Hp ? b1[(int64_t)k * Hp + h] : 0.f;
+        const int h0 = 64 * wave + 16 * ct + 4 * lj;
+        if (h0 < Hq) {
+            const f32x4 bias = h0 < Hp ? *(const f32x4*)(b1 + (int64_t)k * Hp + h0) : zero4;
 #pragma unroll
-            for (int rt = 0; rt < 8; ++rt)
+            for (int rt = 0; rt < 8; ++rt) {
+                f32x4 f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = acc[rt][ct][r] + bias;
-                    float f = v > 0.f ? v : 0.f, df;
-                    if (act != 0) { hidden_act(act, v, f, df); }
-                    if (h >= dm.H) f = 0.f;                      // (also the columns [H, Hq): their accumulators are not meaningful)
-                    ddl[(16 * rt + 4 * lj + r) * ld2 + h] = f32_to_bf16(f);
+                    const float v = acc[rt][ct][r] + bias[r];
+                    f[r] = FAST ? (v > 0.f ? v : 0.f) : hidden_act_call(act, v);
+                    if (h0 + r >= dm.H) f[r] = 0.f;              // (also the columns [H, Hq): their accumulators are not meaningful)
                 }
+                *(bf16x4*)(ddl + (16 * rt + li) * ld2 + h0) = pk4(f);
+            }
         }
     }
     __syncthreads();                                             // (the four waves cover 256 hidden columns: launch_predict sends Hp > 256 to the round-2 kernel)
 
+    PB_STAMP(2);
     // ---- second layer: Z = Dd W2, 16 output tiles per pass (4 per wave) ----
     float lsum0 = 0.f, lsum1 = 0.f;
     const bf16_t* w2k = W2t + (int64_t)k * Hp * dm.Op;
     const int nsteps2 = Hq >> 5;
     for (int ot0 = 0; ot0 < dm.OT; ot0 += 16) {
+        if (ot0) PB_STAMP(4);
 #pragma unroll
         for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
@@ -2148,7 +2179,11 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
         }
         // epilogue: bias, softplus, store / loss.  A lane holds outputs o0 .. o0+3 of batch row 16 rt + li; the four output tiles of a
         // wave are adjacent (64 outputs = 256 contiguous bytes of a row of `out`), written tile after tile for each row tile
-        const bool vec_ok = (dm.O & 3) == 0;
+        PB_STAMP(ot0 ? 5 : 3);
+        const bool vec_ok = FAST || (dm.O & 3) == 0;
+        f32x4 b2v[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) b2v[ct] = ov[ct] ? *(const f32x4*)(b2 + (int64_t)k * dm.Op + 16 * (ot0 + 4 * wave + ct) + 4 * lj) : zero4;
 #pragma unroll
         for (int rt = 0; rt < 8; ++rt) {
             const int64_t i = r0 + 16 * rt + li;
@@ -2160,7 +2195,7 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
                 if (!ov[ct] || !row_ok || o0 >= dm.O) continue;
                 f32x4 yh;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) yh[r] = softplus_out(acc[rt][ct][r] + b2[(int64_t)k * dm.Op + o0 + r]);      // (b2 is padded to Op)
+                for (int r = 0; r < 4; ++r) yh[r] = softplus_out(acc[rt][ct][r] + b2v[ct][r]);      // (b2 is padded to Op)
                 // (measured: the cheaper two-transcendental softplus of the training kernels changes nothing here -- 5.8 ms either way;
                 //  without softplus AND without the stores the kernel takes 3.9 ms: epilogue and GEMMs overlap across the two
                 //  workgroups of a CU, and what remains is the request stream of the first layer)
@@ -2170,7 +2205,7 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
                     else
                         for (int r = 0; r < 4; ++r) if (o0 + r < dm.O) dst[r] = yh[r];
                 }
-                if (loss_part) {
+                if (LOSS) {
                     const float* yrow = Y + ((int64_t)k * n_cells + row) * dm.Op + o0;
                     float acc_l = 0.f;
 #pragma unroll
@@ -2186,7 +2221,8 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
             }
         }
     }
-    if (loss_part) {
+    PB_STAMP(6);
+    if (LOSS) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { lsum0 += __shfl_xor(lsum0, off); lsum1 += __shfl_xor(lsum1, off); }
         __syncthreads();                                         // (the activations are no longer read: redl may alias nothing, but keep the order explicit)
@@ -2274,8 +2310,8 @@ __global__ __launch_bounds__(256) void k_predict_bf16_r2(const SubnetDev* __rest
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = acc[mt][nt][r] + bias;
-                    float f = v > 0.f ? v : 0.f, df;
-                    if (act != 0) { hidden_act(act, v, f, df); if (h >= dm.H) f = 0.f; }
+                    float f = v > 0.f ? v : 0.f;
+                    if (act != 0) { f = hidden_act_call(act, v); if (h >= dm.H) f = 0.f; }     // (out of line: 64 inlined switches were 100 KB of code)
                     ddl[(16 * mt + 4 * lj + r) * ldb + h] = f32_to_bf16(f);
                 }
         }
