@@ -227,6 +227,7 @@ struct dimn_handle_s {
     std::vector<double> ev_bytes;   // algorithmic bytes of the W1 launch bracketed by each event triple
     // comm
     ncclComm_t comm = nullptr; int n_ranks = 1, rank = 0;
+    bf16_t* d_zero1k = nullptr;            // 1 KB of zeros (k_predict_bf16)
     bf16_t *d_W1b = nullptr, *d_W2t = nullptr; bool predict_bf16 = false;   // bf16 images of the weights for k_predict_bf16
     float* d_W2tf = nullptr;                                                // W2 in the operand form of k_predict's second layer (k_prep_w2t)
     int prec = 0;                          // DIMN_PREC_*: 1 = X arena in bfloat16, inference GEMMs on the bf16 matrix cores
@@ -639,7 +640,13 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
     if (h->prec == DIMN_PREC_BF16) {
         // inference / validation on the bf16 matrix cores unless DIMN_PREDICT_BF16=0 (then only the arena is bf16)
         h->predict_bf16 = !(getenv("DIMN_PREDICT_BF16") && atoi(getenv("DIMN_PREDICT_BF16")) == 0);
-        if (h->predict_bf16) { TRY(dev_alloc(&h->d_W1b, (size_t)w1)); TRY(dev_alloc(&h->d_W2t, w2n)); }
+        if (h->predict_bf16) {
+            const size_t w1pad = 4096;                           // k_predict_bf16 reads up to 64 hidden units past the last one of a chunk (accumulators nobody uses): mapped memory there
+            TRY(dev_alloc(&h->d_W1b, (size_t)w1 + w1pad)); TRY(dev_alloc(&h->d_W2t, w2n));
+            TRY(hipMemset(h->d_W1b + w1, 0, w1pad * 2) == hipSuccess ? 0 : fail(DIMN_ERR_HIP, "hipMemset failed"));
+            TRY(dev_alloc(&h->d_zero1k, (size_t)512));           // the zeros k_predict_bf16 fetches for predictor chunks past a sub-net's last one
+            TRY(hipMemset(h->d_zero1k, 0, 1024) == hipSuccess ? 0 : fail(DIMN_ERR_HIP, "hipMemset failed"));
+        }
     }
     if (!h->predict_bf16) TRY(dev_alloc(&h->d_W2tf, w2n));
     if (h->res_G) {
@@ -731,7 +738,7 @@ extern "C" int dimn_destroy(dimn_handle h) {
     DEV_FREE(h->d_midwork); DEV_FREE(h->d_midk); DEV_FREE(h->d_P2); DEV_FREE(h->d_G);
     DEV_FREE(h->d_epoch_rows); DEV_FREE(h->d_val_rows); DEV_FREE(h->d_pred_rows); DEV_FREE(h->d_out);
     DEV_FREE(h->d_loss_part); DEV_FREE(h->d_full); DEV_FREE(h->d_stage); DEV_FREE(h->d_red);
-    DEV_FREE(h->d_W1b); DEV_FREE(h->d_W2t); DEV_FREE(h->d_W2tf);
+    DEV_FREE(h->d_W1b); DEV_FREE(h->d_W2t); DEV_FREE(h->d_W2tf); DEV_FREE(h->d_zero1k);
     DEV_FREE(h->d_res_P); DEV_FREE(h->d_res_D); DEV_FREE(h->d_res_T); DEV_FREE(h->d_res_A); DEV_FREE(h->d_res_b1); DEV_FREE(h->d_res_alpha); DEV_FREE(h->d_res_flags); DEV_FREE(h->d_res_loss); DEV_FREE(h->d_res_snap); DEV_FREE(h->d_res_Xe); DEV_FREE(h->d_res_Ye); DEV_FREE(h->d_res_iota);
     for (auto& ln : h->lanes) (void)hipStreamDestroy(ln.stream);
     delete h;
@@ -1207,14 +1214,14 @@ static void launch_predict_impl(dimn_handle h, const int32_t* rows, int64_t n_ro
             // 128 rows per workgroup, 32-deep bf16 matrix instructions, X staged through LDS (dimn_kernels.h); loss slots stay 64-row tiles
             const unsigned tiles128 = (unsigned)((n_rows + DIMN_PB_M - 1) / DIMN_PB_M);
             const int hq = (h->dm.Hp + 31) & ~31;
-            const size_t ldsb = std::max<size_t>((size_t)2 * DIMN_PB_M * DIMN_PB_XLD * 2, (size_t)DIMN_PB_M * (hq + 8) * 2) + 64;
+            const size_t ldsb = std::max<size_t>((size_t)3 * DIMN_PB_XST, (size_t)DIMN_PB_M * (hq + 8) * 2) + 64;
             const bool fast = h->act == 0 && (h->dm.O & 3) == 0;            // (the instantiation without the activation switch and the scalar stores)
 #define PB_LAUNCH(F, L)                                                                                                                                          \
             {                                                                                                                                                    \
                 (void)hipFuncSetAttribute((const void*)k_predict_bf16<F, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);                             \
                 hipLaunchKernelGGL((k_predict_bf16<F, L>), dim3(tiles128, (unsigned)h->K), dim3(256), ldsb, h->stream, h->d_sn, (const bf16_t*)h->d_X,           \
                                    (const bf16_t*)h->d_W1b, (const float*)h->d_b1, (const bf16_t*)h->d_W2t, (const float*)h->d_b2, rows, n_rows, out,            \
-                                   (const float*)h->d_Y, h->n, loss_part, (int64_t)tiles, h->dm, h->cfg.loss_binary, h->act);                                    \
+                                   (const float*)h->d_Y, h->n, loss_part, (int64_t)tiles, h->dm, h->cfg.loss_binary, h->act, (const bf16_t*)h->d_zero1k);        \
             }
             if (fast) { if (loss_part) PB_LAUNCH(true, true) else PB_LAUNCH(true, false) }
             else { if (loss_part) PB_LAUNCH(false, true) else PB_LAUNCH(false, false) }

@@ -190,10 +190,17 @@ __device__ __forceinline__ float softplus_out(float x) {
     t = fmaf(t, pe * 0.693147182f, t);                       // exp(-|x|)
     const float u = 1.0f + t, d = u - 1.0f;
     const float lg = __builtin_amdgcn_logf(u) * 0.693147182f;
-    const float l = t < 2.44140625e-4f ? t * fmaf(t, fmaf(t, 0.333333343f, -0.5f), 1.0f)      // series below 2^-12: no cancellation in u - 1
-                                       : lg * (t * __builtin_amdgcn_rcpf(d));
+    // (both forms computed, then selected: written as a conditional expression over the two computations the compiler emits a BRANCH per
+    //  element -- exec-mask juggling and a scheduling barrier 128 times per thread in the unrolled output epilogues)
+    const float l_series = t * fmaf(t, fmaf(t, 0.333333343f, -0.5f), 1.0f);                   // below 2^-12: no cancellation in u - 1
+    const float l_log = lg * (t * __builtin_amdgcn_rcpf(d));
+    const float l = t < 2.44140625e-4f ? l_series : l_log;
     const float sp = fmaxf(x, 0.f) + l;
-    return x > thr ? x : (x < -thr ? t : sp);
+    float r = x < -thr ? t : sp;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(r));                              // (or the compiler turns the select below into a branch around everything above)
+#endif
+    return x > thr ? x : r;
 }
 
 // Hidden activation f and derivative f' at pre-activation a (multinet.py:137; ids = DIMN_ACT_* of dimn.h, elu alpha = 1).
@@ -1957,7 +1964,7 @@ __global__ __launch_bounds__(256) void k_prep_bf16(const SubnetDev* __restrict__
 // ---------------------------------------------------------------------------------------
 typedef __bf16 bf16x8n __attribute__((ext_vector_type(8)));
 #define DIMN_PB_M 128
-#define DIMN_PB_XLD 40                 // bf16 per staged X row: 32 + 8 of padding (80 bytes)
+#define DIMN_PB_XST 16384              // bytes of one stage of the X ring: 128 rows x 64 k's
 #ifndef DIMN_PB_NT
 #define DIMN_PB_NT 0        // plain 16-byte stores: 5.82 vs 6.04 ms with non-temporal ones
 #endif
@@ -1987,9 +1994,10 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
                                                          const bf16_t* __restrict__ W2t, const float* __restrict__ b2,
                                                          const int32_t* __restrict__ rows, int64_t n_rows,
                                                          float* __restrict__ out, const float* __restrict__ Y, int64_t n_cells,
-                                                         float* __restrict__ loss_part, int64_t lp_stride, Dims dm, int loss_binary, int act) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char pl_lds[];
-    bf16_t* xs = (bf16_t*)pl_lds;                                // X ring [2][128][XLD]                       20 480 B
+                                                         float* __restrict__ loss_part, int64_t lp_stride, Dims dm, int loss_binary, int act,
+                                                         const bf16_t* __restrict__ zeros) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the LDS address space below makes the host pass drop the stub silently otherwise)
+    extern __shared__ __attribute__((aligned(1024))) unsigned char pl_lds[];                 // X ring: 3 stages of DIMN_PB_XST bytes
     bf16_t* ddl = (bf16_t*)pl_lds;                               // hidden activations [128][ld2] (aliases the ring once the first layer is done)
     const int Hp = dm.Hp, Hq = (Hp + 31) & ~31;                  // hidden width padded to whole 32-deep steps
     const int ld2 = Hq + 8;
@@ -2003,101 +2011,115 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
     typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
     PB_STAMP(0);
-    // ---- first layer: A = X W1 over 32-deep steps ----
+    // ---- first layer: A = X W1 over 64-deep steps ----
+    // X goes from global memory straight into LDS (global_load_lds: no staging registers, no ds_write) in FRAGMENT ORDER: a stage of the
+    // ring is [8 row tiles][2 k-halves] blocks of 1 KB, lane (li, lj) of block (rt, kh) holding row 16 rt + li, k's 64 step + 32 kh + 8 lj ..+7
+    // -- the operand of one matrix instruction is ds_read_b128 at lane * 16, conflict-free.  Wave w brings in blocks 4w .. 4w + 3 of every
+    // stage.  One barrier per 64-deep step (64 matrix instructions per wave): with one per 32-deep step the loop took 62 us per workgroup
+    // against 38 with the barrier removed (round 4, phase stamps); W1b stays a direct global -> register operand (private to its wave).
+    // Chunks past the sub-net's last one are fetched from 1 KB of zeros.
     f32x4 acc[8][4];
 #pragma unroll
     for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = zero4;
-    const int nsteps = (s.nchunk + 1) >> 1;
-    // staging: 512 pieces of 16 bytes (row p >> 2, quarter p & 3), two per thread
-    const bf16_t* xp[2];
-    int xdst[2], xq[2];
+    const int nsteps = (s.nchunk + 3) >> 2;
+    const bf16_t* xsrc[4];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int p = tid + 256 * e, row = p >> 2, q = p & 3;
-        const int64_t i = r0 + row;
-        const int64_t src = i < n_rows ? (rows ? (int64_t)rows[i] : i) : 0;           // rows past the end read row 0 and are dropped
-        xp[e] = X + s.xoff + src * s.Dp;
-        xdst[e] = row * DIMN_PB_XLD + 8 * q;
-        xq[e] = q;
+    for (int u = 0; u < 4; ++u) {
+        const int b = 4 * wave + u, rt = b >> 1, kh = b & 1;
+        const int64_t i = r0 + 16 * rt + li;
+        const int64_t src = i < n_rows ? (rows ? (int64_t)rows[i] : i) : 0;            // rows past the end read row 0 and are dropped
+        xsrc[u] = X + s.xoff + src * s.Dp + 32 * kh + 8 * lj;
     }
-    auto xload = [&](int step, u32x4v (&xr)[2]) {
+    const bf16_t* zp = zeros + 8 * lane;
+    auto xissue = [&](int step, int stage) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            int c = 2 * step + (xq[e] >> 1);
-            c = c < s.nchunk ? c : s.nchunk - 1;                                       // an odd chunk count: the second half of the last step re-reads the
-            xr[e] = *(const u32x4v*)(xp[e] + 16 * c + 8 * (xq[e] & 1));                // last chunk (its W1 operand is zeroed below)
+        for (int u = 0; u < 4; ++u) {
+            const int c = 4 * step + 2 * (u & 1) + (lj >> 1);
+            const bf16_t* g = c < s.nchunk ? xsrc[u] + 64 * step : zp;
+            __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)(pl_lds + stage * DIMN_PB_XST + (4 * wave + u) * 1024), 16, 0, 0);
         }
     };
-    // W1 operand of column tile ct at a step: eight consecutive d's of hidden unit h = 64 wave + 16 ct + li from chunk 2 step + (lj >> 1)
-    const int64_t cstride = (int64_t)Hp * 16;
-    const bf16_t* wb[4];
-    bool hv[4];
+    // W1 operand of column tile ct, k-half kh of a step: eight consecutive d's of hidden unit h = 64 wave + 16 ct + li from chunk 4 step + 2 kh + (lj >> 1).
+    // Address = a wave-uniform chunk base (one of two, chosen by lj >> 1) + ONE 32-bit lane offset + 512 ct as the instruction's immediate:
+    // sixteen 64-bit lane addresses per step cost 32 registers this loop does not have.  Not masked: a hidden column beyond Hp only produces
+    // accumulators nobody reads (dimn_create leaves 8 KB of zeros behind the image for the reads past the last unit of the last chunk); a
+    // chunk past the sub-net's last one is clamped to it and meets the zeros on the X side.
+    const unsigned cstride_b = (unsigned)Hp * 32u;               // bytes of one chunk of W1b
+    const int hw = 64 * wave + li;
+    const unsigned char* wsub = (const unsigned char*)(W1b + s.w1off) + (unsigned)(hw < Hp ? hw : 0) * 32u + 16u * (lj & 1);
+    const bool odd_half = (lj >> 1) != 0;
+    auto bload = [&](int step, u32x4v (&b)[2][4]) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        const int h = 64 * wave + 16 * ct + li;
-        hv[ct] = h < Hp;
-        wb[ct] = W1b + s.w1off + (int64_t)(hv[ct] ? h : 0) * 16 + 8 * (lj & 1);
-    }
-    // (no masking of the W1 operands: a loaded value consumed at once would pin the wait for it right behind the request.  A hidden
-    //  column beyond Hp only produces accumulators the epilogue discards; the half step beyond an odd chunk count is zeroed on
-    //  the X side, where the value is touched anyway when it goes to LDS)
-    auto bload = [&](int step, u32x4v (&b)[4]) {
-        int c = 2 * step + (lj >> 1);
-        c = c < s.nchunk ? c : s.nchunk - 1;
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) b[ct] = *(const u32x4v*)(wb[ct] + c * cstride);
-    };
-    auto xstore = [&](int step, int buf, const u32x4v (&xr)[2]) {     // the pieces of `step` -> ring buffer `buf`; chunks past the sub-net's last one as zeros
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const unsigned m = (2 * step + (xq[e] >> 1)) < s.nchunk ? 0xffffffffu : 0u;
-            *(u32x4v*)(xs + buf * DIMN_PB_M * DIMN_PB_XLD + xdst[e]) = (u32x4v){xr[e][0] & m, xr[e][1] & m, xr[e][2] & m, xr[e][3] & m};
+        for (int kh = 0; kh < 2; ++kh) {
+            int c0 = 4 * step + 2 * kh, c1 = c0 + 1;
+            c0 = c0 < s.nchunk ? c0 : s.nchunk - 1;
+            c1 = c1 < s.nchunk ? c1 : s.nchunk - 1;
+            const unsigned char* wa = wsub + (size_t)(odd_half ? c1 : c0) * cstride_b;
+            // (as inline asm, with the wait for them written by hand in one_step: across the loop's back edge the compiler's own counting gives
+            //  up and waits for EVERY outstanding request -- the X stage requested a moment ago included -- before the step's first matrix
+            //  instruction.  The price: the compiler does not know that these registers are written LATER -- every set that is requested must
+            //  stay live until a wait that names it, or its registers are handed to something else while the data is still on its way)
+            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:512\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:1024\n\tglobal_load_dwordx4 %3, %4, off offset:1536"
+                         : "=&v"(b[kh][0]), "=&v"(b[kh][1]), "=&v"(b[kh][2]), "=&v"(b[kh][3]) : "v"(wa) : "memory");
         }
     };
-    auto mma1 = [&](const bf16_t* xt, const u32x4v (&b)[4]) {
+    // the 16 operand blocks of a step two at a time, the next pair requested before the eight matrix instructions of this one (left to
+    // itself the scheduler hoists LDS reads until the accumulators spill)
+    auto mma1 = [&](const unsigned char* st, const u32x4v (&b)[2][4]) {
+        auto rd = [&](int j) { return *(const bf16x8n*)(st + (2 * (j & 7) + (j >> 3)) * 1024 + lane * 16); };       // j = 8 kh + rt
+        bf16x8n A[2][2];
+        A[0][0] = rd(0); A[0][1] = rd(1);
 #pragma unroll
-        for (int rt = 0; rt < 8; ++rt) {
-            const bf16x8n a = *(const bf16x8n*)(xt + (16 * rt + li) * DIMN_PB_XLD + 8 * lj);
+        for (int p = 0; p < 8; ++p) {
+            if (p < 7) { A[(p + 1) & 1][0] = rd(2 * p + 2); A[(p + 1) & 1][1] = rd(2 * p + 3); }
 #pragma unroll
-            // A^T tile = W1b (16 hidden units x 32 d) x X^T (32 d x 16 rows): a lane's accumulator is then four CONSECUTIVE HIDDEN UNITS of one
-            // row (acc[rt][ct][r] = A[16 rt + li][64 wave + 16 ct + 4 lj + r]) -- one packed conversion and one 8-byte LDS store per tile below
-            for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8n, b[ct]), a, acc[rt][ct], 0, 0, 0);
+            for (int e = 0; e < 2; ++e) {
+                const int j = 2 * p + e, kh = j >> 3, rt = j & 7;
+#pragma unroll
+                // A^T tile = W1b (16 hidden units x 32 d) x X^T (32 d x 16 rows): a lane's accumulator is then four CONSECUTIVE HIDDEN UNITS of one
+                // row (acc[rt][ct][r] = A[16 rt + li][64 wave + 16 ct + 4 lj + r]) -- one packed conversion and one 8-byte LDS store per tile below
+                for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8n, b[kh][ct]), A[p & 1][e], acc[rt][ct], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     {
-        // Software pipeline: the W1 operands of step s+2 and the X pieces of step s+3 are requested while step s computes -- three
-        // named sets each, the loop unrolled by three so that every set index is a constant (a rotated or run-time-indexed set
-        // would be a register copy that waits for the load, or scratch).  One step = 32 matrix instructions (~0.4 us for the two
-        // co-resident workgroups of a SIMD): one step of distance does not cover even an L2 round trip (measured: the first
-        // matrix instruction of every step waited for its operand), an X row piece comes from HBM.  The W1 requests go first:
-        // waits are in order, and the W1 operand of step s must not queue behind the X pieces requested with it.
-        u32x4v XR[3][2], BR[3][4];
+        // Request queue of a wave at the top of step s, oldest first: X(s) x 4 (requested in step s - 2), W(s) x 8, X(s + 1) x 4 (both in
+        // step s - 1).  "All but 12 done" = this wave's part of X(s) has landed; the barrier makes that true of every wave's part, and says
+        // that every wave has finished step s - 1, whose stage X(s + 2) then overwrites.  Requests past the last step repeat it (into a stage
+        // nobody reads), so that the counts hold in every step.
+        u32x4v B0[2][4], B1[2][4];
         const int last = nsteps - 1;
         auto clampi = [&](int v) { return v < last ? v : last; };
-        bload(0, BR[0]); bload(clampi(1), BR[1]);
-        xload(0, XR[0]); xload(clampi(1), XR[1]); xload(clampi(2), XR[2]);
-        xstore(0, 0, XR[0]);
-        __syncthreads();
-#ifndef DIMN_PB_ABL
-#define DIMN_PB_ABL 0          // diagnostic builds: 1 no W1 requests in the loop, 2 no X requests, 4 no barrier / LDS store, 8 no matrix instructions
-#endif
-#define PB_STEP(S, U)                                                                                                                  \
-        {                                                                                                                              \
-            if (!(DIMN_PB_ABL & 1)) bload(clampi((S) + 2), BR[((U) + 2) % 3]);                                                         \
-            if (!(DIMN_PB_ABL & 2)) xload(clampi((S) + 3), XR[(U) % 3]);                                                               \
-            __builtin_amdgcn_sched_barrier(0);                                                                                         \
-            if (!(DIMN_PB_ABL & 8)) mma1(xs + ((S) & 1) * DIMN_PB_M * DIMN_PB_XLD, BR[(U) % 3]);                                       \
-            if (!(DIMN_PB_ABL & 4)) { xstore(clampi((S) + 1), ((S) + 1) & 1, XR[((U) + 1) % 3]); __syncthreads(); }                    \
-        }
+        int stage = 0;                                           // ring stage of X(step)
+        auto one_step = [&](int step, u32x4v (&bcur)[2][4], u32x4v (&bnext)[2][4]) {
+            __builtin_amdgcn_s_waitcnt(0x0f7c);                  // vmcnt(12) (as the instruction, not as inline asm: the compiler's own counting goes on through it)
+            __builtin_amdgcn_s_barrier();
+            bload(clampi(step + 1), bnext);
+            xissue(clampi(step + 2), stage >= 1 ? stage - 1 : 2);        // (stage + 2) mod 3
+            // queue now: W(step) x 8, X(step + 1) x 4, W(step + 1) x 8, X(step + 2) x 4
+            asm volatile("s_waitcnt vmcnt(16)" : "+v"(bcur[0][0]), "+v"(bcur[0][1]), "+v"(bcur[0][2]), "+v"(bcur[0][3]),
+                                                 "+v"(bcur[1][0]), "+v"(bcur[1][1]), "+v"(bcur[1][2]), "+v"(bcur[1][3]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma1(pl_lds + stage * DIMN_PB_XST, bcur);
+            __builtin_amdgcn_sched_barrier(0);
+            stage = stage == 2 ? 0 : stage + 1;
+        };
+        xissue(0, 0);
+        bload(0, B0);
+        xissue(clampi(1), 1);
         int step = 0;
-        for (; step + 3 <= nsteps; step += 3) { PB_STEP(step, 0) PB_STEP(step + 1, 1) PB_STEP(step + 2, 2) }
-        // 0..2 steps left (same code, guarded; the requests past the last step re-read it)
-        if (step < nsteps) PB_STEP(step, 0)
-        if (step + 1 < nsteps) PB_STEP(step + 1, 1)
-#undef PB_STEP
-        // (every PB_STEP ends with a barrier: every wave is done with the ring -- the activations take its place)
+        for (; step + 2 <= nsteps; step += 2) { one_step(step, B0, B1); one_step(step + 1, B1, B0); }
+        if (step < nsteps) one_step(step, B0, B1);
+        // (both operand sets named: the last step requested one of them for a step that does not exist)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(B0[0][0]), "+v"(B0[0][1]), "+v"(B0[0][2]), "+v"(B0[0][3]),
+                                            "+v"(B0[1][0]), "+v"(B0[1][1]), "+v"(B0[1][2]), "+v"(B0[1][3]) :: "memory");
+        asm volatile("" : "+v"(B1[0][0]), "+v"(B1[0][1]), "+v"(B1[0][2]), "+v"(B1[0][3]),
+                          "+v"(B1[1][0]), "+v"(B1[1][1]), "+v"(B1[1][2]), "+v"(B1[1][3]) :: "memory");
+        __syncthreads();                                         // every wave is done with the ring (and every request has landed): the activations take its place
     }
     PB_STAMP(1);
     // bias + activation, rounded to bf16 into LDS (four hidden units of a row at a time); columns [Hp, Hq) zero.
@@ -2183,7 +2205,7 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
         const bool vec_ok = FAST || (dm.O & 3) == 0;
         f32x4 b2v[4];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) b2v[ct] = ov[ct] ? *(const f32x4*)(b2 + (int64_t)k * dm.Op + 16 * (ot0 + 4 * wave + ct) + 4 * lj) : zero4;
+        for (int ct = 0; ct < 4; ++ct) b2v[ct] = *(const f32x4*)(b2 + (int64_t)k * dm.Op + 16 * (ov[ct] ? ot0 + 4 * wave + ct : 0) + 4 * lj);
 #pragma unroll
         for (int rt = 0; rt < 8; ++rt) {
             const int64_t i = r0 + 16 * rt + li;
@@ -2192,20 +2214,20 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 const int o0 = 16 * (ot0 + 4 * wave + ct) + 4 * lj;
-                if (!ov[ct] || !row_ok || o0 >= dm.O) continue;
+                const bool ok = ov[ct] && row_ok && o0 < dm.O;
+                // softplus for every lane, store / loss under `ok`: with the whole block skipped by a branch (as it was) every second block began
+                // with a wait for ALL outstanding memory operations -- the previous block's store included, 16 store round trips per pass -- and
+                // the scheduler could not move anything across the 32 branch pairs (round 4: 36 + 27 us for the two epilogues of a workgroup)
                 f32x4 yh;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) yh[r] = softplus_out(acc[rt][ct][r] + b2v[ct][r]);      // (b2 is padded to Op)
-                // (measured: the cheaper two-transcendental softplus of the training kernels changes nothing here -- 5.8 ms either way;
-                //  without softplus AND without the stores the kernel takes 3.9 ms: epilogue and GEMMs overlap across the two
-                //  workgroups of a CU, and what remains is the request stream of the first layer)
-                if (out) {
+                if (out && ok) {
                     float* dst = out + (i * dm.K + k) * dm.O + o0;
                     if (vec_ok) DIMN_PB_STORE((f32x4*)dst, yh);
                     else
                         for (int r = 0; r < 4; ++r) if (o0 + r < dm.O) dst[r] = yh[r];
                 }
-                if (LOSS) {
+                if (LOSS && ok) {
                     const float* yrow = Y + ((int64_t)k * n_cells + row) * dm.Op + o0;
                     float acc_l = 0.f;
 #pragma unroll
@@ -2234,6 +2256,7 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
             if (t64 + 1 < lp_stride) loss_part[(int64_t)k * lp_stride + t64 + 1] = redl[4] + redl[5] + redl[6] + redl[7];
         }
     }
+#endif
 }
 
 // the round-2 form (64 rows per workgroup, 16-deep instructions, every operand an 8-byte global load): hidden widths beyond 256
