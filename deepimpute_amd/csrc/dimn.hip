@@ -1214,7 +1214,7 @@ static void launch_predict_impl(dimn_handle h, const int32_t* rows, int64_t n_ro
             // 128 rows per workgroup, 32-deep bf16 matrix instructions, X staged through LDS (dimn_kernels.h); loss slots stay 64-row tiles
             const unsigned tiles128 = (unsigned)((n_rows + DIMN_PB_M - 1) / DIMN_PB_M);
             const int hq = (h->dm.Hp + 31) & ~31;
-            const size_t ldsb = std::max<size_t>((size_t)3 * DIMN_PB_XST, (size_t)DIMN_PB_M * (hq + 8) * 2) + 64;
+            const size_t ldsb = std::max<size_t>((size_t)4 * DIMN_PB_XST, (size_t)DIMN_PB_M * (hq + 8) * 2) + 64;
             const bool fast = h->act == 0 && (h->dm.O & 3) == 0;            // (the instantiation without the activation switch and the scalar stores)
 #define PB_LAUNCH(F, L)                                                                                                                                          \
             {                                                                                                                                                    \

@@ -1954,8 +1954,11 @@ __global__ __launch_bounds__(256) void k_prep_bf16(const SubnetDev* __restrict__
 //     the second layer, four output tiles per pass -- 32 matrix instructions per 32-deep step against 8 LDS reads (A) and four
 //     16-byte global loads (B, from the bf16 weight images in L2).  Round 2's kernel (64 rows, 16-deep, every operand an 8-byte
 //     global load) issued one vector-memory instruction per matrix instruction: 215 TFLOP/s, VMEM-issue bound.
-//   * X tile [128][32] of every step staged ONCE per workgroup through a double-buffered LDS ring (two 16-byte pieces per thread,
-//     requested one step ahead); the hidden activations [128][Hp] are rounded to bf16 into the same LDS (aliasing the ring).
+//   * X tile of every step staged ONCE per workgroup through an LDS ring, since round 4 by the LDS DMA in 64-deep steps (below);
+//     the hidden activations [128][Hp] are rounded to bf16 into the same LDS (aliasing the ring).
+//   * Round 4, found with per-workgroup phase stamps (tools/pb_trace.sh), 5.87 -> 3.97 ms on 50k cells x 40 sub-nets: the kernel was 250 KB
+//     of code (the activation switch inlined 128 times) against a 64 KB instruction cache; its output epilogue waited for the previous
+//     block's store at every second block and branched per element; its first layer held a barrier every 32 matrix instructions.
 //   * A lane's eight k's of an operand are eight CONSECUTIVE k's on both operands -- which of the 32 k's of the instruction they
 //     occupy does not matter for a dot product (the k-slot argument of this file), so no layout of the 32-deep instruction is
 //     assumed beyond "A and B use the same one".
@@ -1997,7 +2000,7 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
                                                          float* __restrict__ loss_part, int64_t lp_stride, Dims dm, int loss_binary, int act,
                                                          const bf16_t* __restrict__ zeros) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (the LDS address space below makes the host pass drop the stub silently otherwise)
-    extern __shared__ __attribute__((aligned(1024))) unsigned char pl_lds[];                 // X ring: 3 stages of DIMN_PB_XST bytes
+    extern __shared__ __attribute__((aligned(1024))) unsigned char pl_lds[];                 // X ring: 4 stages of DIMN_PB_XST bytes
     bf16_t* ddl = (bf16_t*)pl_lds;                               // hidden activations [128][ld2] (aliases the ring once the first layer is done)
     const int Hp = dm.Hp, Hq = (Hp + 31) & ~31;                  // hidden width padded to whole 32-deep steps
     const int ld2 = Hq + 8;
@@ -2015,7 +2018,7 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
     // X goes from global memory straight into LDS (global_load_lds: no staging registers, no ds_write) in FRAGMENT ORDER: a stage of the
     // ring is [8 row tiles][2 k-halves] blocks of 1 KB, lane (li, lj) of block (rt, kh) holding row 16 rt + li, k's 64 step + 32 kh + 8 lj ..+7
     // -- the operand of one matrix instruction is ds_read_b128 at lane * 16, conflict-free.  Wave w brings in blocks 4w .. 4w + 3 of every
-    // stage.  One barrier per 64-deep step (64 matrix instructions per wave): with one per 32-deep step the loop took 62 us per workgroup
+    // stage.  One barrier per PAIR of steps (128 matrix instructions per wave): with one per 32-deep step the loop took 62 us per workgroup
     // against 38 with the barrier removed (round 4, phase stamps); W1b stays a direct global -> register operand (private to its wave).
     // Chunks past the sub-net's last one are fetched from 1 KB of zeros.
     f32x4 acc[8][4];
@@ -2033,13 +2036,20 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
         xsrc[u] = X + s.xoff + src * s.Dp + 32 * kh + 8 * lj;
     }
     const bf16_t* zp = zeros + 8 * lane;
-    auto xissue = [&](int step, int stage) {
+    // X(sa) -> stage, X(sb) -> stage + 1, requested together: the two steps' pieces of a row are 256 contiguous bytes, asked for back to back
+    // (a predictor row is ~5 KB: a visit of 128 bytes per row and step left the HBM pages half used)
+    auto xissue2 = [&](int sa, int sb, int stage) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = 4 * step + 2 * (u & 1) + (lj >> 1);
-            const bf16_t* g = c < s.nchunk ? xsrc[u] + 64 * step : zp;
-            __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)(pl_lds + stage * DIMN_PB_XST + (4 * wave + u) * 1024), 16, 0, 0);
-        }
+        for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+            for (int which = 0; which < 2; ++which)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int u = 2 * uu + e, step = which ? sb : sa;
+                    const int c = 4 * step + 2 * e + (lj >> 1);
+                    const bf16_t* g = c < s.nchunk ? xsrc[u] + 64 * step : zp;
+                    __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)(pl_lds + (stage + which) * DIMN_PB_XST + (4 * wave + u) * 1024), 16, 0, 0);
+                }
     };
     // W1 operand of column tile ct, k-half kh of a step: eight consecutive d's of hidden unit h = 64 wave + 16 ct + li from chunk 4 step + 2 kh + (lj >> 1).
     // Address = a wave-uniform chunk base (one of two, chosen by lj >> 1) + ONE 32-bit lane offset + 512 ct as the instruction's immediate:
@@ -2087,33 +2097,40 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
         }
     };
     {
-        // Request queue of a wave at the top of step s, oldest first: X(s) x 4 (requested in step s - 2), W(s) x 8, X(s + 1) x 4 (both in
-        // step s - 1).  "All but 12 done" = this wave's part of X(s) has landed; the barrier makes that true of every wave's part, and says
-        // that every wave has finished step s - 1, whose stage X(s + 2) then overwrites.  Requests past the last step repeat it (into a stage
-        // nobody reads), so that the counts hold in every step.
+        // Steps in pairs (s even, s + 1), ring of four stages, stage of X(t) = t mod 4.  Request queue of a wave at the top of a pair, oldest
+        // first: X(s), X(s + 1) x 8 (requested at the top of the pair before), W(s) x 8.  "All but 8 done" = this wave's part of both X stages
+        // has landed; the barrier makes that true of every wave's part and says that every wave has finished the pair before, whose stages
+        // X(s + 2), X(s + 3) then overwrite -- ONE barrier per 128 k's.  W(s) lives in B0, W(s + 1) in B1, each requested one step ahead; the
+        // waits for them are counted by hand (see bload).  Requests past the last step repeat it (into stages nobody reads), so that the
+        // counts hold in every pair; an odd step count skips the second half of the last pair.
         u32x4v B0[2][4], B1[2][4];
         const int last = nsteps - 1;
         auto clampi = [&](int v) { return v < last ? v : last; };
-        int stage = 0;                                           // ring stage of X(step)
-        auto one_step = [&](int step, u32x4v (&bcur)[2][4], u32x4v (&bnext)[2][4]) {
-            __builtin_amdgcn_s_waitcnt(0x0f7c);                  // vmcnt(12) (as the instruction, not as inline asm: the compiler's own counting goes on through it)
-            __builtin_amdgcn_s_barrier();
-            bload(clampi(step + 1), bnext);
-            xissue(clampi(step + 2), stage >= 1 ? stage - 1 : 2);        // (stage + 2) mod 3
-            // queue now: W(step) x 8, X(step + 1) x 4, W(step + 1) x 8, X(step + 2) x 4
-            asm volatile("s_waitcnt vmcnt(16)" : "+v"(bcur[0][0]), "+v"(bcur[0][1]), "+v"(bcur[0][2]), "+v"(bcur[0][3]),
-                                                 "+v"(bcur[1][0]), "+v"(bcur[1][1]), "+v"(bcur[1][2]), "+v"(bcur[1][3]) :: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            mma1(pl_lds + stage * DIMN_PB_XST, bcur);
-            __builtin_amdgcn_sched_barrier(0);
-            stage = stage == 2 ? 0 : stage + 1;
-        };
-        xissue(0, 0);
+        int half = 0;                                            // stages 2 half, 2 half + 1 hold this pair
+        xissue2(0, clampi(1), 0);
         bload(0, B0);
-        xissue(clampi(1), 1);
-        int step = 0;
-        for (; step + 2 <= nsteps; step += 2) { one_step(step, B0, B1); one_step(step + 1, B1, B0); }
-        if (step < nsteps) one_step(step, B0, B1);
+        for (int step = 0; step < nsteps; step += 2) {
+            __builtin_amdgcn_s_waitcnt(0x0f78);                  // vmcnt(8)
+            __builtin_amdgcn_s_barrier();
+            bload(clampi(step + 1), B1);
+            xissue2(clampi(step + 2), clampi(step + 3), half ? 0 : 2);
+            // queue now: W(step) x 8, W(step + 1) x 8, X x 8
+            asm volatile("s_waitcnt vmcnt(16)" : "+v"(B0[0][0]), "+v"(B0[0][1]), "+v"(B0[0][2]), "+v"(B0[0][3]),
+                                                 "+v"(B0[1][0]), "+v"(B0[1][1]), "+v"(B0[1][2]), "+v"(B0[1][3]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma1(pl_lds + (2 * half) * DIMN_PB_XST, B0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 1 < nsteps) {
+                bload(clampi(step + 2), B0);
+                // queue now: W(step + 1) x 8, X x 8, W(step + 2) x 8
+                asm volatile("s_waitcnt vmcnt(16)" : "+v"(B1[0][0]), "+v"(B1[0][1]), "+v"(B1[0][2]), "+v"(B1[0][3]),
+                                                     "+v"(B1[1][0]), "+v"(B1[1][1]), "+v"(B1[1][2]), "+v"(B1[1][3]) :: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma1(pl_lds + (2 * half + 1) * DIMN_PB_XST, B1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            half ^= 1;
+        }
         // (both operand sets named: the last step requested one of them for a step that does not exist)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(B0[0][0]), "+v"(B0[0][1]), "+v"(B0[0][2]), "+v"(B0[0][3]),
                                             "+v"(B0[1][0]), "+v"(B0[1][1]), "+v"(B0[1][2]), "+v"(B0[1][3]) :: "memory");
@@ -2185,7 +2202,7 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
                 for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8n, b[ct]), a, acc[rt][ct], 0, 0, 0);
             }
         };
-        {
+        if constexpr (LOSS) {                                    // (the loss variant has no registers for a third set)
             u32x4v C0[4], C1[4];
             b2load(0, C0);
             int st = 0;
@@ -2198,6 +2215,28 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
                 mma2(st + 1, C1);
             }
             if (st < nsteps2) mma2(st, C0);
+        } else {
+            // three named operand sets, requested two steps ahead (one step = 32 matrix instructions per wave does not cover an L2 round trip:
+            // with one step of distance this phase took 10-11 us per pass for 3.4 us of matrix-pipe time)
+            u32x4v C0[4], C1[4], C2[4];
+            const int l2 = nsteps2 - 1;
+            auto cl = [&](int v) { return v < l2 ? v : l2; };
+            b2load(0, C0);
+            b2load(cl(1), C1);
+            int st = 0;
+            for (; st + 3 <= nsteps2; st += 3) {
+                b2load(cl(st + 2), C2);
+                __builtin_amdgcn_sched_barrier(0);
+                mma2(st, C0);
+                b2load(cl(st + 3), C0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma2(st + 1, C1);
+                b2load(cl(st + 4), C1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma2(st + 2, C2);
+            }
+            if (st < nsteps2) mma2(st, C0);
+            if (st + 1 < nsteps2) mma2(st + 1, C1);
         }
         // epilogue: bias, softplus, store / loss.  A lane holds outputs o0 .. o0+3 of batch row 16 rt + li; the four output tiles of a
         // wave are adjacent (64 outputs = 256 contiguous bytes of a row of `out`), written tile after tile for each row tile
