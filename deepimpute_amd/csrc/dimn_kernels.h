@@ -203,6 +203,33 @@ __device__ __forceinline__ float softplus_out(float x) {
     return x > thr ? x : r;
 }
 
+// The same function on two elements at a time: every multiply / add / fma becomes ONE packed instruction (v_pk_mul_f32, v_pk_add_f32,
+// v_pk_fma_f32: IEEE results, element for element those of softplus_out), only the three transcendentals and the selects stay per element --
+// 18 instead of 27 instructions per element in k_predict_bf16's output epilogue.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 softplus_out2(f32x2 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float thr = 13.942385f;
+    const f32x2 ax = __builtin_elementwise_abs(x);
+    const f32x2 p = -ax * 1.44269502f;
+    f32x2 pe = __builtin_elementwise_fma(-ax, (f32x2)1.44269502f, -p);
+    pe = __builtin_elementwise_fma(-ax, (f32x2)1.92596299e-8f, pe);
+    f32x2 t = (f32x2){__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
+    t = __builtin_elementwise_fma(t, pe * 0.693147182f, t);                                   // exp(-|x|)
+    const f32x2 u = 1.0f + t, d = u - 1.0f;
+    const f32x2 lg = (f32x2){__builtin_amdgcn_logf(u.x), __builtin_amdgcn_logf(u.y)} * 0.693147182f;
+    const f32x2 l_series = t * __builtin_elementwise_fma(t, __builtin_elementwise_fma(t, (f32x2)0.333333343f, (f32x2)-0.5f), (f32x2)1.0f);
+    const f32x2 l_log = lg * (t * (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)});
+    const f32x2 l = t < 2.44140625e-4f ? l_series : l_log;
+    const f32x2 sp = __builtin_elementwise_max(x, (f32x2)0.f) + l;
+    f32x2 r = x < -thr ? t : sp;
+    asm volatile("" : "+v"(r));                              // (as in softplus_out)
+    return x > thr ? x : r;
+#else
+    return (f32x2){softplus_out(x.x), softplus_out(x.y)};
+#endif
+}
+
 // Hidden activation f and derivative f' at pre-activation a (multinet.py:137; ids = DIMN_ACT_* of dimn.h, elu alpha = 1).
 // relu is handled inline by the kernels (bit-identical to the path that has no activation switch).
 __device__ __forceinline__ void hidden_act(int act, float a, float& f, float& df) {
@@ -229,7 +256,8 @@ __device__ __attribute__((noinline)) float hidden_act_call(int act, float a) {
 // only the loss and dZ (absolute error ~1e-7); the inference kernels use softplus_out (within ~3 ulp of libm's).
 __device__ __forceinline__ void softplus_sigmoid_fast(float x, float& sp, float& sg) {
     const float t = __expf(-fabsf(x));
-    const float l = t < 2.44140625e-4f ? t * (1.0f - 0.5f * t) : __logf(1.0f + t);
+    const float l_series = t * (1.0f - 0.5f * t), l_log = __logf(1.0f + t);    // (both, then a select: as a conditional expression over the
+    const float l = t < 2.44140625e-4f ? l_series : l_log;                        //  computations it compiles to a branch per element)
     sp = fmaxf(x, 0.f) + l;
     const float r = __builtin_amdgcn_rcpf(1.0f + t);
     sg = x >= 0.f ? r : t * r;
@@ -927,17 +955,16 @@ __global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ m
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int b = 16 * (m0 + j) + 4 * lj + r;
-                float dz = 0.f;
-                if (b < b_act && col_ok) {
-                    const float z = acc[j][r] + bias;
-                    const float y = yv[j][r];
-                    const float w = loss_binary ? (y > 0.f ? 1.f : 0.f) : y;   // multinet.py:37-40
-                    float sp, sg;
-                    softplus_sigmoid_fast(z, sp, sg);
-                    const float e = y - sp;
-                    lsum += w * e * e;
-                    dz = -2.f * w * e * inv_n * sg;
-                }
+                // (computed for every lane and selected: under a branch per element the 16 softplus chains of a lane ran one after the other)
+                const bool ok = b < b_act && col_ok;
+                const float z = acc[j][r] + bias;
+                const float y = yv[j][r];
+                const float w = loss_binary ? (y > 0.f ? 1.f : 0.f) : y;       // multinet.py:37-40
+                float sp, sg;
+                softplus_sigmoid_fast(z, sp, sg);
+                const float e = y - sp;
+                lsum += ok ? w * e * e : 0.f;
+                const float dz = ok ? -2.f * w * e * inv_n * sg : 0.f;
                 zb[b * 16 + li] = dz;
                 gb += dz;
             }
@@ -2257,9 +2284,9 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
                 // softplus for every lane, store / loss under `ok`: with the whole block skipped by a branch (as it was) every second block began
                 // with a wait for ALL outstanding memory operations -- the previous block's store included, 16 store round trips per pass -- and
                 // the scheduler could not move anything across the 32 branch pairs (round 4: 36 + 27 us for the two epilogues of a workgroup)
-                f32x4 yh;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) yh[r] = softplus_out(acc[rt][ct][r] + b2v[ct][r]);      // (b2 is padded to Op)
+                const f32x4 zz = acc[rt][ct] + b2v[ct];                                              // (b2 is padded to Op)
+                const f32x2 y01 = softplus_out2((f32x2){zz[0], zz[1]}), y23 = softplus_out2((f32x2){zz[2], zz[3]});
+                const f32x4 yh = (f32x4){y01.x, y01.y, y23.x, y23.y};
                 if (out && ok) {
                     float* dst = out + (i * dm.K + k) * dm.O + o0;
                     if (vec_ok) DIMN_PB_STORE((f32x4*)dst, yh);

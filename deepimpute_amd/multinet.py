@@ -347,8 +347,14 @@ class MultiNet:
             with open(os.path.join(self.outputdir, "model.json"), "w") as fh:
                 json.dump(keras_io.model_json(dims, layers, self.sub_outputdim, self.seed, meta), fh)
         blobs = {}
+        import time
+        laps = getattr(self, "timings", None)                # (fit.save split into its device and its file-system part: the latter varies 20x between boxes)
+        t_fetch = time.perf_counter()
         # (the K device-to-host copies + re-layouts are independent reads of the handle: fetched on the host pool)
         fetched = _hostpar.pmap(model.get_weights, range(model.K)) if hasattr(model, "predict_device") else [model.get_weights(k) for k in range(model.K)]
+        if isinstance(laps, dict):
+            laps["fit.save.fetch_weights"] = laps.get("fit.save.fetch_weights", 0.0) + time.perf_counter() - t_fetch
+        t_write = time.perf_counter()
         for k in range(model.K):                         # dense layer l (1-based, the last one is the output layer): Wl_<k>, bl_<k>
             arrays = fetched[k]
             for i, arr in enumerate(arrays):
@@ -399,6 +405,8 @@ class MultiNet:
             keras_io.write_weights_h5(os.path.join(self.outputdir, "model.h5"), order, weights)
         if comm is not None:
             comm.barrier()                               # every file is on disk when any rank returns
+        if isinstance(laps, dict):
+            laps["fit.save.write_files"] = laps.get("fit.save.write_files", 0.0) + time.perf_counter() - t_write
         written = {"h5": "model.json + model.h5 (Keras save_weights layout)", "npz": "model.json + model.npz (no HDF5 library found: set DIMN_LIBHDF5, "
                    "or DIMN_MODEL_FORMAT=h5 to insist)" if not os.environ.get("DIMN_MODEL_FORMAT") else "model.json + model.npz",
                    "both": "model.json + model.h5 + model.npz"}[fmt]

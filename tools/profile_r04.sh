@@ -12,7 +12,10 @@ timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_k5 -o run -- $B --limit-
 python tools/kstats.py $O/prof_k5 > $O/kernel_stats_k5.txt 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_gen -o run -- $B --general --epochs 1 --warmup 0 > $O/bench_general_under_rocprof.json 2>> $O/prof.err
 python tools/kstats.py $O/prof_gen > $O/kernel_stats_general.txt 2>&1
-rm -rf $O/prof $O/prof_k5 $O/prof_gen
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_bf -o run -- $B --precision bf16 --epochs 2 > $O/bench_bf16_under_rocprof.json 2>> $O/prof.err
+python tools/kstats.py $O/prof_bf > $O/kernel_stats_bf16.txt 2>&1
+rm -rf $O/prof $O/prof_k5 $O/prof_gen $O/prof_bf
+bash tools/pb_trace.sh > $O/predict_bf16_phases.txt 2>&1; tail -9 $O/predict_bf16_phases.txt
 head -8 $O/kernel_stats.txt; head -5 $O/kernel_stats_k5.txt; head -10 $O/kernel_stats_general.txt
 P="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-dropin --no-accuracy --epochs 1"
 for c in FETCH_SIZE WRITE_SIZE; do timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o pmc -- $P > /dev/null 2> $O/pmc_$c.err; done
