@@ -152,6 +152,33 @@ def test_bf16_matrix_core_inference_matches_oracle_rounding(H, O, B, Ds, monkeyp
         e.close()
 
 
+@pytest.mark.parametrize("H,O,B,Ds,n,act", [
+    (256, 101, 64, [300, 77], 330, "tanh"),       # the instantiation WITH the activation switch and the scalar output stores (O % 4 != 0)
+    (256, 512, 64, [10, 40], 200, "relu"),        # one-chunk and three-chunk sub-nets: steps, pairs and k-halves that do not exist
+    (64, 32, 16, [129], 100, "sigmoid"),          # fewer rows than one 128-row workgroup, hidden width below a wave's 64 columns, an odd step count
+    (256, 512, 64, [520], 300, "relu"),           # nine 64-deep steps: an odd count above one pair
+])
+def test_bf16_matrix_core_inference_edge_shapes(H, O, B, Ds, n, act, monkeypatch):
+    """k_predict_bf16's round-4 loop (64-deep steps in pairs through the LDS DMA, chunks past a sub-net's last one fetched as zeros,
+    hand-counted waits) and both of its instantiations, at the shapes where a count could be off; tolerances as above."""
+    monkeypatch.setenv("DIMN_TRAIN_BF16", "0")
+    prob = make_problem(n=n, g=700, Ds=Ds, H=H, O=O, seed=5)
+    kw = dict(batch_size=B, dropout_rate=0.2, learning_rate=1e-3, seed=77, activation=act)
+    a = load_problem(_hip(), prob, precision="bf16", **kw)
+    b = load_problem(_oracle(), prob, precision="bf16", infer_bf16=True, **kw)
+    for e in (a, b):
+        e.init_weights()
+    np.testing.assert_allclose(a.train_epoch(0), b.train_epoch(0), rtol=1e-4)
+    np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=5e-4)
+    pa, pb = a.predict(), b.predict()
+    assert np.isfinite(pa).all()
+    np.testing.assert_allclose(pa, pb, rtol=2e-3, atol=2e-4)
+    rows = prob["val"]
+    np.testing.assert_allclose(a.predict(rows), pa[rows], rtol=0, atol=0)
+    for e in (a, b):
+        e.close()
+
+
 def test_bf16_matrix_core_training_of_the_second_layer(monkeypatch):
     """precision="bf16" on the fused second-layer kernel (k_mid_fused<KEEP, BF>): Z = Dd W2, gW2 = Dd^T dZ and dD = dZ W2^T take
     bf16 operands (rounded to nearest even in registers, fp32 accumulation, fp32 master weights and Adam state).  The oracle
