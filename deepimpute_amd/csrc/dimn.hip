@@ -20,6 +20,7 @@
 
 #include "../../include/dimn.h"
 #include "dimn_kernels.h"
+#include "dimn_mid_pipe.h"
 #include "dimn_corr.h"
 #include "dimn_resident.h"
 #include "dimn_general.h"
@@ -177,6 +178,7 @@ struct dimn_handle_s {
     std::vector<MidWork> midwork;          // work table of the fused second-layer kernel (k_mid_fused)
     int mid_fused = 0, mid_slices = 0;     // 1: RED -> MFB -> RED2 -> B1F1; 0: RED -> MF -> MB -> B1F1
     int mid_keep = 0;                      // 1: k_mid_fused<true> (the W2 column blocks stay in LDS between its phases)
+    int mid_pipe = 0;                      // 1: k_mid_pipe (dimn_mid_pipe.h: the slice's tiles as a software pipeline; fp32 operands) instead of k_mid_fused
     int train_bf16 = 0;                    // 1: precision bf16 and the fused second layer runs its three GEMMs on the bf16 matrix cores
     MidWork* d_midwork = nullptr; int32_t* d_midk = nullptr; float* d_P2 = nullptr;
     std::vector<std::vector<int32_t>> pred, targ;
@@ -471,6 +473,7 @@ static void build_mid(dimn_handle h) {
     for (auto& m : h->midwork) tmax = std::max(tmax, m.ot1 - m.ot0);
     h->mid_keep = tmax <= 6;
     h->train_bf16 = h->mid_keep && h->prec == DIMN_PREC_BF16 && !(getenv("DIMN_TRAIN_BF16") && atoi(getenv("DIMN_TRAIN_BF16")) == 0);
+    h->mid_pipe = !h->train_bf16 && !(getenv("DIMN_MID_PIPE") && atoi(getenv("DIMN_MID_PIPE")) == 0);   // DIMN_MID_PIPE=0: the three-phase kernel (A/B, tests)
 }
 
 static bool resident_plan(dimn_handle h, int Kg, int& S1o, int& T1o) {
@@ -671,6 +674,7 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
         (void)hipFuncSetAttribute((const void*)k_mid_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)k_mid_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)k_mid_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_mid_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     auto zero = [&](void* p, size_t bytes) { return hipMemset(p, 0, bytes) == hipSuccess ? 0 : fail(DIMN_ERR_HIP, "hipMemset failed"); };
     TRY(zero(h->d_W1, w1 * 4)); TRY(zero(h->d_M1, w1 * 4)); TRY(zero(h->d_V1, w1 * 4));
@@ -1332,7 +1336,12 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
                                              h->d_W2, h->d_M2, h->d_V2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_P2,        \
                                              h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary)
         // keep: every slice <= 6 tiles, W2 read once (DIMN_MID_KEEP=0: off); with precision bf16 its GEMMs take bf16 operands
-        if (h->mid_keep && h->train_bf16) {
+        if (h->mid_pipe) {
+            hipLaunchKernelGGL(k_mid_pipe, dim3(nk * (unsigned)h->mid_slices), dim3(512), (size_t)DIMN_MIDP_LDS_FLOATS * sizeof(float), st,
+                               h->d_midwork + (size_t)ln.k0 * h->mid_slices,
+                               h->d_W2, h->d_M2, h->d_V2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_P2,
+                               h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary);
+        } else if (h->mid_keep && h->train_bf16) {
             hipLaunchKernelGGL((k_mid_fused<true, true>), dim3(nk * (unsigned)h->mid_slices), dim3(512), lds, st, h->d_midwork + (size_t)ln.k0 * h->mid_slices,
                                h->d_W2, h->d_M2, h->d_V2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_P2,
                                h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary);
@@ -1966,7 +1975,7 @@ extern "C" int dimn_path_info(dimn_handle h, int32_t* out8) {
     out8[2] = h->res_S1;                                        // resident: D-splits per hidden tile
     out8[3] = h->mid_fused;                                     // streaming: 1 fused second layer (RED -> MFB -> RED2), 0 two kernels (MF + MB)
     out8[4] = h->mid_fused ? h->mid_slices : 0;                 // ... output slices per sub-net
-    out8[5] = h->mid_keep;                                      // ... W2 column blocks kept in LDS between the phases
+    out8[5] = h->mid_fused && h->mid_pipe ? 2 : h->mid_keep;                                      // ... W2 column blocks kept in LDS between the phases
     out8[6] = h->res_G ? 2 * h->res_bf16 : h->train_bf16;      // training GEMMs on the bf16 matrix cores: 1 the second layer's (fused kernel), 2 all (resident kernel)
     out8[7] = h->dm.HT == 16 ? 1 : (h->dm.HT == 20 ? 2 : 0);    // first layer: 1 ring B1F1 (H = 256), 2 shared-staging (H = 300), 0 generic
     return DIMN_OK;

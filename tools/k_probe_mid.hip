@@ -1,10 +1,12 @@
 // k_probe_mid.hip -- standalone timing of the middle kernels (RED / MF / MB) on cfg3-shaped
 // synthetic state (K=40, H=256, O=512, n=50000).  Diagnostics only.
 #define DIMN_MID_TL 1
+#define DIMN_MIDP_TL 1
 #ifndef PROBE_KEEP
 #define PROBE_KEEP true
 #endif
 #include "../deepimpute_amd/csrc/dimn_kernels.h"
+#include "../deepimpute_amd/csrc/dimn_mid_pipe.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -69,6 +71,56 @@ int main(int argc, char** argv) {
         printf("fused: %zu workgroups (%d slices per sub-net)\n", mw.size(), Sm);
         T("k_mid_fused (warm)", k_mid_fused<PROBE_KEEP>, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0)
         T("k_reduce_dd", k_reduce_dd, dim3(4, K), dim3(1024), 0, 0, dmk, P2, Dd, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 0, (const float*)nullptr)
+
+        {   // k_mid_pipe (dimn_mid_pipe.h): same state, same outputs within summation order; then its timings
+            CK(hipFuncSetAttribute((const void*)k_mid_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            const size_t ldsp = (size_t)DIMN_MIDP_LDS_FLOATS * 4;
+            const size_t nw2 = (size_t)K * 256 * 512, nb2 = (size_t)3 * K * 512, np2 = mw.size() * 64 * 256;
+            std::vector<float> w0(nw2), m0(nw2), v0(nw2), bb0(nb2);
+            CK(hipMemcpy(w0.data(), W2, nw2 * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(m0.data(), M2, nw2 * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(v0.data(), V2, nw2 * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(bb0.data(), b2, nb2 * 4, hipMemcpyDeviceToHost));
+            std::vector<float> out[2][6];
+            for (int which = 0; which < 2; ++which) {
+                CK(hipMemcpy(W2, w0.data(), nw2 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(M2, m0.data(), nw2 * 4, hipMemcpyHostToDevice));
+                CK(hipMemcpy(V2, v0.data(), nw2 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(b2, bb0.data(), nb2 * 4, hipMemcpyHostToDevice));
+                CK(hipMemset(P2, 0, np2 * 4)); CK(hipMemset(ls, 0, K * 8 * 4));
+                if (which == 0) hipLaunchKernelGGL(k_mid_fused<PROBE_KEEP>, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 61, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
+                else hipLaunchKernelGGL(k_mid_pipe, dim3((unsigned)mw.size()), dim3(512), ldsp, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 61, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
+                CK(hipDeviceSynchronize());
+                const float* src[6] = {W2, M2, V2, b2, P2, ls}; const size_t cnt[6] = {nw2, nw2, nw2, nb2, np2, (size_t)K * 8};
+                for (int j = 0; j < 6; ++j) { out[which][j].resize(cnt[j]); CK(hipMemcpy(out[which][j].data(), src[j], cnt[j] * 4, hipMemcpyDeviceToHost)); }
+            }
+            const char* nm[6] = {"W2", "M2", "V2", "b2 (w, m, v)", "P2", "loss"};
+            for (int j = 0; j < 6; ++j) {
+                double md = 0, mx = 0; size_t bad = 0;
+                for (size_t i = 0; i < out[0][j].size(); ++i) { const double a = out[0][j][i], b = out[1][j][i]; md = std::max(md, fabs(a - b)); mx = std::max(mx, fabs(a)); if (!(fabs(a - b) <= 1e-5 * (fabs(a) + 1e-3))) ++bad; }
+                printf("pipe vs fused  %-14s max |delta| %.3e  (max |value| %.3e)  beyond 1e-5 rel: %zu of %zu\n", nm[j], md, mx, bad, out[0][j].size());
+            }
+            T("k_mid_pipe (warm)", k_mid_pipe, dim3((unsigned)mw.size()), dim3(512), ldsp, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0)
+            float* big2 = dalloc((size_t)256 << 20, 1.f, 12);
+            hipEvent_t ea, eb; CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
+            double cold_p = 0, cold_f2 = 0; const int R = 10;
+            for (int it = 0; it < R; ++it) {
+                float ms;
+                hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, big2, (size_t)256 << 20, 1.f, 13u + it);
+                CK(hipEventRecord(ea));
+                hipLaunchKernelGGL(k_mid_pipe, dim3((unsigned)mw.size()), dim3(512), ldsp, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
+                CK(hipEventRecord(eb)); CK(hipEventSynchronize(eb)); CK(hipEventElapsedTime(&ms, ea, eb)); cold_p += ms;
+                hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, big2, (size_t)256 << 20, 1.f, 13u + it);
+                CK(hipEventRecord(ea));
+                hipLaunchKernelGGL(k_mid_fused<PROBE_KEEP>, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
+                CK(hipEventRecord(eb)); CK(hipEventSynchronize(eb)); CK(hipEventElapsedTime(&ms, ea, eb)); cold_f2 += ms;
+            }
+            printf("cold (after 1 GB of other traffic): k_mid_pipe %.1f us   k_mid_fused %.1f us\n", 1e3 * cold_p / R, 1e3 * cold_f2 / R);
+            hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, big2, (size_t)256 << 20, 1.f, 99u);
+            hipLaunchKernelGGL(k_mid_pipe, dim3((unsigned)mw.size()), dim3(512), ldsp, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> tl(512 * 8 * 12); CK(hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_midp_tl), tl.size() * 8));
+            double ph[4] = {0, 0, 0, 0}; unsigned long long tmin = ~0ull, tmax = 0; const size_t nw = mw.size() * 8;
+            for (size_t i = 0; i < nw; ++i) { const unsigned long long* o = &tl[i * 12]; for (int j = 0; j < 4; ++j) ph[j] += (double)(o[j + 1] - o[j]); if (o[0] < tmin) tmin = o[0]; if (o[4] > tmax) tmax = o[4]; }
+            printf("pipe timeline, mean clk (100 MHz) per wave: Dd staged %.0f | forward(0)+softplus(0) %.0f | tile blocks %.0f | P2, b2, loss %.0f | first start -> last end %.0f\n",
+                   ph[0] / nw, ph[1] / nw, ph[2] / nw, ph[3] / nw, (double)(tmax - tmin));
+        }
         // cold: 1 GB of unrelated traffic between launches, as the W1 update does in a real step
         float* big = dalloc((size_t)256 << 20, 1.f, 12);
         hipEvent_t ea, eb; CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
