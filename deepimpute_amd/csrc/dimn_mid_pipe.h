@@ -19,9 +19,12 @@
 // within the parity tolerance of the oracle (oracle/dimo.c sums in its own order).
 #pragma once
 
-#define DIMN_MIDP_LDD 260                                 // as DIMN_MID_LDD
-#define DIMN_MIDP_LDS_FLOATS (64 * DIMN_MIDP_LDD + 2 * 8192 + 2 * 1024 + 8 * 512 + 8 * 128 + 8)
+#define DIMN_MIDP_LDW 36                                  // row stride of a wave's Dd slab [64 b][32 h]: 16-byte aligned rows, 4 mod 32 words
+#define DIMN_MIDP_LDS_FLOATS (8 * 64 * DIMN_MIDP_LDW + 2 * 8192 + 2 * 1024 + 8 * 128 + 8)     // 151 584 bytes
 
+#ifndef DIMN_MIDP_ABL
+#define DIMN_MIDP_ABL 0   // tools/k_probe_mid.hip ablations (wrong results): 1 no state stores, 2 no backward MFMAs, 4 no forward MFMAs, 8 no softplus arithmetic, 16 no Adam
+#endif
 #ifdef DIMN_MIDP_TL   // tools/k_probe_mid.hip: per-wave stamps
 __device__ unsigned long long g_midp_tl[512 * 8 * 12];
 #define MIDP_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_midp_tl[(blockIdx.x * 8 + wave) * 12 + (i)] = t_; }
@@ -38,82 +41,89 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
                                                   float* __restrict__ loss_step, double* __restrict__ loss_acc,
                                                   Dims dm, AdamP ap, float inv_n, int loss_binary) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const MidWork mw = mwork[blockIdx.x];
+    // slices of one sub-net on ONE XCD (workgroup b runs on XCD b % 8, every XCD has its own L2): the sub-net's Dd block and batch rows of Y
+    // come from memory once per sub-net instead of once per slice
+    const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
+    const MidWork mw = mwork[xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3)];
     const int k = mw.k, ot0 = mw.ot0, ot_last = mw.ot1 - 1, T = mw.ot1 - mw.ot0;
     const int Hp = dm.Hp, OT = dm.OT, Op = dm.Op;
-    constexpr int ldd = DIMN_MIDP_LDD;
-    float* ddl = lds;                                        // Dd [64][ldd]
-    float* zpl = ddl + 64 * ldd;                             // partial Z [2][wave][mt][half][64 lanes][2]
+    constexpr int ldw = DIMN_MIDP_LDW;
+    float* ddl = lds;                                        // Dd[:, 32w .. 32w+31] of every wave [8][64][ldw]: all a wave ever reads of Dd are ITS hidden columns
+    float* zpl = ddl + 8 * 64 * ldw;                         // partial Z [2][wave][mt][half][64 lanes][2]
     float* dzl = zpl + 2 * 8192;                             // dZ [2][64 b][16 o]
-    float* wsl = dzl + 2 * 1024;                             // per-wave W2 transposes [8][2 tiles][256]
-    float* gbl = wsl + 8 * 512;                              // b2 gradient parts [tile <= 8][wave][16]
+    float* gbl = dzl + 2 * 1024;                             // b2 gradient parts [tile <= 8][wave][16]
     float* lsl = gbl + 8 * 128;                              // loss partials [8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     MIDP_STAMP(0)
 
-    // ---- requests, in the order they are needed ----
-    const float* ddk = Dd + (int64_t)k * DIMN_TB * Hp;
-    f32x4 ddv[8];
+    // ---- requests, in the order they are needed: the wave's Dd slab and the first tile's w, then everything else ----
+    const float* ddk = Dd + (int64_t)k * DIMN_TB * Hp + 32 * wave;
+    f32x4 ddv[8];                                            // 8 lanes per row of 128 bytes, 8 rows per request
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ddv[i] = *(const f32x4*)(ddk + tid * 4 + i * 2048);
+    for (int i = 0; i < 8; ++i) ddv[i] = *(const f32x4*)(ddk + (8 * i + (lane >> 3)) * Hp + 4 * (lane & 7));
     struct Set { f32x4 w[2], m[2], v[2]; };
-    Set s[3];
+    Set sA, sB, sC;                                          // (named, not an array: blocks that differ only in the set they use must not be merged into one with a runtime index)
     const int64_t tbase = (int64_t)k * Hp * Op + li * 16 + 4 * lj;                     // lane <-> W2[h = 16 ht' + li][o = 16 ot + 4 lj ..]
+#if DIMN_MIDP_ABL & 32    // probe: output-tile-major tiles (a slice's W2 is one contiguous range)
+    auto tidx = [&](int ht, int ot) { return tbase + ((int64_t)ot * 16 + (2 * wave + ht)) * 256; };
+#else
     auto tidx = [&](int ht, int ot) { return tbase + ((int64_t)(2 * wave + ht) * OT + ot) * 256; };
-    auto fetch = [&](Set& st, int t) {
-        const int o2 = ot0 + t < ot_last ? ot0 + t : ot_last;                          // clamped: requests beyond the slice stay in bounds
+#endif
+    // Every block issues the same requests (so the compiler's vmcnt arithmetic is exact on every path); those of a tile beyond the
+    // slice's last one ask all 64 lanes for the SAME 16 bytes of the slice's first tile -- one cache line per instruction, no traffic.
+    const int64_t tdummy = (int64_t)k * Hp * Op + (int64_t)ot0 * 256;
+    auto fidx = [&](int ht, int t) { return t < T ? tidx(ht, ot0 + t) : tdummy; };
+    auto fetch_w = [&](Set& st, int t) {
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht) st.w[ht] = *(const f32x4*)(W2 + tidx(ht, o2));
+        for (int ht = 0; ht < 2; ++ht) st.w[ht] = *(const f32x4*)(W2 + fidx(ht, t));
+    };
+    auto fetch_mv = [&](Set& st, int t) {
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht) { st.m[ht] = DIMN_LD_MV(M2 + tidx(ht, o2)); st.v[ht] = DIMN_LD_MV(V2 + tidx(ht, o2)); }
+        for (int ht = 0; ht < 2; ++ht) { st.m[ht] = DIMN_LD_MV(M2 + fidx(ht, t)); st.v[ht] = DIMN_LD_MV(V2 + fidx(ht, t)); }
     };
     // softplus stage: thread <-> two elements of the [64 b][16 o] tile: b = 16 mt + 4 lj + 2 hf + {0, 1}, o = li
     const int hf = wave >> 2, smt = wave & 3;
     const int sb0 = 16 * smt + 4 * lj + 2 * hf;
     const int64_t yrow0 = ((int64_t)k * n_cells + rows[sb0 < b_act ? sb0 : 0]) * Op + li;
     const int64_t yrow1 = ((int64_t)k * n_cells + rows[sb0 + 1 < b_act ? sb0 + 1 : 0]) * Op + li;
-    float yn[2][2], bn[2];
-    auto fetch_y = [&](int g, int t) {
-        const int o2 = ot0 + t < ot_last ? ot0 + t : ot_last;
-        yn[g][0] = Y[yrow0 + 16 * o2]; yn[g][1] = Y[yrow1 + 16 * o2];
-        bn[g] = b2w[(int64_t)k * Op + 16 * o2 + li];
+    struct YGen { float y0, y1, b; };
+    YGen gE, gO;                                             // targets and bias of the next even / odd tile
+    auto fetch_y = [&](YGen& g, int t) {
+        const int o2 = t < T ? ot0 + t : ot_last;
+        g.y0 = Y[yrow0 + 16 * o2]; g.y1 = Y[yrow1 + 16 * o2];
+        g.b = b2w[(int64_t)k * Op + 16 * o2 + li];
     };
-    fetch(s[0], 0);
-    fetch_y(0, 0);
-    fetch(s[1], 1);
-    fetch_y(1, 1);
+    fetch_w(sA, 0);
+    __builtin_amdgcn_sched_barrier(0);                       // (what forward(0) waits for goes first, chip-wide; the rest follows when the slab has arrived)
+    float* slab = ddl + wave * 64 * ldw;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *(f32x4*)(slab + (8 * i + (lane >> 3)) * ldw + 4 * (lane & 7)) = ddv[i];
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_y(gE, 0);
+    fetch_mv(sA, 0);
+    fetch_w(sB, 1); fetch_mv(sB, 1);
+    fetch_y(gO, 1);
     // Adam(b2) happens once, after the last tile: thread tid < 16 T <-> (tile tid >> 4, column tid & 15)
     const bool b2_owner = tid < 16 * T;
     const int64_t b2i = (int64_t)k * Op + 16 * (ot0 + (b2_owner ? tid >> 4 : 0)) + (tid & 15);
     float b2w0 = 0.f, b2m0 = 0.f, b2v0 = 0.f;
     if (b2_owner) { b2w0 = b2w[b2i]; b2m0 = b2m[b2i]; b2v0 = b2v[b2i]; }
-
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int e = tid * 4 + i * 2048, b = e >> 8, h = e & 255;
-        *(f32x4*)(ddl + b * ldd + h) = ddv[i];
-    }
-    __syncthreads();
     MIDP_STAMP(1)
-    float ddf[16][2];    // B operand of gW2^T: Dd[b = 4kb+lj][h = 16(2w+ht)+li]
-#pragma unroll
-    for (int kb = 0; kb < 16; ++kb)
-#pragma unroll
-        for (int ht = 0; ht < 2; ++ht) ddf[kb][ht] = ddl[(4 * kb + lj) * ldd + 16 * (2 * wave + ht) + li];
     f32x4 dacc[4][2];
 #pragma unroll
     for (int m4 = 0; m4 < 4; ++m4)
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht) dacc[m4][ht] = zero4;
-    float* ws = wsl + wave * 512;
     float lsum = 0.f;
 
     // forward(t): partial Z[64 b][16 o] over this wave's 32 hidden rows -> zp[t & 1]
     auto forward = [&](const Set& st, int t) {
         // k-slot form: MFMA r of a hidden tile takes k = 4 lj + r, so one 16-byte LDS read of a Dd row feeds four MFMAs (A)
         // and the W2 operand is the transposed tile read at row 4 lj + r (B)
+        float* zp = zpl + (t & 1) * 8192 + wave * 1024;      // this wave's part of the tile's partial-Z buffer; until the partial is written, its transpose scratch
+        float* ws = zp;                                      // (the buffer's last readers passed a barrier since; LDS operations of one wave complete in order)
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht) *(f32x4*)(ws + ht * 256 + li * 16 + 4 * lj) = st.w[ht];
         float bq[2][4];
@@ -122,18 +132,17 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
 #pragma unroll
             for (int r = 0; r < 4; ++r) bq[ht][r] = ws[ht * 256 + (4 * lj + r) * 16 + li];       // W2[h = 16 ht' + 4lj + r][o = li]
         f32x4 acc[4] = {zero4, zero4, zero4, zero4};
-        const float* arow = ddl + li * ldd + 32 * wave + 4 * lj;
+        const float* arow = slab + li * ldw + 4 * lj;
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht) {
             f32x4 a4[4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) a4[mt] = *(const f32x4*)(arow + 16 * mt * ldd + 16 * ht);
+            for (int mt = 0; mt < 4; ++mt) a4[mt] = *(const f32x4*)(arow + 16 * mt * ldw + 16 * ht);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = MFMA16(a4[mt][r], bq[ht][r], acc[mt]);
+                for (int mt = 0; mt < 4; ++mt) { if (DIMN_MIDP_ABL & 4) acc[mt][r] += a4[mt][r] * bq[ht][r]; else acc[mt] = MFMA16(a4[mt][r], bq[ht][r], acc[mt]); }
         }
-        float* zp = zpl + (t & 1) * 8192 + wave * 1024;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {                     // halves apart: the readers' 8-byte reads are lane-contiguous
             *(float2*)(zp + (mt * 2 + 0) * 128 + lane * 2) = make_float2(acc[mt][0], acc[mt][1]);
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
         }
     };
     // softplus(t): Z = sum of the partials + b2 ; loss ; dZ -> dz[t & 1] ; column sums of dZ -> gbl[t]
-    auto softplus = [&](int g, int t) {
+    auto softplus = [&](const YGen& g, int t) {
         const float* zp = zpl + (t & 1) * 8192 + (smt * 2 + hf) * 128 + lane * 2;
         float2 z2 = *(const float2*)zp;
 #pragma unroll
@@ -153,10 +162,11 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
         for (int e = 0; e < 2; ++e) {
             const int b = sb0 + e;
             const bool ok = b < b_act && col_ok;
-            const float z = (e ? z2.y : z2.x) + bn[g];
-            const float y = yn[g][e];
+            const float z = (e ? z2.y : z2.x) + g.b;
+            const float y = e ? g.y1 : g.y0;
             const float w = loss_binary ? (y > 0.f ? 1.f : 0.f) : y;       // multinet.py:37-40
             float sp, sg;
+            if (DIMN_MIDP_ABL & 8) { sp = z; sg = 1.f; } else
             softplus_sigmoid_fast(z, sp, sg);
             const float er = y - sp;
             lsum += ok ? w * er * er : 0.f;
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
         for (int kb = 0; kb < 16; ++kb) {
             const float az = zb[64 * kb + lane];                             // dZ^T[o = li][b = 4kb+lj]
 #pragma unroll
-            for (int ht = 0; ht < 2; ++ht) g[ht] = MFMA16(az, ddf[kb][ht], g[ht]);
+            for (int ht = 0; ht < 2; ++ht) { if (DIMN_MIDP_ABL & 2) g[ht][kb & 3] += az * slab[(4 * kb + lj) * ldw + 16 * ht + li]; else g[ht] = MFMA16(az, slab[(4 * kb + lj) * ldw + 16 * ht + li], g[ht]); }   // Dd[b = 4kb+lj][h = 16(2w+ht)+li]
         }
         f32x4 zf[4];
 #pragma unroll
@@ -186,32 +196,42 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int m4 = 0; m4 < 4; ++m4) dacc[m4][ht] = MFMA16(zf[m4][r], cur.w[ht][r], dacc[m4][ht]);    // OLD W2
+                for (int m4 = 0; m4 < 4; ++m4) { if (DIMN_MIDP_ABL & 2) dacc[m4][ht][r] += zf[m4][r] * cur.w[ht][r]; else dacc[m4][ht] = MFMA16(zf[m4][r], cur.w[ht][r], dacc[m4][ht]); }   // OLD W2
+            if (DIMN_MIDP_ABL & 16) { cur.w[ht] += g[ht]; } else
             adam4(cur.w[ht], cur.m[ht], cur.v[ht], g[ht], ap);
             const int64_t i = tidx(ht, ot0 + t);
-            DIMN_ST_STATE(W2 + i, cur.w[ht]); DIMN_ST_STATE(M2 + i, cur.m[ht]); DIMN_ST_STATE(V2 + i, cur.v[ht]);
+            if (!(DIMN_MIDP_ABL & 1) || cur.w[ht][0] == 123.456f) { DIMN_ST_STATE(W2 + i, cur.w[ht]); DIMN_ST_STATE(M2 + i, cur.m[ht]); DIMN_ST_STATE(V2 + i, cur.v[ht]); }
         }
     };
 
-    forward(s[0], 0);
+    forward(sA, 0);
     __syncthreads();
-    softplus(0, 0);
+    softplus(gE, 0);
     MIDP_STAMP(2)
-    // straight-line code, one block per tile, left at the slice's last tile: the compiler counts the exact vmcnt of every wait
-#define DIMN_MIDP_BLOCK(I)                                                              \
+    // Straight-line code, one block per tile, left at the slice's last tile (CUR / NXT / FRE: the sets of tiles I, I+1, I+2;
+    // GN / GF: the targets of tiles I+1, I+2).  No path joins another with a different number of requests in flight, so every wait is
+    // an exact vmcnt and none of them covers the stores of the tile before.
+#define DIMN_MIDP_BLOCK(I, CUR, NXT, FRE, GN, GF)                                       \
     {                                                                                   \
         const bool more = (I) + 1 < T;                                                  \
-        fetch(s[((I) + 2) % 3], (I) + 2);                                               \
-        fetch_y((I) & 1, (I) + 2);                                                      \
-        if (more) forward(s[((I) + 1) % 3], (I) + 1);                                   \
+        fetch_w(FRE, (I) + 2); fetch_mv(FRE, (I) + 2);                                  \
+        fetch_y(GF, (I) + 2);                                                           \
+        if (more) forward(NXT, (I) + 1);                                                \
         __syncthreads();                                                                \
-        if (more) softplus(((I) + 1) & 1, (I) + 1);                                     \
-        backward(s[(I) % 3], (I));                                                      \
+        if (more) softplus(GN, (I) + 1);                                                \
+        backward(CUR, (I));                                                             \
+        MIDP_STAMP(5 + (I) % 7)                                                         \
         if (!more) break;                                                               \
     }
     do {
-        DIMN_MIDP_BLOCK(0) DIMN_MIDP_BLOCK(1) DIMN_MIDP_BLOCK(2) DIMN_MIDP_BLOCK(3)
-        DIMN_MIDP_BLOCK(4) DIMN_MIDP_BLOCK(5) DIMN_MIDP_BLOCK(6) DIMN_MIDP_BLOCK(7)
+        DIMN_MIDP_BLOCK(0, sA, sB, sC, gO, gE)
+        DIMN_MIDP_BLOCK(1, sB, sC, sA, gE, gO)
+        DIMN_MIDP_BLOCK(2, sC, sA, sB, gO, gE)
+        DIMN_MIDP_BLOCK(3, sA, sB, sC, gE, gO)
+        DIMN_MIDP_BLOCK(4, sB, sC, sA, gO, gE)
+        DIMN_MIDP_BLOCK(5, sC, sA, sB, gE, gO)
+        DIMN_MIDP_BLOCK(6, sA, sB, sC, gO, gE)
+        DIMN_MIDP_BLOCK(7, sB, sC, sA, gE, gO)
     } while (0);
 #undef DIMN_MIDP_BLOCK
     MIDP_STAMP(3)

@@ -70,7 +70,7 @@ def test_two_epochs_match_oracle(H, O, B, Ds, p):
     np.testing.assert_allclose(pa, pb, rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("mid", ["1", "0", "1:6", "1:4", "1:10", "R", "R:1", "R:2", "RG"])     # fused (auto slices), two-kernel, fused with 6 / 4 / 10 slices; R: register-resident epoch kernel (auto / 1 / 2 D-splits; RG: sub-nets in groups of two, one launch each)
+@pytest.mark.parametrize("mid", ["1", "0", "1:6", "1:4", "1:10", "1:16", "1:32", "1F", "1F:6", "1F:4", "1F:10", "R", "R:1", "R:2", "RG"])     # fused (the tile pipeline k_mid_pipe; auto slices), two-kernel, fused with 6 / 4 / 10 / 16 / 32 slices (8 .. 1 tiles per workgroup); 1F: the three-phase fused kernel k_mid_fused (DIMN_MID_PIPE=0); R: register-resident epoch kernel (auto / 1 / 2 D-splits; RG: sub-nets in groups of two, one launch each)
 @pytest.mark.parametrize("O,B,Ds,p", [
     (512, 64, [300, 150, 77], 0.2),     # the default architecture: H = 256, O = 512
     (500, 37, [97, 260], 0.3),          # ragged output width and partial batches
@@ -87,7 +87,9 @@ def test_h256_both_second_layer_paths_match_oracle(O, B, Ds, p, mid, monkeypatch
             monkeypatch.setenv("DIMN_RES_MIN_GROUPS", "2")
     else:
         monkeypatch.setenv("DIMN_RESIDENT", "0")
-        monkeypatch.setenv("DIMN_MID", mid.split(":")[0])
+        monkeypatch.setenv("DIMN_MID", mid.split(":")[0].rstrip("F"))
+        if "F" in mid:
+            monkeypatch.setenv("DIMN_MID_PIPE", "0")
         if ":" in mid:                   # tiles per workgroup: 5-6 (units shared over SIMDs), 8, 3-4
             monkeypatch.setenv("DIMN_MID_SLICES", mid.split(":")[1])
     prob = make_problem(n=330, g=700, Ds=Ds, H=256, O=O, seed=17)

@@ -18,6 +18,7 @@ __global__ void k_fill(float* p, size_t n, float scale, unsigned seed) {
         p[i] = scale * ((x >> 8) * (1.0f / 16777216.0f) - 0.5f);
     }
 }
+__global__ void k_abs(float* p, size_t n) { for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = fabsf(p[i]); }
 template <typename F> static double timeit(F launch, int R = 30) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int i = 0; i < 3; ++i) launch();
@@ -43,6 +44,8 @@ int main(int argc, char** argv) {
     float* b1 = dalloc((size_t)3 * K * 256, 0.01f, 2); float* b2 = dalloc((size_t)3 * K * 512, 0.01f, 3);
     float* Dd = dalloc((size_t)K * 64 * 256, 1.f, 4); float* dZ = dalloc((size_t)K * 64 * 512, 1e-3f, 5); float* dA = dalloc((size_t)K * 64 * 256, 1e-3f, 6);
     float* W2 = dalloc((size_t)K * 256 * 512, 0.1f, 7); float* M2 = dalloc((size_t)K * 256 * 512, 1e-6f, 8); float* V2 = dalloc((size_t)K * 256 * 512, 1e-6f, 9);
+    hipLaunchKernelGGL(k_abs, dim3(2048), dim3(256), 0, 0, V2, (size_t)K * 256 * 512);       // second moments are non-negative
+    hipLaunchKernelGGL(k_abs, dim3(64), dim3(256), 0, 0, b2 + 2 * (size_t)K * 512, (size_t)K * 512);
     float* Y = dalloc((size_t)K * n * 512, 4.f, 10);
     float* ls; CK(hipMalloc(&ls, K * 8 * 4)); double* la; CK(hipMalloc(&la, K * 8 * 8)); CK(hipMemset(la, 0, K * 8 * 8));
     std::vector<int32_t> rows(64); for (int i = 0; i < 64; ++i) rows[i] = (int32_t)((i * 7919LL + 13) % n);
@@ -118,6 +121,10 @@ int main(int argc, char** argv) {
             std::vector<unsigned long long> tl(512 * 8 * 12); CK(hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_midp_tl), tl.size() * 8));
             double ph[4] = {0, 0, 0, 0}; unsigned long long tmin = ~0ull, tmax = 0; const size_t nw = mw.size() * 8;
             for (size_t i = 0; i < nw; ++i) { const unsigned long long* o = &tl[i * 12]; for (int j = 0; j < 4; ++j) ph[j] += (double)(o[j + 1] - o[j]); if (o[0] < tmin) tmin = o[0]; if (o[4] > tmax) tmax = o[4]; }
+            { double bl[6] = {0, 0, 0, 0, 0, 0}; size_t n6 = 0;       // blocks of the six-tile slices: stamps 5 .. 10 follow stamp 2
+              for (size_t i = 0; i < nw; ++i) { const unsigned long long* o = &tl[i * 12]; const MidWork& m = mw[((i / 8) & 7) * (mw.size() / 8) + (i / 8) / 8]; if (m.ot1 - m.ot0 != 6) continue; ++n6;
+                  bl[0] += (double)(o[5] - o[2]); for (int j = 1; j < 6; ++j) bl[j] += (double)(o[5 + j] - o[4 + j]); }
+              if (n6) printf("pipe blocks of the 6-tile slices, mean clk per wave: %.0f %.0f %.0f %.0f %.0f %.0f\n", bl[0] / n6, bl[1] / n6, bl[2] / n6, bl[3] / n6, bl[4] / n6, bl[5] / n6); }
             printf("pipe timeline, mean clk (100 MHz) per wave: Dd staged %.0f | forward(0)+softplus(0) %.0f | tile blocks %.0f | P2, b2, loss %.0f | first start -> last end %.0f\n",
                    ph[0] / nw, ph[1] / nw, ph[2] / nw, ph[3] / nw, (double)(tmax - tmin));
         }
