@@ -20,7 +20,7 @@
 #pragma once
 
 #define DIMN_MIDP_LDW 36                                  // row stride of a wave's Dd slab [64 b][32 h]: 16-byte aligned rows, 4 mod 32 words
-#define DIMN_MIDP_LDS_FLOATS (8 * 64 * DIMN_MIDP_LDW + 2 * 8192 + 2 * 1024 + 8 * 128 + 8)     // 151 584 bytes
+#define DIMN_MIDP_LDS_FLOATS (8 * 64 * DIMN_MIDP_LDW + 2 * 8192 + 2 * 1024 + 9 * 128 + 8)     // 152 096 bytes
 
 #ifndef DIMN_MIDP_ABL
 #define DIMN_MIDP_ABL 0   // tools/k_probe_mid.hip ablations (wrong results): 1 no state stores, 2 no backward MFMAs, 4 no forward MFMAs, 8 no softplus arithmetic, 16 no Adam
@@ -51,8 +51,8 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
     float* ddl = lds;                                        // Dd[:, 32w .. 32w+31] of every wave [8][64][ldw]: all a wave ever reads of Dd are ITS hidden columns
     float* zpl = ddl + 8 * 64 * ldw;                         // partial Z [2][wave][mt][half][64 lanes][2]
     float* dzl = zpl + 2 * 8192;                             // dZ [2][64 b][16 o]
-    float* gbl = dzl + 2 * 1024;                             // b2 gradient parts [tile <= 8][wave][16]
-    float* lsl = gbl + 8 * 128;                              // loss partials [8]
+    float* gbl = dzl + 2 * 1024;                             // b2 gradient parts [tile <= 8][wave][16] (+ one block for the pass behind the last tile)
+    float* lsl = gbl + 9 * 128;                              // loss partials [8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -65,23 +65,26 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
     for (int i = 0; i < 8; ++i) ddv[i] = *(const f32x4*)(ddk + (8 * i + (lane >> 3)) * Hp + 4 * (lane & 7));
     struct Set { f32x4 w[2], m[2], v[2]; };
     Set sA, sB, sC;                                          // (named, not an array: blocks that differ only in the set they use must not be merged into one with a runtime index)
-    const int64_t tbase = (int64_t)k * Hp * Op + li * 16 + 4 * lj;                     // lane <-> W2[h = 16 ht' + li][o = 16 ot + 4 lj ..]
-#if DIMN_MIDP_ABL & 32    // probe: output-tile-major tiles (a slice's W2 is one contiguous range)
-    auto tidx = [&](int ht, int ot) { return tbase + ((int64_t)ot * 16 + (2 * wave + ht)) * 256; };
-#else
-    auto tidx = [&](int ht, int ot) { return tbase + ((int64_t)(2 * wave + ht) * OT + ot) * 256; };
-#endif
+    // addresses: a wave-uniform base (sub-net, output tile: scalar registers) + a 32-bit lane offset that never changes (hidden tile, lane)
+    const size_t kbase = (size_t)k * Hp * Op;
+    const char *w2k = (const char*)(W2 + kbase), *m2k = (const char*)(M2 + kbase), *v2k = (const char*)(V2 + kbase);
+    unsigned voff[2];                                        // lane <-> W2[h = 16 ht' + li][o = 16 ot + 4 lj ..], bytes
+#pragma unroll
+    for (int ht = 0; ht < 2; ++ht) voff[ht] = 4u * (unsigned)(((2 * wave + ht) * OT) * 256 + li * 16 + 4 * lj);
     // Every block issues the same requests (so the compiler's vmcnt arithmetic is exact on every path); those of a tile beyond the
     // slice's last one ask all 64 lanes for the SAME 16 bytes of the slice's first tile -- one cache line per instruction, no traffic.
-    const int64_t tdummy = (int64_t)k * Hp * Op + (int64_t)ot0 * 256;
-    auto fidx = [&](int ht, int t) { return t < T ? tidx(ht, ot0 + t) : tdummy; };
     auto fetch_w = [&](Set& st, int t) {
+        const size_t tb = (size_t)(t < T ? ot0 + t : ot0) * 1024;
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht) st.w[ht] = *(const f32x4*)(W2 + fidx(ht, t));
+        for (int ht = 0; ht < 2; ++ht) st.w[ht] = *(const f32x4*)(w2k + tb + (t < T ? voff[ht] : 0u));
     };
     auto fetch_mv = [&](Set& st, int t) {
+        const size_t tb = (size_t)(t < T ? ot0 + t : ot0) * 1024;
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht) { st.m[ht] = DIMN_LD_MV(M2 + fidx(ht, t)); st.v[ht] = DIMN_LD_MV(V2 + fidx(ht, t)); }
+        for (int ht = 0; ht < 2; ++ht) {
+            const unsigned vo = t < T ? voff[ht] : 0u;
+            st.m[ht] = DIMN_LD_MV(m2k + tb + vo); st.v[ht] = DIMN_LD_MV(v2k + tb + vo);
+        }
     };
     // softplus stage: thread <-> two elements of the [64 b][16 o] tile: b = 16 mt + 4 lj + 2 hf + {0, 1}, o = li
     const int hf = wave >> 2, smt = wave & 3;
@@ -111,6 +114,11 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
     float b2w0 = 0.f, b2m0 = 0.f, b2v0 = 0.f;
     if (b2_owner) { b2w0 = b2w[b2i]; b2m0 = b2m[b2i]; b2v0 = b2v[b2i]; }
     MIDP_STAMP(1)
+    float ddf[16][2];    // B operand of gW2^T, kept for every tile: Dd[b = 4kb+lj][h = 16(2w+ht)+li]   (the slab is private to the wave: no barrier)
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) ddf[kb][ht] = slab[(4 * kb + lj) * ldw + 16 * ht + li];
     f32x4 dacc[4][2];
 #pragma unroll
     for (int m4 = 0; m4 < 4; ++m4)
@@ -149,13 +157,15 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
             *(float2*)(zp + (mt * 2 + 1) * 128 + lane * 2) = make_float2(acc[mt][2], acc[mt][3]);
         }
     };
-    // softplus(t): Z = sum of the partials + b2 ; loss ; dZ -> dz[t & 1] ; column sums of dZ -> gbl[t]
-    auto softplus = [&](const YGen& g, int t) {
+    // softplus(t): Z = sum of the partials + b2 ; loss ; dZ -> dz[t & 1] ; column sums of dZ -> gbl[t].  Branch-free (selects only), so that it
+    // shares a scheduling region with backward(t - 1) and its arithmetic issues under that tile's matrix instructions; the block of the slice's last
+    // tile runs it once more on stale data (live = false: nothing of it is kept).
+    auto softplus = [&](const YGen& g, int t, bool live) {
         const float* zp = zpl + (t & 1) * 8192 + (smt * 2 + hf) * 128 + lane * 2;
         float2 z2 = *(const float2*)zp;
 #pragma unroll
         for (int wv = 1; wv < 8; ++wv) { const float2 p = *(const float2*)(zp + wv * 1024); z2.x += p.x; z2.y += p.y; }
-        const bool col_ok = 16 * (ot0 + t) + li < dm.O;
+        const bool col_ok = live && 16 * (ot0 + t) + li < dm.O;
         float* dz = dzl + (t & 1) * 1024;
         float gb = 0.f;
 #pragma unroll
@@ -169,14 +179,15 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
             if (DIMN_MIDP_ABL & 8) { sp = z; sg = 1.f; } else
             softplus_sigmoid_fast(z, sp, sg);
             const float er = y - sp;
-            lsum += ok ? w * er * er : 0.f;
-            const float d = ok ? -2.f * w * er * inv_n * sg : 0.f;
+            const float le = w * er * er, de = -2.f * w * er * inv_n * sg;
+            lsum += ok ? le : 0.f;
+            const float d = ok ? de : 0.f;
             dz[b * 16 + li] = d;
             gb += d;
         }
         gb += __shfl_xor(gb, 16);
         gb += __shfl_xor(gb, 32);
-        if (lj == 0) gbl[t * 128 + wave * 16 + li] = gb;
+        gbl[(live ? t : 8) * 128 + wave * 16 + li] = gb;     // (every lj writes the same sum to the same word)
     };
     // backward(t): as phase 2 of k_mid_fused, the old W2 from the set's registers
     auto backward = [&](Set& cur, int t) {
@@ -186,7 +197,7 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
         for (int kb = 0; kb < 16; ++kb) {
             const float az = zb[64 * kb + lane];                             // dZ^T[o = li][b = 4kb+lj]
 #pragma unroll
-            for (int ht = 0; ht < 2; ++ht) { if (DIMN_MIDP_ABL & 2) g[ht][kb & 3] += az * slab[(4 * kb + lj) * ldw + 16 * ht + li]; else g[ht] = MFMA16(az, slab[(4 * kb + lj) * ldw + 16 * ht + li], g[ht]); }   // Dd[b = 4kb+lj][h = 16(2w+ht)+li]
+            for (int ht = 0; ht < 2; ++ht) { if (DIMN_MIDP_ABL & 2) g[ht][kb & 3] += az * ddf[kb][ht]; else g[ht] = MFMA16(az, ddf[kb][ht], g[ht]); }
         }
         f32x4 zf[4];
 #pragma unroll
@@ -199,14 +210,14 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
                 for (int m4 = 0; m4 < 4; ++m4) { if (DIMN_MIDP_ABL & 2) dacc[m4][ht][r] += zf[m4][r] * cur.w[ht][r]; else dacc[m4][ht] = MFMA16(zf[m4][r], cur.w[ht][r], dacc[m4][ht]); }   // OLD W2
             if (DIMN_MIDP_ABL & 16) { cur.w[ht] += g[ht]; } else
             adam4(cur.w[ht], cur.m[ht], cur.v[ht], g[ht], ap);
-            const int64_t i = tidx(ht, ot0 + t);
-            if (!(DIMN_MIDP_ABL & 1) || cur.w[ht][0] == 123.456f) { DIMN_ST_STATE(W2 + i, cur.w[ht]); DIMN_ST_STATE(M2 + i, cur.m[ht]); DIMN_ST_STATE(V2 + i, cur.v[ht]); }
+            const size_t tb = (size_t)(ot0 + t) * 1024;
+            if (!(DIMN_MIDP_ABL & 1) || cur.w[ht][0] == 123.456f) { DIMN_ST_STATE(const_cast<char*>(w2k) + tb + voff[ht], cur.w[ht]); DIMN_ST_STATE(const_cast<char*>(m2k) + tb + voff[ht], cur.m[ht]); DIMN_ST_STATE(const_cast<char*>(v2k) + tb + voff[ht], cur.v[ht]); }
         }
     };
 
     forward(sA, 0);
     __syncthreads();
-    softplus(gE, 0);
+    softplus(gE, 0, true);
     MIDP_STAMP(2)
     // Straight-line code, one block per tile, left at the slice's last tile (CUR / NXT / FRE: the sets of tiles I, I+1, I+2;
     // GN / GF: the targets of tiles I+1, I+2).  No path joins another with a different number of requests in flight, so every wait is
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
         fetch_y(GF, (I) + 2);                                                           \
         if (more) forward(NXT, (I) + 1);                                                \
         __syncthreads();                                                                \
-        if (more) softplus(GN, (I) + 1);                                                \
+        softplus(GN, (I) + 1, more);                                                    \
         backward(CUR, (I));                                                             \
         MIDP_STAMP(5 + (I) % 7)                                                         \
         if (!more) break;                                                               \
