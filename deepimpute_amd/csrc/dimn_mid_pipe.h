@@ -9,14 +9,16 @@
 // [32w, 32w + 32) of W2 for the WHOLE kernel and the slice's output tiles go through it one after the other:
 //
 //   block i:   request w / m / v of tile i+2 (16-byte loads, each wave its own rows: W2 is read ONCE, in one layout)
-//              forward(i+1): partial Z over the wave's 32 hidden rows (32 MFMAs) -> LDS                      } barrier
-//              softplus / wMSE / dZ(i+1): all 512 threads, two elements each, summing the 8 partials
-//              backward(i): gW2^T = dZ^T Dd (32 MFMAs), dD += dZ W2old^T (32), Adam in registers, 16-byte stores
+//              forward(i+1): partial Z over the wave's 32 hidden rows (32 MFMAs) -> LDS                      | one barrier
+//              softplus / wMSE / dZ(i+1): all 512 threads, two elements each, summing the 8 partials    }  one scheduling region: the
+//              backward(i): gW2^T = dZ^T Dd (32 MFMAs), dD += dZ W2old^T (32), Adam, 16-byte stores      }  VALU work issues under the MFMAs
 //
-// so tile i's stores, tile i+2's loads and the MFMAs of tiles i, i+1 are in flight together, from the first
-// microsecond to the last; one barrier per tile; no phase in which the memory system waits for the matrix pipe.
-// Summation orders differ from k_mid_fused (Z over 8 partial sums of 32, b2's gradient over 8 x 8 rows); both are
-// within the parity tolerance of the oracle (oracle/dimo.c sums in its own order).
+// so tile i's stores, tile i+2's loads and the MFMAs of tiles i, i+1 are in flight together; one barrier per tile.  Dd lives in
+// wave-private LDS slabs (all a wave ever reads of Dd are ITS 32 hidden columns: no staging barrier); the slices of one sub-net run on
+// one XCD.  In the cfg3 step: 36.1 us against k_mid_fused's 39.9 (rocprofv3, same box); DESIGN.md section 2 has the history and what
+// bounds it now.  Summation orders differ from k_mid_fused (Z over 8 partial sums of 32, b2's gradient over 8 x 8 rows); both are
+// within the parity tolerance of the oracle (oracle/dimo.c sums in its own order).  LDS: 8 slabs (73.7 KB) + two partial-Z buffers
+// (64 KB; a wave's part doubles as its W2 transpose scratch) + two dZ tiles (8 KB) + b2 gradient parts (4.5 KB) = 152 096 bytes.
 #pragma once
 
 #define DIMN_MIDP_LDW 36                                  // row stride of a wave's Dd slab [64 b][32 h]: 16-byte aligned rows, 4 mod 32 words
