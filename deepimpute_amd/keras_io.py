@@ -30,19 +30,28 @@ def _libhdf5():
     """The HDF5 C library, or None."""
     global _H5
     if _H5 is None:
-        names = [os.environ.get("DIMN_LIBHDF5"), ctypes.util.find_library("hdf5"), "libhdf5.so", "/opt/conda/lib/libhdf5.so",
-                 "libhdf5_serial.so", "/usr/lib/x86_64-linux-gnu/libhdf5_serial.so"]
+        # Names the dynamic loader can try by itself first.  ctypes.util.find_library() comes LAST and only when none of them loads: it forks
+        # ldconfig / gcc / ld, and a fork of a process that holds the 8 GB frame, the pinned bounce buffers and a HIP context took 0.8 s on a
+        # quiet host and 15 s on a loaded one -- inside fit()'s save (round 4, profiles/r04_bench.json stages_s).
+        import glob
+        names = [os.environ.get("DIMN_LIBHDF5"), "libhdf5.so", "libhdf5_serial.so", "/opt/conda/lib/libhdf5.so",
+                 "/usr/lib/x86_64-linux-gnu/libhdf5_serial.so"]
+        names += sorted(glob.glob("/usr/lib/x86_64-linux-gnu/libhdf5*.so*") + glob.glob("/usr/lib64/libhdf5*.so*") + glob.glob("/opt/conda/lib/libhdf5.so*"))
         _H5 = False
-        for name in names:
-            if not name:
-                continue
+
+        def attempt(name):
+            global _H5
             try:
                 lib = C.CDLL(name)
                 lib.H5open()
                 _H5 = _bind(lib)
-                break
+                return True
             except (OSError, AttributeError):
-                continue
+                return False
+        if not any(attempt(name) for name in names if name):
+            found = ctypes.util.find_library("hdf5") or ctypes.util.find_library("hdf5_serial")
+            if found:
+                attempt(found)
     return _H5 or None
 
 
