@@ -178,7 +178,7 @@ struct dimn_handle_s {
     std::vector<MidWork> midwork;          // work table of the fused second-layer kernel (k_mid_fused)
     int mid_fused = 0, mid_slices = 0;     // 1: RED -> MFB -> RED2 -> B1F1; 0: RED -> MF -> MB -> B1F1
     int mid_keep = 0;                      // 1: k_mid_fused<true> (the W2 column blocks stay in LDS between its phases)
-    int mid_pipe = 0;                      // 1: k_mid_pipe (dimn_mid_pipe.h: the slice's tiles as a software pipeline; fp32 operands) instead of k_mid_fused
+    int mid_pipe = 0;                      // 1: k_mid_pipe (dimn_mid_pipe.h: the slice's tiles as a software pipeline) instead of k_mid_fused
     int train_bf16 = 0;                    // 1: precision bf16 and the fused second layer runs its three GEMMs on the bf16 matrix cores
     MidWork* d_midwork = nullptr; int32_t* d_midk = nullptr; float* d_P2 = nullptr;
     std::vector<std::vector<int32_t>> pred, targ;
@@ -472,8 +472,8 @@ static void build_mid(dimn_handle h) {
     int tmax = 0;
     for (auto& m : h->midwork) tmax = std::max(tmax, m.ot1 - m.ot0);
     h->mid_keep = tmax <= 6;
-    h->train_bf16 = h->mid_keep && h->prec == DIMN_PREC_BF16 && !(getenv("DIMN_TRAIN_BF16") && atoi(getenv("DIMN_TRAIN_BF16")) == 0);
-    h->mid_pipe = !h->train_bf16 && !(getenv("DIMN_MID_PIPE") && atoi(getenv("DIMN_MID_PIPE")) == 0);   // DIMN_MID_PIPE=0: the three-phase kernel (A/B, tests)
+    h->mid_pipe = !(getenv("DIMN_MID_PIPE") && atoi(getenv("DIMN_MID_PIPE")) == 0);   // DIMN_MID_PIPE=0: the three-phase kernel (A/B, tests)
+    h->train_bf16 = (h->mid_keep || h->mid_pipe) && h->prec == DIMN_PREC_BF16 && !(getenv("DIMN_TRAIN_BF16") && atoi(getenv("DIMN_TRAIN_BF16")) == 0);   // (the pipeline has the bf16 form at any slice size)
 }
 
 static bool resident_plan(dimn_handle h, int Kg, int& S1o, int& T1o) {
@@ -674,7 +674,8 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
         (void)hipFuncSetAttribute((const void*)k_mid_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)k_mid_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)k_mid_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_mid_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_mid_pipe<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_mid_pipe<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     auto zero = [&](void* p, size_t bytes) { return hipMemset(p, 0, bytes) == hipSuccess ? 0 : fail(DIMN_ERR_HIP, "hipMemset failed"); };
     TRY(zero(h->d_W1, w1 * 4)); TRY(zero(h->d_M1, w1 * 4)); TRY(zero(h->d_V1, w1 * 4));
@@ -1337,10 +1338,12 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
                                              h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary)
         // keep: every slice <= 6 tiles, W2 read once (DIMN_MID_KEEP=0: off); with precision bf16 its GEMMs take bf16 operands
         if (h->mid_pipe) {
-            hipLaunchKernelGGL(k_mid_pipe, dim3(nk * (unsigned)h->mid_slices), dim3(512), (size_t)DIMN_MIDP_LDS_FLOATS * sizeof(float), st,
-                               h->d_midwork + (size_t)ln.k0 * h->mid_slices,
-                               h->d_W2, h->d_M2, h->d_V2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_P2,
-                               h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary);
+#define LAUNCH_MFP(BFV) hipLaunchKernelGGL(k_mid_pipe<BFV>, dim3(nk * (unsigned)h->mid_slices), dim3(512), (size_t)DIMN_MIDP_LDS_FLOATS * sizeof(float), st, \
+                               h->d_midwork + (size_t)ln.k0 * h->mid_slices,                                                                         \
+                               h->d_W2, h->d_M2, h->d_V2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_P2,     \
+                               h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary)
+            if (h->train_bf16) LAUNCH_MFP(true); else LAUNCH_MFP(false);
+#undef LAUNCH_MFP
         } else if (h->mid_keep && h->train_bf16) {
             hipLaunchKernelGGL((k_mid_fused<true, true>), dim3(nk * (unsigned)h->mid_slices), dim3(512), lds, st, h->d_midwork + (size_t)ln.k0 * h->mid_slices,
                                h->d_W2, h->d_M2, h->d_V2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_P2,

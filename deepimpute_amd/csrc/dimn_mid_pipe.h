@@ -34,6 +34,10 @@ __device__ unsigned long long g_midp_tl[512 * 8 * 12];
 #define MIDP_STAMP(i)
 #endif
 
+// BF (handles of precision bf16): the three GEMMs take bf16 operands -- Dd, W2, dZ rounded to nearest even in registers, one v_mfma_f32_16x16x16_bf16 where
+// four fp32 MFMAs were (the k-slot register groups ARE its operands), fp32 accumulation, fp32 master weights and Adam state; as k_mid_fused<KEEP, BF>, which
+// oracle/dimo.c restates (dimo_set_training_bf16).
+template <bool BF>
 __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mwork,
                                                   float* __restrict__ W2, float* __restrict__ M2, float* __restrict__ V2,
                                                   float* __restrict__ b2w, float* __restrict__ b2m, float* __restrict__ b2v,
@@ -148,10 +152,16 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
             f32x4 a4[4];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) a4[mt] = *(const f32x4*)(arow + 16 * mt * ldw + 16 * ht);
+            if constexpr (BF) {
+                const bf16x4 bp = pk4((f32x4){bq[ht][0], bq[ht][1], bq[ht][2], bq[ht][3]});
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = MFMA_BF16(pk4(a4[mt]), bp, acc[mt]);
+            } else {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) { if (DIMN_MIDP_ABL & 4) acc[mt][r] += a4[mt][r] * bq[ht][r]; else acc[mt] = MFMA16(a4[mt][r], bq[ht][r], acc[mt]); }
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) { if (DIMN_MIDP_ABL & 4) acc[mt][r] += a4[mt][r] * bq[ht][r]; else acc[mt] = MFMA16(a4[mt][r], bq[ht][r], acc[mt]); }
+            }
         }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {                     // halves apart: the readers' 8-byte reads are lane-contiguous
@@ -195,21 +205,37 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
     auto backward = [&](Set& cur, int t) {
         const float* zb = dzl + (t & 1) * 1024;
         f32x4 g[2] = {zero4, zero4};
+        if constexpr (BF) {
 #pragma unroll
-        for (int kb = 0; kb < 16; ++kb) {
-            const float az = zb[64 * kb + lane];                             // dZ^T[o = li][b = 4kb+lj]
+            for (int q = 0; q < 4; ++q) {                                    // four batch rows per lane and instruction: k-slot i of lane (.., lj) <-> b = 16q + 4i + lj
+                const bf16x4 ap = pk4((f32x4){zb[64 * (4 * q) + lane], zb[64 * (4 * q + 1) + lane], zb[64 * (4 * q + 2) + lane], zb[64 * (4 * q + 3) + lane]});
 #pragma unroll
-            for (int ht = 0; ht < 2; ++ht) { if (DIMN_MIDP_ABL & 2) g[ht][kb & 3] += az * ddf[kb][ht]; else g[ht] = MFMA16(az, ddf[kb][ht], g[ht]); }
+                for (int ht = 0; ht < 2; ++ht)
+                    g[ht] = MFMA_BF16(ap, pk4((f32x4){ddf[4 * q][ht], ddf[4 * q + 1][ht], ddf[4 * q + 2][ht], ddf[4 * q + 3][ht]}), g[ht]);
+            }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 16; ++kb) {
+                const float az = zb[64 * kb + lane];                         // dZ^T[o = li][b = 4kb+lj]
+#pragma unroll
+                for (int ht = 0; ht < 2; ++ht) { if (DIMN_MIDP_ABL & 2) g[ht][kb & 3] += az * ddf[kb][ht]; else g[ht] = MFMA16(az, ddf[kb][ht], g[ht]); }
+            }
         }
         f32x4 zf[4];
 #pragma unroll
         for (int m4 = 0; m4 < 4; ++m4) zf[m4] = *(const f32x4*)(zb + (16 * m4 + li) * 16 + 4 * lj);   // dZ[b][o = 4lj+r]
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht) {
+            if constexpr (BF) {
+                const bf16x4 wp = pk4(cur.w[ht]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int m4 = 0; m4 < 4; ++m4) dacc[m4][ht] = MFMA_BF16(pk4(zf[m4]), wp, dacc[m4][ht]);      // OLD W2
+            } else {
 #pragma unroll
-                for (int m4 = 0; m4 < 4; ++m4) { if (DIMN_MIDP_ABL & 2) dacc[m4][ht][r] += zf[m4][r] * cur.w[ht][r]; else dacc[m4][ht] = MFMA16(zf[m4][r], cur.w[ht][r], dacc[m4][ht]); }   // OLD W2
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int m4 = 0; m4 < 4; ++m4) { if (DIMN_MIDP_ABL & 2) dacc[m4][ht][r] += zf[m4][r] * cur.w[ht][r]; else dacc[m4][ht] = MFMA16(zf[m4][r], cur.w[ht][r], dacc[m4][ht]); }   // OLD W2
+            }
             if (DIMN_MIDP_ABL & 16) { cur.w[ht] += g[ht]; } else
             adam4(cur.w[ht], cur.m[ht], cur.v[ht], g[ht], ap);
             const size_t tb = (size_t)(ot0 + t) * 1024;

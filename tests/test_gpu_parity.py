@@ -121,6 +121,35 @@ def test_h256_both_second_layer_paths_match_oracle(O, B, Ds, p, mid, monkeypatch
     np.testing.assert_allclose(a.train_step(rows, keep_mask=mask), b.train_step(rows, keep_mask=mask), rtol=1e-4)
 
 
+@pytest.mark.parametrize("O,B,slices", [(512, 64, "6"), (500, 37, "4"), (96, 64, "6")])
+def test_tile_pipeline_and_three_phase_kernel_agree(O, B, slices, monkeypatch):
+    """The two forms of the fused second layer -- the tile pipeline k_mid_pipe (what runs) and the three-phase k_mid_fused
+    (DIMN_MID_PIPE=0; what bf16 handles run) -- are the same arithmetic in different summation orders: after two epochs from the same
+    seeds their weights and Adam moments agree far inside the tolerance either has against the oracle, and path_info says which ran."""
+    monkeypatch.setenv("DIMN_RESIDENT", "0")
+    monkeypatch.setenv("DIMN_MID", "1")
+    monkeypatch.setenv("DIMN_MID_SLICES", slices)
+    prob = make_problem(n=330, g=700, Ds=[300, 150, 77], H=256, O=O, seed=29)
+    kw = dict(batch_size=B, dropout_rate=0.2, learning_rate=1e-3, seed=5)
+    runs = []
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("DIMN_MID_PIPE", pipe)
+        e = load_problem(_hip(), prob, **kw)
+        assert e.path_info()["mid_keep"] == (2 if pipe == "1" else 1), e.path_info()
+        e.init_weights()
+        losses = [e.train_epoch(epoch) for epoch in range(2)]
+        runs.append((losses, [e.get_weights(k) for k in range(e.K)], [e.get_adam_state(k, 0) for k in range(e.K)], e.predict()))
+        e.close()
+    (la, wa, ma, pa), (lb, wb, mb, pb) = runs
+    np.testing.assert_allclose(la, lb, rtol=2e-6)
+    for k in range(len(wa)):
+        for x, y, name in zip(wa[k], wb[k], ("W1", "b1", "W2", "b2")):
+            np.testing.assert_allclose(x, y, rtol=1e-4, atol=2e-6, err_msg="%s k=%d" % (name, k))
+        for x, y, name in zip(ma[k], mb[k], ("W1", "b1", "W2", "b2")):
+            np.testing.assert_allclose(x, y, rtol=1e-3, atol=1e-8, err_msg="adam m %s k=%d" % (name, k))
+    np.testing.assert_allclose(pa, pb, rtol=2e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("name", ["linear", "sigmoid", "tanh", "elu", "softplus"])
 def test_hidden_activations_match_autograd_golden(name):
     from helpers import check_activation_kat

@@ -76,7 +76,7 @@ int main(int argc, char** argv) {
         T("k_reduce_dd", k_reduce_dd, dim3(4, K), dim3(1024), 0, 0, dmk, P2, Dd, b1, b1 + kh, b1 + 2 * kh, dA, dm, ap, 1.25f, 0, (const float*)nullptr)
 
         {   // k_mid_pipe (dimn_mid_pipe.h): same state, same outputs within summation order; then its timings
-            CK(hipFuncSetAttribute((const void*)k_mid_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            CK(hipFuncSetAttribute((const void*)k_mid_pipe<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             const size_t ldsp = (size_t)DIMN_MIDP_LDS_FLOATS * 4;
             const size_t nw2 = (size_t)K * 256 * 512, nb2 = (size_t)3 * K * 512, np2 = mw.size() * 64 * 256;
             std::vector<float> w0(nw2), m0(nw2), v0(nw2), bb0(nb2);
@@ -88,7 +88,7 @@ int main(int argc, char** argv) {
                 CK(hipMemcpy(V2, v0.data(), nw2 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(b2, bb0.data(), nb2 * 4, hipMemcpyHostToDevice));
                 CK(hipMemset(P2, 0, np2 * 4)); CK(hipMemset(ls, 0, K * 8 * 4));
                 if (which == 0) hipLaunchKernelGGL(k_mid_fused<PROBE_KEEP>, dim3((unsigned)mw.size()), dim3(512), ldsb, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 61, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
-                else hipLaunchKernelGGL(k_mid_pipe, dim3((unsigned)mw.size()), dim3(512), ldsp, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 61, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
+                else hipLaunchKernelGGL(k_mid_pipe<false>, dim3((unsigned)mw.size()), dim3(512), ldsp, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 61, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
                 CK(hipDeviceSynchronize());
                 const float* src[6] = {W2, M2, V2, b2, P2, ls}; const size_t cnt[6] = {nw2, nw2, nw2, nb2, np2, (size_t)K * 8};
                 for (int j = 0; j < 6; ++j) { out[which][j].resize(cnt[j]); CK(hipMemcpy(out[which][j].data(), src[j], cnt[j] * 4, hipMemcpyDeviceToHost)); }
@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
                 for (size_t i = 0; i < out[0][j].size(); ++i) { const double a = out[0][j][i], b = out[1][j][i]; md = std::max(md, fabs(a - b)); mx = std::max(mx, fabs(a)); if (!(fabs(a - b) <= 1e-5 * (fabs(a) + 1e-3))) ++bad; }
                 printf("pipe vs fused  %-14s max |delta| %.3e  (max |value| %.3e)  beyond 1e-5 rel: %zu of %zu\n", nm[j], md, mx, bad, out[0][j].size());
             }
-            T("k_mid_pipe (warm)", k_mid_pipe, dim3((unsigned)mw.size()), dim3(512), ldsp, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0)
+            T("k_mid_pipe (warm)", k_mid_pipe<false>, dim3((unsigned)mw.size()), dim3(512), ldsp, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0)
             float* big2 = dalloc((size_t)256 << 20, 1.f, 12);
             hipEvent_t ea, eb; CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
             double cold_p = 0, cold_f2 = 0; const int R = 10;
@@ -107,7 +107,7 @@ int main(int argc, char** argv) {
                 float ms;
                 hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, big2, (size_t)256 << 20, 1.f, 13u + it);
                 CK(hipEventRecord(ea));
-                hipLaunchKernelGGL(k_mid_pipe, dim3((unsigned)mw.size()), dim3(512), ldsp, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
+                hipLaunchKernelGGL(k_mid_pipe<false>, dim3((unsigned)mw.size()), dim3(512), ldsp, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
                 CK(hipEventRecord(eb)); CK(hipEventSynchronize(eb)); CK(hipEventElapsedTime(&ms, ea, eb)); cold_p += ms;
                 hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, big2, (size_t)256 << 20, 1.f, 13u + it);
                 CK(hipEventRecord(ea));
@@ -116,7 +116,7 @@ int main(int argc, char** argv) {
             }
             printf("cold (after 1 GB of other traffic): k_mid_pipe %.1f us   k_mid_fused %.1f us\n", 1e3 * cold_p / R, 1e3 * cold_f2 / R);
             hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, big2, (size_t)256 << 20, 1.f, 99u);
-            hipLaunchKernelGGL(k_mid_pipe, dim3((unsigned)mw.size()), dim3(512), ldsp, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
+            hipLaunchKernelGGL(k_mid_pipe<false>, dim3((unsigned)mw.size()), dim3(512), ldsp, 0, dmw, W2, M2, V2, b2, b2 + ko, b2 + 2 * ko, Y, n, drows, 64, Dd, P2, ls, la, dm, ap, 1.f / (64 * 512), 0);
             CK(hipDeviceSynchronize());
             std::vector<unsigned long long> tl(512 * 8 * 12); CK(hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_midp_tl), tl.size() * 8));
             double ph[4] = {0, 0, 0, 0}; unsigned long long tmin = ~0ull, tmax = 0; const size_t nw = mw.size() * 8;
