@@ -387,7 +387,7 @@ def test_resident_hand_off_retry_path():
     (20, "fp32", dict(path="resident", resident_groups=4, resident_splits=3)),       # 2-GPU share: four groups of 5
     (16, "fp32", dict(path="streaming", mid_fused=0, first_layer=1)),                 # four groups of 4 would only draw: the streaming kernels (two-kernel second layer)
     (40, "fp32", dict(path="streaming", mid_fused=1, mid_slices=6, mid_keep=2, train_bf16=0, first_layer=1)),   # the single-GPU job (mid_keep 2: the tile pipeline k_mid_pipe)
-    (40, "bf16", dict(path="streaming", mid_fused=1, mid_slices=6, mid_keep=1, train_bf16=1)),          # bf16 operands: the three-phase kernel
+    (40, "bf16", dict(path="streaming", mid_fused=1, mid_slices=6, mid_keep=2, train_bf16=1)),          # bf16 operands: k_mid_pipe<BF>
 ])
 def test_automatic_path_choice(K, precision, want, monkeypatch):
     """The kernels dimn_create picks BY ITSELF (no DIMN_* variable set) for the sub-net counts a rank of the 50k x 20k job

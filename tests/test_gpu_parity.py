@@ -135,7 +135,7 @@ def test_tile_pipeline_and_three_phase_kernel_agree(O, B, slices, monkeypatch):
     for pipe in ("1", "0"):
         monkeypatch.setenv("DIMN_MID_PIPE", pipe)
         e = load_problem(_hip(), prob, **kw)
-        assert e.path_info()["mid_keep"] == (2 if pipe == "1" else 1), e.path_info()
+        assert (e.path_info()["mid_keep"] == 2) == (pipe == "1"), e.path_info()      # 2: the pipeline; 1 / 0: k_mid_fused with / without W2 kept in LDS
         e.init_weights()
         losses = [e.train_epoch(epoch) for epoch in range(2)]
         runs.append((losses, [e.get_weights(k) for k in range(e.K)], [e.get_adam_state(k, 0) for k in range(e.K)], e.predict()))
