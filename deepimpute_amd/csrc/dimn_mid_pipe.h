@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
     __builtin_amdgcn_sched_barrier(0);
     fetch_y(gE, 0);
     fetch_mv(sA, 0);
-    fetch_w(sB, 1); fetch_mv(sB, 1);
+    fetch_w(sB, 1);                                          // (its m and v: in block 0 -- the less the start burst carries, the sooner forward(0) has its operands)
     fetch_y(gO, 1);
     // Adam(b2) happens once, after the last tile: thread tid < 16 T <-> (tile tid >> 4, column tid & 15)
     const bool b2_owner = tid < 16 * T;
@@ -253,6 +253,7 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
 #define DIMN_MIDP_BLOCK(I, CUR, NXT, FRE, GN, GF)                                       \
     {                                                                                   \
         const bool more = (I) + 1 < T;                                                  \
+        if ((I) == 0) fetch_mv(NXT, 1);                                                 \
         fetch_w(FRE, (I) + 2); fetch_mv(FRE, (I) + 2);                                  \
         fetch_y(GF, (I) + 2);                                                           \
         if (more) forward(NXT, (I) + 1);                                                \
