@@ -150,6 +150,27 @@ def test_tile_pipeline_and_three_phase_kernel_agree(O, B, slices, monkeypatch):
     np.testing.assert_allclose(pa, pb, rtol=2e-5, atol=1e-6)
 
 
+def test_more_second_layer_workgroups_than_compute_units(monkeypatch):
+    """67 sub-nets x 4 slices = 268 workgroups of the fused second-layer kernel on 256 CUs: a second dispatch round, and a launch size that is
+    no multiple of the eight XCDs (the pipeline's workgroup -> table-entry map has a remainder branch).  One epoch against the oracle."""
+    monkeypatch.setenv("DIMN_RESIDENT", "0")
+    monkeypatch.setenv("DIMN_MID", "1")
+    prob = make_problem(n=150, g=300, Ds=[24 + (k % 5) for k in range(67)], H=256, O=512, seed=41)
+    kw = dict(batch_size=64, dropout_rate=0.2, learning_rate=1e-3, seed=3)
+    a = load_problem(_hip(), prob, **kw)
+    info = a.path_info()
+    assert info["mid_fused"] == 1 and info["mid_keep"] == 2 and info["mid_slices"] * 67 > 256, info
+    b = load_problem(_oracle(), prob, **kw)
+    a.init_weights(); b.init_weights()
+    np.testing.assert_allclose(a.train_epoch(0), b.train_epoch(0), rtol=1e-4)
+    np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
+    for k in (0, 33, 66):
+        for x, y, name in zip(a.get_weights(k), b.get_weights(k), ("W1", "b1", "W2", "b2")):
+            np.testing.assert_allclose(x, y, rtol=1e-3, atol=2e-5, err_msg="%s k=%d" % (name, k))
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=1e-4, atol=1e-6)
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("name", ["linear", "sigmoid", "tanh", "elu", "softplus"])
 def test_hidden_activations_match_autograd_golden(name):
     from helpers import check_activation_kat
