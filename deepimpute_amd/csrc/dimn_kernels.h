@@ -1494,7 +1494,9 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void k_w1_update_fwd_ring(const Wo
     constexpr int XTS = DIMN_TB * 16, XN = DIMN_TB * 20;
     constexpr int DUMMY = 2 * (XTS + XN);                       // LDS words nobody reads: target of non-staging threads
     __shared__ __attribute__((aligned(16))) float sm[2 * (XTS + XN) + 4 * WAVES * 64];
-    const Work wk = work[blockIdx.x];
+    // the D-slices of one sub-net on ONE XCD (workgroup b runs on XCD b % 8; the table is sub-net-major): they all read the sub-net's dA block
+    const int nwg_ = gridDim.x, xq_ = nwg_ >> 3, xr_ = nwg_ & 7, xcd_ = blockIdx.x & 7;
+    const Work wk = work[xcd_ * xq_ + (xcd_ < xr_ ? xcd_ : xr_) + (blockIdx.x >> 3)];
     const SubnetDev s = sn[wk.k];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
