@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256) void k_fwd1(const Work* __restrict__ work, con
                                               const XT* __restrict__ X, const float* __restrict__ W1,
                                               const int32_t* __restrict__ rows, int b_act,
                                               float* __restrict__ P, Dims dm) {
-    const Work wk = work[blockIdx.x];
+    const int nwg_ = gridDim.x, xq_ = nwg_ >> 3, xr_ = nwg_ & 7, xcd_ = blockIdx.x & 7;        // a sub-net's D-slices on one XCD (see the ring kernel)
+    const Work wk = work[xcd_ * xq_ + (xcd_ < xr_ ? xcd_ : xr_) + (blockIdx.x >> 3)];
     const SubnetDev s = sn[wk.k];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lj = lane >> 4;
@@ -1192,7 +1193,8 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
     constexpr int XTS = DIMN_TB * 16, XN = DIMN_TB * 20;         // floats per staged tile
     constexpr int WSZ = 2 * (XTS + XN);                          // floats of LDS per wave
     __shared__ __attribute__((aligned(16))) float sm_all[8 * WSZ];
-    const Work wk = work[blockIdx.x];
+    const int nwg_ = gridDim.x, xq_ = nwg_ >> 3, xr_ = nwg_ & 7, xcd_ = blockIdx.x & 7;        // a sub-net's D-slices on one XCD (see the ring kernel)
+    const Work wk = work[xcd_ * xq_ + (xcd_ < xr_ ? xcd_ : xr_) + (blockIdx.x >> 3)];
     const SubnetDev s = sn[wk.k];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
@@ -1354,7 +1356,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
                                                                 const float* __restrict__ dA, float* __restrict__ P, Dims dm, AdamP ap) {
     constexpr int XTS = DIMN_TB * 16, XN = DIMN_TB * 20;
     __shared__ __attribute__((aligned(16))) float sm[2 * (XTS + XN)];
-    const Work wk = work[blockIdx.x];
+    const int nwg_ = gridDim.x, xq_ = nwg_ >> 3, xr_ = nwg_ & 7, xcd_ = blockIdx.x & 7;        // a sub-net's D-slices on one XCD (see the ring kernel)
+    const Work wk = work[xcd_ * xq_ + (xcd_ < xr_ ? xcd_ : xr_) + (blockIdx.x >> 3)];
     const SubnetDev s = sn[wk.k];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
