@@ -50,19 +50,48 @@ def device_count():
 _warm = {}
 
 
+def _join_warm_ups():
+    """atexit: a warm-up thread still inside hipHostMalloc / hipMalloc when the interpreter tears down can hang or crash the
+    process (a short script, a failed argument check, inspect_data() calling exit(1)); wait for it first."""
+    for t in list(_warm.values()):
+        if t is not True and t.is_alive():
+            t.join(timeout=30.0)
+
+
 def warm_up_async(device_id=0):
     """Bring the GPU up on a helper thread (dimn_warm_up: HIP context + the pinned bounce buffers, ~0.1 s) while the caller still
     parses arguments / reads its matrix; returns at once.  Once per (process, device); silent when there is no library or GPU --
-    the first real call then reports that."""
+    the first real call then reports that.  Called by what is about to use the GPU anyway (the top of MultiNet.fit / predict, the
+    CLI before it parses its CSV, bench.py at start-up) -- never by a constructor: building a MultiNet has no side effects, as in
+    the reference, so load-only use, inspection, or a fork() after construction see no HIP context."""
+    import atexit
     import threading
     device_id = int(device_id)
     if device_id in _warm:
         return
-    _warm[device_id] = True
+    if not _warm:
+        atexit.register(_join_warm_ups)
 
     def work():
         try:
             load()["warm_up"](device_id)
         except Exception:
             pass
-    threading.Thread(target=work, name="dimn-warm-up", daemon=True).start()
+    t = threading.Thread(target=work, name="dimn-warm-up", daemon=True)
+    _warm[device_id] = t
+    t.start()
+
+
+def release_cached_memory():
+    """Give the process-wide cache of large device blocks (include/dimn.h: dimn_release_cached_memory) back to the driver: after
+    MultiNet.close() / engine.close() the blocks of >= 32 MB otherwise wait, up to DIMN_ARENA_CACHE_GB (default 48), for the next
+    fit() of this process.  MultiNet.close() calls it.  A no-op when the library was never loaded."""
+    if _fns is not None:
+        _fns["release_cached_memory"]()
+
+
+def cached_memory_info():
+    """(bytes of idle device blocks in the library's cache, bytes of cached-class blocks handles currently own)."""
+    out = (C.c_int64 * 2)()
+    load()["cached_memory_info"](out)
+    return int(out[0]), int(out[1])

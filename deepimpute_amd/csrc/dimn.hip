@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -28,7 +29,7 @@
 #include "dimn_hoststats.h"
 #include "dimn_counts_dev.h"
 
-#define DIMN_ABI_VERSION 7
+#define DIMN_ABI_VERSION 8
 
 // DIMN_TRACE=1: stage times of the host-heavy entry points on stderr (diagnostic)
 struct Trace {
@@ -133,7 +134,7 @@ static int g_fin_dev = -1;                         // the device they live on
 static hipStream_t g_fin_st[2] = {nullptr, nullptr};     // ... and the pipeline's two streams / events (an HSA queue per stream: ~10-25 ms to create)
 static hipEvent_t g_fin_ev[2] = {nullptr, nullptr};
 static size_t g_fin_cap = 0;                       // (the first hipMalloc of that size in a process cost 17-86 ms inside predict(); dimn_warm_up makes them)
-static volatile int g_pin_warming = 0;         // dimn_warm_up holds the lock while it pins the shared set: a pipeline that arrives meanwhile waits for it
+static std::atomic<int> g_pin_warming{0};         // dimn_warm_up holds the lock while it pins the shared set: a pipeline that arrives meanwhile waits for it
 struct PinLease {
     std::unique_lock<std::mutex> lock;
     void* buf[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -178,6 +179,7 @@ struct dimn_handle_s {
     std::vector<MidWork> midwork;          // work table of the fused second-layer kernel (k_mid_fused)
     int mid_fused = 0, mid_slices = 0;     // 1: RED -> MFB -> RED2 -> B1F1; 0: RED -> MF -> MB -> B1F1
     int mid_keep = 0;                      // 1: k_mid_fused<true> (the W2 column blocks stay in LDS between its phases)
+    int w1_rev = 0;                        // 1: the ring B1F1 walks its D-slices backwards on odd steps (memory-side cache: DESIGN section 2)
     int mid_pipe = 0;                      // 1: k_mid_pipe (dimn_mid_pipe.h: the slice's tiles as a software pipeline) instead of k_mid_fused
     int train_bf16 = 0;                    // 1: precision bf16 and the fused second layer runs its three GEMMs on the bf16 matrix cores
     MidWork* d_midwork = nullptr; int32_t* d_midk = nullptr; float* d_P2 = nullptr;
@@ -263,17 +265,23 @@ static int use_device(dimn_handle h) {
 // block waits here for the next request it fits (at most 25 % larger than asked for), and requests are rounded up to an eighth of
 // their power of two (19.49 and 19.55 GB both take a 20 GiB block: the arena of the next fit(), whose predictor lists differ by
 // a few columns, fits the previous one's).  dimn_release_cached_memory() empties the cache; an allocation that fails empties it
-// and tries once more; the cache never holds more than DIMN_ARENA_CACHE_GB (default 96, 0 = no cache, no rounding).
+// and tries once more WITH THE EXACT SIZE (the rounding must never turn a request that fits into one that does not); the cache never holds
+// more than DIMN_ARENA_CACHE_GB (default 48: the ~37 GB of arenas of the 50k x 20k job -- a sixth of the device; 0 = no cache, no
+// rounding).  MultiNet.close() and deepimpute_amd.release_cached_memory() give everything back (other tenants of the GPU, RCCL, other libraries in the process).
+// hipFree() synchronises the whole device before it returns and callers relied on that (a block may still be read or written by queued
+// kernels of its previous owner on streams the caller does not know about), so put() does the same before a block becomes visible to the
+// next owner: one hipDeviceSynchronize() on the block's device -- microseconds on an idle device, and only for blocks of >= 32 MB.
 static const size_t kArenaMin = (size_t)32 << 20;
 struct ArenaPool {
     struct Blk { void* p; size_t bytes; int dev; };
     std::mutex mu;
     std::vector<Blk> idle, live;
     size_t idle_bytes = 0;
-    double cap_gb() { const char* e = getenv("DIMN_ARENA_CACHE_GB"); return e ? atof(e) : 96.0; }
+    double cap_gb() { const char* e = getenv("DIMN_ARENA_CACHE_GB"); return e ? atof(e) : 48.0; }
     hipError_t get(void** out, size_t bytes) {
         int dev = 0;
         (void)hipGetDevice(&dev);
+        const size_t asked = bytes;
         if (cap_gb() > 0.0) {                                    // size classes: multiples of 2^floor(log2(bytes)) / 8
             size_t p2 = (size_t)1 << 25;
             while ((p2 << 1) <= bytes) p2 <<= 1;
@@ -294,7 +302,7 @@ struct ArenaPool {
             }
         }
         hipError_t e = hipMalloc(out, bytes);
-        if (e != hipSuccess) { (void)hipGetLastError(); trim(0); e = hipMalloc(out, bytes); }
+        if (e != hipSuccess) { (void)hipGetLastError(); trim(0); bytes = asked; e = hipMalloc(out, bytes); }   // (the exact size: what fit without the cache still fits)
         if (e == hipSuccess) { std::lock_guard<std::mutex> lk(mu); live.push_back({*out, bytes, dev}); }
         return e;
     }
@@ -306,9 +314,18 @@ struct ArenaPool {
             for (size_t i = 0; i < live.size(); ++i)
                 if (live[i].p == p) { b = live[i]; live.erase(live.begin() + (long)i); break; }
             if (!b.p) return false;
-            if ((double)(idle_bytes + b.bytes) <= cap_gb() * 1073741824.0) { idle.push_back(b); idle_bytes += b.bytes; return true; }
         }
-        (void)hipFree(p);
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != b.dev) (void)hipSetDevice(b.dev);
+        bool kept = false;
+        if ((double)b.bytes <= cap_gb() * 1073741824.0) {
+            (void)hipDeviceSynchronize();                           // what hipFree() would have done: nothing queued still touches the block
+            std::lock_guard<std::mutex> lk(mu);
+            if ((double)(idle_bytes + b.bytes) <= cap_gb() * 1073741824.0) { idle.push_back(b); idle_bytes += b.bytes; kept = true; }
+        }
+        if (!kept) (void)hipFree(p);
+        if (cur != b.dev) (void)hipSetDevice(cur);
         return true;
     }
     void trim(size_t keep_bytes) {
@@ -372,6 +389,15 @@ extern "C" int dimn_warm_up(int32_t device_id) {
 
 extern "C" int dimn_release_cached_memory(void) {
     g_arena.trim(0);
+    return DIMN_OK;
+}
+extern "C" int dimn_cached_memory_info(int64_t* out2) {
+    if (!out2) return fail(DIMN_ERR_ARG, "dimn_cached_memory_info: null");
+    std::lock_guard<std::mutex> lk(g_arena.mu);
+    size_t live = 0;
+    for (auto& b : g_arena.live) live += b.bytes;
+    out2[0] = (int64_t)g_arena.idle_bytes;
+    out2[1] = (int64_t)live;
     return DIMN_OK;
 }
 
@@ -599,6 +625,7 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
     }
     h->w1_total = w1;
     build_work(h);
+    h->w1_rev = getenv("DIMN_W1_REV") && atoi(getenv("DIMN_W1_REV")) != 0;
     if (!general) { build_mid(h); build_resident(h); }
     // One lane: every sub-net on the handle's stream.  (Two free-running lanes on two streams, a "W token" ring between them and a fixed
     // CU partition with CU-masked streams were all measured and lost to the serial step: DESIGN.md section 2, profiles/r03_cu_partition_sweep.txt.)
@@ -1189,19 +1216,19 @@ static void launch_fwd1(dimn_handle h, const dimn_handle_s::Lane& ln, hipStream_
 }
 template <int NT2>
 static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, hipStream_t stw, const int32_t* rows, int b_act, const int32_t* rows_n, int b_next,
-                      AdamP ap, hipEvent_t ev_begin, hipEvent_t ev_end) {
+                      AdamP ap, hipEvent_t ev_begin, hipEvent_t ev_end, int64_t rev_t) {
     const dim3 grid((unsigned)(ln.w1 - ln.w0));
     const Work* wk = h->d_work + ln.w0;
     // ev_begin/ev_end (timed launches only): hipExtLaunchKernelGGL stamps them with the kernel's own begin and end,
     // so the elapsed time is the launch's duration without the dispatch latency an event pair around it would add
-#define W1_LAUNCH(KERNEL, THREADS) hipExtLaunchKernelGGL((KERNEL), grid, dim3(THREADS), 0, stw, ev_begin, ev_end, 0, wk, h->d_sn,      \
+#define W1_LAUNCH(KERNEL, THREADS, ...) hipExtLaunchKernelGGL((KERNEL), grid, dim3(THREADS), 0, stw, ev_begin, ev_end, 0, wk, h->d_sn,      \
                                                          (const XT*)h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, \
-                                                         (const float*)h->d_dA, h->d_P, h->dm, ap)
+                                                         (const float*)h->d_dA, h->d_P, h->dm, ap, ##__VA_ARGS__)
     WITH_XT(h, {
         if (h->dm.HT == 20)                           // H = 300 (padded to 320): 10 waves x 2 hidden tiles, two-set shared-staging variant
             W1_LAUNCH((k_w1_update_fwd_sh<10, 2, 1, XT>), 640);
         else if (h->dm.HT == 16)                      // H = 256: 16 waves x 1 hidden tile, X tiles staged once per workgroup, 3-set register ring
-            W1_LAUNCH((k_w1_update_fwd_ring<16, 1, 3, 1, XT>), 1024);
+            W1_LAUNCH((k_w1_update_fwd_ring<16, 1, 3, 1, XT>), 1024, (int)(h->w1_rev && (rev_t & 1)));   // odd steps walk the slices backwards
         else if (h->dm.HT == 8 * NT2)
             W1_LAUNCH((k_w1_update_fwd<NT2, true, XT>), 512);
         else
@@ -1378,7 +1405,7 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     else { if (dm.OT == 4 * h->OTW) LAUNCH_MB(true, 4); else LAUNCH_MB(false, 4); }
 #undef LAUNCH_MB
     }
-    DISPATCH_NT2(launch_w1, h, ln, stw, d_rows, b_act, d_rows_n, b_next, ap, e1, e2);   // e1/e2 (timed steps): the kernel's own begin/end
+    DISPATCH_NT2(launch_w1, h, ln, stw, d_rows, b_act, d_rows_n, b_next, ap, e1, e2, t);   // e1/e2 (timed steps): the kernel's own begin/end
     HIPCHK(hipGetLastError());
     return DIMN_OK;
 }

@@ -95,6 +95,7 @@ class Engine:
     def set_split(self, train_rows, val_rows):
         tr, va = i32(train_rows), i32(val_rows)
         self.n_train, self.n_val = tr.size, va.size
+        self.train_rows, self.val_rows = tr, va          # (kept for callers that replay an epoch: the permutation indexes train_rows)
         self._check(self._f["set_split"](self._h, p_i32(tr), tr.size, p_i32(va), va.size))
 
     # -- weights ----------------------------------------------------------

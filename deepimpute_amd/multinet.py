@@ -242,12 +242,16 @@ class MultiNet:
             # one process per GPU: the rank's device is known before any planning touches a GPU
             self.device_id = int(os.environ.get("LOCAL_RANK", str(device_id)))
         self.setCores(ncores)
-        if self._device_planning and comm is None:     # the GPU comes up (context, pinned bounce buffers) while the caller still prepares its frame
+
+    def _warm_up(self):
+        """The GPU comes up (HIP context, pinned bounce buffers, the finish pipeline's blocks: dimn_warm_up) on a helper thread while
+        fit() / predict() still look at their frame.  Not in __init__: the reference's constructor has no side effects."""
+        if self._device_planning and self._comm_spec is None:
             try:
                 from . import _lib
                 _lib.warm_up_async(self.device_id)
             except (ImportError, OSError):
-                pass                                   # no library: fit() says so
+                pass                                   # no library: the engine's constructor says so
 
     def setCores(self, ncores):
         # the reference only sizes TensorFlow's CPU thread pools with this (multinet.py:222-223);
@@ -486,6 +490,7 @@ class MultiNet:
     def fit(self, raw, cell_subset=1, NN_lim=None, genes_to_impute=None, n_pred=None, ntop=5,
             minVMR=0.5, mode='random'):
         tm = self.timings = _Stages()
+        self._warm_up()
         # Fast path (a frame of raw counts, one GPU, resident matrix): the counts go to the device first, as float32 (exact), and
         # everything the planning needs is computed from that copy -- the gene statistics (pandas' additions in pandas' order, one
         # thread per gene: DataFrame.mean() / .var() to the bit), the candidate pool of the correlation (genes that vary, with a
@@ -713,9 +718,18 @@ class MultiNet:
             self._engine = None
         self._drop_resident()                           # (after the engine that read them)
 
-    def close(self):
-        """Extension: release the GPU (and, in a sharded job, the RCCL communicator) now instead of at exit."""
+    def close(self, release_cache=True):
+        """Extension: release the GPU (and, in a sharded job, the RCCL communicator) now instead of at exit -- the engine, the resident
+        counts, and the library's process-wide cache of large device blocks (which otherwise waits for the next fit() of this process:
+        deepimpute_amd.release_cached_memory; release_cache=False leaves it for a fit() that follows)."""
         self._release_engine()
+        if not release_cache:
+            return
+        try:
+            from . import _lib
+            _lib.release_cached_memory()
+        except (ImportError, OSError):
+            pass
 
     def _shard_plan(self, inputdims):
         """(rank, world, counts) of this process for the sub-networks of `inputdims` under the caller's comm spec (contiguous blocks
@@ -803,6 +817,7 @@ class MultiNet:
         tm = self.timings = _Stages(getattr(self, "timings", None) or {})
         for key in [k for k in tm if k.startswith("predict.")]:
             del tm[key]
+        self._warm_up()
         with tm.stage("predict.load"):
             engine = self.load()
         # The counts of this very frame may still be on the GPU from fit() (verified bit for bit by a checksum pass), or go there

@@ -110,8 +110,11 @@ int dimn_destroy(dimn_handle h);
  * when a handle / counts object releases them and are handed to the next request they fit: memory that was hipFree'd earlier
  * in the same process comes back from hipMalloc slowly (the driver wipes it first), which made the hand-over of a second fit()
  * cost 0.2-0.6 s instead of 0.02 s.  dimn_release_cached_memory() gives every idle block back to the driver;
- * DIMN_ARENA_CACHE_GB caps what is kept (default 96, 0: nothing).  ABI 7. */
+ * DIMN_ARENA_CACHE_GB caps what is kept (default 48, 0: nothing); a request that fails empties the cache and is retried with its
+ * exact size.  ABI 7.  The host side calls it from MultiNet.close() (deepimpute_amd.release_cached_memory()). */
 int dimn_release_cached_memory(void);
+/* out2[0] = bytes of idle blocks the cache holds, out2[1] = bytes of cached-class blocks currently owned by handles.  ABI 8. */
+int dimn_cached_memory_info(int64_t* out2);
 /* Start-up cost moved out of fit(): creates the HIP context of the device and pins the process-wide bounce buffers (~0.1 s).
  * Idempotent, thread-safe; host code calls it from a helper thread as soon as it knows which GPU it will use.  ABI 7. */
 int dimn_warm_up(int32_t device_id);

@@ -215,12 +215,13 @@ def _round_bf16(x):
     return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
 
 
-def find_relu_flip_candidates(oracle_cls, norm, pred_k, targ_k, k_global, units, train, steps, H, O, slack=4.0, **kw):
+def find_relu_flip_candidates(oracle_cls, norm, pred_k, targ_k, k_global, units, train, steps, H, O, slack=4.0, epochs=1, **kw):
     """The mechanism behind a (rare) disagreement of two fp32 paths that sum a first-layer dot product in different orders:
-    relu'(a) is discontinuous at a = 0.  The fp64 oracle replays epoch 0 of sub-net `k_global` alone (Philox streams are keyed
-    by GLOBAL sub-net index) and reports every (step, batch position, unit) among `units` whose pre-activation lies within the
-    reordering error of an fp32 dot product of zero: |a| <= slack * eps32 * (sum_i |x_i w_i| + |b|) -- the places where the
-    SIGN of a is not defined at fp32 precision.  Records (step, b, unit, a, bound), closest to zero first."""
+    relu'(a) is discontinuous at a = 0.  The fp64 oracle replays the first `epochs` epochs (`steps` optimiser steps each) of sub-net
+    `k_global` alone (Philox streams are keyed by GLOBAL sub-net index) and reports every (epoch, step, batch position, unit) among
+    `units` whose pre-activation lies within the reordering error of an fp32 dot product of zero: |a| <= slack * eps32 *
+    (sum_i |x_i w_i| + |b|) -- the places where the SIGN of a is not defined at fp32 precision.
+    Records (epoch, step, b, unit, a, bound), closest to zero first."""
     o64 = oracle_cls([len(pred_k)], H, O, fp64=True, subnet_offset=int(k_global), **kw)
     o64.set_matrix(norm)
     o64.set_indices(0, pred_k, targ_k)
@@ -228,38 +229,43 @@ def find_relu_flip_candidates(oracle_cls, norm, pred_k, targ_k, k_global, units,
     o64.set_split(train, train[:1])
     o64.init_weights()
     B = o64.B
-    perm = o64.epoch_permutation(0)
     units = np.asarray(units)
+    bf16 = str(kw.get("precision", "fp32")).lower() in ("bf16", "bfloat16")
     out = []
-    for t in range(steps):
-        rows = train[perm[t * B:(t + 1) * B]]
-        W1, b1 = o64.get_weights(0)[:2]
-        X = norm[rows][:, pred_k]
-        if str(kw.get("precision", "fp32")).lower() in ("bf16", "bfloat16"):      # the arena stores the predictors rounded to nearest even
-            X = _round_bf16(X)
-        X = X.astype(np.float64)
-        w = W1[:, units].astype(np.float64)
-        a = X @ w + b1[units].astype(np.float64)
-        bound = slack * np.finfo(np.float32).eps * (np.abs(X) @ np.abs(w) + np.abs(b1[units].astype(np.float64)))
-        for i, j in zip(*np.nonzero(np.abs(a) <= bound)):
-            out.append((t, int(i), int(units[j]), float(a[i, j]), float(bound[i, j])))
-        o64.train_step(rows, epoch_key=0, step_key=t, want_loss=False)
+    for e in range(epochs):
+        perm = o64.epoch_permutation(e)
+        for t in range(steps):
+            rows = train[perm[t * B:(t + 1) * B]]
+            W1, b1 = o64.get_weights(0)[:2]
+            X = norm[rows][:, pred_k]
+            if bf16:                                                   # the arena stores the predictors rounded to nearest even
+                X = _round_bf16(X)
+            X = X.astype(np.float64)
+            w = W1[:, units].astype(np.float64)
+            a = X @ w + b1[units].astype(np.float64)
+            bound = slack * np.finfo(np.float32).eps * (np.abs(X) @ np.abs(w) + np.abs(b1[units].astype(np.float64)))
+            for i, j in zip(*np.nonzero(np.abs(a) <= bound)):
+                out.append((e, t, int(i), int(units[j]), float(a[i, j]), float(bound[i, j])))
+            o64.train_step(rows, epoch_key=e, step_key=t, want_loss=False)
     o64.close()
-    return sorted(out, key=lambda r: abs(r[3]) / r[4])
+    return sorted(out, key=lambda r: abs(r[4]) / r[5])
 
 
-def oracle_with_inverted_gates(oracle_cls, norm, pred_k, targ_k, k_global, train, val, H, O, inversions, **kw):
-    """The fp32 oracle of sub-net `k_global` alone, trained for epoch 0 with the listed (step, b, unit) relu gates taken on the
-    other side of zero (oracle/dimo.c dimo_invert_gate: a test instrument for pre-activations at fp32 noise level)."""
+def oracle_with_inverted_gates(oracle_cls, norm, pred_k, targ_k, k_global, train, val, H, O, inversions, epochs=1, **kw):
+    """The fp32 oracle of sub-net `k_global` alone, trained for `epochs` epochs with the listed (epoch, step, b, unit) relu gates taken
+    on the other side of zero (oracle/dimo.c dimo_invert_gate: a test instrument for pre-activations at fp32 noise level).
+    Returns the engine and the last epoch's training loss."""
     o = oracle_cls([len(pred_k)], H, O, subnet_offset=int(k_global), **kw)
     o.set_matrix(norm)
     o.set_indices(0, pred_k, targ_k)
     o.gather(True)
     o.set_split(train, val)
     o.init_weights()
-    for step, b, unit in inversions:
-        o.invert_gate(0, 0, step, b, unit)
-    loss = o.train_epoch(0)
+    for epoch, step, b, unit in inversions:
+        o.invert_gate(0, epoch, step, b, unit)
+    loss = None
+    for e in range(epochs):
+        loss = o.train_epoch(e)
     return o, loss
 
 

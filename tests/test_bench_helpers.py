@@ -134,3 +134,38 @@ def test_rccl_failure_yields_a_null_value_line_on_every_rank(monkeypatch):
     for key in ("metric", "unit", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line
     assert not hasattr(bench, "FileBenchComm")          # no transport other than RCCL can produce a number
+
+
+def test_deviation_reports_the_tolerance_of_the_parity_tests():
+    b = np.array([1.0, 2.0, 1e-3, 4.0])
+    a = b * np.array([1.0, 1.0 + 5e-5, 1.0, 1.0 + 3e-4])
+    d = bench.deviation(a, b)
+    assert abs(d["max_rel"] - 3e-4) < 1e-9 and d["elements"] == 4
+    assert abs(d["outside_tolerance"] - 0.25) < 1e-12 and abs(d["max_abs"] - 1.2e-3) < 1e-9      # only the last element misses 1e-4 |b| + 1e-5
+
+
+def test_accuracy_leg_compares_element_wise_at_the_full_horizon(monkeypatch):
+    """bench.accuracy_pair's plumbing on the CPU: the oracle stands in for the HIP engine (so `hip` must equal `cpu_port` to the bit,
+    and float32 vs float64 must differ a little): all K sub-nets on the `hip` side, the first n_subnets on the ports, the element-wise
+    deviation over every sample cell."""
+    from deepimpute_amd import engine
+    from oracle.dimo import OracleEngine
+
+    class Standin(OracleEngine):
+        def path_info(self):
+            return {"path": "oracle stand-in"}
+    monkeypatch.setattr(engine, "HipEngine", Standin)
+    cfg = {"H": 24, "O": 32, "B": 16, "n": 240, "g": 200}
+    norm = bench.synth_counts(cfg["n"], cfg["g"], seed=1, threads=2)
+    targets, preds = bench.synth_indices(cfg["g"], cfg["O"], seed=0)
+    acc = bench.accuracy_pair(cfg, targets, preds, norm, 3, 1e-3, n_cells=200, n_subnets=3)
+    iv = acc["imputed_values"]["log1p_space"]
+    assert acc["hip"]["subnets_trained"] == targets.shape[0] and acc["cpu_port"]["subnets_trained"] == 3
+    assert iv["hip_vs_cpu_port"]["max_abs"] == 0.0                                        # global Philox keys: K does not change a sub-net
+    assert iv["hip_share_vs_cpu_port_fp64"] == iv["hip_vs_cpu_port_fp64"] == iv["cpu_port_fp32_vs_fp64"]
+    assert set(acc["imputed_values"]["by_epoch"]) == {"1", "3"} and acc["imputed_values"]["within_noise_floor"] is True
+    assert len(acc["imputed_values"]["rms_rel_per_subnet"]) == 3
+    assert iv["hip_vs_cpu_port"]["elements"] == 200 * 3 * 32
+    assert 0 < iv["cpu_port_fp32_vs_fp64"]["max_rel"] < 1e-3 and iv["cpu_port_fp32_vs_fp64"]["outside_tolerance"] == 0.0
+    assert acc["relative_difference"]["val_loss"] == 0.0
+    assert acc["imputed_values"]["counts_expm1"]["hip_vs_cpu_port"]["max_rel"] == 0.0

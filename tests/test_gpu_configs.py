@@ -107,7 +107,7 @@ def _compare_with_oracle(a, b, norm, preds, targets, ks, train, val, steps, cfg,
                       "error of zero in any step -- not a relu flip" % (ks[i], units.tolist())
         last = None
         for inv in [c for c in itertools.chain(((x,) for x in cands[:4]), itertools.combinations(cands[:4], 2))]:
-            o, lo = oracle_with_inverted_gates(*args, train, val, cfg["H"], O, [r[:3] for r in inv], **kw, **(oracle_kw or {}))
+            o, lo = oracle_with_inverted_gates(*args, train, val, cfg["H"], O, [r[:4] for r in inv], **kw, **(oracle_kw or {}))
             try:
                 same(i, o, 0, lo[0], o.val_loss()[0], o.predict(rows))
                 flipped[ks[i]] = inv
@@ -119,7 +119,7 @@ def _compare_with_oracle(a, b, norm, preds, targets, ks, train, val, steps, cfg,
         else:
             raise last
     if flipped:
-        print("relu flips (mechanism asserted, oracle re-run with the gate on the other side): (step, batch position, unit, a, bound)", flipped)
+        print("relu flips (mechanism asserted, oracle re-run with the gate on the other side): (epoch, step, batch position, unit, a, bound)", flipped)
     return flipped
 
 

@@ -201,3 +201,111 @@ def test_resident_counts_path_equals_host_path(tmp_path, monkeypatch):
     net = MultiNet(output_prefix=str(tmp_path / "s"), **kw).fit(scaled, NN_lim=200)
     assert getattr(net, "_resident", None) is None and np.isfinite(net.predict(scaled).values).all()
     net.close()
+
+
+def test_cfg2_full_size_through_the_drop_in_matches_oracle(tmp_path):
+    """BASELINE configs[1] at its FULL size -- 5 000 cells x 5 000 genes, K = 10 sub-nets (D_k ~ 1 935), the reference's own defaults
+    (hidden 256, output 512, batch 64, dropout 0.2, Adam 1e-4) -- through the DROP-IN surface: `MultiNet.fit + predict` on the HIP
+    engine (counts resident, planning on the device, whatever kernels the library picks: two resident groups of five) against the same
+    shell on the CPU oracle in float32 AND in float64 (host planning), three epochs = 225 optimiser steps, a partial last batch in each
+    (multinet.py:238-244, 278-305).  Asserted:
+      * the same plan from the device and from the host (targets, predictor lists), the same number of epochs, the loss curves to 2e-4;
+      * element-wise, over every sub-net's predictions for ALL 5 000 cells: the STATED tolerance of DESIGN section 4 at this horizon
+        (99.9 % of the values within 1e-4 relative, none beyond 1e-3) -- after 225 steps two float32 evaluations of the same trajectory
+        differ by more than 1e-4 in a few elements per ten thousand whatever computes them, which is why the second assertion is the
+        one that carries the weight:
+      * the NOISE FLOOR criterion: against the float64 oracle, the HIP path is no further away than twice the plain-loop float32 oracle
+        is (maximum and rms, per sub-net) -- unless the fp64 replay finds the relu-flip mechanism of tests/test_gpu_configs.py (a
+        pre-activation of a unit within fp32 reordering error of zero), in which case the float32 oracle re-run with that gate on the
+        other side must agree at the stated tolerance;
+      * the imputed frames (multinet.py:282-305) at the same tolerance, observed counts restored exactly, held-out metrics to 1e-4."""
+    import ctypes
+    import itertools
+    import bench
+    from helpers import find_relu_flip_candidates, oracle_with_inverted_gates, relu_flip_units
+    from deepimpute_amd import _hostpar
+    from deepimpute_amd.multinet import MultiNet
+    from oracle.dimo import OracleEngine
+    ctypes.CDLL("libgomp.so.1").omp_set_num_threads(min(32, os.cpu_count() or 1))      # (tiny OpenMP regions: 256 threads spend their time in fork / join)
+    cfg = bench.CONFIGS["cfg2"]
+    n, g, O, H, epochs = cfg["n"], cfg["g"], cfg["O"], cfg["H"], 3
+    assert (n, g, O, H, cfg["B"]) == (5000, 5000, 512, 256, 64)
+    norm = bench.synth_counts(n, g, seed=0)
+    raw = pd.DataFrame(np.rint(np.expm1(norm.astype(np.float64))), index=["c%d" % i for i in range(n)], columns=["g%d" % j for j in range(g)])
+    kw = dict(verbose=0, max_epochs=epochs, patience=10 ** 6, seed=1234, ncores=1)      # everything else: the reference's defaults
+
+    class Oracle64(OracleEngine):
+        def __init__(self, *a, **k):
+            super().__init__(*a, fp64=True, **k)
+    a = MultiNet(output_prefix=str(tmp_path / "a"), **kw).fit(raw, NN_lim=g)
+    b = multinet_with(OracleEngine, output_prefix=str(tmp_path / "b"), **kw).fit(raw, NN_lim=g)
+    c = multinet_with(Oracle64, output_prefix=str(tmp_path / "c"), **kw).fit(raw, NN_lim=g)
+    K = len(a.predictors)
+    assert K == 10 == len(b.predictors) and np.array_equal(a.targets, b.targets) and np.array_equal(a.targets, c.targets)
+    assert all(list(x) == list(y) for x, y in zip(a.predictors, b.predictors))            # device planning == host planning at full size
+    assert a._engine.path_info()["path"] == "resident"
+    assert a.trained_epochs == b.trained_epochs == c.trained_epochs == epochs
+    np.testing.assert_allclose(a.history["val_loss"], b.history["val_loss"], rtol=2e-4)
+    np.testing.assert_allclose(a.history["loss"], b.history["loss"], rtol=2e-4)
+    pa, pb, pc = a._engine.predict(), b._engine.predict(), c._engine.predict()            # [n, K * O]: model.predict's hstack over all cells
+    rel = lambda x, y: np.abs(x.astype(np.float64) - y) / np.maximum(np.abs(y.astype(np.float64)), 1e-30)
+    logn = _hostpar.log1p_float32(raw).values
+    where = pd.Index(raw.columns)
+    rows_train, rows_val = b._engine.train_rows.copy(), b._engine.val_rows.copy()
+    assert np.array_equal(rows_train, a._engine.train_rows) and np.array_equal(rows_val, a._engine.val_rows)
+    steps = -(-rows_train.size // 64)
+    ekw = dict(batch_size=64, dropout_rate=0.2, learning_rate=1e-4, seed=1234)
+    flipped = {}
+    print()
+    for k in range(K):
+        blk = slice(k * O, (k + 1) * O)
+        r_ab, r_ac, r_bc = rel(pa[:, blk], pb[:, blk]), rel(pa[:, blk], pc[:, blk]), rel(pb[:, blk], pc[:, blk])
+        rms = lambda r: float(np.sqrt(np.mean(r ** 2)))
+        out_ab = float(np.mean(np.abs(pa[:, blk] - pb[:, blk]) > 1e-4 * np.abs(pb[:, blk]) + 1e-5))
+        print("sub-net %d: HIP vs f32 oracle max %.2e p99.9 %.2e outside(1e-4,1e-5) %.1e | vs f64: HIP max %.2e rms %.2e, f32 oracle max %.2e rms %.2e"
+              % (k, r_ab.max(), np.quantile(r_ab, 0.999), out_ab, r_ac.max(), rms(r_ac), r_bc.max(), rms(r_bc)))
+        ok_floor = r_ac.max() <= 2 * r_bc.max() + 1e-6 and rms(r_ac) <= 2 * rms(r_bc) + 1e-8
+        ok_stated = np.quantile(r_ab, 0.999) <= 1e-4 and r_ab.max() <= 1e-3
+        if ok_floor and ok_stated:
+            continue
+        # not at the noise floor: it must be the relu-flip mechanism, shown and reproduced
+        assert len(flipped) < 3, "more than three sub-nets off after 225 steps: not the rare event this path is for"
+        units = relu_flip_units(a._engine, b._engine, k, rtol=2e-4, atol=5e-6)
+        assert units.size, "sub-net %d is beyond the float32 noise floor and no first-layer column differs: not a relu flip" % k
+        cols_in, cols_out = where.get_indexer(a.predictors[k]), where.get_indexer(a.targets[k])
+        args = (OracleEngine, logn, cols_in, cols_out, k)
+        cands = find_relu_flip_candidates(*args, units, rows_train, steps, H, O, epochs=epochs, **ekw)
+        assert cands, "sub-net %d: units %s differ and no pre-activation of theirs is within fp32 reordering error of zero in any of the " \
+                      "%d steps -- not a relu flip" % (k, units.tolist(), epochs * steps)
+        last = None
+        for inv in itertools.chain(((x,) for x in cands[:4]), itertools.combinations(cands[:4], 2)):
+            o, _ = oracle_with_inverted_gates(*args, rows_train, rows_val, H, O, [r[:4] for r in inv], epochs=epochs, **ekw)
+            try:
+                r_inv = rel(pa[:, blk], o.predict())
+                assert np.quantile(r_inv, 0.999) <= 1e-4 and r_inv.max() <= 1e-3, "sub-net %d (gate inverted): max %.2e" % (k, r_inv.max())
+                flipped[k] = inv
+                break
+            except AssertionError as e:
+                last = e
+            finally:
+                o.close()
+        else:
+            raise last
+    if flipped:
+        print("relu flips (mechanism asserted, oracle re-run with the gate on the other side): (epoch, step, batch position, unit, a, bound)", flipped)
+    # the imputed frame (multinet.py:282-305), on the genes none of whose target slots belongs to a flipped sub-net
+    fa, fb = a.predict(raw, imputed_only=True), b.predict(raw, imputed_only=True)
+    assert list(fa.columns) == list(fb.columns) and fa.index.equals(fb.index)
+    tainted = set(np.asarray(a.targets)[sorted(flipped)].ravel()) if flipped else set()
+    keep = np.array([col not in tainted for col in fa.columns])
+    r_f = rel(fa.values[:, keep], fb.values[:, keep])
+    zero = (fa.values[:, keep] == 0) & (fb.values[:, keep] == 0)
+    r_f[zero] = 0.0
+    print("imputed frame (counts): max rel %.2e, 99.9th percentile %.2e" % (r_f.max(), np.quantile(r_f, 0.999)))
+    assert np.quantile(r_f, 0.999) <= 1e-4 and r_f.max() <= 1e-3
+    pos = raw.values > 0
+    full = a.predict(raw)
+    assert np.array_equal(full.values[pos], raw.values[pos])                             # restore policy: observed counts come back exactly
+    np.testing.assert_allclose(float(a.test_metrics["MSE"]), float(b.test_metrics["MSE"]), rtol=1e-4)
+    np.testing.assert_allclose(float(a.test_metrics["correlation"]), float(b.test_metrics["correlation"]), rtol=1e-4)
+    a.close(); b.close(); c.close()
