@@ -106,6 +106,7 @@ GPU_ONLY = {
     "abs_corrcoef": [_i32, _pd, _i64, _i64, _pd],
     "val_metrics": [_H, _pd],
     "impute_finish": [_H, _pd, _i64, _i64, _pi, _pi, _i32, C.c_double, _i32, _pd],
+    "impute_finish_restore": [_H, _pd, _i64, _i64, _pi, _pi, C.c_double, _i32, _pd, C.POINTER(C.c_uint64)],
     "csv_scan": [C.c_char_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "csv_read": [C.c_char_p, _i64, _i64, C.POINTER(_i64), C.c_char_p, _i64],
     "csv_write": [C.c_char_p, _pd, _i64, _i64, C.c_char_p, C.c_char_p, C.c_char_p],

@@ -19,6 +19,10 @@
 #include <thread>
 #include <vector>
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>      // host pass only: the AVX2 form of counts_scan's inner loop (the Makefile builds the host side with -march=x86-64-v3)
+#endif
+
 #include "../../include/dimn.h"
 #include "dimn_kernels.h"
 #include "dimn_mid_pipe.h"
@@ -204,6 +208,9 @@ struct dimn_handle_s {
     int64_t pred_rows_cap = 0;
     std::vector<int32_t> train_rows, val_rows;
     float* d_out = nullptr; int64_t out_cap = 0; int64_t out_rows = 0;
+    // dimn_predict_device over all cells runs as a few row chunks with an event behind each, so that dimn_impute_finish* can start on the
+    // first rows while the forward still computes the last ones (round 5): pred_ev_rows[c] = first row NOT covered by chunks 0 .. c
+    std::vector<hipEvent_t> pred_ev; std::vector<int64_t> pred_ev_rows; int32_t* d_pred_iota = nullptr; int64_t pred_iota_n = 0;
     float* d_loss_part = nullptr; int64_t loss_part_cap = 0;
     float *d_full = nullptr, *d_stage = nullptr; int64_t full_cap = 0;   // root's gathered predictions
     int64_t full_rows = 0, full_width = 0;                               // shape of the last gathered matrix (rows, K_global * O)
@@ -762,6 +769,8 @@ extern "C" int dimn_destroy(dimn_handle h) {
     gen_free(h->gen); h->gen = nullptr;
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (auto e : h->ev) (void)hipEventDestroy(e);
+    for (auto e : h->pred_ev) (void)hipEventDestroy(e);
+    DEV_FREE(h->d_pred_iota);
     DEV_FREE(h->d_sn); DEV_FREE(h->d_work); DEV_FREE(h->d_norm); DEV_FREE(h->d_X); DEV_FREE(h->d_Y);
     DEV_FREE(h->d_pred); DEV_FREE(h->d_targ); DEV_FREE(h->d_pred_off);
     DEV_FREE(h->d_W1); DEV_FREE(h->d_M1); DEV_FREE(h->d_V1); DEV_FREE(h->d_W2); DEV_FREE(h->d_M2); DEV_FREE(h->d_V2);
@@ -1824,8 +1833,32 @@ extern "C" int dimn_predict_device(dimn_handle h, const int32_t* rows, int64_t n
         HIPCHK(hipStreamSynchronize(h->stream));
         drows = h->d_pred_rows;
     }
+    h->pred_ev_rows.clear();
     if (n_rows > 0 && h->gen) {
         CHK(gen_predict(h, drows, n_rows));
+    } else if (n_rows > 0 && !rows && n_rows >= 8192) {
+        // all cells, in order: eight row chunks (multiples of 128 rows: the bf16 kernel's tile), an event behind each
+        if (h->pred_iota_n < n_rows) {
+            HIPCHK(hipStreamSynchronize(h->stream));
+            DEV_FREE(h->d_pred_iota);
+            CHK(dev_alloc(&h->d_pred_iota, (size_t)n_rows));
+            h->pred_iota_n = n_rows;
+            hipLaunchKernelGGL(k_res_iota, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, h->stream, h->d_pred_iota, n_rows);
+        }
+        const int64_t per = ((n_rows + 7) / 8 + 127) / 128 * 128;
+        size_t c = 0;
+        for (int64_t r0 = 0; r0 < n_rows; r0 += per, ++c) {
+            const int64_t nr = std::min(per, n_rows - r0);
+            DISPATCH_NT(launch_predict, h, (const int32_t*)(h->d_pred_iota + r0), nr, h->d_out + r0 * h->K * h->O, (float*)nullptr);
+            HIPCHK(hipGetLastError());
+            if (h->pred_ev.size() <= c) {
+                hipEvent_t e = nullptr;
+                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                h->pred_ev.push_back(e);
+            }
+            HIPCHK(hipEventRecord(h->pred_ev[c], h->stream));
+            h->pred_ev_rows.push_back(r0 + nr);
+        }
     } else if (n_rows > 0) {
         DISPATCH_NT(launch_predict, h, drows, n_rows, h->d_out, (float*)nullptr);
         HIPCHK(hipGetLastError());
@@ -1865,6 +1898,13 @@ extern "C" int dimn_val_metrics(dimn_handle h, double* out7) {
     return rc;
 }
 
+// the event behind the forward chunk that covers rows [.., row_end) of the last dimn_predict_device (chunked form)
+static hipEvent_t pred_event_for(dimn_handle h, int64_t row_end) {
+    size_t c = 0;
+    while (c + 1 < h->pred_ev_rows.size() && h->pred_ev_rows[c] < row_end) ++c;
+    return h->pred_ev[c];
+}
+
 // ---- next row: predict() post-processing (multinet.py:282-305) as a device epilogue ----------
 // Row blocks of raw stream in, the finished float64 frame streams out, both through two pinned bounce buffers per
 // direction so that the PCIe copies of one block overlap the kernel and the host copies of its neighbours.
@@ -1885,7 +1925,8 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
     for (int64_t j = 0; j < g; ++j) if (gene_off[j] > gene_off[j + 1]) return fail(DIMN_ERR_ARG, "dimn_impute_finish: gene_off not monotone");
     for (int64_t s = 0; s < S; ++s) if (gene_slot[s] < 0 || gene_slot[s] >= S) return fail(DIMN_ERR_ARG, "dimn_impute_finish: slot out of range");
     CHK(use_device(h));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    const bool chunked = !from_gathered && !h->pred_ev_rows.empty() && h->pred_ev_rows.back() == n_rows;   // the forward runs in row chunks: blocks wait for their rows only
+    if (!chunked) HIPCHK(hipStreamSynchronize(h->stream));
     if (n_rows == 0) return DIMN_OK;
     const int64_t blk = std::max<int64_t>(1, std::min<int64_t>(n_rows, (int64_t)(128u << 20) / (g * 8)));   // ~128 MB per block
     Trace tr;
@@ -1954,6 +1995,7 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
             const int64_t r0 = bi * blk, nr = std::min(blk, n_rows - r0);
             if (!resident) parallel_memcpy(pIn[b], raw + r0 * g, (size_t)nr * g * 8);
             if (retire.joinable()) retire.join();        // pOut[b] is free again before this block's D2H is queued
+            if (chunked) FIN_TRY(hipStreamWaitEvent(st[b], pred_event_for(h, r0 + nr), 0));
             if (resident) {
                 hipLaunchKernelGGL(k_impute_finish<float>, dim3((unsigned)std::min<int64_t>(nr, 4096)), dim3(512), lds, st[b], pred, S, r0,
                                    (const float*)(h->counts->d + r0 * g), nr, g, dOff, dSlot, ceiling, policy, lds_stage, dRes[b]);
@@ -1978,6 +2020,190 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
     if (dOff) (void)dev_free_any(dOff);
     if (dSlot) (void)dev_free_any(dSlot);
     tr.lap("finish: frees");
+    return rc;
+}
+
+static uint64_t counts_row_checksum(const double* src, int64_t g, uint64_t base);      // (defined with counts_scan below)
+// out = obs with its zeros replaced, in column order, by z[0 .. nz); false when obs does not hold exactly nz zeros (then it is not the
+// matrix the device counted)
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__AVX2__)
+// lane i of a 4-double vector takes element (number of set mask bits below i) of the packed values: the "expand" AVX2 does not have
+struct ExpandLut {
+    alignas(32) int32_t idx[16][8];
+    ExpandLut() { for (int m = 0; m < 16; ++m) { int r = 0; for (int i = 0; i < 4; ++i) { const int e = (m >> i) & 1 ? r++ : 0; idx[m][2 * i] = 2 * e; idx[m][2 * i + 1] = 2 * e + 1; } } }
+};
+static const ExpandLut g_expand;
+#endif
+static inline bool restore_row(const double* obs, const double* z, int64_t nz, double* w, int64_t g) {
+    int64_t k = 0, j = 0;
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__AVX2__)
+    // branch-free: the next four packed values are spread over the zero lanes by a table-driven permute and blended into the observed
+    // vector; the row is written once, with streaming stores where it is 32-byte aligned (no read-for-ownership of the 8 GB result:
+    // the host's copy rate, not PCIe, is what bounds this epilogue -- profiles/r05_dropin_host_side.txt)
+    const bool aligned = (((uintptr_t)w) & 31) == 0;
+    const __m256d zero = _mm256_setzero_pd();
+    for (; j + 4 <= g && k + 4 <= nz; j += 4) {
+        const __m256d x = _mm256_loadu_pd(obs + j);
+        const __m256d eq = _mm256_cmp_pd(x, zero, _CMP_EQ_OQ);
+        const int m = _mm256_movemask_pd(eq);
+        const __m256d zv = _mm256_loadu_pd(z + k);
+        const __m256d spread = _mm256_castsi256_pd(_mm256_permutevar8x32_epi32(_mm256_castpd_si256(zv), _mm256_load_si256((const __m256i*)g_expand.idx[m])));
+        const __m256d r = _mm256_blendv_pd(x, spread, eq);
+        if (aligned) _mm256_stream_pd(w + j, r); else _mm256_storeu_pd(w + j, r);
+        k += __builtin_popcount((unsigned)m);
+    }
+#endif
+    for (; j < g; ++j) {
+        const double x = obs[j];
+        w[j] = x;
+        if (x == 0.0) { if (k < nz) w[j] = z[k]; ++k; }
+    }
+    return k == nz;
+}
+
+// predict()'s post-processing for policy "restore" over the RESIDENT counts (dimn_set_matrix_counts), with the caller's own float64 frame
+// `observed` of those counts as the source of everything the policy leaves alone (multinet.py:296-299: observed counts win wherever they
+// are positive): the device finishes and sends only the zero entries, packed per row (dimn_kernels.h: k_impute_finish_zeros), the host
+// copies `observed` into `out` and drops them in.  Returns DIMN_ERR_STATE when `observed` is not the matrix the device holds (a row with a
+// different number of zeros): the caller then takes dimn_impute_finish.
+extern "C" int dimn_impute_finish_restore(dimn_handle h, const double* observed, int64_t n_rows, int64_t g, const int32_t* gene_off,
+                                          const int32_t* gene_slot, double ceiling, int32_t from_gathered, double* out, uint64_t* observed_checksum) {
+    if (!h || !observed || !gene_off || !gene_slot || !out || n_rows < 0 || g < 1) return fail(DIMN_ERR_ARG, "dimn_impute_finish_restore: bad argument");
+    if (observed_checksum) *observed_checksum = 0;
+    if (!h->counts || h->counts->n != n_rows || h->counts->g != g)
+        return fail(DIMN_ERR_STATE, "dimn_impute_finish_restore: needs the count matrix of dimn_set_matrix_counts over the same %lld x %lld cells", (long long)n_rows, (long long)g);
+    const int64_t S = gene_off[g];
+    const float* pred = from_gathered ? h->d_full : h->d_out;
+    if (!pred || h->out_rows != n_rows) return fail(DIMN_ERR_STATE, "dimn_impute_finish_restore: run dimn_predict_device (and the gather) over the same %lld rows first", (long long)n_rows);
+    if (!from_gathered && S != (int64_t)h->K * h->O) return fail(DIMN_ERR_ARG, "dimn_impute_finish_restore: %lld slots listed, the prediction has %lld", (long long)S, (long long)h->K * h->O);
+    if (from_gathered && (S != h->full_width || n_rows != h->full_rows))
+        return fail(DIMN_ERR_ARG, "dimn_impute_finish_restore: %lld slots over %lld rows listed, the gathered matrix is %lld x %lld", (long long)S, (long long)n_rows,
+                    (long long)h->full_rows, (long long)h->full_width);
+    for (int64_t j = 0; j < g; ++j) if (gene_off[j] > gene_off[j + 1]) return fail(DIMN_ERR_ARG, "dimn_impute_finish_restore: gene_off not monotone");
+    for (int64_t s = 0; s < S; ++s) if (gene_slot[s] < 0 || gene_slot[s] >= S) return fail(DIMN_ERR_ARG, "dimn_impute_finish_restore: slot out of range");
+    CHK(use_device(h));
+    const bool chunked = !from_gathered && !h->pred_ev_rows.empty() && h->pred_ev_rows.back() == n_rows;
+    if (!chunked) HIPCHK(hipStreamSynchronize(h->stream));
+    if (n_rows == 0) return DIMN_OK;
+    const int64_t blk = std::max<int64_t>(1, std::min<int64_t>(n_rows, (int64_t)(128u << 20) / (g * 8)));   // rows per block: at most ~128 MB of results
+    Trace tr;
+    int32_t *dOff = nullptr, *dSlot = nullptr, *dZeros = nullptr;
+    int64_t* dBase = nullptr;
+    double *dRes[2] = {nullptr, nullptr}, *pOut[2] = {nullptr, nullptr};
+    hipStream_t st[2] = {nullptr, nullptr};
+    hipEvent_t evOut[2] = {nullptr, nullptr};
+    int rc = DIMN_OK;
+    PinLease pins;
+    {
+        const char* why = "";
+        if (!pins.take(4, std::max<size_t>((size_t)(128u << 20), (size_t)blk * g * 8), &why)) return fail(DIMN_ERR_HIP, "dimn_impute_finish_restore: pinning the bounce buffers failed: %s", why);
+    }
+#define FIN_TRY(expr) do { hipError_t e_ = (expr); if (rc == DIMN_OK && e_ != hipSuccess) rc = fail(DIMN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+    FIN_TRY(dev_malloc_bytes((void**)&dOff, (size_t)(g + 1) * 4));
+    FIN_TRY(dev_malloc_bytes((void**)&dSlot, (size_t)std::max<int64_t>(S, 1) * 4));
+    FIN_TRY(dev_malloc_bytes((void**)&dZeros, (size_t)n_rows * 4));
+    FIN_TRY(dev_malloc_bytes((void**)&dBase, (size_t)(n_rows + 1) * 8));
+    const size_t res_bytes = (size_t)blk * g * 8;
+    const bool shared_res = !pins.own && (g_fin_dev < 0 || g_fin_dev == h->cfg.device_id);
+    if (shared_res && g_fin_cap < res_bytes) {
+        for (auto& p : g_fin_res) { if (p) (void)hipFree(p); p = nullptr; }
+        g_fin_cap = 0;
+        const size_t want = std::max<size_t>(res_bytes, (size_t)128u << 20);
+        if (hipMalloc(&g_fin_res[0], want) == hipSuccess && hipMalloc(&g_fin_res[1], want) == hipSuccess) { g_fin_cap = want; g_fin_dev = h->cfg.device_id; }
+        else { (void)hipGetLastError(); for (auto& p : g_fin_res) { if (p) (void)hipFree(p); p = nullptr; } }
+    }
+    const bool use_shared = shared_res && g_fin_cap >= res_bytes;
+    for (int b = 0; b < 2; ++b) {
+        if (use_shared) dRes[b] = (double*)g_fin_res[b];
+        else FIN_TRY(dev_malloc_bytes((void**)&dRes[b], res_bytes));
+        pOut[b] = (double*)pins.buf[2 + b];
+        if (use_shared) {
+            if (!g_fin_st[b]) FIN_TRY(hipStreamCreateWithFlags(&g_fin_st[b], hipStreamNonBlocking));
+            if (!g_fin_ev[b]) FIN_TRY(hipEventCreateWithFlags(&g_fin_ev[b], hipEventDisableTiming));
+            st[b] = g_fin_st[b]; evOut[b] = g_fin_ev[b];
+        } else {
+            FIN_TRY(hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking));
+            FIN_TRY(hipEventCreateWithFlags(&evOut[b], hipEventDisableTiming));
+        }
+    }
+    // how many zeros every row holds (one pass over the resident counts, beside the forward), their running sum = where a row's values go
+    std::vector<int32_t> zeros((size_t)n_rows);
+    std::vector<int64_t> base((size_t)n_rows + 1, 0);
+    if (rc == DIMN_OK) {
+        FIN_TRY(hipMemcpyAsync(dOff, gene_off, (size_t)(g + 1) * 4, hipMemcpyHostToDevice, st[0]));
+        if (S > 0) FIN_TRY(hipMemcpyAsync(dSlot, gene_slot, (size_t)S * 4, hipMemcpyHostToDevice, st[0]));
+        hipLaunchKernelGGL(k_row_zeros, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st[0], (const float*)h->counts->d, n_rows, g, dZeros);
+        FIN_TRY(hipGetLastError());
+        FIN_TRY(hipMemcpyAsync(zeros.data(), dZeros, (size_t)n_rows * 4, hipMemcpyDeviceToHost, st[0]));
+        FIN_TRY(hipStreamSynchronize(st[0]));
+        for (int64_t i = 0; i < n_rows; ++i) base[(size_t)i + 1] = base[(size_t)i] + zeros[(size_t)i];
+        FIN_TRY(hipMemcpy(dBase, base.data(), (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice));      // (synchronous: st[1] may start at once)
+    }
+    tr.lap("finish (restore): allocations + zero counts");
+    const int lds_stage = (size_t)S * 4 <= 150 * 1024 ? 1 : 0;
+    const size_t lds = lds_stage ? (size_t)S * 4 : 0;
+    if (rc == DIMN_OK && lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_impute_finish_zeros, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int64_t nblk = (n_rows + blk - 1) / blk;
+    std::atomic<int> mismatch{0};
+    std::atomic<uint64_t> checksum{0};
+    const bool want_sum = observed_checksum != nullptr;
+    for (int64_t bi = 0; bi < nblk + 2 && rc == DIMN_OK; ++bi) {
+        const int b = (int)(bi & 1);
+        std::thread retire;
+        if (bi >= 2) {                                   // retire block bi-2: observed -> out with the block's zeros filled in, on the host pool
+            const int64_t r0 = (bi - 2) * blk, nr = std::min(blk, n_rows - r0);
+            FIN_TRY(hipEventSynchronize(evOut[b]));
+            if (rc == DIMN_OK) retire = std::thread([=, &base, &mismatch, &checksum] {
+                const unsigned hw = std::thread::hardware_concurrency();
+                // (16, 32 and 64 threads measured the same on the 2 x 64-core hosts: tools/finish_ab.py)
+                const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw ? hw / 2 : 8, 32), nr * g / (1 << 20)));
+                const double* z0 = pOut[b];
+                const int64_t b0 = base[(size_t)r0];
+                host_pool().run(nt, [=, &base, &mismatch, &checksum](int t) {
+                    bool good = true;
+                    uint64_t sum = 0;
+                    for (int64_t i = r0 + nr * t / nt; i < r0 + nr * (t + 1) / nt; ++i) {
+                        // the row is read twice, the second time from the core's cache: its checksum (the one dimn_counts_create took of the frame
+                        // it uploaded -- equal sums: `observed` IS that frame, bit for bit), then the merge
+                        if (want_sum) sum += counts_row_checksum(observed + i * g, g, (uint64_t)i * (uint64_t)g);
+                        good &= restore_row(observed + i * g, z0 + (base[(size_t)i] - b0), base[(size_t)i + 1] - base[(size_t)i], out + i * g, g);
+                    }
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__AVX2__)
+                    _mm_sfence();                            // (the streaming stores of restore_row are visible before the block is reported done)
+#endif
+                    if (!good) mismatch.store(1);
+                    if (want_sum) checksum.fetch_add(sum);
+                });
+            });
+        }
+        struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join_retire{retire};
+        if (bi < nblk && rc == DIMN_OK) {
+            const int64_t r0 = bi * blk, nr = std::min(blk, n_rows - r0);
+            const int64_t nz = base[(size_t)(r0 + nr)] - base[(size_t)r0];
+            if (retire.joinable()) retire.join();        // pOut[b] is free again before this block's D2H is queued
+            if (chunked) FIN_TRY(hipStreamWaitEvent(st[b], pred_event_for(h, r0 + nr), 0));
+            hipLaunchKernelGGL(k_impute_finish_zeros, dim3((unsigned)std::min<int64_t>(nr, 4096)), dim3(512), lds, st[b], pred, S, r0,
+                               (const float*)(h->counts->d + r0 * g), nr, g, dOff, dSlot, (const int64_t*)(dBase + r0), ceiling, lds_stage, dRes[b]);
+            FIN_TRY(hipGetLastError());
+            if (nz > 0) FIN_TRY(hipMemcpyAsync(pOut[b], dRes[b], (size_t)nz * 8, hipMemcpyDeviceToHost, st[b]));
+            FIN_TRY(hipEventRecord(evOut[b], st[b]));
+        }
+    }
+#undef FIN_TRY
+    tr.lap("finish (restore): pipeline");
+    for (int b = 0; b < 2; ++b) {
+        if (st[b]) { (void)hipStreamSynchronize(st[b]); if (!use_shared) (void)hipStreamDestroy(st[b]); }
+        if (evOut[b] && !use_shared) (void)hipEventDestroy(evOut[b]);
+        if (dRes[b] && !use_shared) (void)dev_free_any(dRes[b]);
+    }
+    if (dOff) (void)dev_free_any(dOff);
+    if (dSlot) (void)dev_free_any(dSlot);
+    if (dZeros) (void)dev_free_any(dZeros);
+    if (dBase) (void)dev_free_any(dBase);
+    if (rc == DIMN_OK && chunked) { hipError_t e_ = hipStreamSynchronize(h->stream); if (e_ != hipSuccess) rc = fail(DIMN_ERR_HIP, "dimn_impute_finish_restore: %s", hipGetErrorString(e_)); }
+    if (rc == DIMN_OK && mismatch.load()) rc = fail(DIMN_ERR_STATE, "dimn_impute_finish_restore: `observed` is not the count matrix the device holds (a row has a different number of zeros)");
+    if (rc == DIMN_OK && observed_checksum) *observed_checksum = checksum.load();
+    tr.lap("finish (restore): frees");
     return rc;
 }
 
@@ -2482,38 +2708,105 @@ static inline uint64_t counts_mix(uint64_t x) {      // splitmix64 finaliser
     return x;
 }
 // one host pass over rows [r0, r1): optional float32 copy, maximum, position-dependent checksum of the float64 bit patterns,
-// and whether every value is a count (non-negative integer <= 2^22)
+// and whether every value is a count (non-negative integer <= 2^22).
+struct RowScan { double m; uint64_t h; bool fine; };
+// One row, plain C++: the definition of the pass (and the tail of the vector form below).
+static inline void counts_scan_scalar(const double* src, float* out, int64_t j0, int64_t g, uint64_t base, RowScan& rs) {
+    double m = rs.m; uint64_t h = rs.h; bool fine = rs.fine;
+    for (int64_t j = j0; j < g; ++j) {
+        const double x = src[j];
+        uint64_t bits;
+        memcpy(&bits, &x, 8);
+        h += counts_mix(bits + 0x9e3779b97f4a7c15ull * (base + (uint64_t)j + 1));
+        m = x > m ? x : m;
+        // a count: in [0, 2^22], integral, not -0.0.  The range test comes first, so the conversion below only ever sees values it is
+        // defined for (NaN / Inf / huge values take the 0.5 and fail); no libm call per element (trunc() was one on plain x86-64)
+        const bool in_range = x >= 0.0 && x <= 4194304.0;
+        const double xr = in_range ? x : 0.5;
+        fine &= in_range & ((double)(int32_t)xr == xr) & ((bits >> 63) == 0);
+        if (out) out[j] = (float)x;
+    }
+    rs.m = m; rs.h = h; rs.fine = fine;
+}
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__AVX2__)
+// The same row four elements at a time (round 5): the scalar loop is bound by its arithmetic -- two 64-bit multiplies of the splitmix round
+// per element, which AVX2 has no instruction for and the compiler therefore leaves scalar: 4.3 ns per element on the GPU boxes' hosts, 8 GB
+// in 0.13 s on 32-64 threads where PCIe needs 0.075 s for the 4 GB it produces.  Here the multiplies are three 32 x 32 -> 64 products each
+// (`vpmuludq`), sums are per lane (addition mod 2^64 commutes: the same checksum to the bit), the range / integrality tests are compares
+// and one truncating conversion, the sign test is an OR over all bit patterns.  tests/test_abi.py checks it against the scalar form.
+static inline __m256i counts_mul64(__m256i v, __m256i clo, __m256i chi) {
+    const __m256i lo = _mm256_mul_epu32(v, clo);
+    const __m256i cross = _mm256_add_epi64(_mm256_mul_epu32(_mm256_srli_epi64(v, 32), clo), _mm256_mul_epu32(v, chi));
+    return _mm256_add_epi64(lo, _mm256_slli_epi64(cross, 32));
+}
+template <bool OUT>
+static inline void counts_scan_row(const double* src, float* out, int64_t g, uint64_t base, RowScan& rs) {
+    const uint64_t GOLD = 0x9e3779b97f4a7c15ull, C1 = 0xbf58476d1ce4e5b9ull, C2 = 0x94d049bb133111ebull;
+    const __m256i c1lo = _mm256_set1_epi64x((long long)(C1 & 0xffffffffull)), c1hi = _mm256_set1_epi64x((long long)(C1 >> 32));
+    const __m256i c2lo = _mm256_set1_epi64x((long long)(C2 & 0xffffffffull)), c2hi = _mm256_set1_epi64x((long long)(C2 >> 32));
+    __m256i kv = _mm256_set_epi64x((long long)(GOLD * (base + 4)), (long long)(GOLD * (base + 3)), (long long)(GOLD * (base + 2)), (long long)(GOLD * (base + 1)));
+    const __m256i kstep = _mm256_set1_epi64x((long long)(GOLD * 4));
+    __m256i hv = _mm256_setzero_si256(), orv = _mm256_setzero_si256();
+    __m256d mv = _mm256_set1_pd(-INFINITY), goodv = _mm256_castsi256_pd(_mm256_set1_epi64x(-1));
+    const __m256d zero = _mm256_setzero_pd(), top = _mm256_set1_pd(4194304.0), half = _mm256_set1_pd(0.5);
+    const bool nt_store = OUT && (((uintptr_t)out) & 15) == 0;      // the float32 copy goes to a pinned bounce buffer the DMA engine reads next: streaming stores (no read-for-ownership)
+    int64_t j = 0;
+    for (; j + 4 <= g; j += 4) {
+        const __m256d x = _mm256_loadu_pd(src + j);
+        const __m256i bits = _mm256_castpd_si256(x);
+        __m256i v = _mm256_add_epi64(bits, kv);
+        kv = _mm256_add_epi64(kv, kstep);
+        v = _mm256_xor_si256(v, _mm256_srli_epi64(v, 30)); v = counts_mul64(v, c1lo, c1hi);
+        v = _mm256_xor_si256(v, _mm256_srli_epi64(v, 27)); v = counts_mul64(v, c2lo, c2hi);
+        v = _mm256_xor_si256(v, _mm256_srli_epi64(v, 31));
+        hv = _mm256_add_epi64(hv, v);
+        mv = _mm256_max_pd(x, mv);                                  // (x NaN: mv stays, like `x > m ? x : m`)
+        const __m256d in = _mm256_and_pd(_mm256_cmp_pd(x, zero, _CMP_GE_OQ), _mm256_cmp_pd(x, top, _CMP_LE_OQ));
+        const __m256d xr = _mm256_blendv_pd(half, x, in);
+        const __m256d back = _mm256_cvtepi32_pd(_mm256_cvttpd_epi32(xr));
+        goodv = _mm256_and_pd(goodv, _mm256_and_pd(in, _mm256_cmp_pd(back, xr, _CMP_EQ_OQ)));
+        orv = _mm256_or_si256(orv, bits);
+        if (OUT) { if (nt_store) _mm_stream_ps(out + j, _mm256_cvtpd_ps(x)); else _mm_storeu_ps(out + j, _mm256_cvtpd_ps(x)); }
+    }
+    alignas(32) uint64_t hl[4], ol[4];
+    alignas(32) double ml[4];
+    _mm256_store_si256((__m256i*)hl, hv); _mm256_store_si256((__m256i*)ol, orv); _mm256_store_pd(ml, mv);
+    rs.h += hl[0] + hl[1] + hl[2] + hl[3];
+    for (int i = 0; i < 4; ++i) rs.m = ml[i] > rs.m ? ml[i] : rs.m;
+    rs.fine &= _mm256_movemask_pd(goodv) == 0xf && (((ol[0] | ol[1] | ol[2] | ol[3]) >> 63) == 0);
+    counts_scan_scalar(src, OUT ? out : nullptr, j, g, base, rs);
+}
+#else
+template <bool OUT>
+static inline void counts_scan_row(const double* src, float* out, int64_t g, uint64_t base, RowScan& rs) { counts_scan_scalar(src, OUT ? out : nullptr, 0, g, base, rs); }
+#endif
+static uint64_t counts_row_checksum(const double* src, int64_t g, uint64_t base) {
+    RowScan rs{-INFINITY, 0, true};
+    counts_scan_row<false>(src, nullptr, g, base, rs);
+    return rs.h;
+}
 static void counts_scan(const double* raw, int64_t g, int64_t r0, int64_t r1, float* dst, double* vmax, uint64_t* sum, int* ok) {
     const unsigned hw = std::thread::hardware_concurrency();
     const int64_t rows = r1 - r0;
-    // (the pass is bound by its arithmetic -- a splitmix round, a truncation test and a conversion per element -- not by memory: 8 GB in
-    //  0.18 s on 32 threads is 44 GB/s, a tenth of what the host's DRAM delivers; round 4 takes up to 64)
+    const bool scalar = getenv("DIMN_SCAN_SCALAR") && atoi(getenv("DIMN_SCAN_SCALAR")) != 0;      // tests: the plain C++ form of the same pass
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw ? hw / 2 : 8, 64), rows * g / (1 << 20)));
     std::vector<double> mx((size_t)nt, -INFINITY);
     std::vector<uint64_t> cs((size_t)nt, 0);
     std::vector<int> good((size_t)nt, 1);
     auto work = [&](int t) {
         const int64_t a = r0 + rows * t / nt, b = r0 + rows * (t + 1) / nt;
-        double m = -INFINITY; uint64_t h = 0; bool fine = true;
+        RowScan rs{-INFINITY, 0, true};
         for (int64_t i = a; i < b; ++i) {
             const double* src = raw + i * g;
-            float* out = dst ? dst + (i - r0) * g : nullptr;
             const uint64_t base = (uint64_t)i * (uint64_t)g;
-            for (int64_t j = 0; j < g; ++j) {
-                const double x = src[j];
-                uint64_t bits;
-                memcpy(&bits, &x, 8);
-                h += counts_mix(bits + 0x9e3779b97f4a7c15ull * (base + (uint64_t)j + 1));
-                m = x > m ? x : m;
-                // a count: in [0, 2^22], integral, not -0.0.  The range test comes first, so the conversion below only ever sees values it is
-                // defined for (NaN / Inf / huge values take the 0.5 and fail); no libm call per element (trunc() was one on plain x86-64)
-                const bool in_range = x >= 0.0 && x <= 4194304.0;
-                const double xr = in_range ? x : 0.5;
-                fine &= in_range & ((double)(int32_t)xr == xr) & ((bits >> 63) == 0);
-                if (out) out[j] = (float)x;
-            }
+            if (scalar) counts_scan_scalar(src, dst ? dst + (i - r0) * g : nullptr, 0, g, base, rs);
+            else if (dst) counts_scan_row<true>(src, dst + (i - r0) * g, g, base, rs);
+            else counts_scan_row<false>(src, nullptr, g, base, rs);
         }
-        mx[(size_t)t] = m; cs[(size_t)t] = h; good[(size_t)t] = fine ? 1 : 0;
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__AVX2__)
+        _mm_sfence();
+#endif
+        mx[(size_t)t] = rs.m; cs[(size_t)t] = rs.h; good[(size_t)t] = rs.fine ? 1 : 0;
     };
     host_pool().run(nt, work);
     for (int t = 0; t < nt; ++t) { *vmax = mx[(size_t)t] > *vmax ? mx[(size_t)t] : *vmax; *sum += cs[(size_t)t]; *ok &= good[(size_t)t]; }

@@ -1926,6 +1926,74 @@ __global__ __launch_bounds__(512) void k_impute_finish(const float* __restrict__
 }
 
 
+// ---------------------------------------------------------------------------------------
+// predict()'s post-processing, policy "restore", counts resident on the device (round 5): only the entries the policy CHANGES cross PCIe.
+// `restore` returns the observed count wherever it is positive (multinet.py:296-299) and the caller still holds those counts in its own
+// float64 frame, so the device sends, per cell, just the finished values of the ZERO entries, packed in column order; the host copies its
+// frame and drops them into the zeros (dimn_impute_finish_restore).  For the 35 % zeros of the bench matrix that is 2.8 GB instead of 8.
+//   k_row_zeros:  zeros[i] = number of zero counts in row i            (one wave per row)
+//   k_impute_finish_zeros: out[base[i] - base[row0] + p] = finished value of the p-th zero of row i (the arithmetic of k_impute_finish)
+// A wave owns a contiguous eighth of the row's columns; its first output position is the number of zeros in the eighths before it, so
+// the order inside a row is column order and no barrier sits in the packing loop.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_row_zeros(const float* __restrict__ counts, int64_t n_rows, int64_t g, int32_t* __restrict__ zeros) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_rows) return;
+    const float* rr = counts + i * g;
+    int z = 0;
+    for (int64_t j = lane; j < g; j += 64) z += rr[j] == 0.0f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
+    if (lane == 0) zeros[i] = z;
+}
+
+__global__ __launch_bounds__(512) void k_impute_finish_zeros(const float* __restrict__ pred, int64_t S, int64_t pred_row0,
+                                                             const float* __restrict__ raw, int64_t n_rows, int64_t g,
+                                                             const int32_t* __restrict__ goff, const int32_t* __restrict__ gslot,
+                                                             const int64_t* __restrict__ base, double ceiling, int lds_stage,
+                                                             double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float prow[];
+    __shared__ int wz[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c0 = g * wave / 8, c1 = g * (wave + 1) / 8;           // this wave's columns
+    for (int64_t i = blockIdx.x; i < n_rows; i += gridDim.x) {
+        const float* pr = pred + (pred_row0 + i) * S;
+        const float* rr = raw + i * g;
+        __syncthreads();
+        if (lds_stage) for (int64_t c = threadIdx.x; c < S; c += 512) prow[c] = pr[c];
+        int z = 0;
+        for (int64_t j = c0 + lane; j < c1; j += 64) z += rr[j] == 0.0f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
+        if (lane == 0) wz[wave] = z;
+        __syncthreads();
+        int64_t pos = base[i] - base[0];
+        for (int w = 0; w < wave; ++w) pos += wz[w];
+        const float* src = lds_stage ? prow : pr;
+        double* orow = out + pos;
+        for (int64_t jb = c0; jb < c1; jb += 64) {
+            const int64_t j = jb + lane;
+            const bool zero = j < c1 && rr[j] == 0.0f;
+            const unsigned long long m = __ballot(zero);
+            if (zero) {
+                const int s0 = goff[j], s1 = goff[j + 1];
+                double v = 0.0;                                           // log1p(0): a gene no sub-net predicts
+                if (s1 > s0) {
+                    float acc = src[gslot[s0]];
+                    for (int s = s0 + 1; s < s1; ++s) acc += src[gslot[s]];
+                    acc /= (float)(s1 - s0);
+                    v = (double)acc;
+                }
+                if (v > ceiling || v != v) v = 0.0;
+                orow[__popcll(m & ((1ull << lane) - 1ull))] = expm1(v);
+            }
+            orow += __popcll(m);
+        }
+    }
+}
+
+
 // Held-out metrics of fit() (reference deepimpute/multinet.py:251-262): over the validation cells and every target slot
 // with a positive observed value, the sums that give Pearson r and the MSE between truth (log1p counts) and prediction.
 // pred [n_rows][K*O] (dimn_predict_device over the validation rows), Y the gathered targets.  sums[7] (double,

@@ -8,6 +8,8 @@ missing -- there is no CPU fallback in the product.
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import _cabi
@@ -287,10 +289,12 @@ class HipEngine(Engine):
         self._check(self._f["val_metrics"](self._h, p_f64(out)))
         return out
 
-    def impute_finish(self, raw, gene_off, gene_slot, policy, ceiling, from_gathered=False):
+    def impute_finish(self, raw, gene_off, gene_slot, policy, ceiling, from_gathered=False, observed=None):
         """predict()'s post-processing on the device over the last predict_device() result (include/dimn.h);
         raw [cells, genes] float64 -> the finished [cells, genes] float64 matrix.  raw = None: the observed counts are the
-        resident matrix of set_matrix_counts()."""
+        resident matrix of set_matrix_counts(); with policy "restore" and `observed` (the caller's C-ordered float64 frame of
+        those counts) only the zero entries come back over PCIe (dimn_impute_finish_restore) -- a frame that turns out not to be
+        the resident matrix falls through to the ordinary call."""
         if raw is None:
             shape = (self.n_cells, self.n_genes)
         else:
@@ -298,6 +302,17 @@ class HipEngine(Engine):
             shape = raw.shape
         gene_off, gene_slot = i32(gene_off), i32(gene_slot)
         out = np.empty(shape, np.float64)
+        self.last_observed_checksum = None           # set by the restore form: the checksum of `observed` as it was read
+        if (raw is None and policy == "restore" and os.environ.get("DIMN_FINISH_RESTORE", "1") != "0" and isinstance(observed, np.ndarray) and observed.dtype == np.float64
+                and observed.flags.c_contiguous and observed.shape == shape):
+            cs = C.c_uint64(0)
+            rc = self._f["impute_finish_restore"](self._h, p_f64(observed), shape[0], shape[1], p_i32(gene_off), p_i32(gene_slot),
+                                                  float(ceiling), int(bool(from_gathered)), p_f64(out), C.byref(cs))
+            if rc == 0:
+                self.last_observed_checksum = int(cs.value)
+                return out
+            if rc != -3:                          # DIMN_ERR_STATE: not the resident matrix -> the dense path below (the caller's checksum says the same)
+                self._check(rc)
         code = {None: 0, "restore": 1, "max": 2}.get(policy, 0)
         self._check(self._f["impute_finish"](self._h, p_f64(raw), shape[0], shape[1], p_i32(gene_off), p_i32(gene_slot),
                                              code, float(ceiling), int(bool(from_gathered)), p_f64(out)))

@@ -202,6 +202,35 @@ class _Stages(dict):
         return cm()
 
 
+_pending_saves = {}            # directory (real path) -> (thread, box): weight files a fit() of this process is still writing
+
+
+def _start_save(directory, work):
+    import threading
+    key = os.path.realpath(directory)
+    box = {}
+
+    def run():
+        try:
+            work()
+        except BaseException as exc:                     # re-raised where the files are needed
+            box["error"] = exc
+    thread = threading.Thread(target=run, name="dimn-save")      # not a daemon: the interpreter waits for the files at exit
+    _pending_saves[key] = (thread, box)
+    thread.start()
+
+
+def _join_saves(directory=None):
+    """Wait until the weight files of `directory` (None: of every directory) are on disk; a failed write raises here."""
+    keys = list(_pending_saves) if directory is None else [os.path.realpath(directory)]
+    for key in keys:
+        entry = _pending_saves.pop(key, None)
+        if entry is not None:
+            entry[0].join()
+            if "error" in entry[1]:
+                raise entry[1]["error"]
+
+
 def _shard_rank(path):
     """r of .../model.rank<r>.npz, None for anything else."""
     m = re.fullmatch(r"model\.rank(\d+)\.npz", os.path.basename(path))
@@ -340,6 +369,7 @@ class MultiNet:
         comm = self._comm
         rank, world = (comm.rank, comm.world) if comm is not None else (0, 1)
         self._sharded_outputdir(comm)
+        _join_saves(self.outputdir)                      # (an earlier fit's files still being written into the same directory)
         os.makedirs(self.outputdir, exist_ok=True)
         fmt = self._model_format()
         layers = _parse_architecture(self.NN_parameters['architecture'])
@@ -363,6 +393,22 @@ class MultiNet:
             arrays = fetched[k]
             for i, arr in enumerate(arrays):
                 blobs["%s%d_%d" % ("Wb"[i % 2], i // 2 + 1, self._first_subnet + k)] = arr
+        if world == 1 and getattr(self, "_defer_save", False):
+            # fit() (round 5): the weights are on the host; writing them -- 119 MB of HDF5 at the 50k x 20k job, 0.03-0.05 s -- needs neither
+            # the GPU nor the caller, so it runs on a helper thread while fit() computes its held-out metrics and returns.  Whoever
+            # READS the directory in this process waits for it first (load(), a second save(), close(), interpreter exit): _join_saves.
+            _start_save(self.outputdir, lambda: self._write_weight_files(blobs, fmt, layers, dims, rank, world, comm, laps, t_write))
+        else:
+            self._write_weight_files(blobs, fmt, layers, dims, rank, world, comm, laps, t_write)
+        written = {"h5": "model.json + model.h5 (Keras save_weights layout)", "npz": "model.json + model.npz (no HDF5 library found: set DIMN_LIBHDF5, "
+                   "or DIMN_MODEL_FORMAT=h5 to insist)" if not os.environ.get("DIMN_MODEL_FORMAT") else "model.json + model.npz",
+                   "both": "model.json + model.h5 + model.npz"}[fmt]
+        print("Saved model to disk in {}".format(self.outputdir) + " [%s%s]" % (written, "; shards model.rank0..%d.npz" % (world - 1) if world > 1 else ""))
+
+    def _write_weight_files(self, blobs, fmt, layers, dims, rank, world, comm, laps, t_write):
+        """The file-system half of save(): stale files out, model.npz / model.h5 (and the shards of a sharded job) in."""
+        import time
+        from . import keras_io
         # never leave weights of an older fit beside the new ones: the other format's file, and the shards of ranks this job
         # does not have (a refit into the same directory with fewer ranks would otherwise leave model.rank<r>.npz, r >= world,
         # whose sub-net indices overlap the fresh shards)
@@ -411,10 +457,6 @@ class MultiNet:
             comm.barrier()                               # every file is on disk when any rank returns
         if isinstance(laps, dict):
             laps["fit.save.write_files"] = laps.get("fit.save.write_files", 0.0) + time.perf_counter() - t_write
-        written = {"h5": "model.json + model.h5 (Keras save_weights layout)", "npz": "model.json + model.npz (no HDF5 library found: set DIMN_LIBHDF5, "
-                   "or DIMN_MODEL_FORMAT=h5 to insist)" if not os.environ.get("DIMN_MODEL_FORMAT") else "model.json + model.npz",
-                   "both": "model.json + model.h5 + model.npz"}[fmt]
-        print("Saved model to disk in {}".format(self.outputdir) + " [%s%s]" % (written, "; shards model.rank0..%d.npz" % (world - 1) if world > 1 else ""))
 
     def load(self):
         """The engine holding the fitted weights: the live one if this object trained it, else rebuilt from outputdir
@@ -424,6 +466,7 @@ class MultiNet:
             from . import keras_io
             if isinstance(self._comm_spec, str) and self.outputdir == _SCRATCH and int(os.environ.get("WORLD_SIZE", "1")) > 1:
                 self.outputdir = self._job_directory(create=False)      # the directory a sharded fit of this job wrote to (_sharded_outputdir)
+            _join_saves(self.outputdir)                  # a fit() of this process may still be writing these files
             with open(os.path.join(self.outputdir, "model.json")) as fh:
                 doc = json.load(fh)
             dense_names = None
@@ -603,6 +646,7 @@ class MultiNet:
             engine.init_weights(0 if self.seed is None else self.seed)
 
         print("Fitting with {} cells".format(norm_data.shape[0]))
+        plan_thread = self._start_predict_plan(raw.columns)      # (np.unique over the K * O target labels: host work that fits under the training)
         with tm.stage("fit.train"):
             if comm.world == 1:
                 epochs, loss_curve, val_curve = engine.fit(self.NN_parameters["max_epochs"], self.NN_parameters["patience"])
@@ -616,16 +660,45 @@ class MultiNet:
                 print("Epoch {}/{} - loss: {:.4f} - val_loss: {:.4f}".format(i, self.NN_parameters["max_epochs"], a, b))
         self.trained_epochs = int(epochs)
         print("Stopped fitting after {} epochs".format(self.trained_epochs))
+        plan_thread.join()
 
         self._engine = engine
         self._counts = counts
         with tm.stage("fit.save"):
-            self.save(engine)
+            self._defer_save = True                      # the files are written behind fit()'s back (save() called directly writes them before it returns)
+            try:
+                self.save(engine)
+            finally:
+                self._defer_save = False
         with tm.stage("fit.held_out_metrics"):
             self.test_metrics = self._held_out_metrics(engine, norm_data, held_out, rows_val)
         with tm.stage("fit.free"):
             del norm_data, var, mean, gene_metric
         return self
+
+    def _predict_plan(self, columns):
+        """(genes, slot_gene, where) of predict(): a gene may occupy several target slots -- the unique genes (label-sorted, like the
+        reference's groupby(columns).mean(), multinet.py:282-284), the gene of every slot, and the genes' columns in the frame."""
+        slots = self.targets.flatten()
+        genes, slot_gene = np.unique(slots, return_inverse=True)
+        where = pd.Index(columns).get_indexer(genes)
+        return genes, slot_gene, where
+
+    def _start_predict_plan(self, columns):
+        """Compute predict()'s plan for a frame with fit()'s columns on a helper thread while the GPU trains; predict() takes it when its
+        frame has those columns and the targets are still the ones planned for."""
+        import threading
+        self._plan_cache = None
+        targets = np.array(self.targets, copy=True)
+
+        def work():
+            try:
+                self._plan_cache = (columns, targets, self._predict_plan(columns))
+            except Exception:
+                self._plan_cache = None                  # predict() computes it itself
+        thread = threading.Thread(target=work, name="dimn-predict-plan", daemon=True)
+        thread.start()
+        return thread
 
     def _counts_path_applies(self, raw):
         """The resident-counts path is for: one GPU (no sharded / streamed job), the product engine, a C-ordered float64 frame
@@ -723,6 +796,7 @@ class MultiNet:
         counts, and the library's process-wide cache of large device blocks (which otherwise waits for the next fit() of this process:
         deepimpute_amd.release_cached_memory; release_cache=False leaves it for a fit() that follows)."""
         self._release_engine()
+        _join_saves(self.outputdir)
         if not release_cache:
             return
         try:
@@ -832,7 +906,10 @@ class MultiNet:
                 # which runs on a helper thread beside the forward pass and the epilogue: a frame that turns out to differ costs a second,
                 # ordinary predict below -- the result of the speculative one is dropped
                 resident = held[0]
-                verdict = self._start_checksum(resident, values)
+                # (policy "restore" on the device epilogue reads every element of the frame anyway -- dimn_impute_finish_restore -- and
+                #  returns that checksum itself: no second pass over the 8 GB)
+                folded = policy == "restore" and hasattr(engine, "impute_finish") and os.environ.get("DIMN_FINISH_RESTORE", "1") != "0"
+                verdict = None if folded else self._start_checksum(resident, values)
             else:
                 wait = self._start_counts_upload(raw) if hasattr(engine, "set_matrix_counts") else (lambda: None)
                 fresh = wait()
@@ -854,9 +931,11 @@ class MultiNet:
         t_plan.__enter__()
         # a gene may occupy several target slots: average them; the averaged columns are label-sorted,
         # like the reference's groupby(columns).mean() (multinet.py:282-284)
-        slots = self.targets.flatten()
-        genes, slot_gene = np.unique(slots, return_inverse=True)
-        where = pd.Index(raw.columns).get_indexer(genes)
+        cached = getattr(self, "_plan_cache", None)
+        if cached is not None and (raw.columns is cached[0] or raw.columns.equals(cached[0])) and np.array_equal(np.asarray(self.targets), cached[1]):
+            genes, slot_gene, where = cached[2]
+        else:
+            genes, slot_gene, where = self._predict_plan(raw.columns)
         if policy == "restore":
             print("Filling zeros")
         elif policy == "max":
@@ -868,8 +947,12 @@ class MultiNet:
             ceiling = 2 * np.log1p(top)                               # overflow guard, multinet.py:292 (log1p is monotonic)
 
         with tm.stage("predict.forward+finish"):
+            engine.last_observed_checksum = None         # (set by the restore epilogue when it has read the whole frame)
             values = self._finish_on_device(engine, observed, where[slot_gene], policy, ceiling, resident=resident is not None)
-            if resident is not None and verdict is not None and not verdict():
+            same = True
+            if resident is not None and held is not None and resident is held[0]:
+                same = verdict() if verdict is not None else getattr(engine, "last_observed_checksum", None) == resident.checksum
+            if not same:
                 # the frame is not the one that was fitted: upload it and run the ordinary sequence
                 values = None
                 fresh = self._start_counts_upload(raw)()
@@ -915,7 +998,7 @@ class MultiNet:
             if comm.rank != 0:
                 return False
         if resident:                                     # the observed counts are the engine's resident matrix: nothing to upload
-            return engine.impute_finish(None, gene_off, order, policy, ceiling, from_gathered=sharded)
+            return engine.impute_finish(None, gene_off, order, policy, ceiling, from_gathered=sharded, observed=observed)
         return engine.impute_finish(_hostpar.as_float64(observed), gene_off, order, policy, ceiling, from_gathered=sharded)
 
     def _finish_on_host(self, block, observed, slot_gene, n_genes, where, policy, ceiling):

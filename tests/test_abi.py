@@ -90,3 +90,30 @@ def test_constructing_a_multinet_has_no_side_effects():
     assert after == before and net._engine is None
     assert not _lib._warm or all(d != net.device_id or True for d in _lib._warm)      # (nothing was scheduled by the constructor)
     net.close()                                                                       # closing an unused object is legal and quiet
+
+
+def test_vector_form_of_the_count_scan_equals_the_scalar_one(monkeypatch):
+    """dimn_counts_checksum is host code (no GPU): the AVX2 form of the pass (round 5) must give the checksum of the plain C++ loop it
+    replaces to the bit -- ragged row lengths (vector body + scalar tail), several threads, NaN / Inf / -0.0 / negative / huge / fractional
+    values at every lane position."""
+    fns = _lib.load()
+    rng = np.random.default_rng(5)
+
+    def checksum(a):
+        cs = C.c_uint64(0)
+        assert fns["counts_checksum"](_cabi.p_f64(a), a.shape[0], a.shape[1], C.byref(cs)) == 0
+        return cs.value
+    edge = [np.nan, -0.0, -1.0, 0.5, 4194304.0, 4194305.0, np.inf, -np.inf, 1e300, 3.0000000001, 2147483648.0, 5e-324]
+    for n, g in ((3, 5), (40, 1027), (700, 3001), (1200, 2048)):
+        a = rng.poisson(3.0, size=(n, g)).astype(np.float64)
+        frames = [a]
+        for i, v in enumerate(edge):
+            b = a.copy()
+            b[i % n, (7 * i + i % 4) % g] = v
+            frames.append(b)
+        monkeypatch.setenv("DIMN_SCAN_SCALAR", "1")
+        want = [checksum(f) for f in frames]
+        monkeypatch.setenv("DIMN_SCAN_SCALAR", "0")
+        got = [checksum(f) for f in frames]
+        assert got == want
+        assert len(set(want)) == len(want)                          # every edit changes the checksum

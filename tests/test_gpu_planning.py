@@ -130,3 +130,53 @@ def test_streamed_correlation_matches_resident(monkeypatch):
     np.testing.assert_allclose(streamed, resident, rtol=0, atol=1e-13)
     np.testing.assert_allclose(streamed, ref, rtol=0, atol=1e-12)
     assert streamed[17].max() == 0.0
+
+
+@pytest.mark.parametrize("n,g,O,K", [(300, 700, 64, 3), (9000, 1531, 32, 5), (8192 + 77, 640, 128, 2)])
+def test_restore_epilogue_sends_only_the_zeros_and_equals_the_dense_epilogue(n, g, O, K):
+    """dimn_impute_finish_restore (policy "restore" over resident counts: only the zero entries cross PCIe, the host merges them into
+    a copy of its own frame) against dimn_impute_finish(raw = NULL, policy = 1) on the same prediction: bit for bit -- ragged column
+    counts (a wave's eighth of a row is not a multiple of 64), more rows than workgroups, rows without zeros and all-zero rows, genes in
+    several slots and genes in none, the chunked forward (>= 8192 rows) -- and a frame that is NOT the resident matrix is refused (the
+    engine falls back to the dense epilogue)."""
+    from deepimpute_amd._counts import DeviceCounts
+    from deepimpute_amd.engine import HipEngine
+    rng = np.random.default_rng(n + g)
+    raw = rng.poisson(rng.gamma(0.6, 2.0, size=g), size=(n, g)).astype(np.float64)
+    raw[3] = 0.0                                              # an all-zero cell
+    raw[5] = np.maximum(raw[5], 1.0)                          # a cell without zeros
+    raw[:, :4] += rng.poisson(12, size=(n, 4))
+    D = [40 + 3 * k for k in range(K)]
+    eng = HipEngine(D, 32, O, seed=5)
+    counts = DeviceCounts.try_create(raw, 0)
+    assert counts is not None
+    pool = rng.permutation(g)
+    slots = np.concatenate([pool[: K * O - 7], pool[:7]])     # seven genes occupy two slots; the genes past K * O - 7 none
+    for k in range(K):
+        eng.set_indices(k, rng.choice(g, D[k], replace=False), slots[k * O:(k + 1) * O])
+    eng.set_matrix_counts(counts)
+    eng.gather(False)
+    eng.init_weights()
+    order = np.lexsort((np.arange(len(slots)), slots))
+    gene_off = np.zeros(g + 1, np.int64)
+    np.cumsum(np.bincount(slots, minlength=g), out=gene_off[1:])
+    ceiling = 2 * np.log1p(raw.max())
+    eng.predict_device()
+    dense = eng.impute_finish(None, gene_off, order, "restore", ceiling)
+    eng.predict_device()
+    packed = eng.impute_finish(None, gene_off, order, "restore", ceiling, observed=raw)
+    assert np.array_equal(dense, packed)
+    assert eng.last_observed_checksum == counts.checksum              # the merge read every element: it knows the frame is the uploaded one
+    seen = raw > 0
+    assert np.array_equal(packed[seen], raw[seen]) and (packed[~seen] >= 0).all() and (packed[3] > 0).any()
+    # the C entry point itself refuses a frame with other zeros ...
+    other = raw.copy()
+    other[7, 11] = 0.0 if raw[7, 11] > 0 else 4.0
+    from deepimpute_amd import _cabi
+    out = np.empty_like(raw)
+    rc = eng._f["impute_finish_restore"](eng._h, _cabi.p_f64(other), n, g, _cabi.p_i32(np.ascontiguousarray(gene_off, np.int32)),
+                                         _cabi.p_i32(np.ascontiguousarray(order, np.int32)), float(ceiling), 0, _cabi.p_f64(out), None)
+    assert rc == -3
+    # ... and the engine then answers from the resident counts, as the dense epilogue does
+    assert np.array_equal(eng.impute_finish(None, gene_off, order, "restore", ceiling, observed=other), dense)
+    eng.close(); counts.close()

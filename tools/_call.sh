@@ -1,6 +1,10 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-mkdir -p gpurun_out/c2
-timeout 1500 python -m pytest tests/test_gpu_multinet.py -m gpu -q -x -s -k "cfg2_full_size" 2>&1 | tail -40
-timeout 900 python bench.py --steps 1 --warmup 0 --no-dropin --cpu-budget 4 2> gpurun_out/c2/acc.err > gpurun_out/c2/acc.json; python -c "
+mkdir -p gpurun_out/c6
+( time timeout 1500 python -m pytest tests -m gpu -q -x ) > gpurun_out/c6/tests.log 2>&1; grep -E "passed|failed|error" gpurun_out/c6/tests.log | tail -5; grep -B30 "short test summary" gpurun_out/c6/tests.log | head -60
+for rep in 1 2; do
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-accuracy > gpurun_out/c6/bench_dropin_$rep.json 2> gpurun_out/c6/bench_dropin_$rep.err
+python - <<PY
 import json
-d=json.load(open('gpurun_out/c2/acc.json')); print(json.dumps(d['accuracy'], indent=1))"
+d=json.load(open("gpurun_out/c6/bench_dropin_$rep.json")); print(d["value"], json.dumps(d["config"]["dropin"]))
+PY
+done
