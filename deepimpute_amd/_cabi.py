@@ -106,12 +106,14 @@ GPU_ONLY = {
     "abs_corrcoef": [_i32, _pd, _i64, _i64, _pd],
     "val_metrics": [_H, _pd],
     "impute_finish": [_H, _pd, _i64, _i64, _pi, _pi, _i32, C.c_double, _i32, _pd],
-    "impute_finish_restore": [_H, _pd, _i64, _i64, _pi, _pi, C.c_double, _i32, _pd, C.POINTER(C.c_uint64)],
+    "impute_finish_restore": [_H, C.c_void_p, _i32, _i64, _i64, _pi, _pi, C.c_double, _i32, _pd, C.POINTER(C.c_uint64)],
     "csv_scan": [C.c_char_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "csv_read": [C.c_char_p, _i64, _i64, C.POINTER(_i64), C.c_char_p, _i64],
     "csv_write": [C.c_char_p, _pd, _i64, _i64, C.c_char_p, C.c_char_p, C.c_char_p],
     "counts_create": [_i32, _pd, _i64, _i64, _pd, C.POINTER(C.c_uint64), C.POINTER(_H)],
+    "counts_create_typed": [_i32, C.c_void_p, _i32, _i64, _i64, _pd, C.POINTER(C.c_uint64), C.POINTER(_H)],
     "counts_checksum": [_pd, _i64, _i64, C.POINTER(C.c_uint64)],
+    "counts_checksum_typed": [C.c_void_p, _i32, _i64, _i64, C.POINTER(C.c_uint64)],
     "counts_destroy": [_H],
     "counts_select_predictors": [_H, _pi, _i64, _pi, _i32, _i32, _pi, _i32, _pi],
     "counts_corr": [_H, _pi, _i64],
@@ -168,3 +170,14 @@ def p_i32(a):
 
 def p_u8(a):
     return None if a is None else a.ctypes.data_as(_pu8)
+
+
+# element types a host count matrix may have (include/dimn.h DIMN_DTYPE_*): float64, or int64 (what pd.read_csv makes of a count CSV)
+COUNT_DTYPES = {np.dtype(np.float64): 0, np.dtype(np.int64): 1}
+
+
+def count_dtype(a):
+    """DIMN_DTYPE_* of a C-ordered 2-D float64 / int64 array, else None."""
+    if isinstance(a, np.ndarray) and a.ndim == 2 and a.flags.c_contiguous and a.dtype in COUNT_DTYPES:
+        return COUNT_DTYPES[a.dtype]
+    return None

@@ -18,9 +18,10 @@ class DeviceCounts:
 
     @staticmethod
     def try_create(values, device_id=0):
-        """Upload `values` ([cells, genes] float64, C-ordered) or return None: library missing, no GPU, or values that are
+        """Upload `values` ([cells, genes] float64 or int64, C-ordered) or return None: library missing, no GPU, or values that are
         not counts (the library checks every element on the way)."""
-        if not isinstance(values, np.ndarray) or values.dtype != np.float64 or values.ndim != 2 or not values.flags.c_contiguous or values.size == 0:
+        dtype = _cabi.count_dtype(values)
+        if dtype is None or values.size == 0:
             return None
         try:
             from . import _lib
@@ -28,24 +29,23 @@ class DeviceCounts:
         except (ImportError, OSError):
             return None
         h, vmax, cs = C.c_void_p(), C.c_double(), C.c_uint64()
-        rc = fns["counts_create"](int(device_id), _cabi.p_f64(values), values.shape[0], values.shape[1], C.byref(vmax), C.byref(cs), C.byref(h))
+        rc = fns["counts_create_typed"](int(device_id), values.ctypes.data, dtype, values.shape[0], values.shape[1], C.byref(vmax), C.byref(cs), C.byref(h))
         if rc != 0:
             return None
         return DeviceCounts(h, values.shape[0], values.shape[1], vmax.value, cs.value, device_id)
 
     def shape_matches(self, values):
-        """The cheap half of matches(): a C-ordered float64 frame of the uploaded shape."""
-        return (self.handle is not None and isinstance(values, np.ndarray) and values.dtype == np.float64 and values.shape == (self.n, self.g)
-                and values.flags.c_contiguous)
+        """The cheap half of matches(): a C-ordered float64 / int64 frame of the uploaded shape."""
+        return self.handle is not None and _cabi.count_dtype(values) is not None and values.shape == (self.n, self.g)
 
     def matches(self, values):
         """True when `values` is, bit for bit, the matrix that was uploaded (one threaded host pass: a position-dependent
-        checksum of the float64 bit patterns)."""
-        if self.handle is None or not isinstance(values, np.ndarray) or values.dtype != np.float64 or values.shape != (self.n, self.g) or not values.flags.c_contiguous:
+        checksum of the float64 bit patterns -- of (double)v for an int64 frame: the same numbers match whatever type carries them)."""
+        if not self.shape_matches(values):
             return False
         from . import _lib
         cs = C.c_uint64()
-        if _lib.load()["counts_checksum"](_cabi.p_f64(values), self.n, self.g, C.byref(cs)) != 0:
+        if _lib.load()["counts_checksum_typed"](values.ctypes.data, _cabi.count_dtype(values), self.n, self.g, C.byref(cs)) != 0:
             return False
         return cs.value == self.checksum
 

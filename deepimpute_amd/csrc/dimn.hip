@@ -2023,7 +2023,11 @@ extern "C" int dimn_impute_finish(dimn_handle h, const double* raw, int64_t n_ro
     return rc;
 }
 
-static uint64_t counts_row_checksum(const double* src, int64_t g, uint64_t base);      // (defined with counts_scan below)
+template <typename ST> static uint64_t counts_row_checksum(const ST* src, int64_t g, uint64_t base);      // (defined with counts_scan below)
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__AVX2__)
+static inline bool counts_load4(const double* p, __m256d& x);
+static inline bool counts_load4(const int64_t* p, __m256d& x);
+#endif
 // out = obs with its zeros replaced, in column order, by z[0 .. nz); false when obs does not hold exactly nz zeros (then it is not the
 // matrix the device counted)
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(__AVX2__)
@@ -2034,7 +2038,8 @@ struct ExpandLut {
 };
 static const ExpandLut g_expand;
 #endif
-static inline bool restore_row(const double* obs, const double* z, int64_t nz, double* w, int64_t g) {
+template <typename ST>
+static inline bool restore_row(const ST* obs, const double* z, int64_t nz, double* w, int64_t g) {
     int64_t k = 0, j = 0;
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(__AVX2__)
     // branch-free: the next four packed values are spread over the zero lanes by a table-driven permute and blended into the observed
@@ -2043,7 +2048,11 @@ static inline bool restore_row(const double* obs, const double* z, int64_t nz, d
     const bool aligned = (((uintptr_t)w) & 31) == 0;
     const __m256d zero = _mm256_setzero_pd();
     for (; j + 4 <= g && k + 4 <= nz; j += 4) {
-        const __m256d x = _mm256_loadu_pd(obs + j);
+        __m256d x;
+        if (!counts_load4(obs + j, x)) {                 // (an int64 quad outside the count range: plain C++ for these four)
+            for (int64_t q = j; q < j + 4; ++q) { const double xq = (double)obs[q]; w[q] = xq; if (xq == 0.0) { if (k < nz) w[q] = z[k]; ++k; } }
+            continue;
+        }
         const __m256d eq = _mm256_cmp_pd(x, zero, _CMP_EQ_OQ);
         const int m = _mm256_movemask_pd(eq);
         const __m256d zv = _mm256_loadu_pd(z + k);
@@ -2054,7 +2063,7 @@ static inline bool restore_row(const double* obs, const double* z, int64_t nz, d
     }
 #endif
     for (; j < g; ++j) {
-        const double x = obs[j];
+        const double x = (double)obs[j];
         w[j] = x;
         if (x == 0.0) { if (k < nz) w[j] = z[k]; ++k; }
     }
@@ -2066,8 +2075,9 @@ static inline bool restore_row(const double* obs, const double* z, int64_t nz, d
 // are positive): the device finishes and sends only the zero entries, packed per row (dimn_kernels.h: k_impute_finish_zeros), the host
 // copies `observed` into `out` and drops them in.  Returns DIMN_ERR_STATE when `observed` is not the matrix the device holds (a row with a
 // different number of zeros): the caller then takes dimn_impute_finish.
-extern "C" int dimn_impute_finish_restore(dimn_handle h, const double* observed, int64_t n_rows, int64_t g, const int32_t* gene_off,
-                                          const int32_t* gene_slot, double ceiling, int32_t from_gathered, double* out, uint64_t* observed_checksum) {
+template <typename ST>
+static int impute_finish_restore_impl(dimn_handle h, const ST* observed, int64_t n_rows, int64_t g, const int32_t* gene_off,
+                                      const int32_t* gene_slot, double ceiling, int32_t from_gathered, double* out, uint64_t* observed_checksum) {
     if (!h || !observed || !gene_off || !gene_slot || !out || n_rows < 0 || g < 1) return fail(DIMN_ERR_ARG, "dimn_impute_finish_restore: bad argument");
     if (observed_checksum) *observed_checksum = 0;
     if (!h->counts || h->counts->n != n_rows || h->counts->g != g)
@@ -2205,6 +2215,13 @@ extern "C" int dimn_impute_finish_restore(dimn_handle h, const double* observed,
     if (rc == DIMN_OK && observed_checksum) *observed_checksum = checksum.load();
     tr.lap("finish (restore): frees");
     return rc;
+}
+
+extern "C" int dimn_impute_finish_restore(dimn_handle h, const void* observed, int32_t observed_dtype, int64_t n_rows, int64_t g, const int32_t* gene_off,
+                                          const int32_t* gene_slot, double ceiling, int32_t from_gathered, double* out, uint64_t* observed_checksum) {
+    if (observed_dtype == DIMN_DTYPE_F64) return impute_finish_restore_impl(h, (const double*)observed, n_rows, g, gene_off, gene_slot, ceiling, from_gathered, out, observed_checksum);
+    if (observed_dtype == DIMN_DTYPE_I64) return impute_finish_restore_impl(h, (const int64_t*)observed, n_rows, g, gene_off, gene_slot, ceiling, from_gathered, out, observed_checksum);
+    return fail(DIMN_ERR_ARG, "dimn_impute_finish_restore: observed_dtype must be DIMN_DTYPE_F64 or DIMN_DTYPE_I64");
 }
 
 extern "C" int dimn_synchronize(dimn_handle h) {
@@ -2710,11 +2727,13 @@ static inline uint64_t counts_mix(uint64_t x) {      // splitmix64 finaliser
 // one host pass over rows [r0, r1): optional float32 copy, maximum, position-dependent checksum of the float64 bit patterns,
 // and whether every value is a count (non-negative integer <= 2^22).
 struct RowScan { double m; uint64_t h; bool fine; };
-// One row, plain C++: the definition of the pass (and the tail of the vector form below).
-static inline void counts_scan_scalar(const double* src, float* out, int64_t j0, int64_t g, uint64_t base, RowScan& rs) {
+// One row, plain C++: the definition of the pass (and the tail of the vector form below).  ST = double, or int64_t -- what pd.read_csv
+// makes of a count matrix: every quantity is that of the float64 frame holding the same numbers ((double)v: its bit pattern is hashed).
+template <typename ST>
+static inline void counts_scan_scalar(const ST* src, float* out, int64_t j0, int64_t j1, uint64_t base, RowScan& rs) {
     double m = rs.m; uint64_t h = rs.h; bool fine = rs.fine;
-    for (int64_t j = j0; j < g; ++j) {
-        const double x = src[j];
+    for (int64_t j = j0; j < j1; ++j) {
+        const double x = (double)src[j];
         uint64_t bits;
         memcpy(&bits, &x, 8);
         h += counts_mix(bits + 0x9e3779b97f4a7c15ull * (base + (uint64_t)j + 1));
@@ -2729,18 +2748,28 @@ static inline void counts_scan_scalar(const double* src, float* out, int64_t j0,
     rs.m = m; rs.h = h; rs.fine = fine;
 }
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(__AVX2__)
+// four source elements as doubles; false when the quad cannot take the vector path (int64 values outside [0, 2^22]: AVX2 has no
+// int64 -> double conversion, in-range values convert exactly through their low 32 bits; the caller handles such a quad in plain C++)
+static inline bool counts_load4(const double* p, __m256d& x) { x = _mm256_loadu_pd(p); return true; }
+static inline bool counts_load4(const int64_t* p, __m256d& x) {
+    const __m256i v = _mm256_loadu_si256((const __m256i*)p);
+    const __m256i bad = _mm256_or_si256(_mm256_cmpgt_epi64(v, _mm256_set1_epi64x(4194304)), _mm256_cmpgt_epi64(_mm256_setzero_si256(), v));
+    if (!_mm256_testz_si256(bad, bad)) return false;
+    x = _mm256_cvtepi32_pd(_mm256_castsi256_si128(_mm256_permutevar8x32_epi32(v, _mm256_setr_epi32(0, 2, 4, 6, 0, 0, 0, 0))));
+    return true;
+}
 // The same row four elements at a time (round 5): the scalar loop is bound by its arithmetic -- two 64-bit multiplies of the splitmix round
-// per element, which AVX2 has no instruction for and the compiler therefore leaves scalar: 4.3 ns per element on the GPU boxes' hosts, 8 GB
-// in 0.13 s on 32-64 threads where PCIe needs 0.075 s for the 4 GB it produces.  Here the multiplies are three 32 x 32 -> 64 products each
-// (`vpmuludq`), sums are per lane (addition mod 2^64 commutes: the same checksum to the bit), the range / integrality tests are compares
-// and one truncating conversion, the sign test is an OR over all bit patterns.  tests/test_abi.py checks it against the scalar form.
+// per element, which AVX2 has no instruction for and the compiler therefore leaves scalar: 1.45 ns per element and core on the GPU boxes'
+// hosts against 0.66 here (profiles/r05_dropin_host_side.txt).  The multiplies are three 32 x 32 -> 64 products each (`vpmuludq`), sums are
+// per lane (addition mod 2^64 commutes: the same checksum to the bit), the range / integrality tests are compares and one truncating
+// conversion, the sign test is an OR over all bit patterns.  tests/test_abi.py checks it against the scalar form.
 static inline __m256i counts_mul64(__m256i v, __m256i clo, __m256i chi) {
     const __m256i lo = _mm256_mul_epu32(v, clo);
     const __m256i cross = _mm256_add_epi64(_mm256_mul_epu32(_mm256_srli_epi64(v, 32), clo), _mm256_mul_epu32(v, chi));
     return _mm256_add_epi64(lo, _mm256_slli_epi64(cross, 32));
 }
-template <bool OUT>
-static inline void counts_scan_row(const double* src, float* out, int64_t g, uint64_t base, RowScan& rs) {
+template <bool OUT, typename ST>
+static inline void counts_scan_row(const ST* src, float* out, int64_t g, uint64_t base, RowScan& rs) {
     const uint64_t GOLD = 0x9e3779b97f4a7c15ull, C1 = 0xbf58476d1ce4e5b9ull, C2 = 0x94d049bb133111ebull;
     const __m256i c1lo = _mm256_set1_epi64x((long long)(C1 & 0xffffffffull)), c1hi = _mm256_set1_epi64x((long long)(C1 >> 32));
     const __m256i c2lo = _mm256_set1_epi64x((long long)(C2 & 0xffffffffull)), c2hi = _mm256_set1_epi64x((long long)(C2 >> 32));
@@ -2752,10 +2781,13 @@ static inline void counts_scan_row(const double* src, float* out, int64_t g, uin
     const bool nt_store = OUT && (((uintptr_t)out) & 15) == 0;      // the float32 copy goes to a pinned bounce buffer the DMA engine reads next: streaming stores (no read-for-ownership)
     int64_t j = 0;
     for (; j + 4 <= g; j += 4) {
-        const __m256d x = _mm256_loadu_pd(src + j);
-        const __m256i bits = _mm256_castpd_si256(x);
-        __m256i v = _mm256_add_epi64(bits, kv);
+        __m256d x;
+        const bool quad = counts_load4(src + j, x);
+        const __m256i key = kv;
         kv = _mm256_add_epi64(kv, kstep);
+        if (!quad) { counts_scan_scalar(src, OUT ? out : nullptr, j, j + 4, base, rs); continue; }
+        const __m256i bits = _mm256_castpd_si256(x);
+        __m256i v = _mm256_add_epi64(bits, key);
         v = _mm256_xor_si256(v, _mm256_srli_epi64(v, 30)); v = counts_mul64(v, c1lo, c1hi);
         v = _mm256_xor_si256(v, _mm256_srli_epi64(v, 27)); v = counts_mul64(v, c2lo, c2hi);
         v = _mm256_xor_si256(v, _mm256_srli_epi64(v, 31));
@@ -2777,15 +2809,17 @@ static inline void counts_scan_row(const double* src, float* out, int64_t g, uin
     counts_scan_scalar(src, OUT ? out : nullptr, j, g, base, rs);
 }
 #else
-template <bool OUT>
-static inline void counts_scan_row(const double* src, float* out, int64_t g, uint64_t base, RowScan& rs) { counts_scan_scalar(src, OUT ? out : nullptr, 0, g, base, rs); }
+template <bool OUT, typename ST>
+static inline void counts_scan_row(const ST* src, float* out, int64_t g, uint64_t base, RowScan& rs) { counts_scan_scalar(src, OUT ? out : nullptr, 0, g, base, rs); }
 #endif
-static uint64_t counts_row_checksum(const double* src, int64_t g, uint64_t base) {
+template <typename ST>
+static uint64_t counts_row_checksum(const ST* src, int64_t g, uint64_t base) {
     RowScan rs{-INFINITY, 0, true};
     counts_scan_row<false>(src, nullptr, g, base, rs);
     return rs.h;
 }
-static void counts_scan(const double* raw, int64_t g, int64_t r0, int64_t r1, float* dst, double* vmax, uint64_t* sum, int* ok) {
+template <typename ST>
+static void counts_scan(const ST* raw, int64_t g, int64_t r0, int64_t r1, float* dst, double* vmax, uint64_t* sum, int* ok) {
     const unsigned hw = std::thread::hardware_concurrency();
     const int64_t rows = r1 - r0;
     const bool scalar = getenv("DIMN_SCAN_SCALAR") && atoi(getenv("DIMN_SCAN_SCALAR")) != 0;      // tests: the plain C++ form of the same pass
@@ -2797,7 +2831,7 @@ static void counts_scan(const double* raw, int64_t g, int64_t r0, int64_t r1, fl
         const int64_t a = r0 + rows * t / nt, b = r0 + rows * (t + 1) / nt;
         RowScan rs{-INFINITY, 0, true};
         for (int64_t i = a; i < b; ++i) {
-            const double* src = raw + i * g;
+            const ST* src = raw + i * g;
             const uint64_t base = (uint64_t)i * (uint64_t)g;
             if (scalar) counts_scan_scalar(src, dst ? dst + (i - r0) * g : nullptr, 0, g, base, rs);
             else if (dst) counts_scan_row<true>(src, dst + (i - r0) * g, g, base, rs);
@@ -2811,12 +2845,19 @@ static void counts_scan(const double* raw, int64_t g, int64_t r0, int64_t r1, fl
     host_pool().run(nt, work);
     for (int t = 0; t < nt; ++t) { *vmax = mx[(size_t)t] > *vmax ? mx[(size_t)t] : *vmax; *sum += cs[(size_t)t]; *ok &= good[(size_t)t]; }
 }
-extern "C" int dimn_counts_checksum(const double* raw, int64_t n, int64_t g, uint64_t* checksum) {
+template <typename ST>
+static int counts_checksum_impl(const ST* raw, int64_t n, int64_t g, uint64_t* checksum) {
     if (!raw || !checksum || n < 1 || g < 1) return fail(DIMN_ERR_ARG, "dimn_counts_checksum: bad argument");
     double vmax = -INFINITY; uint64_t sum = 0; int ok = 1;
     counts_scan(raw, g, 0, n, nullptr, &vmax, &sum, &ok);
     *checksum = sum;
     return DIMN_OK;
+}
+extern "C" int dimn_counts_checksum(const double* raw, int64_t n, int64_t g, uint64_t* checksum) { return counts_checksum_impl(raw, n, g, checksum); }
+extern "C" int dimn_counts_checksum_typed(const void* raw, int32_t dtype, int64_t n, int64_t g, uint64_t* checksum) {
+    if (dtype == DIMN_DTYPE_F64) return counts_checksum_impl((const double*)raw, n, g, checksum);
+    if (dtype == DIMN_DTYPE_I64) return counts_checksum_impl((const int64_t*)raw, n, g, checksum);
+    return fail(DIMN_ERR_ARG, "dimn_counts_checksum_typed: dtype must be DIMN_DTYPE_F64 or DIMN_DTYPE_I64");
 }
 extern "C" int dimn_counts_destroy(dimn_counts c) {
     if (!c) return DIMN_OK;
@@ -2826,7 +2867,8 @@ extern "C" int dimn_counts_destroy(dimn_counts c) {
     delete c;
     return DIMN_OK;
 }
-extern "C" int dimn_counts_create(int32_t device_id, const double* raw, int64_t n, int64_t g, double* vmax_out, uint64_t* checksum_out, dimn_counts* out) {
+template <typename ST>
+static int counts_create_impl(int32_t device_id, const ST* raw, int64_t n, int64_t g, double* vmax_out, uint64_t* checksum_out, dimn_counts* out) {
     if (!raw || !out || n < 1 || g < 1) return fail(DIMN_ERR_ARG, "dimn_counts_create: bad argument");
     CHK(corr_device_ok("dimn_counts_create", device_id));
     dimn_counts c = new dimn_counts_s();
@@ -2867,6 +2909,14 @@ extern "C" int dimn_counts_create(int32_t device_id, const double* raw, int64_t 
     if (checksum_out) *checksum_out = c->checksum;
     *out = c;
     return DIMN_OK;
+}
+extern "C" int dimn_counts_create(int32_t device_id, const double* raw, int64_t n, int64_t g, double* vmax_out, uint64_t* checksum_out, dimn_counts* out) {
+    return counts_create_impl(device_id, raw, n, g, vmax_out, checksum_out, out);
+}
+extern "C" int dimn_counts_create_typed(int32_t device_id, const void* raw, int32_t dtype, int64_t n, int64_t g, double* vmax_out, uint64_t* checksum_out, dimn_counts* out) {
+    if (dtype == DIMN_DTYPE_F64) return counts_create_impl(device_id, (const double*)raw, n, g, vmax_out, checksum_out, out);
+    if (dtype == DIMN_DTYPE_I64) return counts_create_impl(device_id, (const int64_t*)raw, n, g, vmax_out, checksum_out, out);
+    return fail(DIMN_ERR_ARG, "dimn_counts_create_typed: dtype must be DIMN_DTYPE_F64 or DIMN_DTYPE_I64");
 }
 // |corr| of the pool columns from the resident counts on the int8 matrix cores (dimn_counts_dev.h part 2); *dOutp: [pool_n][pool_n] float64
 static int corr_counts_i8(dimn_counts c, const int32_t* dCols, int64_t pool_n, hipStream_t st, double** dOutp) {

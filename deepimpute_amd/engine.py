@@ -303,10 +303,10 @@ class HipEngine(Engine):
         gene_off, gene_slot = i32(gene_off), i32(gene_slot)
         out = np.empty(shape, np.float64)
         self.last_observed_checksum = None           # set by the restore form: the checksum of `observed` as it was read
-        if (raw is None and policy == "restore" and os.environ.get("DIMN_FINISH_RESTORE", "1") != "0" and isinstance(observed, np.ndarray) and observed.dtype == np.float64
-                and observed.flags.c_contiguous and observed.shape == shape):
+        obs_dtype = _cabi.count_dtype(observed)          # float64 or int64, C-ordered
+        if raw is None and policy == "restore" and os.environ.get("DIMN_FINISH_RESTORE", "1") != "0" and obs_dtype is not None and observed.shape == shape:
             cs = C.c_uint64(0)
-            rc = self._f["impute_finish_restore"](self._h, p_f64(observed), shape[0], shape[1], p_i32(gene_off), p_i32(gene_slot),
+            rc = self._f["impute_finish_restore"](self._h, observed.ctypes.data, obs_dtype, shape[0], shape[1], p_i32(gene_off), p_i32(gene_slot),
                                                   float(ceiling), int(bool(from_gathered)), p_f64(out), C.byref(cs))
             if rc == 0:
                 self.last_observed_checksum = int(cs.value)

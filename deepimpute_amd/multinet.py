@@ -28,7 +28,6 @@ import warnings
 
 import numpy as np
 import pandas as pd
-from scipy.stats import pearsonr
 
 from . import _hostpar
 
@@ -534,6 +533,8 @@ class MultiNet:
             minVMR=0.5, mode='random'):
         tm = self.timings = _Stages()
         self._warm_up()
+        with tm.stage("fit.as_float64"):
+            raw = self._as_count_frame(raw)
         # Fast path (a frame of raw counts, one GPU, resident matrix): the counts go to the device first, as float32 (exact), and
         # everything the planning needs is computed from that copy -- the gene statistics (pandas' additions in pandas' order, one
         # thread per gene: DataFrame.mean() / .var() to the bit), the candidate pool of the correlation (genes that vary, with a
@@ -551,7 +552,7 @@ class MultiNet:
                 with tm.stage("fit.gene_statistics"):
                     if raw.shape[0] < 2 or not _hostpar.pandas_order_holds():
                         first = None                         # (pandas' var of one row / another pandas: the plain sequence below computes what that gives)
-                    elif os.environ.get("DIMN_DEVICE_STATS", "1") != "0":
+                    elif os.environ.get("DIMN_DEVICE_STATS", "1") != "0" or raw.values.dtype != np.float64:
                         first = dev_early.gene_stats()
                     else:                                    # the host routines (same numbers; dimn_hoststats.h)
                         first = _hostpar.col_stats_first(raw.values)
@@ -700,13 +701,28 @@ class MultiNet:
         thread.start()
         return thread
 
+    def _as_count_frame(self, raw):
+        """An INTEGER frame -- what pd.read_csv / the CLI's reader make of a count matrix (deepImpute.py:13) -- takes the resident-counts
+        path like a float64 frame does: one upload, statistics / correlation / log1p / restore from the device copy.  A C-ordered int64
+        frame (the CLI's reader) is read in place; any other integer layout (pandas' own reader builds column-major blocks) becomes the
+        float64, C-ordered frame of the same numbers first (by row blocks on the host pool).  The reference's own
+        arithmetic converts the same way (np.log1p(raw), raw.var(): float64); positive counts come back from predict() as float64, as
+        multinet.py:296-303 returns them.  Anything else (float frames, object columns, a sharded or streamed job) passes through."""
+        values = getattr(raw, "values", None)
+        if (not isinstance(raw, pd.DataFrame) or not isinstance(values, np.ndarray) or values.ndim != 2 or values.dtype.kind not in "iu"
+                or (values.dtype == np.int64 and values.flags.c_contiguous)      # read in place (dimn_counts_create_typed): no copy at all
+                or os.environ.get("DIMN_RESIDENT_COUNTS", "1") == "0" or self._comm_spec is not None or not self._device_planning
+                or self.stream_matrix or values.size * 4 > (32 << 30) or not _gpu_visible()):
+            return raw
+        return pd.DataFrame(_hostpar.as_float64(values), index=raw.index, columns=raw.columns, copy=False)
+
     def _counts_path_applies(self, raw):
         """The resident-counts path is for: one GPU (no sharded / streamed job), the product engine, a C-ordered float64 frame
         that fits the device (DIMN_RESIDENT_COUNTS=0 switches it off).  Whether the VALUES are counts is decided by the upload."""
         values = getattr(raw, "values", None)
+        from ._cabi import count_dtype
         return not (os.environ.get("DIMN_RESIDENT_COUNTS", "1") == "0" or self._comm_spec is not None or not self._device_planning or self.stream_matrix
-                    or not isinstance(values, np.ndarray) or values.dtype != np.float64 or not values.flags.c_contiguous
-                    or values.size * 4 > (32 << 30) or not _gpu_visible())
+                    or count_dtype(values) is None or values.size * 4 > (32 << 30) or not _gpu_visible())
 
     def _start_correlation(self, dev, pool, n_cells):
         """|corr| of the candidate pool on a helper thread (ctypes releases the GIL; the work is on the GPU) while the caller
@@ -883,6 +899,8 @@ class MultiNet:
         guess = guess.flatten()
         positive = truth > 0
         truth, guess = truth[positive], guess[positive]
+        from scipy.stats import pearsonr                 # (imported where it is used: scipy.stats is a third of the package's import time, and
+        #                                                   the product path computes these sums on the device)
         return {'correlation': pearsonr(truth, guess)[0],
                 'MSE': np.sum((truth - guess) ** 2) / len(truth)}
 
@@ -892,6 +910,8 @@ class MultiNet:
         for key in [k for k in tm if k.startswith("predict.")]:
             del tm[key]
         self._warm_up()
+        with tm.stage("predict.as_float64"):
+            raw = self._as_count_frame(raw)
         with tm.stage("predict.load"):
             engine = self.load()
         # The counts of this very frame may still be on the GPU from fit() (verified bit for bit by a checksum pass), or go there
@@ -1150,4 +1170,5 @@ class MultiNet:
                       DeprecationWarning)
         estimate = self.predict(data, policy=policy)
         truth = data.loc[estimate.index, estimate.columns]
+        from scipy.stats import pearsonr
         return pearsonr(estimate.values.reshape(-1), truth.values.reshape(-1))

@@ -117,3 +117,15 @@ def test_vector_form_of_the_count_scan_equals_the_scalar_one(monkeypatch):
         got = [checksum(f) for f in frames]
         assert got == want
         assert len(set(want)) == len(want)                          # every edit changes the checksum
+        # an int64 frame of the same numbers hashes like its float64 twin (dimn_counts_checksum_typed), vector and scalar form alike
+        ai = a.astype(np.int64)
+        for v in (0, -1, 4194304, 4194305, 1 << 33, -(1 << 40)):
+            ai[n // 2, g // 3] = v
+            twin = ai.astype(np.float64)
+            sums = []
+            for mode in ("1", "0"):
+                monkeypatch.setenv("DIMN_SCAN_SCALAR", mode)
+                cs = C.c_uint64(0)
+                assert fns["counts_checksum_typed"](ai.ctypes.data, 1, n, g, C.byref(cs)) == 0
+                sums.append(cs.value)
+            assert sums[0] == sums[1] == checksum(twin), v

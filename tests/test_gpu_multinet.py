@@ -309,3 +309,41 @@ def test_cfg2_full_size_through_the_drop_in_matches_oracle(tmp_path):
     np.testing.assert_allclose(float(a.test_metrics["MSE"]), float(b.test_metrics["MSE"]), rtol=1e-4)
     np.testing.assert_allclose(float(a.test_metrics["correlation"]), float(b.test_metrics["correlation"]), rtol=1e-4)
     a.close(); b.close(); c.close()
+
+
+def test_integer_frame_takes_the_resident_counts_path_like_its_float_twin(tmp_path):
+    """pd.read_csv / the CLI's reader hand fit() an int64 frame (deepImpute.py:13).  It must go the way its float64 twin goes -- counts
+    uploaded once, planning and restore from the device copy -- and give the same plan, history and imputed frame, bit for bit; predict()
+    on the integer frame finds the counts resident and returns float64 with the observed counts restored."""
+    from deepimpute_amd.multinet import MultiNet
+    raw_f = _raw(n=260, g=520, seed=3)
+    raw_i = raw_f.astype(np.int64)
+    assert raw_i.values.dtype == np.int64
+    kw = dict(sub_outputdim=64, seed=11, ncores=1, verbose=0, max_epochs=3, patience=10, learning_rate=1e-3)
+    a = MultiNet(output_prefix=str(tmp_path / "f"), **kw).fit(raw_f, NN_lim=200)
+    b = MultiNet(output_prefix=str(tmp_path / "i"), **kw).fit(raw_i, NN_lim=200)
+    assert getattr(b, "_resident", None) is not None and b.timings["fit.counts_upload"] > 0
+    from deepimpute_amd._counts import DeviceCounts
+    dev = DeviceCounts.try_create(raw_i.values, 0)                       # the int64 frame is read in place (dimn_counts_create_typed) ...
+    assert dev is not None and dev.matches(raw_i.values) and dev.matches(raw_f.values) and dev.checksum == b._resident[0].checksum
+    # ... and its statistics are, to the bit, pandas' of the float64 frame of the same numbers AND of the integer frame pd.read_csv builds
+    # (one contiguous block row per gene: the frame the reference's CLI ranks its genes on, deepImpute.py:13 + multinet.py:191).  [pandas'
+    # own var of a C-ORDERED int64 frame differs from both in the last ulp: its astype keeps the strides and the sums run sequentially.]
+    stats = dev.gene_stats()
+    as_read_csv = pd.DataFrame({c: raw_i[c].values.copy() for c in raw_i.columns}, index=raw_i.index)
+    assert as_read_csv._mgr.blocks[0].values.flags.c_contiguous
+    for frame in (raw_f, as_read_csv):
+        assert np.array_equal(stats["mean"], frame.mean().values) and np.array_equal(stats["var"], frame.var().values)
+    edited = raw_i.values.copy(); edited[3, 4] += 1 << 33                # (low 32 bits unchanged: the int64 scan must still notice)
+    assert not dev.matches(edited)
+    dev.close()
+    assert all(list(x) == list(y) for x, y in zip(a.predictors, b.predictors)) and a.history == b.history
+    pa, pb = a.predict(raw_f), b.predict(raw_i)
+    assert "predict.log1p" not in b.timings                              # the resident counts served predict() as well
+    assert pb.values.dtype == np.float64 and np.array_equal(pa.values, pb.values)
+    pos = raw_i.values > 0
+    assert np.array_equal(pb.values[pos], raw_i.values[pos].astype(np.float64))
+    # a column-major integer frame (what pandas' own reader builds) as well
+    raw_p = pd.DataFrame({c: raw_i[c].values for c in raw_i.columns}, index=raw_i.index)
+    assert np.array_equal(b.predict(raw_p).values, pb.values)
+    a.close(); b.close()

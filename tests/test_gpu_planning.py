@@ -174,9 +174,13 @@ def test_restore_epilogue_sends_only_the_zeros_and_equals_the_dense_epilogue(n, 
     other[7, 11] = 0.0 if raw[7, 11] > 0 else 4.0
     from deepimpute_amd import _cabi
     out = np.empty_like(raw)
-    rc = eng._f["impute_finish_restore"](eng._h, _cabi.p_f64(other), n, g, _cabi.p_i32(np.ascontiguousarray(gene_off, np.int32)),
+    rc = eng._f["impute_finish_restore"](eng._h, other.ctypes.data, 0, n, g, _cabi.p_i32(np.ascontiguousarray(gene_off, np.int32)),
                                          _cabi.p_i32(np.ascontiguousarray(order, np.int32)), float(ceiling), 0, _cabi.p_f64(out), None)
     assert rc == -3
     # ... and the engine then answers from the resident counts, as the dense epilogue does
     assert np.array_equal(eng.impute_finish(None, gene_off, order, "restore", ceiling, observed=other), dense)
+    # an int64 frame of the same counts (what pd.read_csv hands over) is merged in place: same float64 result, same checksum
+    eng.predict_device()
+    assert np.array_equal(eng.impute_finish(None, gene_off, order, "restore", ceiling, observed=raw.astype(np.int64)), dense)
+    assert eng.last_observed_checksum == counts.checksum
     eng.close(); counts.close()
