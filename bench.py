@@ -423,6 +423,9 @@ def dropin_run(norm, epochs):
     stages = {k: round(float(v), 4) for k, v in getattr(net, "timings", {}).items()}
     net.close()
     return {"fit_s": t1 - t0, "predict_s": t2 - t1, "cells_per_s": n / (t2 - t0), "subnets": len(net.predictors), "epochs": int(net.trained_epochs),
+            # what the first call of a process pays on top (lazy imports, dlopen, the epilogue's device blocks): the untimed warm-up counted in;
+            # the CLI as one cold process, CSV edges included: profiles/r05_cli_cold.txt
+            "cells_per_s_with_warmup": n / (t2 - t0 + warmup_s),
             "test_metrics": metrics, "stages_s": stages, "warmup_s": round(warmup_s, 3),
             "note": "MultiNet.fit + predict on the same matrix as raw counts: host planning, host<->device copies of the counts and of the "
                     "imputed frame included; warmup_s: an untimed one-epoch fit + predict on a 512 x 1024 corner first (lazy imports, dlopen)"}
@@ -706,6 +709,11 @@ def main():
                        "train_steps_per_epoch": steps_per_epoch, "parallelism": "subnets sharded x%d" % world,
                        "final_val_loss": vsum, "subnet_lanes": int(timers[5]), "matrix": "streamed from host (pinned row blocks)" if args.stream else "resident",
                        "lane_step_ms": lane_step_ms,
+                       # `value` is the ENGINE figure: the matrix resident in HBM when the timed region starts, the predictions left in HBM, no
+                       # planning, no PCIe (the bench contract); the figure BASELINE's metric wording describes -- MultiNet.fit + predict from a
+                       # host frame to a host frame -- is config.dropin.cells_per_s.  The timed region carries the HIP-event stamps of one
+                       # launch in eight (set_profiling): they make `value` conservative, never optimistic.
+                       "value_scope": "engine: resident matrix -> predictions in HBM; host-to-host figure: config.dropin; event stamps inside the timed region",
                        # host wall time of the train_epoch calls per optimiser step (every path, also the general one, which has no event timers)
                        "train_step_ms_wall": 1e3 * eng._bench_train_s / max(1, eng._bench_train_steps)},
             "roofline": roofline,
@@ -719,9 +727,16 @@ def main():
         if pred_s:
             mine = preds[offs[0]:offs[0] + counts[0]]
             pf = n * sum(2.0 * len(p) * H_ + 2.0 * H_ * O_ for p in mine)
-            peak = 2500.0 if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
-            result["roofline"]["predict"] = {"kernel": "k_predict_bf16" if args.precision == "bf16" else "k_predict", "ms": 1e3 * pred_s, "achieved": pf / pred_s / 1e12,
-                                             "peak": peak, "unit": "TFLOP/s", "frac": pf / pred_s / 1e12 / peak}
+            if args.precision == "bf16":
+                # 217 flop per byte: BELOW the bf16 ridge (2.5 PFLOP/s / 8 TB/s = 312), so the forward on the bf16 matrix cores is bounded by
+                # HBM: algorithmic bytes = the bf16 predictor blocks once + the fp32 predictions written once
+                pb = n * sum(2.0 * len(p) + 4.0 * O_ for p in mine)
+                result["roofline"]["predict"] = {"kernel": "k_predict_bf16", "bound": "hbm", "ms": 1e3 * pred_s, "achieved": pb / pred_s / 1e9, "peak": HBM_PEAK_GBS,
+                                                 "unit": "GB/s", "frac": pb / pred_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": pb,
+                                                 "mfma": {"achieved": pf / pred_s / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": pf / pred_s / 1e12 / 2500.0}}
+            else:
+                result["roofline"]["predict"] = {"kernel": "k_predict", "bound": "mfma", "ms": 1e3 * pred_s, "achieved": pf / pred_s / 1e12,
+                                                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": pf / pred_s / 1e12 / F32_MFMA_PEAK_TFLOPS}
         if args.early_stop_probe:
             eng.gather(True); eng.init_weights()
             t1 = time.perf_counter()

@@ -43,6 +43,7 @@ def _block_for(frame_or_shape, axis, target_bytes=32 << 20):
 
 
 _pandas_order_ok = None
+_pandas_order_lock = __import__("threading").RLock()      # (re-entrant: the probe itself calls _native_col_stats, which may ask again)
 
 
 def pandas_order_holds():
@@ -52,19 +53,27 @@ def pandas_order_holds():
     native routine equal to pandas TO THE BIT; otherwise the native paths are switched off for the process (pandas computes the
     statistics: the gene ranking of fit() then follows the installed library, as the reference's does) and a warning says so."""
     global _pandas_order_ok
-    if _pandas_order_ok is None:
-        _pandas_order_ok = True                      # (re-entrancy: the probe below calls _native_col_stats)
-        rng = np.random.default_rng(20240607)
-        probe = pd.DataFrame(rng.poisson(rng.gamma(2.0, 3.0, size=(8200, 6))).astype(np.float64))
-        got = _native_col_stats(probe.values)
-        if got is not None:
-            same = np.array_equal(got[0], probe.mean().values) and np.array_equal(got[1], probe.var().values)
-            if not same:
-                import warnings
-                warnings.warn("deepimpute_amd: the native gene statistics differ from this pandas' DataFrame.mean()/var() at ulp level "
-                              "(pandas %s, numpy %s); using pandas' own reductions" % (pd.__version__, np.__version__), RuntimeWarning)
-            _pandas_order_ok = bool(same)
-    return _pandas_order_ok
+    if _pandas_order_ok is not None and _pandas_order_ok != "probing":
+        return _pandas_order_ok
+    with _pandas_order_lock:                         # other threads (pmap workers, the upload / correlation helpers) wait for the verdict
+        if _pandas_order_ok == "probing":
+            return True                              # only the probing thread itself gets here (RLock): its own call of the native routine
+        if _pandas_order_ok is None:
+            _pandas_order_ok = "probing"
+            verdict = True
+            try:
+                rng = np.random.default_rng(20240607)
+                probe = pd.DataFrame(rng.poisson(rng.gamma(2.0, 3.0, size=(8200, 6))).astype(np.float64))
+                got = _native_col_stats(probe.values)
+                if got is not None:
+                    verdict = bool(np.array_equal(got[0], probe.mean().values) and np.array_equal(got[1], probe.var().values))
+                    if not verdict:
+                        import warnings
+                        warnings.warn("deepimpute_amd: the native gene statistics differ from this pandas' DataFrame.mean()/var() at ulp level "
+                                      "(pandas %s, numpy %s); using pandas' own reductions" % (pd.__version__, np.__version__), RuntimeWarning)
+            finally:
+                _pandas_order_ok = verdict
+        return _pandas_order_ok
 
 
 def _native_col_stats(values, want_var=True):

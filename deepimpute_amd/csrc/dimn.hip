@@ -183,7 +183,6 @@ struct dimn_handle_s {
     std::vector<MidWork> midwork;          // work table of the fused second-layer kernel (k_mid_fused)
     int mid_fused = 0, mid_slices = 0;     // 1: RED -> MFB -> RED2 -> B1F1; 0: RED -> MF -> MB -> B1F1
     int mid_keep = 0;                      // 1: k_mid_fused<true> (the W2 column blocks stay in LDS between its phases)
-    int w1_rev = 0;                        // 1: the ring B1F1 walks its D-slices backwards on odd steps (memory-side cache: DESIGN section 2)
     int mid_pipe = 0;                      // 1: k_mid_pipe (dimn_mid_pipe.h: the slice's tiles as a software pipeline) instead of k_mid_fused
     int train_bf16 = 0;                    // 1: precision bf16 and the fused second layer runs its three GEMMs on the bf16 matrix cores
     MidWork* d_midwork = nullptr; int32_t* d_midk = nullptr; float* d_P2 = nullptr;
@@ -632,7 +631,6 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
     }
     h->w1_total = w1;
     build_work(h);
-    h->w1_rev = getenv("DIMN_W1_REV") && atoi(getenv("DIMN_W1_REV")) != 0;
     if (!general) { build_mid(h); build_resident(h); }
     // One lane: every sub-net on the handle's stream.  (Two free-running lanes on two streams, a "W token" ring between them and a fixed
     // CU partition with CU-masked streams were all measured and lost to the serial step: DESIGN.md section 2, profiles/r03_cu_partition_sweep.txt.)
@@ -1225,19 +1223,19 @@ static void launch_fwd1(dimn_handle h, const dimn_handle_s::Lane& ln, hipStream_
 }
 template <int NT2>
 static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, hipStream_t stw, const int32_t* rows, int b_act, const int32_t* rows_n, int b_next,
-                      AdamP ap, hipEvent_t ev_begin, hipEvent_t ev_end, int64_t rev_t) {
+                      AdamP ap, hipEvent_t ev_begin, hipEvent_t ev_end) {
     const dim3 grid((unsigned)(ln.w1 - ln.w0));
     const Work* wk = h->d_work + ln.w0;
     // ev_begin/ev_end (timed launches only): hipExtLaunchKernelGGL stamps them with the kernel's own begin and end,
     // so the elapsed time is the launch's duration without the dispatch latency an event pair around it would add
-#define W1_LAUNCH(KERNEL, THREADS, ...) hipExtLaunchKernelGGL((KERNEL), grid, dim3(THREADS), 0, stw, ev_begin, ev_end, 0, wk, h->d_sn,      \
+#define W1_LAUNCH(KERNEL, THREADS) hipExtLaunchKernelGGL((KERNEL), grid, dim3(THREADS), 0, stw, ev_begin, ev_end, 0, wk, h->d_sn,      \
                                                          (const XT*)h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, \
-                                                         (const float*)h->d_dA, h->d_P, h->dm, ap, ##__VA_ARGS__)
+                                                         (const float*)h->d_dA, h->d_P, h->dm, ap)
     WITH_XT(h, {
         if (h->dm.HT == 20)                           // H = 300 (padded to 320): 10 waves x 2 hidden tiles, two-set shared-staging variant
             W1_LAUNCH((k_w1_update_fwd_sh<10, 2, 1, XT>), 640);
         else if (h->dm.HT == 16)                      // H = 256: 16 waves x 1 hidden tile, X tiles staged once per workgroup, 3-set register ring
-            W1_LAUNCH((k_w1_update_fwd_ring<16, 1, 3, 1, XT>), 1024, (int)(h->w1_rev && (rev_t & 1)));   // odd steps walk the slices backwards
+            W1_LAUNCH((k_w1_update_fwd_ring<16, 1, 3, 1, XT>), 1024);
         else if (h->dm.HT == 8 * NT2)
             W1_LAUNCH((k_w1_update_fwd<NT2, true, XT>), 512);
         else
@@ -1414,7 +1412,7 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     else { if (dm.OT == 4 * h->OTW) LAUNCH_MB(true, 4); else LAUNCH_MB(false, 4); }
 #undef LAUNCH_MB
     }
-    DISPATCH_NT2(launch_w1, h, ln, stw, d_rows, b_act, d_rows_n, b_next, ap, e1, e2, t);   // e1/e2 (timed steps): the kernel's own begin/end
+    DISPATCH_NT2(launch_w1, h, ln, stw, d_rows, b_act, d_rows_n, b_next, ap, e1, e2);   // e1/e2 (timed steps): the kernel's own begin/end
     HIPCHK(hipGetLastError());
     return DIMN_OK;
 }

@@ -1493,7 +1493,7 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void k_w1_update_fwd_ring(const Wo
                                                                   float* __restrict__ M1, float* __restrict__ V1,
                                                                   const int32_t* __restrict__ rows_t, int b_act,
                                                                   const int32_t* __restrict__ rows_n, int b_next,
-                                                                  const float* __restrict__ dA, float* __restrict__ P, Dims dm, AdamP ap, int rev) {
+                                                                  const float* __restrict__ dA, float* __restrict__ P, Dims dm, AdamP ap) {
     constexpr int XTS = DIMN_TB * 16, XN = DIMN_TB * 20;
     constexpr int DUMMY = 2 * (XTS + XN);                       // LDS words nobody reads: target of non-staging threads
     __shared__ __attribute__((aligned(16))) float sm[2 * (XTS + XN) + 4 * WAVES * 64];
@@ -1540,13 +1540,8 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void k_w1_update_fwd_ring(const Wo
         for (int nt = 0; nt < NT2; ++nt) pacc[mt][nt] = zero4;
 
     const int clast = wk.c1 - 1;
-    // rev (odd optimiser steps): the slice's chunks are walked from its last to its first, so that what step t streamed LAST -- the part of
-    // the 590 MB of state the 256 MB memory-side cache may still hold -- is what step t+1 asks for FIRST (same order every step is the
-    // worst case of any LRU-like policy).  The loop counts c0 .. c1-1 either way; phys() is the chunk it touches.
-    const int crev = wk.c0 + clast;
-    auto phys = [&](int c) { return rev ? crev - c : c; };
     auto fetch = [&](W1Set<NT2, XT>& st, int c) {           // issue the loads of chunk c (clamped)
-        const int cc = phys(c < clast ? c : clast);
+        const int cc = c < clast ? c : clast;
         // X tile first: one iteration later it is the oldest request of this wave, so waiting for it
         // (in-order vmcnt) leaves the three state loads issued after it in flight
         st.x.load(xsrc + 16 * cc);
@@ -1577,7 +1572,7 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void k_w1_update_fwd_ring(const Wo
         *(f32x4*)(sm + sdst + (par ^ 1) * sbuf) = svalid ? nx1.x.get() : zero4;
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
-            const int64_t idx = wb[nt] + phys(c) * cstride;
+            const int64_t idx = wb[nt] + c * cstride;
             DIMN_ST_STATE(W1 + idx, cur.w[nt]); DIMN_ST_STATE(M1 + idx, cur.m[nt]); DIMN_ST_STATE(V1 + idx, cur.v[nt]);
         }
         if (have_next) {

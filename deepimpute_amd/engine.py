@@ -289,6 +289,8 @@ class HipEngine(Engine):
         self._check(self._f["val_metrics"](self._h, p_f64(out)))
         return out
 
+    restore_epilogue = True      # (tools/finish_ab.py sets it False to time the dense epilogue on the same box)
+
     def impute_finish(self, raw, gene_off, gene_slot, policy, ceiling, from_gathered=False, observed=None):
         """predict()'s post-processing on the device over the last predict_device() result (include/dimn.h);
         raw [cells, genes] float64 -> the finished [cells, genes] float64 matrix.  raw = None: the observed counts are the
@@ -304,7 +306,7 @@ class HipEngine(Engine):
         out = np.empty(shape, np.float64)
         self.last_observed_checksum = None           # set by the restore form: the checksum of `observed` as it was read
         obs_dtype = _cabi.count_dtype(observed)          # float64 or int64, C-ordered
-        if raw is None and policy == "restore" and os.environ.get("DIMN_FINISH_RESTORE", "1") != "0" and obs_dtype is not None and observed.shape == shape:
+        if raw is None and policy == "restore" and self.restore_epilogue and obs_dtype is not None and observed.shape == shape:
             cs = C.c_uint64(0)
             rc = self._f["impute_finish_restore"](self._h, observed.ctypes.data, obs_dtype, shape[0], shape[1], p_i32(gene_off), p_i32(gene_slot),
                                                   float(ceiling), int(bool(from_gathered)), p_f64(out), C.byref(cs))
@@ -331,8 +333,9 @@ class HipEngine(Engine):
         """The kernels dimn_create chose for this handle (include/dimn.h dimn_path_info), as a dict."""
         out = np.zeros(8, np.int32)
         self._check(self._f["path_info"](self._h, p_i32(out)))
-        keys = ("path", "resident_groups", "resident_splits", "mid_fused", "mid_slices", "mid_keep", "train_bf16", "first_layer")
+        keys = ("path", "resident_groups", "resident_splits", "mid_fused", "mid_slices", "mid_kernel", "train_bf16", "first_layer")
         d = dict(zip(keys, (int(x) for x in out)))
+        d["mid_keep"] = d["mid_kernel"]              # (the key's name until round 4, when 2 = the tile pipeline joined 1 / 0 = k_mid_fused with / without W2 kept in LDS)
         d["path"] = ("streaming", "resident", "general")[d["path"]]
         return d
 

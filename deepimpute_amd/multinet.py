@@ -928,7 +928,7 @@ class MultiNet:
                 resident = held[0]
                 # (policy "restore" on the device epilogue reads every element of the frame anyway -- dimn_impute_finish_restore -- and
                 #  returns that checksum itself: no second pass over the 8 GB)
-                folded = policy == "restore" and hasattr(engine, "impute_finish") and os.environ.get("DIMN_FINISH_RESTORE", "1") != "0"
+                folded = policy == "restore" and getattr(engine, "restore_epilogue", False)
                 verdict = None if folded else self._start_checksum(resident, values)
             else:
                 wait = self._start_counts_upload(raw) if hasattr(engine, "set_matrix_counts") else (lambda: None)

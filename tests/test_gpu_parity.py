@@ -124,7 +124,7 @@ def test_h256_both_second_layer_paths_match_oracle(O, B, Ds, p, mid, monkeypatch
 @pytest.mark.parametrize("O,B,slices", [(512, 64, "6"), (500, 37, "4"), (96, 64, "6")])
 def test_tile_pipeline_and_three_phase_kernel_agree(O, B, slices, monkeypatch):
     """The two forms of the fused second layer -- the tile pipeline k_mid_pipe (what runs) and the three-phase k_mid_fused
-    (DIMN_MID_PIPE=0; what bf16 handles run) -- are the same arithmetic in different summation orders: after two epochs from the same
+    (DIMN_MID_PIPE=0; the A/B form, fp32 and bf16 operands alike) -- are the same arithmetic in different summation orders: after two epochs from the same
     seeds their weights and Adam moments agree far inside the tolerance either has against the oracle, and path_info says which ran."""
     monkeypatch.setenv("DIMN_RESIDENT", "0")
     monkeypatch.setenv("DIMN_MID", "1")

@@ -14,10 +14,8 @@ with contextlib.redirect_stdout(io.StringIO()):
     net.fit(raw, NN_lim=g)
     ref = None
     for rep in range(4):
-        for label, env in (("dense", {"DIMN_FINISH_RESTORE": "0"}), ("restore", {})):
-            for k in ("DIMN_FINISH_RESTORE",):
-                os.environ.pop(k, None)
-            os.environ.update(env)
+        for label, restore in (("dense", False), ("restore", True)):
+            type(net._engine).restore_epilogue = restore
             t0 = time.perf_counter()
             out = net.predict(raw)
             dt = time.perf_counter() - t0
