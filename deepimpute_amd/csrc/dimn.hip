@@ -1834,8 +1834,10 @@ extern "C" int dimn_predict_device(dimn_handle h, const int32_t* rows, int64_t n
     h->pred_ev_rows.clear();
     if (n_rows > 0 && h->gen) {
         CHK(gen_predict(h, drows, n_rows));
-    } else if (n_rows > 0 && !rows && n_rows >= 8192) {
-        // all cells, in order: eight row chunks (multiples of 128 rows: the bf16 kernel's tile), an event behind each
+    } else if (n_rows > 0 && !rows && n_rows >= 8192 && !h->predict_bf16) {
+        // all cells, in order: eight row chunks, an event behind each, so that the epilogue (dimn_impute_finish*) starts on the first rows
+        // while the last are still computed: ~23 of the fp32 forward's 26 ms at 50k cells x 40 sub-nets.  (Not for the bf16 forward: 4 ms
+        // as one launch, 4.4 ms as eight -- rocprofv3, round 5 -- with nothing worth hiding.)
         if (h->pred_iota_n < n_rows) {
             HIPCHK(hipStreamSynchronize(h->stream));
             DEV_FREE(h->d_pred_iota);

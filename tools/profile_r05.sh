@@ -1,8 +1,8 @@
 #!/bin/bash
-# End-of-round evidence of round 4 (one box): the driver's bench command, the same workload under rocprofv3 --kernel-trace --stats, one rank of
+# End-of-round evidence of round 5 (one box): the driver's bench command, the same workload under rocprofv3 --kernel-trace --stats, one rank of
 # the 8-GPU job (resident kernel), PMC passes (separate: traffic, MFMA), the shape families, configs[1], precision bf16.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-O=gpurun_out/r04p; mkdir -p $O
+O=gpurun_out/r05p; mkdir -p $O
 export TMPDIR=/tmp
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 B="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dropin --no-accuracy"
@@ -15,7 +15,6 @@ python tools/kstats.py $O/prof_gen > $O/kernel_stats_general.txt 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_bf -o run -- $B --precision bf16 --epochs 2 > $O/bench_bf16_under_rocprof.json 2>> $O/prof.err
 python tools/kstats.py $O/prof_bf > $O/kernel_stats_bf16.txt 2>&1
 rm -rf $O/prof $O/prof_k5 $O/prof_gen $O/prof_bf
-bash tools/pb_trace.sh > $O/predict_bf16_phases.txt 2>&1; tail -9 $O/predict_bf16_phases.txt
 head -8 $O/kernel_stats.txt; head -5 $O/kernel_stats_k5.txt; head -10 $O/kernel_stats_general.txt
 P="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-dropin --no-accuracy --epochs 1"
 for c in FETCH_SIZE WRITE_SIZE; do timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o pmc -- $P > /dev/null 2> $O/pmc_$c.err; done
@@ -47,7 +46,9 @@ run fam_h256_general "--general --epochs 4"
 run fam_b128_general "--batch 128 --epochs 4"
 run fam_h512_b128_general "--batch 128 --hidden 512 --epochs 4"
 } | tee $O/families.txt
-timeout 600 python tools/res_timeline.py 5 > $O/resident_timeline.txt 2>&1; tail -32 $O/resident_timeline.txt
+bash tools/cli_cold.sh both > $O/cli_default.txt 2>&1
+bash tools/cli_cold.sh big --hidden-neurons 256 --max-epochs 18 > $O/cli_h256_e18.txt 2>&1; grep -v "^    " $O/cli_h256_e18.txt | tail -12
+python tools/finish_ab.py 2>&1 | grep -v "^\[dimn\]" | tail -8 | tee $O/finish_ab.txt
 python - <<PY
 import json
 d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1]); print("BENCH", d["value"], d["ms_per_step"], d["config"]["lane_step_ms"], d["roofline"]["frac"], json.dumps(d["config"]["dropin"])[:900]); print(json.dumps(d["cpu_baseline"])[:300])
