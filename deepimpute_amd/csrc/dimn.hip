@@ -857,6 +857,7 @@ static HostPool& host_pool() {
     static HostPool* pool = new HostPool(std::min<unsigned>(64, std::max(4u, std::thread::hardware_concurrency() / 2)));
     return *pool;
 }
+static void csv_parallel(int n, const std::function<void(int)>& fn) { host_pool().run(n, fn); }      // (dimn_csv.h)
 
 // memcpy of a large block on several host threads (one pageable <-> pinned copy per pipeline stage: a single thread
 // moves ~10 GB/s, the PCIe link five times that)

@@ -239,3 +239,28 @@ def test_sharded_fit_and_gather_on_hip_engines_as_threads_of_one_gpu():
     np.testing.assert_allclose(results[0][3], ora.predict(), rtol=1e-4, atol=1e-6)
     for e in engines + [whole, ora]:
         e.close()
+
+
+def test_multinet_close_gives_the_cached_device_blocks_back(tmp_path):
+    """MultiNet.close() is documented as releasing the GPU; since the process-wide block cache (round 4) it must also empty
+    that cache (dimn_release_cached_memory) -- close(release_cache=False) keeps it for a fit() that follows -- and a constructor touches
+    nothing.  Observed through dimn_cached_memory_info (ABI 8)."""
+    import pandas as pd
+    from deepimpute_amd import _lib, release_cached_memory
+    from deepimpute_amd.multinet import MultiNet
+    release_cached_memory()
+    assert _lib.cached_memory_info() == (0, 0)
+    rng = np.random.default_rng(3)
+    n, g = 9000, 1600                                            # counts 58 MB, X arena > 32 MB: cached-class blocks
+    raw = pd.DataFrame(rng.poisson(rng.gamma(2.0, 2.0, size=g), size=(n, g)).astype(np.float64), index=["c%d" % i for i in range(n)],
+                       columns=["g%d" % j for j in range(g)])
+    net = MultiNet(output_prefix=str(tmp_path), sub_outputdim=256, verbose=0, max_epochs=1, seed=3)
+    assert _lib.cached_memory_info() == (0, 0)                   # constructing allocates nothing
+    net.fit(raw, NN_lim=g)
+    idle, owned = _lib.cached_memory_info()
+    assert owned > (32 << 20)
+    net.close(release_cache=False)
+    idle2, owned2 = _lib.cached_memory_info()
+    assert owned2 == 0 and idle2 >= owned                        # everything the handle and the counts owned waits in the cache
+    net.close()
+    assert _lib.cached_memory_info() == (0, 0)
