@@ -536,6 +536,8 @@ def main():
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in MultiNet.fit+predict run (config.dropin)")
     ap.add_argument("--no-accuracy", action="store_true", help="skip the HIP vs CPU-port held-out metrics after E epochs on a sub-problem (accuracy)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--accuracy-cells", type=int, default=4096, help="cells of the accuracy leg's problem (the bench's own 50000 for the full horizon: the CPU oracles then take minutes)")
+    ap.add_argument("--accuracy-subnets", type=int, default=4, help="sub-nets the CPU oracles of the accuracy leg run")
     ap.add_argument("--limit-subnets", type=int, default=0, help="diagnostic: keep only the first N sub-nets (what one rank of an N-GPU job sees)")
     ap.add_argument("--hidden", type=int, default=0, help="diagnostic: hidden width (default: the config's 256; the reference CLI defaults to 300)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="bf16: X arena in bfloat16, inference / validation on the bf16 matrix cores")
@@ -760,9 +762,9 @@ def main():
             result["config"]["dropin"] = dropin_run(norm, args.epochs)
         except Exception as e:
             result["config"]["dropin"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_accuracy and not args.no_cpu_baseline and not args.limit_subnets and not args.hidden and not general and args.precision == "fp32":
+    if rank == 0 and world == 1 and not args.no_accuracy and not args.limit_subnets and not args.hidden and not general and args.precision == "fp32":
         try:
-            result["accuracy"] = accuracy_pair(cfg, targets, preds, norm, args.epochs, args.lr)
+            result["accuracy"] = accuracy_pair(cfg, targets, preds, norm, args.epochs, args.lr, n_cells=args.accuracy_cells, n_subnets=args.accuracy_subnets)
         except Exception as e:
             result["accuracy"] = {"error": repr(e)}
     if rank == 0:
