@@ -2166,7 +2166,7 @@ static int impute_finish_restore_impl(dimn_handle h, const ST* observed, int64_t
             FIN_TRY(hipEventSynchronize(evOut[b]));
             if (rc == DIMN_OK) retire = std::thread([=, &base, &mismatch, &checksum] {
                 const unsigned hw = std::thread::hardware_concurrency();
-                // (16, 32 and 64 threads measured the same on the 2 x 64-core hosts: tools/finish_ab.py)
+                // (same box, tools/finish_ab.py, round 5: 16 threads 0.134-0.146 s per epilogue, 32: 0.114-0.126, 64: 0.119-0.137)
                 const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw ? hw / 2 : 8, 32), nr * g / (1 << 20)));
                 const double* z0 = pOut[b];
                 const int64_t b0 = base[(size_t)r0];
