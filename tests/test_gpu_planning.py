@@ -132,7 +132,8 @@ def test_streamed_correlation_matches_resident(monkeypatch):
     assert streamed[17].max() == 0.0
 
 
-@pytest.mark.parametrize("n,g,O,K", [(300, 700, 64, 3), (9000, 1531, 32, 5), (8192 + 77, 640, 128, 2)])
+@pytest.mark.parametrize("n,g,O,K", [(300, 700, 64, 3), (9000, 1531, 32, 5), (8192 + 77, 640, 128, 2), (70, 5, 16, 1), (260, 900, 512, 76)])
+# (70 x 5: a wave's eighth of a row is empty; 76 x 512 = 38 912 slots: the prediction row no longer fits the kernel's LDS stage)
 def test_restore_epilogue_sends_only_the_zeros_and_equals_the_dense_epilogue(n, g, O, K):
     """dimn_impute_finish_restore (policy "restore" over resident counts: only the zero entries cross PCIe, the host merges them into
     a copy of its own frame) against dimn_impute_finish(raw = NULL, policy = 1) on the same prediction: bit for bit -- ragged column
@@ -146,12 +147,15 @@ def test_restore_epilogue_sends_only_the_zeros_and_equals_the_dense_epilogue(n, 
     raw[3] = 0.0                                              # an all-zero cell
     raw[5] = np.maximum(raw[5], 1.0)                          # a cell without zeros
     raw[:, :4] += rng.poisson(12, size=(n, 4))
-    D = [40 + 3 * k for k in range(K)]
+    D = [min(g - 1, 40 + 3 * (k % 9)) for k in range(K)]
     eng = HipEngine(D, 32, O, seed=5)
     counts = DeviceCounts.try_create(raw, 0)
     assert counts is not None
     pool = rng.permutation(g)
-    slots = np.concatenate([pool[: K * O - 7], pool[:7]])     # seven genes occupy two slots; the genes past K * O - 7 none
+    if K * O - 7 <= g:
+        slots = np.concatenate([pool[: K * O - 7], pool[:7]])     # seven genes occupy two slots; the genes past K * O - 7 none
+    else:
+        slots = np.concatenate([pool[:g - 3], rng.choice(pool[:g - 3], K * O - (g - 3))])   # many slots per gene, three genes in none
     for k in range(K):
         eng.set_indices(k, rng.choice(g, D[k], replace=False), slots[k * O:(k + 1) * O])
     eng.set_matrix_counts(counts)
@@ -171,7 +175,8 @@ def test_restore_epilogue_sends_only_the_zeros_and_equals_the_dense_epilogue(n, 
     assert np.array_equal(packed[seen], raw[seen]) and (packed[~seen] >= 0).all() and (packed[3] > 0).any()
     # the C entry point itself refuses a frame with other zeros ...
     other = raw.copy()
-    other[7, 11] = 0.0 if raw[7, 11] > 0 else 4.0
+    c = min(11, g - 1)
+    other[7, c] = 0.0 if raw[7, c] > 0 else 4.0
     from deepimpute_amd import _cabi
     out = np.empty_like(raw)
     rc = eng._f["impute_finish_restore"](eng._h, other.ctypes.data, 0, n, g, _cabi.p_i32(np.ascontiguousarray(gene_off, np.int32)),
