@@ -13,7 +13,8 @@ ABI_VERSION = 8
 MAX_BATCH = 64
 COMM_ID_BYTES = 128
 # hidden-layer activations the kernels implement (ids = DIMN_ACT_* of include/dimn.h; Keras names)
-ACTIVATIONS = {"relu": 0, "linear": 1, "sigmoid": 2, "tanh": 3, "elu": 4, "softplus": 5}
+ACTIVATIONS = {"relu": 0, "linear": 1, "sigmoid": 2, "tanh": 3, "elu": 4, "softplus": 5,
+               "selu": 6, "softsign": 7, "swish": 8, "gelu": 9, "exponential": 10, "hard_sigmoid": 11}
 
 
 class Config(C.Structure):

@@ -735,7 +735,7 @@ extern "C" int dimn_create_general(const dimn_config* cfg, const int32_t* D, con
     if (loss < DIMN_LOSS_WMSE || loss > DIMN_LOSS_MAE) return fail(DIMN_ERR_UNSUP, "dimn_create_general: unknown loss id %d", loss);
     for (int l = 0; l < n_layers; ++l) {
         if (layers[l].neurons < 1) return fail(DIMN_ERR_ARG, "dimn_create_general: layer %d has no neurons", l);
-        if (layers[l].activation < DIMN_ACT_RELU || layers[l].activation > DIMN_ACT_SOFTPLUS) return fail(DIMN_ERR_UNSUP, "dimn_create_general: unknown activation id in layer %d", l);
+        if (layers[l].activation < DIMN_ACT_RELU || layers[l].activation > DIMN_ACT_LAST) return fail(DIMN_ERR_UNSUP, "dimn_create_general: unknown activation id in layer %d", l);
         if (!(layers[l].dropout_rate >= 0.f && layers[l].dropout_rate < 1.f)) return fail(DIMN_ERR_ARG, "dimn_create_general: dropout rate of layer %d not in [0,1)", l);
     }
     dimn_config c = *cfg;
@@ -1082,7 +1082,7 @@ static int zero_opt(dimn_handle h) {
 extern "C" int dimn_set_activation(dimn_handle h, int32_t activation) {
     if (!h) return fail(DIMN_ERR_ARG, "null handle");
     if (h->gen) return fail(DIMN_ERR_ARG, "dimn_set_activation: a general handle takes its activations from dimn_create_general");
-    if (activation < DIMN_ACT_RELU || activation > DIMN_ACT_SOFTPLUS) return fail(DIMN_ERR_UNSUP, "dimn_set_activation: unknown activation %d", activation);
+    if (activation < DIMN_ACT_RELU || activation > DIMN_ACT_LAST) return fail(DIMN_ERR_UNSUP, "dimn_set_activation: unknown activation %d", activation);
     CHK(use_device(h));
     CHK(sync_lanes_fwd(h));
     if (activation != DIMN_ACT_RELU && !h->d_G) {

@@ -239,6 +239,14 @@ __device__ __forceinline__ void hidden_act(int act, float a, float& f, float& df
         case 3: { const float t = tanhf(a); f = t; df = 1.f - t * t; break; }
         case 4: { const float e = expm1f(a); f = a > 0.f ? a : e; df = a > 0.f ? 1.f : e + 1.f; break; }
         case 5: f = softplus_f(a); df = sigmoid_f(a); break;
+        case 6: { const float e = expm1f(a); f = 1.0507009873554805f * (a > 0.f ? a : 1.6732632423543772f * e);          // selu
+                  df = 1.0507009873554805f * (a > 0.f ? 1.f : 1.6732632423543772f * (e + 1.f)); break; }
+        case 7: { const float r = 1.f / (1.f + fabsf(a)); f = a * r; df = r * r; break; }                                  // softsign
+        case 8: { const float s = sigmoid_f(a); f = a * s; df = s + a * s * (1.f - s); break; }                           // swish
+        case 9: { const float c = 0.5f * (1.f + erff(a * 0.70710678118654752f)); f = a * c;                                // gelu (erf form)
+                  df = c + a * 0.3989422804014327f * expf(-0.5f * a * a); break; }
+        case 10: { const float e = expf(a); f = e; df = e; break; }                                                        // exponential
+        case 11: { const float y = 0.2f * a + 0.5f; f = y < 0.f ? 0.f : (y > 1.f ? 1.f : y); df = (a > -2.5f && a < 2.5f) ? 0.2f : 0.f; break; }   // hard_sigmoid
         default: f = a > 0.f ? a : 0.f; df = a > 0.f ? 1.f : 0.f; break;
     }
 }

@@ -162,6 +162,14 @@ int dimn_get_adam_state(dimn_handle h, int32_t k, int32_t which, float* W1, floa
 #define DIMN_ACT_TANH 3
 #define DIMN_ACT_ELU 4       /* alpha = 1 (Keras default) */
 #define DIMN_ACT_SOFTPLUS 5
+/* ABI 8: the rest of keras.activations' element-wise names (TF / Keras 2.x definitions; `softmax` is not element-wise and stays loud) */
+#define DIMN_ACT_SELU 6          /* scale * (x > 0 ? x : alpha * expm1(x)), scale = 1.0507009873554805, alpha = 1.6732632423543772 */
+#define DIMN_ACT_SOFTSIGN 7      /* x / (1 + |x|)                                     */
+#define DIMN_ACT_SWISH 8         /* x * sigmoid(x)                                    */
+#define DIMN_ACT_GELU 9          /* 0.5 x (1 + erf(x / sqrt 2)): keras gelu(approximate=False) */
+#define DIMN_ACT_EXPONENTIAL 10  /* exp(x)                                            */
+#define DIMN_ACT_HARD_SIGMOID 11 /* clip(0.2 x + 0.5, 0, 1) (Keras 2.x)               */
+#define DIMN_ACT_LAST DIMN_ACT_HARD_SIGMOID
 int dimn_set_activation(dimn_handle h, int32_t activation);
 
 int dimn_reset_optimizer(dimn_handle h);

@@ -236,13 +236,23 @@ static inline void hidden_act(int act, real a, real* f, real* df) {
         case DIMN_ACT_TANH: { const real t = (real)tanh((double)a); *f = t; *df = 1 - t * t; break; }
         case DIMN_ACT_ELU: { const real e = (real)expm1((double)a); *f = a > 0 ? a : e; *df = a > 0 ? (real)1 : e + 1; break; }
         case DIMN_ACT_SOFTPLUS: *f = softplus_r(a); *df = sigmoid_r(a); break;
+        /* keras.activations, TF / Keras 2.x: selu (scale, alpha as published), softsign, swish, gelu (erf form), exponential, hard_sigmoid */
+        case DIMN_ACT_SELU: { const real e = (real)expm1((double)a); *f = (real)1.0507009873554805 * (a > 0 ? a : (real)1.6732632423543772 * e);
+                              *df = (real)1.0507009873554805 * (a > 0 ? (real)1 : (real)1.6732632423543772 * (e + 1)); break; }
+        case DIMN_ACT_SOFTSIGN: { const real r = 1 / (1 + (a < 0 ? -a : a)); *f = a * r; *df = r * r; break; }
+        case DIMN_ACT_SWISH: { const real s = sigmoid_r(a); *f = a * s; *df = s + a * s * (1 - s); break; }
+        case DIMN_ACT_GELU: { const real c = (real)(0.5 * (1.0 + erf((double)a * 0.70710678118654752))); *f = a * c;
+                              *df = c + a * (real)(0.3989422804014327 * exp(-0.5 * (double)a * (double)a)); break; }
+        case DIMN_ACT_EXPONENTIAL: { const real e = (real)exp((double)a); *f = e; *df = e; break; }
+        case DIMN_ACT_HARD_SIGMOID: { const real y = (real)0.2 * a + (real)0.5; *f = y < 0 ? 0 : (y > 1 ? (real)1 : y);
+                                      *df = (a > (real)-2.5 && a < (real)2.5) ? (real)0.2 : 0; break; }
         default: *f = a > 0 ? a : 0; *df = a > 0 ? (real)1 : (real)0; break;     /* relu */
     }
 }
 
 int dimo_set_activation(dimo_handle h, int32_t activation) {
     if (!h) return fail(DIMN_ERR_ARG, "null handle");
-    if (activation < DIMN_ACT_RELU || activation > DIMN_ACT_SOFTPLUS) return fail(DIMN_ERR_UNSUP, "unknown activation id");
+    if (activation < DIMN_ACT_RELU || activation > DIMN_ACT_LAST) return fail(DIMN_ERR_UNSUP, "unknown activation id");
     h->act = activation;
     return DIMN_OK;
 }

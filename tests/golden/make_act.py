@@ -13,7 +13,11 @@ import torch
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_act.npz")
 ACTS = {"linear": lambda a: a, "sigmoid": torch.sigmoid, "tanh": torch.tanh,
-        "elu": torch.nn.functional.elu, "softplus": torch.nn.functional.softplus}
+        "elu": torch.nn.functional.elu, "softplus": torch.nn.functional.softplus,
+        # round 5: the rest of keras.activations' element-wise names, in their TF / Keras 2.x definitions
+        "selu": torch.nn.functional.selu, "softsign": torch.nn.functional.softsign, "swish": torch.nn.functional.silu,
+        "gelu": lambda a: torch.nn.functional.gelu(a, approximate="none"), "exponential": torch.exp,
+        "hard_sigmoid": lambda a: torch.clamp(0.2 * a + 0.5, 0.0, 1.0)}
 
 
 def main():

@@ -171,13 +171,13 @@ def test_more_second_layer_workgroups_than_compute_units(monkeypatch):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("name", ["linear", "sigmoid", "tanh", "elu", "softplus"])
+@pytest.mark.parametrize("name", ["linear", "sigmoid", "tanh", "elu", "softplus", "selu", "softsign", "swish", "gelu", "exponential", "hard_sigmoid"])
 def test_hidden_activations_match_autograd_golden(name):
     from helpers import check_activation_kat
     check_activation_kat(_hip(), name, rtol=2e-3, atol=3e-6)
 
 
-@pytest.mark.parametrize("name,mid", [("tanh", "1"), ("sigmoid", "0"), ("elu", "1"), ("linear", "0")])
+@pytest.mark.parametrize("name,mid", [("tanh", "1"), ("sigmoid", "0"), ("elu", "1"), ("linear", "0"), ("gelu", "1"), ("selu", "0"), ("swish", "1")])
 def test_hidden_activation_training_matches_oracle_h256(name, mid, monkeypatch):
     """Other activations carry their gate f'(A)*keep*scale in a buffer (relu derives it from Dd > 0): both
     second-layer paths of the H = 256 kernels, two epochs against the oracle."""

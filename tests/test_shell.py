@@ -154,7 +154,7 @@ def test_module_functions():
 
 def test_unsupported_architecture_is_loud():
     net = multinet_with(FakeEngine, ncores=1,
-                   architecture=[{"type": "dense", "neurons": 8, "activation": "swish"}])
+                   architecture=[{"type": "dense", "neurons": 8, "activation": "softmax"}])
     with pytest.raises(NotImplementedError):
         net.build([10])
     with pytest.raises(NotImplementedError):           # two hidden layers: the general path, which this injected factory lacks
