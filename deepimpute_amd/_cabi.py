@@ -44,7 +44,9 @@ class Layer(C.Structure):
 
 
 PRECISIONS = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
-LOSSES = {"wmse": 0, "wmse_binary": 1, "mean_squared_error": 2, "mse": 2, "mean_absolute_error": 3, "mae": 3}
+LOSSES = {"wmse": 0, "wmse_binary": 1, "mean_squared_error": 2, "mse": 2, "mean_absolute_error": 3, "mae": 3,
+          # round 5: the other element-wise keras.losses names (and their Keras aliases)
+          "mean_squared_logarithmic_error": 4, "msle": 4, "logcosh": 5, "log_cosh": 5, "huber": 6, "huber_loss": 6, "poisson": 7}
 
 _H = C.c_void_p
 _i32 = C.c_int32

@@ -732,7 +732,7 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
 // rate of the Dropout layer that follows it (0: none); the softplus output layer of out_dim units is implied.
 extern "C" int dimn_create_general(const dimn_config* cfg, const int32_t* D, const dimn_layer* layers, int32_t n_layers, int32_t loss, dimn_handle* out) {
     if (!cfg || !layers || n_layers < 1 || n_layers > 16) return fail(DIMN_ERR_ARG, "dimn_create_general: 1..16 hidden layers expected");
-    if (loss < DIMN_LOSS_WMSE || loss > DIMN_LOSS_MAE) return fail(DIMN_ERR_UNSUP, "dimn_create_general: unknown loss id %d", loss);
+    if (loss < DIMN_LOSS_WMSE || loss > DIMN_LOSS_LAST) return fail(DIMN_ERR_UNSUP, "dimn_create_general: unknown loss id %d", loss);
     for (int l = 0; l < n_layers; ++l) {
         if (layers[l].neurons < 1) return fail(DIMN_ERR_ARG, "dimn_create_general: layer %d has no neurons", l);
         if (layers[l].activation < DIMN_ACT_RELU || layers[l].activation > DIMN_ACT_LAST) return fail(DIMN_ERR_UNSUP, "dimn_create_general: unknown activation id in layer %d", l);

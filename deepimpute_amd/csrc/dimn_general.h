@@ -313,7 +313,18 @@ __global__ __launch_bounds__(256) void k_gen_output(float* __restrict__ Z, int l
         const float er = y - sp;
         float term, dy;                                          // loss term and dL/dyhat * N
         if (loss == DIMN_LOSS_MAE) { term = fabsf(er); dy = er > 0.f ? -1.f : (er < 0.f ? 1.f : 0.f); }
-        else {
+        else if (loss == DIMN_LOSS_MSLE) {                       // keras: first_log = log(max(yhat, eps) + 1), second_log = log(max(y, eps) + 1)
+            const float a = fmaxf(sp, 1e-7f), d = log1pf(fmaxf(y, 1e-7f)) - log1pf(a);
+            term = d * d; dy = sp > 1e-7f ? -2.f * d / (a + 1.f) : 0.f;
+        } else if (loss == DIMN_LOSS_LOGCOSH) {                  // x + softplus(-2x) - log 2, x = yhat - y; d/dx = tanh x
+            const float x = -er;
+            term = x + softplus_f(-2.f * x) - 0.69314718055994531f; dy = tanhf(x);
+        } else if (loss == DIMN_LOSS_HUBER) {                    // delta = 1
+            const float ae = fabsf(er);
+            term = ae <= 1.f ? 0.5f * er * er : ae - 0.5f; dy = ae <= 1.f ? -er : (er > 0.f ? -1.f : 1.f);
+        } else if (loss == DIMN_LOSS_POISSON) {
+            term = sp - y * logf(sp + 1e-7f); dy = 1.f - y / (sp + 1e-7f);
+        } else {
             const float w = loss == DIMN_LOSS_WMSE ? y : (loss == DIMN_LOSS_WMSE_BINARY ? (y > 0.f ? 1.f : 0.f) : 1.f);
             term = w * er * er; dy = -2.f * w * er;
         }

@@ -98,6 +98,12 @@ typedef struct dimn_layer {
 #define DIMN_LOSS_WMSE_BINARY 1   /* wMSE(binary=True)                                  */
 #define DIMN_LOSS_MSE 2           /* keras.losses.mean_squared_error                    */
 #define DIMN_LOSS_MAE 3           /* keras.losses.mean_absolute_error                   */
+/* ABI 8: the other element-wise keras.losses a regression on log1p counts can be given (Keras 2.x definitions, epsilon = 1e-7) */
+#define DIMN_LOSS_MSLE 4          /* mean_squared_logarithmic_error: (log(max(y, eps) + 1) - log(max(yhat, eps) + 1))^2 */
+#define DIMN_LOSS_LOGCOSH 5       /* logcosh: log(cosh(yhat - y)) = x + softplus(-2x) - log 2                           */
+#define DIMN_LOSS_HUBER 6         /* huber, delta = 1: e^2 / 2 for |e| <= 1, |e| - 1/2 beyond                           */
+#define DIMN_LOSS_POISSON 7       /* poisson: yhat - y log(yhat + eps)                                                  */
+#define DIMN_LOSS_LAST DIMN_LOSS_POISSON
 int dimn_create_general(const dimn_config* cfg, const int32_t* D, const dimn_layer* layers, int32_t n_layers,
                         int32_t loss, dimn_handle* out);
 /* Keras-layout kernel W[in][out] and bias[out] of dense layer `layer` (0 .. n_layers; the last one is the output layer);

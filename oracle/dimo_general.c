@@ -220,6 +220,22 @@ static void forward(struct dimog_s* h, int k, const int32_t* rows, int cnt, int 
 static inline void loss_term(int loss, real y, real yh, real* term, real* dy) {
     const real e = y - yh;
     if (loss == DIMN_LOSS_MAE) { *term = (real)fabs((double)e); *dy = e > 0 ? (real)-1 : (e < 0 ? (real)1 : (real)0); return; }
+    /* keras.losses (2.x, epsilon 1e-7): mean_squared_logarithmic_error, logcosh, huber (delta 1), poisson -- element terms; the mean
+     * over the last axis and over the batch is the caller's 1 / N */
+    if (loss == DIMN_LOSS_MSLE) {
+        const real a = yh > (real)1e-7 ? yh : (real)1e-7, yy = y > (real)1e-7 ? y : (real)1e-7;
+        const real d = (real)log1p((double)yy) - (real)log1p((double)a);
+        *term = d * d; *dy = yh > (real)1e-7 ? (real)-2 * d / (a + 1) : 0; return;
+    }
+    if (loss == DIMN_LOSS_LOGCOSH) {
+        const double x = -(double)e;
+        *term = (real)(x + log1p(exp(-2.0 * x)) - 0.69314718055994531); *dy = (real)tanh(x); return;
+    }
+    if (loss == DIMN_LOSS_HUBER) {
+        const real ae = e < 0 ? -e : e;
+        *term = ae <= 1 ? (real)0.5 * e * e : ae - (real)0.5; *dy = ae <= 1 ? -e : (e > 0 ? (real)-1 : (real)1); return;
+    }
+    if (loss == DIMN_LOSS_POISSON) { *term = yh - y * (real)log((double)yh + 1e-7); *dy = 1 - y / (yh + (real)1e-7); return; }
     const real w = loss == DIMN_LOSS_WMSE ? y : (loss == DIMN_LOSS_WMSE_BINARY ? (real)(y > 0) : (real)1);
     *term = w * e * e; *dy = (real)-2 * w * e;
 }

@@ -18,12 +18,22 @@ import torch
 from make_epochs import dropout_keep
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_general.npz")
-LOSSES = ("wmse", "wmse_binary", "mse", "mae")
+LOSSES = ("wmse", "wmse_binary", "mse", "mae", "msle", "logcosh", "huber", "poisson")
 
 
 def loss_fn(name, y, yh):
     if name == "mae":
         return torch.mean(torch.abs(y - yh))
+    if name == "msle":                                           # keras.losses.mean_squared_logarithmic_error (epsilon 1e-7)
+        return torch.mean((torch.log(torch.clamp(y, min=1e-7) + 1.0) - torch.log(torch.clamp(yh, min=1e-7) + 1.0)) ** 2)
+    if name == "logcosh":                                        # keras.losses.logcosh: x + softplus(-2x) - log 2
+        x = yh - y
+        return torch.mean(x + torch.nn.functional.softplus(-2.0 * x) - np.log(2.0))
+    if name == "huber":                                          # keras.losses.huber, delta = 1
+        e = yh - y
+        return torch.mean(torch.where(e.abs() <= 1.0, 0.5 * e * e, e.abs() - 0.5))
+    if name == "poisson":                                        # keras.losses.poisson
+        return torch.mean(yh - y * torch.log(yh + 1e-7))
     w = y if name == "wmse" else ((y > 0).to(y.dtype) if name == "wmse_binary" else torch.ones_like(y))
     return torch.mean(w * (y - yh) ** 2)
 

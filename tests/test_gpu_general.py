@@ -18,7 +18,7 @@ def _oracle():
     return GeneralOracleEngine
 
 
-@pytest.mark.parametrize("loss", ["wmse", "wmse_binary", "mse", "mae"])
+@pytest.mark.parametrize("loss", ["wmse", "wmse_binary", "mse", "mae", "msle", "logcosh", "huber", "poisson"])
 def test_general_kat_matches_autograd_golden(loss):
     check_general_kat(_hip(), loss, rtol=3e-4, atol=2e-6)
 
