@@ -2763,7 +2763,7 @@ static inline bool counts_load4(const int64_t* p, __m256d& x) {
 // per element, which AVX2 has no instruction for and the compiler therefore leaves scalar: 1.45 ns per element and core on the GPU boxes'
 // hosts against 0.66 here (profiles/r05_dropin_host_side.txt).  The multiplies are three 32 x 32 -> 64 products each (`vpmuludq`), sums are
 // per lane (addition mod 2^64 commutes: the same checksum to the bit), the range / integrality tests are compares and one truncating
-// conversion, the sign test is an OR over all bit patterns.  tests/test_abi.py checks it against the scalar form.
+// conversion, the sign test is an OR over all bit patterns.  tests/test_abi.py checks the checksum against a numpy restatement of its definition.
 static inline __m256i counts_mul64(__m256i v, __m256i clo, __m256i chi) {
     const __m256i lo = _mm256_mul_epu32(v, clo);
     const __m256i cross = _mm256_add_epi64(_mm256_mul_epu32(_mm256_srli_epi64(v, 32), clo), _mm256_mul_epu32(v, chi));
@@ -2823,7 +2823,6 @@ template <typename ST>
 static void counts_scan(const ST* raw, int64_t g, int64_t r0, int64_t r1, float* dst, double* vmax, uint64_t* sum, int* ok) {
     const unsigned hw = std::thread::hardware_concurrency();
     const int64_t rows = r1 - r0;
-    const bool scalar = getenv("DIMN_SCAN_SCALAR") && atoi(getenv("DIMN_SCAN_SCALAR")) != 0;      // tests: the plain C++ form of the same pass
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw ? hw / 2 : 8, 64), rows * g / (1 << 20)));
     std::vector<double> mx((size_t)nt, -INFINITY);
     std::vector<uint64_t> cs((size_t)nt, 0);
@@ -2834,8 +2833,7 @@ static void counts_scan(const ST* raw, int64_t g, int64_t r0, int64_t r1, float*
         for (int64_t i = a; i < b; ++i) {
             const ST* src = raw + i * g;
             const uint64_t base = (uint64_t)i * (uint64_t)g;
-            if (scalar) counts_scan_scalar(src, dst ? dst + (i - r0) * g : nullptr, 0, g, base, rs);
-            else if (dst) counts_scan_row<true>(src, dst + (i - r0) * g, g, base, rs);
+            if (dst) counts_scan_row<true>(src, dst + (i - r0) * g, g, base, rs);
             else counts_scan_row<false>(src, nullptr, g, base, rs);
         }
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(__AVX2__)

@@ -170,7 +170,7 @@ def _parse_architecture(architecture):
 
 def _loss_name(loss):
     """The loss of NN_parameters['loss'] (multinet.py:150-162: the module's wMSE by name or callable, or a keras.losses
-    name) as an id of the engines: wmse / wmse_binary / mean_squared_error / mean_absolute_error."""
+    name) as an id of the engines (_cabi.LOSSES: wmse / wmse_binary / mean_squared_error / mean_absolute_error / msle / logcosh / huber / poisson)."""
     from ._cabi import LOSSES
     if callable(loss):
         binary = bool(getattr(loss, "keywords", {}) and loss.keywords.get("binary"))       # functools.partial(wMSE, binary=True)
@@ -180,7 +180,7 @@ def _loss_name(loss):
     name = str(loss).lower()
     if name in LOSSES:
         return name
-    print('Unknown loss: {}. Aborting.'.format(loss))       # multinet.py:160-161 (keras.losses names beyond mse / mae are not implemented)
+    print('Unknown loss: {}. Aborting.'.format(loss))       # multinet.py:160-161 (_cabi.LOSSES: wMSE and the element-wise keras.losses)
     exit(1)
 
 

@@ -92,10 +92,22 @@ def test_constructing_a_multinet_has_no_side_effects():
     net.close()                                                                       # closing an unused object is legal and quiet
 
 
-def test_vector_form_of_the_count_scan_equals_the_scalar_one(monkeypatch):
-    """dimn_counts_checksum is host code (no GPU): the AVX2 form of the pass (round 5) must give the checksum of the plain C++ loop it
-    replaces to the bit -- ragged row lengths (vector body + scalar tail), several threads, NaN / Inf / -0.0 / negative / huge / fractional
-    values at every lane position."""
+def _checksum_by_definition(frame):
+    """dimn_counts_checksum restated in numpy: sum over the elements of splitmix64(bits((double)x) + GOLD * (position + 1)), mod 2^64."""
+    bits = np.ascontiguousarray(frame, np.float64).reshape(-1).view(np.uint64)
+    with np.errstate(over="ignore"):
+        x = bits + np.uint64(0x9E3779B97F4A7C15) * (np.arange(bits.size, dtype=np.uint64) + np.uint64(1))
+        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+        return int(np.add.reduce(x, dtype=np.uint64))
+
+
+def test_count_scan_checksum_equals_its_definition():
+    """dimn_counts_checksum is host code (no GPU): the AVX2 form of the pass (round 5: three vpmuludq per 64-bit multiply, per-lane sums,
+    a scalar tail, several threads) must give the checksum its definition gives -- restated here in numpy -- to the bit: ragged row
+    lengths, NaN / Inf / -0.0 / negative / huge / fractional values at every lane position; an int64 frame hashes like its float64 twin
+    (dimn_counts_checksum_typed), values outside the count range and beyond 32 bits included."""
     fns = _lib.load()
     rng = np.random.default_rng(5)
 
@@ -111,21 +123,12 @@ def test_vector_form_of_the_count_scan_equals_the_scalar_one(monkeypatch):
             b = a.copy()
             b[i % n, (7 * i + i % 4) % g] = v
             frames.append(b)
-        monkeypatch.setenv("DIMN_SCAN_SCALAR", "1")
-        want = [checksum(f) for f in frames]
-        monkeypatch.setenv("DIMN_SCAN_SCALAR", "0")
         got = [checksum(f) for f in frames]
-        assert got == want
-        assert len(set(want)) == len(want)                          # every edit changes the checksum
-        # an int64 frame of the same numbers hashes like its float64 twin (dimn_counts_checksum_typed), vector and scalar form alike
+        assert got == [_checksum_by_definition(f) for f in frames]
+        assert len(set(got)) == len(got)                            # every edit changes the checksum
         ai = a.astype(np.int64)
         for v in (0, -1, 4194304, 4194305, 1 << 33, -(1 << 40)):
             ai[n // 2, g // 3] = v
-            twin = ai.astype(np.float64)
-            sums = []
-            for mode in ("1", "0"):
-                monkeypatch.setenv("DIMN_SCAN_SCALAR", mode)
-                cs = C.c_uint64(0)
-                assert fns["counts_checksum_typed"](ai.ctypes.data, 1, n, g, C.byref(cs)) == 0
-                sums.append(cs.value)
-            assert sums[0] == sums[1] == checksum(twin), v
+            cs = C.c_uint64(0)
+            assert fns["counts_checksum_typed"](ai.ctypes.data, 1, n, g, C.byref(cs)) == 0
+            assert cs.value == _checksum_by_definition(ai.astype(np.float64)), v
