@@ -731,8 +731,17 @@ extern "C" int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle
 // build(inputdims) for ANY architecture list (multinet.py:126-167): `layers` = the hidden Dense layers in order, each with the
 // rate of the Dropout layer that follows it (0: none); the softplus output layer of out_dim units is implied.
 extern "C" int dimn_create_general(const dimn_config* cfg, const int32_t* D, const dimn_layer* layers, int32_t n_layers, int32_t loss, dimn_handle* out) {
-    if (!cfg || !layers || n_layers < 1 || n_layers > 16) return fail(DIMN_ERR_ARG, "dimn_create_general: 1..16 hidden layers expected");
+    if (!cfg || !layers || n_layers < 1 || n_layers > 17) return fail(DIMN_ERR_ARG, "dimn_create_general: 1..16 hidden layers expected");
     if (loss < DIMN_LOSS_WMSE || loss > DIMN_LOSS_LAST) return fail(DIMN_ERR_UNSUP, "dimn_create_general: unknown loss id %d", loss);
+    // A Dropout layer BEFORE the first Dense layer (dropout on the inputs, multinet.py:139-141 allows it) is written as a leading
+    // entry with neurons == 0 and its rate; the hidden layers follow.
+    float in_rate = 0.f;
+    if (layers[0].neurons == 0) {
+        in_rate = layers[0].dropout_rate;
+        if (!(in_rate > 0.f && in_rate < 1.f) || n_layers < 2) return fail(DIMN_ERR_ARG, "dimn_create_general: an input-dropout entry needs a rate in (0,1) and a hidden layer behind it");
+        ++layers; --n_layers;
+    }
+    if (n_layers > 16) return fail(DIMN_ERR_ARG, "dimn_create_general: 1..16 hidden layers expected");
     for (int l = 0; l < n_layers; ++l) {
         if (layers[l].neurons < 1) return fail(DIMN_ERR_ARG, "dimn_create_general: layer %d has no neurons", l);
         if (layers[l].activation < DIMN_ACT_RELU || layers[l].activation > DIMN_ACT_LAST) return fail(DIMN_ERR_UNSUP, "dimn_create_general: unknown activation id in layer %d", l);
@@ -743,7 +752,7 @@ extern "C" int dimn_create_general(const dimn_config* cfg, const int32_t* D, con
     dimn_handle h = nullptr;
     CHK(create_common(&c, D, true, &h));
     h->cfg.loss_binary = loss == DIMN_LOSS_WMSE_BINARY;
-    const int rc = gen_setup(h, layers, n_layers, loss);
+    const int rc = gen_setup(h, layers, n_layers, loss, in_rate);
     if (rc != DIMN_OK) { dimn_destroy(h); return rc; }
     *out = h;
     return DIMN_OK;

@@ -274,14 +274,21 @@ __global__ __launch_bounds__(256) void k_gen_splitk_fin(const GDesc* __restrict_
 // Xb[k][b][Dp_k] = X_k[rows[b]][:]  (the batch rows of every sub-net, dense, so that every GEMM operand is a plain matrix)
 template <typename XT>
 __global__ __launch_bounds__(256) void k_gen_gather_batch(const SubnetDev* __restrict__ sn, const XT* __restrict__ X, const int32_t* __restrict__ rows,
-                                                          int64_t row0, int b_cnt, float* __restrict__ Xb, int64_t xb_stride, int ldx) {
+                                                          int64_t row0, int b_cnt, float* __restrict__ Xb, int64_t xb_stride, int ldx,
+                                                          float rate, float scale, uint64_t seed, uint32_t epoch, uint32_t step) {
+    // rate > 0: a Dropout layer in front of the first Dense layer (training only): element (b, d) of sub-net kg keeps its value, scaled, iff the
+    // Philox stream of dropout ordinal 0 says so (element index b * D + d, as every dropout layer counts its elements)
     const int k = blockIdx.y;
     const SubnetDev s = sn[k];
     for (int b = blockIdx.x; b < b_cnt; b += gridDim.x) {
         const int64_t row = rows ? rows[b] : row0 + b;
         const XT* src = X + s.xoff + row * s.Dp;
         float* dst = Xb + (int64_t)k * xb_stride + (int64_t)b * ldx;
-        for (int d = threadIdx.x; d < s.Dp; d += 256) dst[d] = sizeof(XT) == 2 ? bf16_to_f32((bf16_t)src[d]) : (float)src[d];
+        for (int d = threadIdx.x; d < s.Dp; d += 256) {
+            float v = sizeof(XT) == 2 ? bf16_to_f32((bf16_t)src[d]) : (float)src[d];
+            if (rate > 0.f) v = (d < s.D && dimn_dropout_keep(seed, (uint32_t)s.kg, epoch, step, (uint32_t)(b * s.D + d), rate)) ? v * scale : 0.f;
+            dst[d] = v;
+        }
     }
 }
 

@@ -198,6 +198,13 @@ class GeneralEngine(Engine):
         self.D = [int(d) for d in D]
         self.K = len(self.D)
         self.layers = [(int(n), "linear" if a is None else str(a).lower(), float(p)) for n, a, p in layers]
+        # a leading (0, _, rate) entry: a Dropout layer BEFORE the first Dense layer (dropout on the inputs; include/dimn.h dimn_create_general)
+        self.input_dropout = 0.0
+        if self.layers and self.layers[0][0] == 0:
+            self.input_dropout = self.layers[0][2]
+            self.layers = self.layers[1:]
+        if not self.layers:
+            raise ValueError("architecture needs at least one dense layer")
         self.L = len(self.layers)
         self.H = self.layers[0][0]
         self.O = int(out_dim)
@@ -214,10 +221,11 @@ class GeneralEngine(Engine):
                           beta2=float(beta2), eps=float(eps), loss_binary=int(self.loss == "wmse_binary"), seed=int(seed),
                           precision=_cabi.PRECISIONS[str(precision).lower()])
         self.precision = "bf16" if self.cfg.precision else "fp32"
-        arr = (_cabi.Layer * self.L)(*[_cabi.Layer(n, _cabi.ACTIVATIONS[a], p) for n, a, p in self.layers])
+        wire = ([(0, "linear", self.input_dropout)] if self.input_dropout > 0 else []) + self.layers
+        arr = (_cabi.Layer * len(wire))(*[_cabi.Layer(n, _cabi.ACTIVATIONS[a], p) for n, a, p in wire])
         self._h = C.c_void_p()
         self.n_cells = self.n_train = self.n_val = 0
-        self._check(self._f["create_general"](C.byref(self.cfg), p_i32(i32(self.D)), arr, self.L, _cabi.LOSSES[self.loss], C.byref(self._h)))
+        self._check(self._f["create_general"](C.byref(self.cfg), p_i32(i32(self.D)), arr, len(wire), _cabi.LOSSES[self.loss], C.byref(self._h)))
         self.activation = self.layers[0][1]
 
     def layer_shape(self, k, layer):

@@ -148,13 +148,17 @@ def _suffix(base, i):
 
 def layer_names(K, layers):
     """Keras' automatic names in build()'s creation order (multinet.py:132-146): inputs input_1..input_K; then for every
-    architecture entry, one layer per branch; the K output Dense layers last.  -> (inputs, hidden[l][k], dropout[l][k] or None, outputs[k])."""
+    architecture entry, one layer per branch; the K output Dense layers last.  -> (inputs, hidden[l][k], dropout[l][k] or None, outputs[k]);
+    hidden[0] is None for a leading (0, _, rate) entry = a Dropout layer before the first Dense layer."""
     inputs = ["input_%d" % (k + 1) for k in range(K)]
     dense_i = drop_i = 0
     hidden, drops = [], []
-    for _, _, rate in layers:
-        hidden.append([_suffix("dense", dense_i + k) for k in range(K)])
-        dense_i += K
+    for units, _, rate in layers:
+        if units == 0:                                   # a Dropout layer before the first Dense layer: no Dense of its own
+            hidden.append(None)
+        else:
+            hidden.append([_suffix("dense", dense_i + k) for k in range(K)])
+            dense_i += K
         if rate > 0:
             drops.append([_suffix("dropout", drop_i + k) for k in range(K)])
             drop_i += K
@@ -180,9 +184,10 @@ def model_json(inputdims, layers, out_dim, seed, extra=None):
                   for nm, d in zip(inputs, inputdims)]
     prev = list(inputs)
     for l, (units, act, rate) in enumerate(layers):
-        for k in range(K):
-            cfg_layers.append(dense(hidden[l][k], units, act, prev[k]))
-        prev = list(hidden[l])
+        if hidden[l] is not None:
+            for k in range(K):
+                cfg_layers.append(dense(hidden[l][k], units, act, prev[k]))
+            prev = list(hidden[l])
         if drops[l] is not None:
             for k in range(K):
                 cfg_layers.append({"class_name": "Dropout", "name": drops[l][k], "inbound_nodes": [[[prev[k], 0, 0, {}]]],

@@ -146,7 +146,8 @@ def _parse_architecture(architecture):
     """[(neurons, activation, dropout rate behind it)] of an architecture list (multinet.py:135-143: a sequence of
     {"type": "dense", "neurons", "activation"} / {"type": "dropout", "rate"} entries; other types are skipped with the
     reference's message).  Consecutive Dropout layers compose (keep probabilities multiply would change the stream
-    semantics, so they are rejected); a Dropout before the first Dense layer (dropout on the inputs) is not implemented."""
+    semantics, so they are rejected).  A Dropout before the first Dense layer (dropout on the inputs) becomes a leading
+    (0, "linear", rate) entry: the general path masks the batch's predictor rows (dimn_create_general)."""
     from ._cabi import ACTIVATIONS
     layers = []
     for spec in architecture:
@@ -158,12 +159,15 @@ def _parse_architecture(architecture):
                 raise NotImplementedError("hidden activation %r: the gfx950 kernels implement %s" % (name, sorted(ACTIVATIONS)))
             layers.append([int(spec["neurons"]), act, 0.0])
         elif kind == "dropout":
-            if not layers or layers[-1][2] > 0.0:
-                raise NotImplementedError("a Dropout layer must follow a Dense layer (got %r)" % (architecture,))
+            if not layers:
+                layers.append([0, "linear", float(spec["rate"])])          # dropout on the inputs
+                continue
+            if layers[-1][2] > 0.0:
+                raise NotImplementedError("two Dropout layers in a row (got %r)" % (architecture,))
             layers[-1][2] = float(spec["rate"])
         else:
             print("Unknown layer type.")       # the reference skips such entries (multinet.py:142-143)
-    if not layers:
+    if not [l for l in layers if l[0] > 0]:
         raise NotImplementedError("architecture needs at least one dense layer")
     return [tuple(l) for l in layers]
 
@@ -431,7 +435,7 @@ class MultiNet:
                         continue
                     with np.load(path) as z:
                         blobs.update({f: z[f] for f in z.files})
-                n_dense = len(layers) + 1
+                n_dense = len([l for l in layers if l[0] > 0]) + 1
                 missing = [key for k in range(len(dims)) for l in range(1, n_dense + 1) for key in ("W%d_%d" % (l, k), "b%d_%d" % (l, k)) if key not in blobs]
                 if missing and not problem:
                     problem = " the shards lack %d arrays (first: %s)" % (len(missing), missing[0])
@@ -445,11 +449,11 @@ class MultiNet:
             inputs, hidden, drops, outputs = keras_io.layer_names(K, layers)
             order = list(inputs)
             for l in range(len(layers)):
-                order += hidden[l] + (drops[l] or [])
+                order += (hidden[l] or []) + (drops[l] or [])
             order += outputs
             weights = {}
             for k in range(K):
-                for l, name in enumerate([h[k] for h in hidden] + [outputs[k]], start=1):
+                for l, name in enumerate([h[k] for h in hidden if h is not None] + [outputs[k]], start=1):
                     weights[name] = (blobs["W%d_%d" % (l, k)], blobs["b%d_%d" % (l, k)])
             keras_io.write_weights_h5(os.path.join(self.outputdir, "model.h5"), order, weights)
         if comm is not None:

@@ -84,7 +84,8 @@ int dimn_create(const dimn_config* cfg, const int32_t* D, dimn_handle* out);
 
 /* build(inputdims) for ANY architecture list and loss (multinet.py:135-143: a sequence of Dense / Dropout layers;
  * :150-162: loss by name; parser.py:50-66: any batch size / hidden width): the hidden Dense layers in order, each with
- * the rate of the Dropout layer behind it (0 = none); Dense(out_dim, softplus) is implied (multinet.py:145).
+ * the rate of the Dropout layer behind it (0 = none); Dense(out_dim, softplus) is implied (multinet.py:145).  A Dropout layer BEFORE
+ * the first Dense layer (dropout on the inputs; ABI 8) is a leading entry with neurons == 0 and its rate: it is dropout layer 0.
  * cfg->hidden / dropout_rate / loss_binary are ignored here.  Every other entry point works on such a handle; weights of
  * models with more than one hidden layer move through dimn_set/get_layer_weights.  Dropout layer j (j-th layer with a
  * rate > 0) draws from the Philox stream keyed (seed, sub-net, epoch, step | j << 24, element): j = 0 is the stream

@@ -44,6 +44,7 @@ typedef struct {
 struct dimog_s {
     dimn_config cfg;
     int K, O, B, L, loss;
+    float in_rate;                             /* rate of a Dropout layer before the first Dense layer (0: none) */
     dimn_layer* layers;
     int* width;                                /* [L+1] */
     gsub* s;
@@ -57,7 +58,14 @@ static int in_of(const struct dimog_s* h, const gsub* s, int l) { return l == 0 
 
 int dimog_create(const dimn_config* cfg, const int32_t* D, const dimn_layer* layers, int32_t L, int32_t loss, dimog_handle* out) {
     if (!cfg || !D || !layers || L < 1 || !out) return fail(DIMN_ERR_ARG, "create: bad argument");
+    float in_rate = 0.f;                 /* a leading entry with neurons == 0: a Dropout layer before the first Dense layer (multinet.py:139-141) */
+    if (layers[0].neurons == 0) {
+        in_rate = layers[0].dropout_rate;
+        if (!(in_rate > 0.f && in_rate < 1.f) || L < 2) return fail(DIMN_ERR_ARG, "create: bad input-dropout entry");
+        ++layers; --L;
+    }
     struct dimog_s* h = calloc(1, sizeof *h);
+    h->in_rate = in_rate;
     h->cfg = *cfg; h->K = cfg->n_subnets; h->O = cfg->out_dim; h->B = cfg->batch_size; h->L = L; h->loss = loss;
     h->layers = malloc((size_t)L * sizeof(dimn_layer)); memcpy(h->layers, layers, (size_t)L * sizeof(dimn_layer));
     h->width = malloc((size_t)(L + 1) * sizeof(int));
@@ -183,11 +191,17 @@ static inline void hidden_act(int act, real a, real* f, real* df) {
 static void forward(struct dimog_s* h, int k, const int32_t* rows, int cnt, int train, uint32_t epoch, uint32_t step) {
     gsub* s = &h->s[k];
     const uint32_t kg = (uint32_t)(h->cfg.subnet_offset + k);
+    const float irate = train ? h->in_rate : 0.f;         /* S3 on the inputs: x * (1 / (1 - p)) * [u >= p], dropout ordinal 0 */
+    const real iscale = irate > 0.f ? (real)(1.0f / (1.0f - irate)) : (real)1;
     for (int b = 0; b < cnt; ++b) {
         const float* r = h->norm + (size_t)rows[b] * h->g;
-        for (int d = 0; d < s->D; ++d) s->x[(size_t)b * s->D + d] = (real)r[s->pred[d]];
+        for (int d = 0; d < s->D; ++d) {
+            real v = (real)r[s->pred[d]];
+            if (irate > 0.f) v = dimn_dropout_keep(h->cfg.seed, kg, epoch, step & 0xFFFFFFu, (uint32_t)(b * s->D + d), irate) ? v * iscale : 0;
+            s->x[(size_t)b * s->D + d] = v;
+        }
     }
-    int dl = 0;
+    int dl = h->in_rate > 0.f ? 1 : 0;
     for (int l = 0; l <= h->L; ++l) {
         const int in = in_of(h, s, l), out = h->width[l];
         const real* prev = l == 0 ? s->x : s->h[l - 1];

@@ -65,7 +65,10 @@ def main():
     lr_, b1_, b2_, eps_ = (float(np.float32(x)) for x in (lr, b1c, b2c, eps))
     normt = torch.tensor(norm, dtype=T)
     fa = {"tanh": torch.tanh, "relu": torch.relu}
-    for name in LOSSES:
+    in_rate = 0.15                       # "wmse+input_dropout": the same model with a Dropout(0.15) layer BEFORE the first Dense layer
+    out["input_dropout_rate"] = np.float32(in_rate)
+    for name in LOSSES + ("wmse+input_dropout",):
+        indrop = name.endswith("+input_dropout")
         for k in range(K):
             params = []
             for l in range(3):
@@ -73,8 +76,10 @@ def main():
             m = [torch.zeros_like(p) for p in params]
             v = [torch.zeros_like(p) for p in params]
 
-            def forward(x, masks):
+            def forward(x, masks, in_mask=None):
                 h = x
+                if in_mask is not None:
+                    h = h * torch.tensor(in_mask, dtype=T) * float(np.float32(1.0) / (np.float32(1.0) - np.float32(in_rate)))
                 for l in range(2):
                     h = fa[acts[l]](h @ params[2 * l] + params[2 * l + 1])
                     if masks is not None:
@@ -84,9 +89,11 @@ def main():
 
             losses = []
             for t, rows in enumerate(batches):
-                masks = [dropout_keep(seed, kg0 + k, 0, t | (dl << 24), len(rows), widths[dl], rates[dl]) for dl in range(2)]
+                first = 1 if indrop else 0          # dropout ordinals count the Dropout layers of the architecture in order
+                masks = [dropout_keep(seed, kg0 + k, 0, t | ((dl + first) << 24), len(rows), widths[dl], rates[dl]) for dl in range(2)]
+                in_mask = dropout_keep(seed, kg0 + k, 0, t, len(rows), Ds[k], in_rate) if indrop else None
                 x, y = normt[rows][:, pred[k]], normt[rows][:, targ[k]]
-                loss = loss_fn(name, y, forward(x, masks))
+                loss = loss_fn(name.split("+")[0], y, forward(x, masks, in_mask))
                 grads = torch.autograd.grad(loss, params)
                 losses.append(float(loss))
                 step = t + 1

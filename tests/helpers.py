@@ -172,8 +172,10 @@ def check_general_kat(cls, loss, rtol, atol, **kw):
     z = np.load(os.path.join(GOLDEN, "kat_general.npz"))
     Ds = [int(d) for d in z["Ds"]]
     layers = [(int(w), str(a), float(p)) for w, a, p in zip(z["widths"], z["acts"], z["rates"])]
+    if loss.endswith("+input_dropout"):                  # a Dropout layer before the first Dense layer: the leading (0, _, rate) entry
+        layers = [(0, "linear", float(z["input_dropout_rate"]))] + layers
     eng = cls(Ds, layers, int(z["O"]), batch_size=int(z["B"]), learning_rate=float(z["lr"]), beta1=float(z["beta1"]), beta2=float(z["beta2"]),
-              eps=float(z["eps"]), loss=loss, seed=int(z["seed"]), subnet_offset=int(z["subnet_offset"]), **kw)
+              eps=float(z["eps"]), loss=loss.split("+")[0], seed=int(z["seed"]), subnet_offset=int(z["subnet_offset"]), **kw)
     eng.set_matrix(z["norm"])
     for k in range(len(Ds)):
         eng.set_indices(k, z["pred%d" % k], z["targ%d" % k])

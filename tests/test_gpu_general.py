@@ -18,7 +18,7 @@ def _oracle():
     return GeneralOracleEngine
 
 
-@pytest.mark.parametrize("loss", ["wmse", "wmse_binary", "mse", "mae", "msle", "logcosh", "huber", "poisson"])
+@pytest.mark.parametrize("loss", ["wmse", "wmse_binary", "mse", "mae", "msle", "logcosh", "huber", "poisson", "wmse+input_dropout"])
 def test_general_kat_matches_autograd_golden(loss):
     check_general_kat(_hip(), loss, rtol=3e-4, atol=2e-6)
 
@@ -42,9 +42,10 @@ def _pair(prob, layers, **kw):
     ([(96, "relu", 0.3), (64, "tanh", 0.0), (48, "elu", 0.1)], 200, "wmse"),   # three hidden layers, one without dropout
     ([(300, "relu", 0.2)], 333, "mse"),                                   # odd batch, keras loss by name
     ([(40, "sigmoid", 0.0)], 16, "mae"),
+    ([(0, "linear", 0.2), (96, "gelu", 0.3), (64, "selu", 0.0)], 100, "huber"),   # a Dropout layer before the first Dense layer; round-5 activations and loss
 ])
 def test_general_two_epochs_match_oracle(layers, B, loss):
-    prob = make_problem(n=700, g=600, Ds=[130, 77, 200], H=layers[0][0], O=100, seed=21)
+    prob = make_problem(n=700, g=600, Ds=[130, 77, 200], H=[l[0] for l in layers if l[0]][0], O=100, seed=21)
     a, b = _pair(prob, layers, batch_size=B, learning_rate=1e-3, seed=4242, loss=loss)
     for k in range(a.K):                                                   # Glorot init per layer: bit-exact
         for x, y in zip(a.get_weights(k), b.get_weights(k)):

@@ -146,6 +146,32 @@ def test_general_architecture_through_the_shell_matches_oracle(tmp_path):
     assert type(fresh._engine).__name__ == "HipGeneralEngine"
 
 
+def test_input_dropout_architecture_through_the_shell_matches_oracle(tmp_path):
+    """build() with a Dropout layer BEFORE the first Dense layer (multinet.py:135-143 accepts any Dense / Dropout sequence): general path,
+    the batch's predictor rows masked by dropout stream 0; fit, save (a Dropout node behind the InputLayer in model.json), reload, predict
+    against the general oracle through the same shell."""
+    from deepimpute_amd.multinet import MultiNet
+    from oracle.dimo import GeneralOracleEngine, OracleEngine
+
+    class Oracles:
+        def __new__(cls, *a, **k):
+            return OracleEngine(*a, **k)
+        general = staticmethod(GeneralOracleEngine)
+    raw = _raw(n=400, g=300, seed=9)
+    kw = dict(sub_outputdim=64, seed=11, ncores=1, verbose=0, max_epochs=3, patience=3, learning_rate=1e-3,
+              architecture=[{"type": "dropout", "rate": 0.15}, {"type": "dense", "neurons": 48, "activation": "relu"}, {"type": "dropout", "rate": 0.2}])
+    a = MultiNet(output_prefix=str(tmp_path / "a"), **kw).fit(raw, NN_lim=128)
+    b = multinet_with(Oracles, output_prefix=str(tmp_path / "b"), **kw).fit(raw, NN_lim=128)
+    assert type(a._engine).__name__ == "HipGeneralEngine" and a._engine.input_dropout == 0.15 and a.trained_epochs == b.trained_epochs == 3
+    np.testing.assert_allclose(a.history["val_loss"], b.history["val_loss"], rtol=1e-4)
+    np.testing.assert_allclose(a.history["loss"], b.history["loss"], rtol=1e-4)
+    np.testing.assert_allclose(a.predict(raw).values, b.predict(raw).values, rtol=1e-4, atol=1e-6)
+    fresh = MultiNet(output_prefix=str(tmp_path / "a"), sub_outputdim=64, seed=11, ncores=1, verbose=0)
+    fresh.predictors, fresh.targets = a.predictors, a.targets
+    np.testing.assert_allclose(fresh.predict(raw).values, a.predict(raw).values, rtol=1e-6)
+    assert fresh._engine.input_dropout == 0.15
+
+
 def test_cli_with_batch_128_and_hidden_512(tmp_path):
     """`deepImpute --batch-size 128 --hidden-neurons 512` (legal for the reference, parser.py:50-66) runs on the general path."""
     from deepimpute_amd.deepImpute import deepImpute

@@ -160,7 +160,7 @@ def test_unsupported_architecture_is_loud():
     with pytest.raises(NotImplementedError):           # two hidden layers: the general path, which this injected factory lacks
         multinet_with(FakeEngine, ncores=1, architecture=[{"type": "dense", "neurons": 8, "activation": "relu"},
                                                                     {"type": "dense", "neurons": 8, "activation": "relu"}]).build([10])
-    with pytest.raises(NotImplementedError):           # dropout on the inputs
+    with pytest.raises(NotImplementedError):           # dropout on the inputs: the general path, which this injected factory lacks
         multinet_with(FakeEngine, ncores=1, architecture=[{"type": "dropout", "rate": 0.1},
                                                                     {"type": "dense", "neurons": 8, "activation": "relu"}]).build([10])
     eng = multinet_with(FakeEngine, ncores=1,
