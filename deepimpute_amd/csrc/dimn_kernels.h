@@ -477,7 +477,9 @@ __global__ __launch_bounds__(256) void k_reduce_act(const SubnetDev* __restrict_
 
 // ---------------------------------------------------------------------------------------
 // MF: middle forward.  Workgroup = (sub-net k, output slice os of 64 columns), 8 waves: wave w
-// owns output tile ot = 4*os + (w&3) and the batch rows [32*(w>>2), +32) (two MFMA row tiles).
+// owns output tile ot = 4*os + (w&3) and the batch rows [32*(w>>2), +32) (two MFMA row tiles).  NTW = 6 (12 waves,
+// hidden 300): 40 sub-nets x 6 slices = 240 workgroups run in ONE round of the 256 CUs where 8 slices of 4 tiles
+// (320 workgroups at one per CU: the Dd image takes 82 KB of LDS) ran in two.
 //  a) Dd[64][Hp] (from k_reduce_act) -> LDS
 //  b) Z[:,slice] = Dd W2[:,slice] + b2 ; yhat = softplus ; wMSE ; dZ ; gb2 -> Adam(b2)
 // The kernel is latency-bound (one workgroup's serial chain), so the chain is kept short: with
@@ -485,8 +487,8 @@ __global__ __launch_bounds__(256) void k_reduce_act(const SubnetDev* __restrict_
 // the targets Y of its batch rows, the bias -- is issued BEFORE the LDS staging; eight waves halve
 // the MFMA chain and the transcendental epilogue, which runs on the hardware exp/log/rcp units.
 // ---------------------------------------------------------------------------------------
-template <int HTC>
-__global__ __launch_bounds__(512) void k_mid_fwd(const float* __restrict__ W2,
+template <int HTC, int NTW = 4>     // NTW output tiles per workgroup = 2 NTW waves (two batch-row halves per tile)
+__global__ __launch_bounds__(128 * NTW) void k_mid_fwd(const float* __restrict__ W2,
                                                  float* __restrict__ b2w, float* __restrict__ b2m, float* __restrict__ b2v,
                                                  const float* __restrict__ Y, int64_t n_cells,
                                                  const int32_t* __restrict__ rows, int b_act,
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(512) void k_mid_fwd(const float* __restrict__ W2,
     const int Hp = dm.Hp, ldd = dm.ldd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lj = lane >> 4;
-    const int ot = os * 4 + (wave & 3), mh = wave >> 2;
+    const int ot = os * NTW + (NTW == 4 ? (wave & 3) : wave % NTW), mh = NTW == 4 ? (wave >> 2) : wave / NTW;
     const bool act = ot < dm.OT;
     const int otc = act ? ot : 0;                       // clamped tile: loads stay in bounds, results are dropped
     const int o = 16 * otc + li;
@@ -525,16 +527,17 @@ __global__ __launch_bounds__(512) void k_mid_fwd(const float* __restrict__ W2,
 
     // ---- a) stage Dd[64][Hp] into LDS (row stride ldd = 2 mod 32 words: conflict-free column reads) ----
     const float* ddk = Dd + (int64_t)k * DIMN_TB * Hp;
-    for (int e0 = threadIdx.x * 4; e0 < DIMN_TB * Hp; e0 += 8 * 2048) {     // eight independent 16-byte loads in flight
+    constexpr int PASS = 128 * NTW * 4;                     // floats one pass of the workgroup moves
+    for (int e0 = threadIdx.x * 4; e0 < DIMN_TB * Hp; e0 += 8 * PASS) {     // eight independent 16-byte loads in flight
         f32x4 dd[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int e = e0 + i * 2048;
+            const int e = e0 + i * PASS;
             dd[i] = *(const f32x4*)(ddk + (e < DIMN_TB * Hp ? e : 0));
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int e = e0 + i * 2048;
+            const int e = e0 + i * PASS;
             if (e < DIMN_TB * Hp) {
                 const int b = e / Hp, h = e - b * Hp;
                 *(float2*)(lds + b * ldd + h) = make_float2(dd[i][0], dd[i][1]);
@@ -602,13 +605,13 @@ __global__ __launch_bounds__(512) void k_mid_fwd(const float* __restrict__ W2,
     if (act && mh == 0 && lj == 0) {
         const int64_t i = (int64_t)k * dm.Op + o;
         float w = bias, m = b2m[i], v = b2v[i];
-        adam1(w, m, v, lds[16 + wave * 16 + li] + lds[16 + (wave + 4) * 16 + li], ap);
+        adam1(w, m, v, lds[16 + wave * 16 + li] + lds[16 + (wave + NTW) * 16 + li], ap);
         b2w[i] = w; b2m[i] = m; b2v[i] = v;
     }
     if (threadIdx.x == 0) {
         float tot = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < 8; ++wv) tot += lds[wv];
+        for (int wv = 0; wv < 2 * NTW; ++wv) tot += lds[wv];
         loss_step[k * dm.LS + os] = tot;
         if (loss_acc) loss_acc[k * dm.LS + os] += (double)tot;
     }
@@ -625,7 +628,9 @@ __global__ __launch_bounds__(512) void k_mid_fwd(const float* __restrict__ W2,
 // (ds_read_b32, lane-linear) and dZ rows (ds_read_b128) -- without 64-byte strided gathers.
 // State and dZ of the next output tile are prefetched while the current one computes.
 // ---------------------------------------------------------------------------------------
-template <bool FULL, int NH, int WV, int WPS = (WV == 4 ? 3 : (WV == 16 ? 4 : 2))>   // NH hidden tiles (16 rows of W2 each) per workgroup, WV waves; FULL: HT % NH == 0 and OT == WV*otw; WPS: waves per SIMD to fit
+template <bool FULL, int NH, int WV, int WPS = (WV == 4 ? 3 : (WV == 16 ? 4 : 2)), bool HCL = false>   // NH hidden tiles (16 rows of W2 each) per workgroup, WV waves; FULL: HT % NH == 0 and OT == WV*otw; WPS: waves per SIMD to fit;
+// HCL (with FULL; HT % NH != 0, hidden 300 = 19 tiles): a hidden tile past the last one IS the last one -- loaded, updated and stored twice by the same wave with identical
+// operands, hence identical results: no predicated memory operation and no wave-uniform branch in the tile loop
 __global__ __launch_bounds__(WV * 64, WPS) void k_mid_bwd(const float* __restrict__ Dd, const float* __restrict__ dZ,
                                                  float* __restrict__ W2, float* __restrict__ M2, float* __restrict__ V2,
                                                  float* __restrict__ b1w, float* __restrict__ b1m, float* __restrict__ b1v,
@@ -666,7 +671,7 @@ __global__ __launch_bounds__(WV * 64, WPS) void k_mid_bwd(const float* __restric
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
-        for (int ht = 0; ht < NH; ++ht) ddf[kb][ht] = ddk[(4 * kb + lj) * Hp + 16 * (ht0 + (ht < nht ? ht : 0)) + li];
+        for (int ht = 0; ht < NH; ++ht) ddf[kb][ht] = ddk[(4 * kb + lj) * Hp + 16 * (HCL ? (ht0 + ht < dm.HT ? ht0 + ht : dm.HT - 1) : ht0 + (ht < nht ? ht : 0)) + li];
 
     f32x4 dacc[4][NH];
 #pragma unroll
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(WV * 64, WPS) void k_mid_bwd(const float* __restric
         for (int ht = 0; ht < NH; ++ht) dacc[mt][ht] = zero4;
 
     const int64_t tbase = (int64_t)k * Hp * Op + li * 16 + 4 * lj;
-    auto tidx = [&](int ht, int ot) { return tbase + ((int64_t)(ht0 + (ht < nht ? ht : 0)) * dm.OT + ot) * 256; };
+    auto tidx = [&](int ht, int ot) { return tbase + ((int64_t)(HCL ? (ht0 + ht < dm.HT ? ht0 + ht : dm.HT - 1) : ht0 + (ht < nht ? ht : 0)) * dm.OT + ot) * 256; };
     // dZ tile staging: pass i moves row 16i + lane/4, quarter lane%4
     const float* zsrc = dzk + (lane >> 2) * Op + 4 * (lane & 3);
 
@@ -1355,7 +1360,7 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
 // grid.y (e.g. <8,1> x 2 for H = 256): two such workgroups fit on one CU, so the prologue/epilogue
 // of one overlaps the streaming of the other.
 // ---------------------------------------------------------------------------------------
-template <int WAVES, int NT2, int MINW = 1, typename XT = float>
+template <int WAVES, int NT2, int MINW = 1, typename XT = float, bool HCL = false>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
                                                                 const XT* __restrict__ X, float* __restrict__ W1,
                                                                 float* __restrict__ M1, float* __restrict__ V1,
@@ -1370,6 +1375,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
     const int nt0 = (blockIdx.y * WAVES + wave) * NT2;     // grid.y splits the hidden tiles when WAVES*NT2 < HT
+    // HCL (hidden 300 = 19 tiles on 10 waves x 2): the tile past the last one IS the last one -- the wave that owns both reads, updates and writes it twice with
+    // identical operands (identical gradient, identical Adam, identical forward partial): no predicated memory operation, and the second copy of every
+    // request is a cache hit (5 % fewer bytes from memory than the zero-padded 20th tile of rounds 2-4)
+    auto tl = [&](int nt) { return HCL ? (nt0 + nt < dm.HT ? nt0 + nt : dm.HT - 1) : nt0 + nt; };
     const int Hp = dm.Hp;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -1378,7 +1387,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) bfr[kb][nt] = dak[(4 * kb + lj) * Hp + 16 * (nt0 + nt) + li];
+        for (int nt = 0; nt < NT2; ++nt) bfr[kb][nt] = dak[(4 * kb + lj) * Hp + 16 * tl(nt) + li];
 
     // staging roles: threads 0..255 move the X_t tile, 256..511 the X_{t+1} tile (others none)
     const bool stager = tid < 512;
@@ -1394,7 +1403,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
     const int64_t cstride = (int64_t)Hp * 16;
     int64_t wb[NT2];
 #pragma unroll
-    for (int nt = 0; nt < NT2; ++nt) wb[nt] = s.w1off + (int64_t)(16 * (nt0 + nt) + li) * 16 + 4 * lj;
+    for (int nt = 0; nt < NT2; ++nt) wb[nt] = s.w1off + (int64_t)(16 * tl(nt) + li) * 16 + 4 * lj;
 
     f32x4 pacc[4][NT2];
 #pragma unroll
@@ -1481,7 +1490,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
 #pragma unroll
             for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p[(16 * mt + 4 * lj + r) * Hp + 16 * (nt0 + nt) + li] = pacc[mt][nt][r];
+                for (int r = 0; r < 4; ++r) p[(16 * mt + 4 * lj + r) * Hp + 16 * tl(nt) + li] = pacc[mt][nt][r];
     }
 }
 

@@ -166,6 +166,30 @@ def test_cfg3_shapes_match_oracle():
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("pad,fwd6", [("0", "1"), ("0", "0"), ("1", "1")])
+def test_cfg3_shapes_hidden_300_match_oracle(pad, fwd6, monkeypatch):
+    """The CLI's default hidden width (parser.py:62-66, 300 = 19 hidden tiles) at the shapes of the 50k x 20k job, all K = 40
+    sub-nets, against the ORACLE: 3 full + 1 partial optimiser step, validation, predict.  pad = 0 (default since round 5): the
+    twentieth tile of the 10 x 2 first-layer kernel and of the last pair of the second layer's backward is an ALIAS of the
+    nineteenth (Hp = 304); fwd6: the second layer's forward in 6 slices of six output tiles (12 waves, one round of workgroups)
+    or 8 slices of four; pad = 1: the zero-padded form of rounds 2-4 (Hp = 320)."""
+    monkeypatch.setenv("DIMN_H300_PAD", pad)
+    monkeypatch.setenv("DIMN_MID_FWD6", fwd6)
+    cfg, norm, targets, preds = _cfg3_sample(2048)
+    cfg = dict(cfg, H=300)
+    K = targets.shape[0]
+    train = np.arange(0, 3 * 64 + 21, dtype=np.int32) * 7 % 1700
+    val = np.arange(1700, 1950, dtype=np.int32)
+    rows = np.arange(3, 3 + 256 * 8, 8, dtype=np.int32) % 2048
+    kw = dict(batch_size=cfg["B"], dropout_rate=0.2, learning_rate=1e-3, seed=1234)
+    a = _load(_hip(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
+    b = _load(_oracle(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
+    info = a.path_info()
+    assert info["path"] == "streaming" and info["mid_fused"] == 0 and info["first_layer"] == 2, info
+    _compare_with_oracle(a, b, norm, preds, targets, list(range(K)), train, val, 4, cfg, kw, rows)
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("split,erows", [("0", "0"), ("1", "0"), ("0", "1")])
 # split: tile order of the kernel's loop, alternating / all gradient tiles first (DIMN_RES_SPLIT); erows: the epoch's rows copied into
 # visiting order before the launch (DIMN_RES_EPOCH_ROWS; what the library does for large arenas)
