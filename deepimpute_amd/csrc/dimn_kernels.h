@@ -2102,6 +2102,9 @@ typedef __bf16 bf16x8n __attribute__((ext_vector_type(8)));
 #ifndef DIMN_PB_TRACE
 #define DIMN_PB_TRACE 0
 #endif
+#ifndef DIMN_PB_ABL
+#define DIMN_PB_ABL 0      // diagnostic builds (tools/pb_ablate.sh; wrong results): 1 no output stores, 2 every workgroup reads the X rows of the first one (L2 hits)
+#endif
 #if DIMN_PB_TRACE
 __device__ unsigned long long* g_pb_trace = nullptr;
 #define PB_STAMP(j) do { if (g_pb_trace && threadIdx.x == 0) g_pb_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (j)] = wall_clock64(); } while (0)
@@ -2148,7 +2151,7 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int b = 4 * wave + u, rt = b >> 1, kh = b & 1;
-        const int64_t i = r0 + 16 * rt + li;
+        const int64_t i = ((DIMN_PB_ABL & 2) ? 0 : r0) + 16 * rt + li;
         const int64_t src = i < n_rows ? (rows ? (int64_t)rows[i] : i) : 0;            // rows past the end read row 0 and are dropped
         xsrc[u] = X + s.xoff + src * s.Dp + 32 * kh + 8 * lj;
     }
@@ -2377,7 +2380,7 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
                 const f32x4 zz = acc[rt][ct] + b2v[ct];                                              // (b2 is padded to Op)
                 const f32x2 y01 = softplus_out2((f32x2){zz[0], zz[1]}), y23 = softplus_out2((f32x2){zz[2], zz[3]});
                 const f32x4 yh = (f32x4){y01.x, y01.y, y23.x, y23.y};
-                if (out && ok) {
+                if (out && ok && (!(DIMN_PB_ABL & 1) || yh[0] == 123.456f)) {
                     float* dst = out + (i * dm.K + k) * dm.O + o0;
                     if (vec_ok) DIMN_PB_STORE((f32x4*)dst, yh);
                     else
