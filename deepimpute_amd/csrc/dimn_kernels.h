@@ -2103,7 +2103,7 @@ typedef __bf16 bf16x8n __attribute__((ext_vector_type(8)));
 #define DIMN_PB_TRACE 0
 #endif
 #ifndef DIMN_PB_ABL
-#define DIMN_PB_ABL 0      // diagnostic builds (tools/pb_ablate.sh; wrong results): 1 no output stores, 2 every workgroup reads the X rows of the first one (L2 hits)
+#define DIMN_PB_ABL 0      // diagnostic builds (tools/pb_trace.sh ablate-build / ablate-run; wrong results): 1 no output stores, 2 every workgroup reads the X rows of the first one (L2 hits)
 #endif
 #if DIMN_PB_TRACE
 __device__ unsigned long long* g_pb_trace = nullptr;
