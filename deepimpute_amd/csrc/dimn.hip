@@ -178,6 +178,7 @@ struct dimn_handle_s {
     Dims dm;
     int K, H, O, B, NT, NT2, OTW, HS;   // NT/NT2 hidden tiles per wave (4-/8-wave kernels); OTW out tiles per wave; HS = ceil(HT/2)
     int ncu = 256;
+    int w1_split = 1;                      // B1F1: the hidden tiles of a D-slice over this many workgroups (grid.y); 2: hidden 300 with enough chunks per CU (build_work)
     std::vector<SubnetDev> sn;
     std::vector<Work> work;
     std::vector<MidWork> midwork;          // work table of the fused second-layer kernel (k_mid_fused)
@@ -432,7 +433,10 @@ static void build_work(dimn_handle h) {
         const int k0 = 0, k1 = h->K;
         int64_t total_chunks = 0;
         for (int k = k0; k < k1; ++k) total_chunks += h->sn[k].nchunk;
-        const int64_t target = (int64_t)h->ncu;
+        // hidden 300 (20 tiles): with >= 16 chunks per CU the D-slices are made twice as long and the tiles of a slice go to TWO workgroups of 10 waves x 1
+        // tile (k_w1_update_fwd_ring<10, 1, 4>, grid.y = 2): three chunks in flight per wave where the 10 x 2 two-set kernel has one (its three-set form spills)
+        h->w1_split = (h->dm.HT == 20 && total_chunks >= 16 * (int64_t)h->ncu && !(getenv("DIMN_W1_SPLIT") && atoi(getenv("DIMN_W1_SPLIT")) == 0)) ? 2 : 1;
+        const int64_t target = (int64_t)h->ncu / h->w1_split;
         std::vector<std::pair<double, int>> frac;
         int64_t assigned = 0;
         // minimum chunks per slice: 8 when there is plenty of work per CU; down to 2 when a GPU owns only a
@@ -590,9 +594,9 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
     // the shared-staging B1F1 kernel can run it as 10 waves x 2 whole tiles with no predicated memory op: 165 vs 204 us
     // per launch, step 0.276 vs 0.298 ms at 50k x 20k (DIMN_HT20=0: off).  The three-set ring needs 168 VGPRs + 50
     // spilled at 10 waves x 2 tiles, and two co-resident 10 x 1 workgroups spill 16: both no faster than the generic kernel
-    // Round 5: the 20th tile is not padding any more but an ALIAS of the 19th (k_w1_update_fwd_sh<.., HCL>, k_mid_bwd<.., HCL>): Hp stays 304, every
-    // buffer and every byte moved per step is 5 % smaller.  DIMN_H300_PAD=1: the zero-padded form of rounds 2-4 (A/B, tests).
-    if (dm.HT == 19 && getenv("DIMN_H300_PAD") && atoi(getenv("DIMN_H300_PAD")) != 0) { dm.Hp = 320; dm.HT = 20; }
+    // (Round 5 measured the 20th tile as an ALIAS of the 19th instead of padding -- Hp = 304, the owning wave updating that tile twice with identical operands:
+    //  neutral in time, profiles/r05_h300_ab.txt, and a second copy's load is only ordered before the first copy's store by timing; removed.)
+    if (dm.HT == 19) { dm.Hp = 320; dm.HT = 20; }
     dm.Op = ceil_div(h->O, 16) * 16; dm.OT = dm.Op / 16;
     dm.ldd = dm.Hp + ((dm.Hp % 32 == 0) ? 2 : 18);   // LDS row stride = 2 (mod 32) words: conflict-free b32 column reads
     dm.ldp = dm.Hp + ((dm.Hp % 32 == 0) ? 4 : 20);   // k_predict: 4 (mod 32) words, rows 16-byte aligned: conflict-free b128 row reads
@@ -1236,7 +1240,7 @@ static void launch_fwd1(dimn_handle h, const dimn_handle_s::Lane& ln, hipStream_
 template <int NT2>
 static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, hipStream_t stw, const int32_t* rows, int b_act, const int32_t* rows_n, int b_next,
                       AdamP ap, hipEvent_t ev_begin, hipEvent_t ev_end) {
-    const dim3 grid((unsigned)(ln.w1 - ln.w0));
+    const dim3 grid((unsigned)(ln.w1 - ln.w0), (unsigned)h->w1_split);
     const Work* wk = h->d_work + ln.w0;
     // ev_begin/ev_end (timed launches only): hipExtLaunchKernelGGL stamps them with the kernel's own begin and end,
     // so the elapsed time is the launch's duration without the dispatch latency an event pair around it would add
@@ -1244,10 +1248,10 @@ static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, hipStream_t 
                                                          (const XT*)h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, \
                                                          (const float*)h->d_dA, h->d_P, h->dm, ap)
     WITH_XT(h, {
-        if (h->dm.HT == 20)                           // H = 300 padded to 320 (DIMN_H300_PAD=1): 10 waves x 2 hidden tiles, two-set shared-staging variant
+        if (h->dm.HT == 20 && h->w1_split == 2)       // H = 300 (padded to 320), plenty of chunks per CU: the hidden tiles in two halves (grid.y), 10 waves x 1 tile, FOUR-set ring
+            W1_LAUNCH((k_w1_update_fwd_ring<10, 1, 4, 1, XT>), 640);
+        else if (h->dm.HT == 20)                      // H = 300 (padded to 320): 10 waves x 2 hidden tiles, two-set shared-staging variant
             W1_LAUNCH((k_w1_update_fwd_sh<10, 2, 1, XT>), 640);
-        else if (h->dm.HT == 19)                      // H = 300: the same kernel, the last wave's second tile an alias of its first
-            W1_LAUNCH((k_w1_update_fwd_sh<10, 2, 1, XT, true>), 640);
         else if (h->dm.HT == 16)                      // H = 256: 16 waves x 1 hidden tile, X tiles staged once per workgroup, 3-set register ring
             W1_LAUNCH((k_w1_update_fwd_ring<16, 1, 3, 1, XT>), 1024);
         else if (h->dm.HT == 8 * NT2)
@@ -1406,15 +1410,14 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
         const size_t lds = (size_t)DIMN_TB * dm.ldd * sizeof(float);
         // hidden = 300, more slices of four tiles than CUs (one workgroup per CU: its Dd image takes 82 KB of LDS): six output tiles per workgroup
         // (12 waves) -- 40 sub-nets x 6 = 240 workgroups in ONE round where 320 ran in two (28.2 us per launch, round 4)
-        if (dm.HT == 19 && (int64_t)dm.OS * nk > (int64_t)h->ncu && !(getenv("DIMN_MID_FWD6") && atoi(getenv("DIMN_MID_FWD6")) == 0))
-            hipLaunchKernelGGL((k_mid_fwd<19, 6>), dim3((unsigned)ceil_div(dm.OT, 6), nk), dim3(768), lds, st, h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y,
+        if (dm.HT == 20 && (int64_t)dm.OS * nk > (int64_t)h->ncu && !(getenv("DIMN_MID_FWD6") && atoi(getenv("DIMN_MID_FWD6")) == 0))
+            hipLaunchKernelGGL((k_mid_fwd<20, 6>), dim3((unsigned)ceil_div(dm.OT, 6), nk), dim3(768), lds, st, h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y,
                                h->n, d_rows, b_act, h->d_Dd, h->d_dZ, h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary, ln.k0);
         else {
 #define LAUNCH_MF(HTC) hipLaunchKernelGGL(k_mid_fwd<HTC>, grid, dim3(512), lds, st, h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, \
                                           h->n, d_rows, b_act, h->d_Dd, h->d_dZ, h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary, ln.k0)
         if (dm.HT == 16) LAUNCH_MF(16);                                             // all W2 operands hoisted, 162 VGPRs
-        else if (dm.HT == 20) LAUNCH_MF(20);                                        // hidden = 300 padded to 320 (DIMN_H300_PAD=1)
-        else if (dm.HT == 19) LAUNCH_MF(19);                                        // hidden = 300
+        else if (dm.HT == 20) LAUNCH_MF(20);                                        // hidden = 300 (padded to 320)
         else LAUNCH_MF(0);                                                          // generic: 78 VGPRs
 #undef LAUNCH_MF
         }
@@ -1425,10 +1428,7 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     // TWO hidden tiles per workgroup where that still leaves a workgroup per CU (round 4): every workgroup reads the whole dZ block of its
     // sub-net (128 KB from L2), so half as many workgroups halve that traffic -- hidden 300 at 40 sub-nets: step 0.228 -> 0.221 ms, same box
     // (with the three-waves-per-SIMD register cap of the one-tile form it spills: 0.27)
-    if (dm.OT == 4 * h->OTW && dm.HT == 19 && (int64_t)10 * nk >= (int64_t)h->ncu)      // hidden = 300: ten pairs, the last one's second tile an alias of its first
-        hipLaunchKernelGGL((k_mid_bwd<true, 2, 4, 2, true>), dim3(10u, nk), dim3(256), 0, st, h->d_Dd, h->d_dZ,
-                           h->d_W2, h->d_M2, h->d_V2, h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0, (const float*)h->d_G);
-    else if (dm.OT == 4 * h->OTW && dm.HT % 2 == 0 && (int64_t)(dm.HT / 2) * nk >= (int64_t)h->ncu)
+    if (dm.OT == 4 * h->OTW && dm.HT % 2 == 0 && (int64_t)(dm.HT / 2) * nk >= (int64_t)h->ncu)
         hipLaunchKernelGGL((k_mid_bwd<true, 2, 4, 2>), dim3((unsigned)(dm.HT / 2), nk), dim3(256), 0, st, h->d_Dd, h->d_dZ,
                            h->d_W2, h->d_M2, h->d_V2, h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, h->OTW, ln.k0, (const float*)h->d_G);
     else if (dm.OT == 4 * h->OTW && (int64_t)dm.HT * nk <= 2 * (int64_t)h->ncu)   // few workgroups (a GPU that owns few sub-nets):
@@ -2275,7 +2275,7 @@ extern "C" int dimn_path_info(dimn_handle h, int32_t* out8) {
     out8[4] = h->mid_fused ? h->mid_slices : 0;                 // ... output slices per sub-net
     out8[5] = h->mid_fused && h->mid_pipe ? 2 : h->mid_keep;                                      // ... W2 column blocks kept in LDS between the phases
     out8[6] = h->res_G ? 2 * h->res_bf16 : h->train_bf16;      // training GEMMs on the bf16 matrix cores: 1 the second layer's (fused kernel), 2 all (resident kernel)
-    out8[7] = h->dm.HT == 16 ? 1 : ((h->dm.HT == 20 || h->dm.HT == 19) ? 2 : 0);    // first layer: 1 ring B1F1 (H = 256), 2 shared-staging (H = 300), 0 generic
+    out8[7] = h->dm.HT == 16 ? 1 : (h->dm.HT == 20 ? (h->w1_split == 2 ? 3 : 2) : 0);    // first layer: 1 ring B1F1 (H = 256), 2 shared-staging (H = 300), 3 four-set ring over two hidden halves (H = 300, many sub-nets), 0 generic
     return DIMN_OK;
 }
 

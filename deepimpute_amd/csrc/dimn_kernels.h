@@ -628,9 +628,7 @@ __global__ __launch_bounds__(128 * NTW) void k_mid_fwd(const float* __restrict__
 // (ds_read_b32, lane-linear) and dZ rows (ds_read_b128) -- without 64-byte strided gathers.
 // State and dZ of the next output tile are prefetched while the current one computes.
 // ---------------------------------------------------------------------------------------
-template <bool FULL, int NH, int WV, int WPS = (WV == 4 ? 3 : (WV == 16 ? 4 : 2)), bool HCL = false>   // NH hidden tiles (16 rows of W2 each) per workgroup, WV waves; FULL: HT % NH == 0 and OT == WV*otw; WPS: waves per SIMD to fit;
-// HCL (with FULL; HT % NH != 0, hidden 300 = 19 tiles): a hidden tile past the last one IS the last one -- loaded, updated and stored twice by the same wave with identical
-// operands, hence identical results: no predicated memory operation and no wave-uniform branch in the tile loop
+template <bool FULL, int NH, int WV, int WPS = (WV == 4 ? 3 : (WV == 16 ? 4 : 2))>   // NH hidden tiles (16 rows of W2 each) per workgroup, WV waves; FULL: HT % NH == 0 and OT == WV*otw; WPS: waves per SIMD to fit
 __global__ __launch_bounds__(WV * 64, WPS) void k_mid_bwd(const float* __restrict__ Dd, const float* __restrict__ dZ,
                                                  float* __restrict__ W2, float* __restrict__ M2, float* __restrict__ V2,
                                                  float* __restrict__ b1w, float* __restrict__ b1m, float* __restrict__ b1v,
@@ -671,7 +669,7 @@ __global__ __launch_bounds__(WV * 64, WPS) void k_mid_bwd(const float* __restric
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
-        for (int ht = 0; ht < NH; ++ht) ddf[kb][ht] = ddk[(4 * kb + lj) * Hp + 16 * (HCL ? (ht0 + ht < dm.HT ? ht0 + ht : dm.HT - 1) : ht0 + (ht < nht ? ht : 0)) + li];
+        for (int ht = 0; ht < NH; ++ht) ddf[kb][ht] = ddk[(4 * kb + lj) * Hp + 16 * (ht0 + (ht < nht ? ht : 0)) + li];
 
     f32x4 dacc[4][NH];
 #pragma unroll
@@ -680,7 +678,7 @@ __global__ __launch_bounds__(WV * 64, WPS) void k_mid_bwd(const float* __restric
         for (int ht = 0; ht < NH; ++ht) dacc[mt][ht] = zero4;
 
     const int64_t tbase = (int64_t)k * Hp * Op + li * 16 + 4 * lj;
-    auto tidx = [&](int ht, int ot) { return tbase + ((int64_t)(HCL ? (ht0 + ht < dm.HT ? ht0 + ht : dm.HT - 1) : ht0 + (ht < nht ? ht : 0)) * dm.OT + ot) * 256; };
+    auto tidx = [&](int ht, int ot) { return tbase + ((int64_t)(ht0 + (ht < nht ? ht : 0)) * dm.OT + ot) * 256; };
     // dZ tile staging: pass i moves row 16i + lane/4, quarter lane%4
     const float* zsrc = dzk + (lane >> 2) * Op + 4 * (lane & 3);
 
@@ -1360,7 +1358,7 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
 // grid.y (e.g. <8,1> x 2 for H = 256): two such workgroups fit on one CU, so the prologue/epilogue
 // of one overlaps the streaming of the other.
 // ---------------------------------------------------------------------------------------
-template <int WAVES, int NT2, int MINW = 1, typename XT = float, bool HCL = false>
+template <int WAVES, int NT2, int MINW = 1, typename XT = float>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
                                                                 const XT* __restrict__ X, float* __restrict__ W1,
                                                                 float* __restrict__ M1, float* __restrict__ V1,
@@ -1375,10 +1373,6 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
     const int nt0 = (blockIdx.y * WAVES + wave) * NT2;     // grid.y splits the hidden tiles when WAVES*NT2 < HT
-    // HCL (hidden 300 = 19 tiles on 10 waves x 2): the tile past the last one IS the last one -- the wave that owns both reads, updates and writes it twice with
-    // identical operands (identical gradient, identical Adam, identical forward partial): no predicated memory operation, and the second copy of every
-    // request is a cache hit (5 % fewer bytes from memory than the zero-padded 20th tile of rounds 2-4)
-    auto tl = [&](int nt) { return HCL ? (nt0 + nt < dm.HT ? nt0 + nt : dm.HT - 1) : nt0 + nt; };
     const int Hp = dm.Hp;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -1387,7 +1381,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) bfr[kb][nt] = dak[(4 * kb + lj) * Hp + 16 * tl(nt) + li];
+        for (int nt = 0; nt < NT2; ++nt) bfr[kb][nt] = dak[(4 * kb + lj) * Hp + 16 * (nt0 + nt) + li];
 
     // staging roles: threads 0..255 move the X_t tile, 256..511 the X_{t+1} tile (others none)
     const bool stager = tid < 512;
@@ -1403,7 +1397,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
     const int64_t cstride = (int64_t)Hp * 16;
     int64_t wb[NT2];
 #pragma unroll
-    for (int nt = 0; nt < NT2; ++nt) wb[nt] = s.w1off + (int64_t)(16 * tl(nt) + li) * 16 + 4 * lj;
+    for (int nt = 0; nt < NT2; ++nt) wb[nt] = s.w1off + (int64_t)(16 * (nt0 + nt) + li) * 16 + 4 * lj;
 
     f32x4 pacc[4][NT2];
 #pragma unroll
@@ -1490,7 +1484,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Wor
 #pragma unroll
             for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p[(16 * mt + 4 * lj + r) * Hp + 16 * tl(nt) + li] = pacc[mt][nt][r];
+                for (int r = 0; r < 4; ++r) p[(16 * mt + 4 * lj + r) * Hp + 16 * (nt0 + nt) + li] = pacc[mt][nt][r];
     }
 }
 

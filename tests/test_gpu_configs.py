@@ -166,14 +166,14 @@ def test_cfg3_shapes_match_oracle():
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("pad,fwd6", [("0", "1"), ("0", "0"), ("1", "1")])
-def test_cfg3_shapes_hidden_300_match_oracle(pad, fwd6, monkeypatch):
-    """The CLI's default hidden width (parser.py:62-66, 300 = 19 hidden tiles) at the shapes of the 50k x 20k job, all K = 40
-    sub-nets, against the ORACLE: 3 full + 1 partial optimiser step, validation, predict.  pad = 0 (default since round 5): the
-    twentieth tile of the 10 x 2 first-layer kernel and of the last pair of the second layer's backward is an ALIAS of the
-    nineteenth (Hp = 304); fwd6: the second layer's forward in 6 slices of six output tiles (12 waves, one round of workgroups)
-    or 8 slices of four; pad = 1: the zero-padded form of rounds 2-4 (Hp = 320)."""
-    monkeypatch.setenv("DIMN_H300_PAD", pad)
+@pytest.mark.parametrize("split,fwd6", [("1", "1"), ("0", "1"), ("1", "0")])
+def test_cfg3_shapes_hidden_300_match_oracle(split, fwd6, monkeypatch):
+    """The CLI's default hidden width (parser.py:62-66; 300 = 19 hidden tiles, zero-padded to 20) at the shapes of the 50k x 20k
+    job, all K = 40 sub-nets, against the ORACLE: 3 full + 1 partial optimiser step, validation, predict.  split = 1 (what the
+    library picks at this size since round 5): the hidden tiles of a D-slice over two workgroups of 10 waves x 1 tile with a
+    four-set register ring (k_w1_update_fwd_ring<10, 1, 4>, grid.y = 2, 128 D-slices); 0: the 10 x 2 two-set kernel of rounds
+    2-4.  fwd6: the second layer's forward in 6 slices of six output tiles (12 waves, one round of workgroups) or 8 of four."""
+    monkeypatch.setenv("DIMN_W1_SPLIT", split)
     monkeypatch.setenv("DIMN_MID_FWD6", fwd6)
     cfg, norm, targets, preds = _cfg3_sample(2048)
     cfg = dict(cfg, H=300)
@@ -185,7 +185,7 @@ def test_cfg3_shapes_hidden_300_match_oracle(pad, fwd6, monkeypatch):
     a = _load(_hip(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
     b = _load(_oracle(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
     info = a.path_info()
-    assert info["path"] == "streaming" and info["mid_fused"] == 0 and info["first_layer"] == 2, info
+    assert info["path"] == "streaming" and info["mid_fused"] == 0 and info["first_layer"] == (3 if split == "1" else 2), info
     _compare_with_oracle(a, b, norm, preds, targets, list(range(K)), train, val, 4, cfg, kw, rows)
     a.close(); b.close()
 
