@@ -190,6 +190,26 @@ def test_cfg3_shapes_hidden_300_match_oracle(split, fwd6, monkeypatch):
     a.close(); b.close()
 
 
+def test_cfg3_shapes_hidden_300_bf16_arena_match_oracle():
+    """The same shapes with precision bf16: the four-set ring over two hidden halves reading a bf16 X arena (its other
+    instantiation), fp32 training GEMMs on this path (no fused second layer at 20 hidden tiles), inference on k_predict_bf16's
+    sibling for hidden widths beyond 256 -- against the oracle in the matching rounding modes, tolerances of DESIGN section 3b."""
+    cfg, norm, targets, preds = _cfg3_sample(2048)
+    cfg = dict(cfg, H=300)
+    K = targets.shape[0]
+    train = np.arange(0, 3 * 64 + 21, dtype=np.int32) * 7 % 1700
+    val = np.arange(1700, 1950, dtype=np.int32)
+    rows = np.arange(3, 3 + 256 * 8, 8, dtype=np.int32) % 2048
+    kw = dict(batch_size=cfg["B"], dropout_rate=0.2, learning_rate=1e-3, seed=1234, precision="bf16")
+    a = _load(_hip(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
+    info = a.path_info()
+    assert info["path"] == "streaming" and info["first_layer"] == 3 and info["train_bf16"] == 0, info
+    b = _load(_oracle(), cfg, norm, preds, targets, list(range(K)), train, val, infer_bf16=True, train_bf16=0, **kw)
+    _compare_with_oracle(a, b, norm, preds, targets, list(range(K)), train, val, 4, cfg, kw, rows,
+                         tol=dict(loss=5e-4, p_rtol=2e-3, p_atol=2e-4), oracle_kw=dict(infer_bf16=True, train_bf16=0))
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("split,erows", [("0", "0"), ("1", "0"), ("0", "1")])
 # split: tile order of the kernel's loop, alternating / all gradient tiles first (DIMN_RES_SPLIT); erows: the epoch's rows copied into
 # visiting order before the launch (DIMN_RES_EPOCH_ROWS; what the library does for large arenas)
