@@ -178,6 +178,7 @@ struct dimn_handle_s {
     Dims dm;
     int K, H, O, B, NT, NT2, OTW, HS;   // NT/NT2 hidden tiles per wave (4-/8-wave kernels); OTW out tiles per wave; HS = ceil(HT/2)
     int ncu = 256;
+    bool mid_fwd6 = true;                  // hidden 300: k_mid_fwd<20, 6> where 8 slices per sub-net would not fit one round of workgroups (DIMN_MID_FWD6=0: off)
     int w1_split = 1;                      // B1F1: the hidden tiles of a D-slice over this many workgroups (grid.y); 2: hidden 300 with enough chunks per CU (build_work)
     std::vector<SubnetDev> sn;
     std::vector<Work> work;
@@ -636,6 +637,7 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
         w1 += (int64_t)s.Dp * dm.Hp;
     }
     h->w1_total = w1;
+    h->mid_fwd6 = !(getenv("DIMN_MID_FWD6") && atoi(getenv("DIMN_MID_FWD6")) == 0);
     build_work(h);
     if (!general) { build_mid(h); build_resident(h); }
     // One lane: every sub-net on the handle's stream.  (Two free-running lanes on two streams, a "W token" ring between them and a fixed
@@ -1410,7 +1412,7 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
         const size_t lds = (size_t)DIMN_TB * dm.ldd * sizeof(float);
         // hidden = 300, more slices of four tiles than CUs (one workgroup per CU: its Dd image takes 82 KB of LDS): six output tiles per workgroup
         // (12 waves) -- 40 sub-nets x 6 = 240 workgroups in ONE round where 320 ran in two (28.2 us per launch, round 4)
-        if (dm.HT == 20 && (int64_t)dm.OS * nk > (int64_t)h->ncu && !(getenv("DIMN_MID_FWD6") && atoi(getenv("DIMN_MID_FWD6")) == 0))
+        if (dm.HT == 20 && (int64_t)dm.OS * nk > (int64_t)h->ncu && h->mid_fwd6)
             hipLaunchKernelGGL((k_mid_fwd<20, 6>), dim3((unsigned)ceil_div(dm.OT, 6), nk), dim3(768), lds, st, h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y,
                                h->n, d_rows, b_act, h->d_Dd, h->d_dZ, h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary, ln.k0);
         else {
