@@ -691,7 +691,12 @@ def main():
         else:
             lane_step_ms = timers[0] / max(1.0, timers[1])
             traffic, traffic_src = measured_traffic("k_w1_update_fwd")
-            roofline = {"bound": "hbm", "kernel": "k_w1_update_fwd_ring<16,1> (W1 grad + Adam + next forward)", "achieved": achieved,
+            try:
+                fl = eng.path_info().get("first_layer", 1)
+            except Exception:
+                fl = 1
+            b1f1 = {1: "k_w1_update_fwd_ring<16,1>", 2: "k_w1_update_fwd_sh<10,2>", 3: "k_w1_update_fwd_ring<waves,1,4> (one hidden tile per wave, four-set ring)"}.get(fl, "k_w1_update_fwd<NT2>")
+            roofline = {"bound": "hbm", "kernel": b1f1 + " (W1 grad + Adam + next forward)", "achieved": achieved,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         # PMC figure of the SAME command from a committed profile (separate rocprofv3 --pmc passes cannot run
                         # inside this process); traffic_source names the file it was read from

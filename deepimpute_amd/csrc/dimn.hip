@@ -179,6 +179,8 @@ struct dimn_handle_s {
     int K, H, O, B, NT, NT2, OTW, HS;   // NT/NT2 hidden tiles per wave (4-/8-wave kernels); OTW out tiles per wave; HS = ceil(HT/2)
     int ncu = 256;
     bool mid_fwd6 = true;                  // hidden 300: k_mid_fwd<20, 6> where 8 slices per sub-net would not fit one round of workgroups (DIMN_MID_FWD6=0: off)
+    int w1_waves = 0;                      // B1F1 as k_w1_update_fwd_ring<w1_waves, 1, 4> (0: the width's older kernel): one hidden tile per wave, four-set register ring
+    int w1_wpc = 1;                        // ... workgroups per CU (2 for 8 waves)
     int w1_split = 1;                      // B1F1: the hidden tiles of a D-slice over this many workgroups (grid.y); 2: hidden 300 with enough chunks per CU (build_work)
     std::vector<SubnetDev> sn;
     std::vector<Work> work;
@@ -436,8 +438,17 @@ static void build_work(dimn_handle h) {
         for (int k = k0; k < k1; ++k) total_chunks += h->sn[k].nchunk;
         // hidden 300 (20 tiles): with >= 16 chunks per CU the D-slices are made twice as long and the tiles of a slice go to TWO workgroups of 10 waves x 1
         // tile (k_w1_update_fwd_ring<10, 1, 4>, grid.y = 2): three chunks in flight per wave where the 10 x 2 two-set kernel has one (its three-set form spills)
-        h->w1_split = (h->dm.HT == 20 && total_chunks >= 16 * (int64_t)h->ncu && !(getenv("DIMN_W1_SPLIT") && atoi(getenv("DIMN_W1_SPLIT")) == 0)) ? 2 : 1;
-        const int64_t target = (int64_t)h->ncu / h->w1_split;
+        // Round 5, every width of 8 .. 24 hidden tiles other than 16 (which has k_w1_update_fwd_ring<16, 1, 3>): the same ring with ONE tile per wave and four
+        // register sets -- HT <= 15: HT waves (8 waves: two workgroups per CU); HT = 18 .. 24: two halves of HT / 2 waves.  The generic kernels of those widths
+        // (8 waves x 1-3 tiles, one or two chunks in flight, 256 registers + spills at 3 tiles) ran at 0.47-0.49 of the HBM peak: profiles/r05_hidden_widths.txt
+        h->w1_split = 1; h->w1_waves = 0; h->w1_wpc = 1;
+        const int HT = h->dm.HT;
+        if (HT >= 8 && HT <= 24 && HT != 16 && total_chunks >= 16 * (int64_t)h->ncu && !(getenv("DIMN_W1_SPLIT") && atoi(getenv("DIMN_W1_SPLIT")) == 0)) {
+            h->w1_split = HT > 16 ? 2 : 1;
+            h->w1_waves = HT / h->w1_split;
+            h->w1_wpc = h->w1_waves == 8 ? 2 : 1;
+        }
+        const int64_t target = (int64_t)h->ncu * h->w1_wpc / h->w1_split;
         std::vector<std::pair<double, int>> frac;
         int64_t assigned = 0;
         // minimum chunks per slice: 8 when there is plenty of work per CU; down to 2 when a GPU owns only a
@@ -598,6 +609,8 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
     // (Round 5 measured the 20th tile as an ALIAS of the 19th instead of padding -- Hp = 304, the owning wave updating that tile twice with identical operands:
     //  neutral in time, profiles/r05_h300_ab.txt, and a second copy's load is only ordered before the first copy's store by timing; removed.)
     if (dm.HT == 19) { dm.Hp = 320; dm.HT = 20; }
+    // the same padding for every odd tile count above 16 (round 5): the first-layer ring kernel takes the hidden tiles of a D-slice in two halves of HT / 2 waves
+    if (!general && dm.HT > 16 && dm.HT <= 24 && (dm.HT & 1)) { dm.HT += 1; dm.Hp = 16 * dm.HT; }
     dm.Op = ceil_div(h->O, 16) * 16; dm.OT = dm.Op / 16;
     dm.ldd = dm.Hp + ((dm.Hp % 32 == 0) ? 2 : 18);   // LDS row stride = 2 (mod 32) words: conflict-free b32 column reads
     dm.ldp = dm.Hp + ((dm.Hp % 32 == 0) ? 4 : 20);   // k_predict: 4 (mod 32) words, rows 16-byte aligned: conflict-free b128 row reads
@@ -1250,9 +1263,18 @@ static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, hipStream_t 
                                                          (const XT*)h->d_X, h->d_W1, h->d_M1, h->d_V1, rows, b_act, rows_n, b_next, \
                                                          (const float*)h->d_dA, h->d_P, h->dm, ap)
     WITH_XT(h, {
-        if (h->dm.HT == 20 && h->w1_split == 2)       // H = 300 (padded to 320), plenty of chunks per CU: the hidden tiles in two halves (grid.y), 10 waves x 1 tile, FOUR-set ring
-            W1_LAUNCH((k_w1_update_fwd_ring<10, 1, 4, 1, XT>), 640);
-        else if (h->dm.HT == 20)                      // H = 300 (padded to 320): 10 waves x 2 hidden tiles, two-set shared-staging variant
+        if (h->w1_waves) {                            // plenty of chunks per CU: one hidden tile per wave, FOUR-set ring, the tiles of a D-slice in w1_split halves (grid.y); H = 300: 10 x 2
+            switch (h->w1_waves) {
+                case 8:  W1_LAUNCH((k_w1_update_fwd_ring<8, 1, 4, 4, XT>), 512); break;      // two workgroups per CU
+                case 9:  W1_LAUNCH((k_w1_update_fwd_ring<9, 1, 4, 1, XT>), 576); break;
+                case 10: W1_LAUNCH((k_w1_update_fwd_ring<10, 1, 4, 1, XT>), 640); break;
+                case 11: W1_LAUNCH((k_w1_update_fwd_ring<11, 1, 4, 1, XT>), 704); break;
+                case 12: W1_LAUNCH((k_w1_update_fwd_ring<12, 1, 4, 1, XT>), 768); break;
+                case 13: W1_LAUNCH((k_w1_update_fwd_ring<13, 1, 4, 1, XT>), 832); break;
+                case 14: W1_LAUNCH((k_w1_update_fwd_ring<14, 1, 4, 1, XT>), 896); break;
+                default: W1_LAUNCH((k_w1_update_fwd_ring<15, 1, 4, 1, XT>), 960); break;
+            }
+        } else if (h->dm.HT == 20)                      // H = 300 (padded to 320): 10 waves x 2 hidden tiles, two-set shared-staging variant
             W1_LAUNCH((k_w1_update_fwd_sh<10, 2, 1, XT>), 640);
         else if (h->dm.HT == 16)                      // H = 256: 16 waves x 1 hidden tile, X tiles staged once per workgroup, 3-set register ring
             W1_LAUNCH((k_w1_update_fwd_ring<16, 1, 3, 1, XT>), 1024);
@@ -1410,19 +1432,24 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     {
         const dim3 grid((unsigned)dm.OS, nk);
         const size_t lds = (size_t)DIMN_TB * dm.ldd * sizeof(float);
-        // hidden = 300, more slices of four tiles than CUs (one workgroup per CU: its Dd image takes 82 KB of LDS): six output tiles per workgroup
-        // (12 waves) -- 40 sub-nets x 6 = 240 workgroups in ONE round where 320 ran in two (28.2 us per launch, round 4)
-        if (dm.HT == 20 && (int64_t)dm.OS * nk > (int64_t)h->ncu && h->mid_fwd6)
-            hipLaunchKernelGGL((k_mid_fwd<20, 6>), dim3((unsigned)ceil_div(dm.OT, 6), nk), dim3(768), lds, st, h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y,
-                               h->n, d_rows, b_act, h->d_Dd, h->d_dZ, h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary, ln.k0);
-        else {
-#define LAUNCH_MF(HTC) hipLaunchKernelGGL(k_mid_fwd<HTC>, grid, dim3(512), lds, st, h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, \
-                                          h->n, d_rows, b_act, h->d_Dd, h->d_dZ, h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary, ln.k0)
-        if (dm.HT == 16) LAUNCH_MF(16);                                             // all W2 operands hoisted, 162 VGPRs
-        else if (dm.HT == 20) LAUNCH_MF(20);                                        // hidden = 300 (padded to 320)
-        else LAUNCH_MF(0);                                                          // generic: 78 VGPRs
-#undef LAUNCH_MF
+        // Every W2 operand of a wave hoisted in front of the LDS staging (HTC = the hidden-tile count at compile time) for 8 .. 16, 18, 20, 22, 24 hidden tiles;
+        // other counts take the generic form (operands requested inside the loop).  From 13 tiles on the kernel holds > 128 VGPRs, from 20 on its Dd image > 80 KB
+        // of LDS -- one workgroup per CU -- and 8 slices of four output tiles per sub-net would need two rounds of workgroups at 40 sub-nets: six output tiles per workgroup then (12 waves),
+        // 40 x 6 = 240 workgroups in ONE round (hidden 300: 28.2 -> 20.5 us per launch; hidden 384 on the generic form: 43.3 us)
+        const bool six = dm.HT >= 13 && (int64_t)dm.OS * nk > (int64_t)h->ncu && h->mid_fwd6;      // (13 tiles on: > 128 VGPRs or > 80 KB of LDS, one workgroup per CU)
+        const dim3 grid6((unsigned)ceil_div(dm.OT, 6), nk);
+#define LAUNCH_MF(HTC, NTW, GRID) hipLaunchKernelGGL((k_mid_fwd<HTC, NTW>), GRID, dim3(128 * NTW), lds, st, h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, \
+                                                     h->n, d_rows, b_act, h->d_Dd, h->d_dZ, h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary, ln.k0)
+#define MF_CASE4(HTC) case HTC: LAUNCH_MF(HTC, 4, grid); break;
+#define MF_CASE46(HTC) case HTC: if (six) LAUNCH_MF(HTC, 6, grid6); else LAUNCH_MF(HTC, 4, grid); break;
+        switch (dm.HT) {
+            MF_CASE4(8) MF_CASE4(9) MF_CASE4(10) MF_CASE4(11) MF_CASE4(12)
+            MF_CASE46(13) MF_CASE46(14) MF_CASE46(15) MF_CASE46(16) MF_CASE46(18) MF_CASE46(20) MF_CASE46(22) MF_CASE46(24)
+            default: LAUNCH_MF(0, 4, grid); break;                                  // generic: 78 VGPRs
         }
+#undef MF_CASE46
+#undef MF_CASE4
+#undef LAUNCH_MF
     }
     // one hidden tile (16 rows of W2) per workgroup; 4 or 8 waves split the output tiles
 #define LAUNCH_MB(FULLV, WV) hipLaunchKernelGGL((k_mid_bwd<FULLV, 1, WV>), dim3((unsigned)dm.HT, nk), dim3(WV * 64), 0, st, h->d_Dd, h->d_dZ, \
@@ -2277,7 +2304,7 @@ extern "C" int dimn_path_info(dimn_handle h, int32_t* out8) {
     out8[4] = h->mid_fused ? h->mid_slices : 0;                 // ... output slices per sub-net
     out8[5] = h->mid_fused && h->mid_pipe ? 2 : h->mid_keep;                                      // ... W2 column blocks kept in LDS between the phases
     out8[6] = h->res_G ? 2 * h->res_bf16 : h->train_bf16;      // training GEMMs on the bf16 matrix cores: 1 the second layer's (fused kernel), 2 all (resident kernel)
-    out8[7] = h->dm.HT == 16 ? 1 : (h->dm.HT == 20 ? (h->w1_split == 2 ? 3 : 2) : 0);    // first layer: 1 ring B1F1 (H = 256), 2 shared-staging (H = 300), 3 four-set ring over two hidden halves (H = 300, many sub-nets), 0 generic
+    out8[7] = h->dm.HT == 16 ? 1 : (h->w1_waves ? 3 : (h->dm.HT == 20 ? 2 : 0));    // first layer: 1 ring B1F1 (H = 256), 2 shared-staging (H = 300), 3 four-set ring over two hidden halves (H = 300, many sub-nets), 0 generic
     return DIMN_OK;
 }
 

@@ -280,7 +280,7 @@ int dimn_set_profiling(dimn_handle h, int32_t on);
  * [5] the fused kernel's form ("mid_kernel"): 2 tile pipeline (k_mid_pipe, fp32 or bf16 operands; since ABI 7) / 1 three phases with W2 kept in
  * LDS between them / 0 three phases, W2 read twice, [6] training GEMMs on the bf16 matrix cores (1: the second layer's three, fused
  * kernel; 2: those of both layers, resident kernel; 0: none), [7] first-layer kernel
- * (1 ring, 2 shared staging, 3 four-set ring over two hidden halves (hidden 300 with many sub-nets), 0 generic).  A handle whose resident launch had to be undone reports 0 from then on.  ABI 5; [5] = 2 since ABI 7. */
+ * (1 ring, 2 shared staging, 3 four-set ring with one hidden tile per wave (8 .. 24 hidden tiles other than 16, many sub-nets), 0 generic).  A handle whose resident launch had to be undone reports 0 from then on.  ABI 5; [5] = 2 since ABI 7. */
 int dimn_path_info(dimn_handle h, int32_t* out8);
 
 /* ---- multi-GPU: sub-nets sharded over ranks, RCCL over xGMI (no reference analogue:

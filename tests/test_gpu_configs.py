@@ -103,8 +103,28 @@ def _compare_with_oracle(a, b, norm, preds, targets, ks, train, val, steps, cfg,
         assert len(flipped) < 2, "more than two sub-nets off: not the rare event this path is for"
         args = (_oracle(), norm, preds[ks[i]], targets[ks[i]], ks[i])
         cands = find_relu_flip_candidates(*args, units, train, steps, cfg["H"], O, **kw, **(oracle_kw or {}))
-        assert cands, "sub-net %d: units %s miss the weight tolerance and no pre-activation of theirs is within fp32 reordering " \
-                      "error of zero in any step -- not a relu flip" % (ks[i], units.tolist())
+        if not cands:
+            # No gate at fp32 noise level.  The other way two fp32 evaluations drift apart in a few steps is Adam's normalisation of a small
+            # gradient (step = lr m / (sqrt(v) + eps): the rounding of g is amplified by 1 / |g|) -- then it is the plain-loop fp32 ORACLE
+            # that may be the one further from the truth.  Accepted only on evidence: the float64 oracle of this sub-net on the same streams,
+            # and the HIP path at most as far from it as the fp32 oracle is (x 2), array by array (first seen: hidden 272, sub-net 37, unit
+            # 249 -- HIP 7e-6 from the float64 weights, the fp32 oracle 2.6e-5, one weight 3.3e-5 apart against 3.2e-5 allowed).
+            o64, l64 = oracle_with_inverted_gates(*args, train, val, cfg["H"], O, [], fp64=True, **kw, **(oracle_kw or {}))
+            try:
+                p64 = o64.predict(rows)
+                pairs = list(zip(a.get_weights(i), b.get_weights(i), o64.get_weights(0), ("W1", "b1", "W2", "b2")))
+                pairs.append((pa[:, i * O:(i + 1) * O], pb[:, i * O:(i + 1) * O], p64, "predict"))
+                pairs.append((np.asarray(la[i]), np.asarray(lb[i]), np.asarray(l64[0]), "train loss"))
+                for x, y, z, name in pairs:
+                    eh, eo = float(np.max(np.abs(x - z))), float(np.max(np.abs(y - z)))
+                    assert eh <= 2.0 * eo + 1e-7, "sub-net %d, %s: units %s miss the tolerance, no relu flip, and the HIP path is %.3e from the " \
+                        "float64 oracle where the fp32 oracle is %.3e" % (ks[i], name, units.tolist(), eh, eo)
+                print("sub-net %d: units %s outside the weight tolerance against the fp32 oracle, which is the one further from the float64 "
+                      "oracle (no relu gate involved)" % (ks[i], units.tolist()))
+                flipped[ks[i]] = ("fp32 oracle further from float64 than the HIP path",)
+            finally:
+                o64.close()
+            continue
         last = None
         for inv in [c for c in itertools.chain(((x,) for x in cands[:4]), itertools.combinations(cands[:4], 2))]:
             o, lo = oracle_with_inverted_gates(*args, train, val, cfg["H"], O, [r[:4] for r in inv], **kw, **(oracle_kw or {}))
@@ -186,6 +206,27 @@ def test_cfg3_shapes_hidden_300_match_oracle(split, fwd6, monkeypatch):
     b = _load(_oracle(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
     info = a.path_info()
     assert info["path"] == "streaming" and info["mid_fused"] == 0 and info["first_layer"] == (3 if split == "1" else 2), info
+    _compare_with_oracle(a, b, norm, preds, targets, list(range(K)), train, val, 4, cfg, kw, rows)
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("H", [128, 192, 208, 272, 384])
+def test_cfg3_shapes_other_hidden_widths_match_oracle(H):
+    """Hidden widths other than 256 / 300 at the shapes of the 50k x 20k job (K = 40, D ~ 2 400) against the ORACLE: every width of 8 .. 24
+    hidden tiles takes the first-layer ring kernel with one tile per wave and four register sets (round 5) -- 8 tiles as two workgroups
+    of 8 waves per CU, 12 / 13 tiles as 12 / 13 waves, 17 tiles (272) padded to 18 = two halves of 9 waves, 24 tiles (384) as two halves
+    of 12 -- and the two-kernel second layer.  3 full + 1 partial optimiser step, validation, predict."""
+    cfg, norm, targets, preds = _cfg3_sample(2048)
+    cfg = dict(cfg, H=H)
+    K = targets.shape[0]
+    train = np.arange(0, 3 * 64 + 21, dtype=np.int32) * 7 % 1700
+    val = np.arange(1700, 1950, dtype=np.int32)
+    rows = np.arange(3, 3 + 256 * 8, 8, dtype=np.int32) % 2048
+    kw = dict(batch_size=cfg["B"], dropout_rate=0.2, learning_rate=1e-3, seed=1234)
+    a = _load(_hip(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
+    b = _load(_oracle(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
+    info = a.path_info()
+    assert info["path"] == "streaming" and info["mid_fused"] == 0 and info["first_layer"] == (0 if os.environ.get("DIMN_W1_SPLIT") == "0" else 3), info
     _compare_with_oracle(a, b, norm, preds, targets, list(range(K)), train, val, 4, cfg, kw, rows)
     a.close(); b.close()
 
