@@ -443,7 +443,10 @@ static void build_work(dimn_handle h) {
         // (8 waves x 1-3 tiles, one or two chunks in flight, 256 registers + spills at 3 tiles) ran at 0.47-0.49 of the HBM peak: profiles/r05_hidden_widths.txt
         h->w1_split = 1; h->w1_waves = 0; h->w1_wpc = 1;
         const int HT = h->dm.HT;
-        if (HT >= 8 && HT <= 24 && HT != 16 && total_chunks >= 16 * (int64_t)h->ncu && !(getenv("DIMN_W1_SPLIT") && atoi(getenv("DIMN_W1_SPLIT")) == 0)) {
+        // From 2 chunks per CU on (same-box A/B at hidden 300, 5 / 10 / 20 / 30 sub-nets of D ~ 2 400 and configs[1]: the ring wins at every size, 3-9 % per step,
+        // thresholds 2 / 4 / 8 / 16 alike where they apply: profiles/r05_hidden_widths.txt).  DIMN_W1_SPLIT: 0 off; N >= 2: from N chunks per CU on.
+        const int w1_env = getenv("DIMN_W1_SPLIT") ? atoi(getenv("DIMN_W1_SPLIT")) : 1;
+        if (HT >= 8 && HT <= 24 && HT != 16 && w1_env != 0 && total_chunks >= (w1_env >= 2 ? w1_env : 2) * (int64_t)h->ncu) {
             h->w1_split = HT > 16 ? 2 : 1;
             h->w1_waves = HT / h->w1_split;
             h->w1_wpc = h->w1_waves == 8 ? 2 : 1;
