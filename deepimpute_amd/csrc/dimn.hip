@@ -451,6 +451,8 @@ static void build_work(dimn_handle h) {
             h->w1_waves = HT / h->w1_split;
             h->w1_wpc = h->w1_waves == 8 ? 2 : 1;
         }
+        // (16 tiles keep k_w1_update_fwd_ring<16, 1, 3>: with four sets -- 144 KB in flight per CU instead of 96 -- it takes 120 us where the three-set ring takes
+        //  108, as two halves of 8 waves with two workgroups per CU 117: profiles/r05_hidden_widths.txt)
         const int64_t target = (int64_t)h->ncu * h->w1_wpc / h->w1_split;
         std::vector<std::pair<double, int>> frac;
         int64_t assigned = 0;
