@@ -70,6 +70,27 @@ def test_two_epochs_match_oracle(H, O, B, Ds, p):
     np.testing.assert_allclose(pa, pb, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("H,O,B,p", [(176, 100, 37, 0.2), (224, 96, 64, 0.0), (340, 200, 50, 0.3)])      # 11 and 14 hidden tiles (one workgroup of 11 / 14 waves), 22 (two halves of 11)
+def test_ring_first_layer_at_ragged_widths_matches_oracle(H, O, B, p):
+    """The four-set ring first-layer kernel (round 5: every width of 8 .. 24 hidden tiles other than 16, from 2 chunks per CU on) at wave counts the
+    cfg3-shape tests do not reach, with ragged predictor counts, a ragged output width and partial batches: 8 sub-nets of D ~ 1 000 - 1 300
+    (572 chunks on 256 CUs), two epochs against the oracle at the tolerances of test_two_epochs_match_oracle."""
+    prob = make_problem(n=330, g=1400, Ds=[1203, 1100, 977, 1290, 1111, 1234, 1007, 1155], H=H, O=O, seed=17)
+    kw = dict(batch_size=B, dropout_rate=p, learning_rate=1e-3, seed=99)
+    a = load_problem(_hip(), prob, **kw)
+    b = load_problem(_oracle(), prob, **kw)
+    assert a.path_info()["first_layer"] == 3, a.path_info()
+    a.init_weights(); b.init_weights()
+    for epoch in range(2):
+        np.testing.assert_allclose(a.train_epoch(epoch), b.train_epoch(epoch), rtol=1e-4)
+        np.testing.assert_allclose(a.val_loss(), b.val_loss(), rtol=1e-4)
+    for k in range(a.K):
+        for x, y, name in zip(a.get_weights(k), b.get_weights(k), ("W1", "b1", "W2", "b2")):
+            np.testing.assert_allclose(x, y, rtol=1e-3, atol=2e-5, err_msg="%s k=%d" % (name, k))
+    np.testing.assert_allclose(a.predict(), b.predict(), rtol=1e-4, atol=1e-6)
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("mid", ["1", "0", "1:6", "1:4", "1:10", "1:16", "1:32", "1F", "1F:6", "1F:4", "1F:10", "R", "R:1", "R:2", "RG"])     # fused (the tile pipeline k_mid_pipe; auto slices), two-kernel, fused with 6 / 4 / 10 / 16 / 32 slices (8 .. 1 tiles per workgroup); 1F: the three-phase fused kernel k_mid_fused (DIMN_MID_PIPE=0); R: register-resident epoch kernel (auto / 1 / 2 D-splits; RG: sub-nets in groups of two, one launch each)
 @pytest.mark.parametrize("O,B,Ds,p", [
     (512, 64, [300, 150, 77], 0.2),     # the default architecture: H = 256, O = 512
