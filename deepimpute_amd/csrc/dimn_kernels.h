@@ -300,6 +300,16 @@ __global__ __launch_bounds__(256) void k_gather(const SubnetDev* __restrict__ sn
 // Same gather with the matrix row staged ONCE in LDS (g floats <= 160 KB): every sub-net of the
 // workgroup's row is served from LDS, so `norm` is read from HBM once instead of once per sub-net
 // (measured on cfg3: 174 GB fetched by k_gather vs 4 GB needed).  grid = rows (grid-stride).
+template <typename XT> __device__ __forceinline__ void x_store4(XT* p, const f32x4 v);      // four consecutive arena elements, one non-temporal store
+template <> __device__ __forceinline__ void x_store4<float>(float* p, const f32x4 v) { __builtin_nontemporal_store(v, (f32x4*)p); }
+template <> __device__ __forceinline__ void x_store4<bf16_t>(bf16_t* p, const f32x4 v) {
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store((u16x4){f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])}, (u16x4*)p);
+}
+// Round 5: a thread takes FOUR consecutive columns -- four independent index loads in flight, four LDS gathers, one 16-byte (bf16: 8-byte) store; Dp and Op are
+// multiples of 16, the arena rows 64-byte aligned; the row itself is staged with 16-byte loads: 9.49 -> 8.57 ms at cfg3 (28 GB: 3.3 TB/s).  Measured and not
+// kept: sub-net descriptors in LDS + the next sub-net's index loads requested before the current stores (9.07 ms) -- the kernel's time hardly depends on its bytes
+// (bf16 arena, 17.8 GB: 7.7 ms) or on its instruction count; it runs once per fit.
 template <typename XT>
 __global__ __launch_bounds__(512) void k_gather_lds(const SubnetDev* __restrict__ sn, const float* __restrict__ norm,
                                                     int64_t n, int64_t g, const int32_t* __restrict__ pred,
@@ -309,17 +319,37 @@ __global__ __launch_bounds__(512) void k_gather_lds(const SubnetDev* __restrict_
     for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
         const float* row = norm + i * g;
         __syncthreads();                                   // previous row fully consumed
-        for (int64_t c = threadIdx.x; c < g; c += 512) rowbuf[c] = row[c];
+        if ((g & 3) == 0 && (((uintptr_t)norm) & 15) == 0) {
+            for (int64_t c = 4 * threadIdx.x; c < g; c += 2048) *(f32x4*)(rowbuf + c) = *(const f32x4*)(row + c);
+        } else {
+            for (int64_t c = threadIdx.x; c < g; c += 512) rowbuf[c] = row[c];
+        }
         __syncthreads();
         for (int k = 0; k < dm.K; ++k) {
             const SubnetDev s = sn[k];
             const int32_t* pk = pred + pred_off[k];
             XT* xr = X + s.xoff + (row0 + i) * s.Dp;
-            for (int d = threadIdx.x; d < s.Dp; d += 512) __builtin_nontemporal_store(x_store<XT>(d < s.D ? rowbuf[pk[d]] : 0.f), &xr[d]);   // written once, read much later
+            for (int d0 = 4 * threadIdx.x; d0 < s.Dp; d0 += 2048) {
+                int32_t ix[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ix[j] = pk[d0 + j < s.D ? d0 + j : s.D - 1];           // (the list has D entries: the padding columns re-read the last one)
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = d0 + j < s.D ? rowbuf[ix[j]] : 0.f;
+                x_store4<XT>(xr + d0, v);                                                          // written once, read much later
+            }
             if (with_targets) {
                 float* yr = Y + ((int64_t)k * n_all + row0 + i) * dm.Op;
                 const int32_t* tk = targ + (int64_t)k * dm.O;
-                for (int o = threadIdx.x; o < dm.Op; o += 512) __builtin_nontemporal_store(o < dm.O ? rowbuf[tk[o]] : 0.f, &yr[o]);
+                for (int o0 = 4 * threadIdx.x; o0 < dm.Op; o0 += 2048) {
+                    int32_t ix[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ix[j] = tk[o0 + j < dm.O ? o0 + j : dm.O - 1];
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = o0 + j < dm.O ? rowbuf[ix[j]] : 0.f;
+                    __builtin_nontemporal_store(v, (f32x4*)(yr + o0));
+                }
             }
         }
     }
