@@ -767,7 +767,7 @@ def main():
             result["config"]["dropin"] = dropin_run(norm, args.epochs)
         except Exception as e:
             result["config"]["dropin"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_accuracy and not args.limit_subnets and not args.hidden and not general and args.precision == "fp32":
+    if rank == 0 and world == 1 and not args.no_accuracy and not args.limit_subnets and not general and args.precision == "fp32":
         try:
             result["accuracy"] = accuracy_pair(cfg, targets, preds, norm, args.epochs, args.lr, n_cells=args.accuracy_cells, n_subnets=args.accuracy_subnets)
         except Exception as e:
