@@ -181,7 +181,7 @@ struct dimn_handle_s {
     bool mid_fwd6 = true;                  // hidden 300: k_mid_fwd<20, 6> where 8 slices per sub-net would not fit one round of workgroups (DIMN_MID_FWD6=0: off)
     int w1_waves = 0;                      // B1F1 as k_w1_update_fwd_ring<w1_waves, 1, 4> (0: the width's older kernel): one hidden tile per wave, four-set register ring
     int w1_wpc = 1;                        // ... workgroups per CU (2 for 8 waves)
-    int w1_split = 1;                      // B1F1: the hidden tiles of a D-slice over this many workgroups (grid.y); 2: hidden 300 with enough chunks per CU (build_work)
+    int w1_split = 1;                      // B1F1: the hidden tiles of a D-slice over this many workgroups (grid.y); 2: 18 .. 24 hidden tiles on the ring (build_work)
     std::vector<SubnetDev> sn;
     std::vector<Work> work;
     std::vector<MidWork> midwork;          // work table of the fused second-layer kernel (k_mid_fused)
@@ -436,8 +436,6 @@ static void build_work(dimn_handle h) {
         const int k0 = 0, k1 = h->K;
         int64_t total_chunks = 0;
         for (int k = k0; k < k1; ++k) total_chunks += h->sn[k].nchunk;
-        // hidden 300 (20 tiles): with >= 16 chunks per CU the D-slices are made twice as long and the tiles of a slice go to TWO workgroups of 10 waves x 1
-        // tile (k_w1_update_fwd_ring<10, 1, 4>, grid.y = 2): three chunks in flight per wave where the 10 x 2 two-set kernel has one (its three-set form spills)
         // Round 5, every width of 8 .. 24 hidden tiles other than 16 (which has k_w1_update_fwd_ring<16, 1, 3>): the same ring with ONE tile per wave and four
         // register sets -- HT <= 15: HT waves (8 waves: two workgroups per CU); HT = 18 .. 24: two halves of HT / 2 waves.  The generic kernels of those widths
         // (8 waves x 1-3 tiles, one or two chunks in flight, 256 registers + spills at 3 tiles) ran at 0.47-0.49 of the HBM peak: profiles/r05_hidden_widths.txt
@@ -2309,7 +2307,7 @@ extern "C" int dimn_path_info(dimn_handle h, int32_t* out8) {
     out8[4] = h->mid_fused ? h->mid_slices : 0;                 // ... output slices per sub-net
     out8[5] = h->mid_fused && h->mid_pipe ? 2 : h->mid_keep;                                      // ... W2 column blocks kept in LDS between the phases
     out8[6] = h->res_G ? 2 * h->res_bf16 : h->train_bf16;      // training GEMMs on the bf16 matrix cores: 1 the second layer's (fused kernel), 2 all (resident kernel)
-    out8[7] = h->dm.HT == 16 ? 1 : (h->w1_waves ? 3 : (h->dm.HT == 20 ? 2 : 0));    // first layer: 1 ring B1F1 (H = 256), 2 shared-staging (H = 300), 3 four-set ring over two hidden halves (H = 300, many sub-nets), 0 generic
+    out8[7] = h->dm.HT == 16 ? 1 : (h->w1_waves ? 3 : (h->dm.HT == 20 ? 2 : 0));    // first layer: 1 ring B1F1 (H = 256), 2 shared-staging (H = 300), 3 four-set ring with one hidden tile per wave (8 .. 24 tiles other than 16, from 2 chunks per CU on), 0 generic
     return DIMN_OK;
 }
 
