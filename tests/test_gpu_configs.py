@@ -165,11 +165,14 @@ def _load(cls, cfg, norm, preds, targets, ks, train, val, streamed=False, **kw):
     return e
 
 
-def test_cfg3_shapes_match_oracle():
+@pytest.mark.parametrize("mid", [None, "0"])      # what the library picks (the fused tile pipeline) / the two-kernel second layer forced (k_mid_fwd<16, 6> at 40 sub-nets + k_mid_bwd)
+def test_cfg3_shapes_match_oracle(mid, monkeypatch):
     """BASELINE configs[2] -- the config the metric is quoted on -- at its real shapes against the ORACLE: all K = 40 sub-nets
     with the D_k of the 50k x 20k job, H = 256, O = 512, batch 64, on whatever path the library picks by itself (no DIMN_*
     switch: ring B1F1 + the fused second layer in 6-tile slices): 3 full + 1 partial optimiser step, validation over 250 cells,
     predict of 256 cells.  (Four oracle steps of this size cost ~3 s on the box's cores.)"""
+    if mid is not None:
+        monkeypatch.setenv("DIMN_MID", mid)
     cfg, norm, targets, preds = _cfg3_sample(2048)
     K = targets.shape[0]
     assert K == 40 and 2300 < min(map(len, preds)) and max(map(len, preds)) < 2500
@@ -180,6 +183,7 @@ def test_cfg3_shapes_match_oracle():
     a = _load(_hip(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
     b = _load(_oracle(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
     a.set_profiling(True)
+    assert a.path_info()["mid_fused"] == (1 if mid is None else 0), a.path_info()
     _compare_with_oracle(a, b, norm, preds, targets, list(range(K)), train, val, 4, cfg, kw, rows)
     t = a.get_timers()
     assert t[7] == 0 and t[1] >= 1            # the streaming kernels ran (step_launch times one step in eight), no resident launch
