@@ -505,6 +505,17 @@ __global__ __launch_bounds__(256) void k_reduce_act(const SubnetDev* __restrict_
     *(f32x4*)(Dd + (int64_t)k * DIMN_TB * Hp + e) = dd;
 }
 
+// (x, y) of a 2-D grid whose workgroups of one y should share an XCD (and its L2): workgroup number b = x + gridDim.x * y is dispatched to XCD b % 8, so
+// the workgroups that land on XCD c take the c-th eighth of the (y-major) list -- the mapping of the work tables of B1F1 and k_mid_pipe.  Round 5 (PMC): the 10
+// workgroups of a sub-net in k_mid_bwd sat on 8 XCDs and each fetched the sub-net's 128 KB dZ block from memory -- 47 MB of 126 MB fetched per launch at hidden 300.
+__device__ __forceinline__ void xcd_grid_remap(int& bx, int& by) {
+    const int total = (int)(gridDim.x * gridDim.y), lin = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+    const int q = total >> 3, r = total & 7, xcd = lin & 7;
+    const int idx = xcd * q + (xcd < r ? xcd : r) + (lin >> 3);
+    by = idx / (int)gridDim.x;
+    bx = idx - by * (int)gridDim.x;
+}
+
 // ---------------------------------------------------------------------------------------
 // MF: middle forward.  Workgroup = (sub-net k, output slice os of 64 columns), 8 waves: wave w
 // owns output tile ot = 4*os + (w&3) and the batch rows [32*(w>>2), +32) (two MFMA row tiles).  NTW = 6 (12 waves,
@@ -526,7 +537,9 @@ __global__ __launch_bounds__(128 * NTW) void k_mid_fwd(const float* __restrict__
                                                  float* __restrict__ dZ, float* __restrict__ loss_step,
                                                  double* __restrict__ loss_acc, Dims dm, AdamP ap, float inv_n, int loss_binary, int k0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int os = blockIdx.x, k = blockIdx.y + k0;
+    int os, ky;
+    xcd_grid_remap(os, ky);                             // the slices of a sub-net on one XCD: its Dd block and the batch rows of Y come from memory once
+    const int k = ky + k0;
     const int Hp = dm.Hp, ldd = dm.ldd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lj = lane >> 4;
@@ -667,7 +680,9 @@ __global__ __launch_bounds__(WV * 64, WPS) void k_mid_bwd(const float* __restric
     constexpr int LDR = 16 * NH + 1;                             // padded row of the reduction buffer
     constexpr int RED = (WV * DIMN_TB * LDR) > WV * 1024 ? (WV * DIMN_TB * LDR) : WV * 1024;                       // floats: cross-wave dD reduction buffer
     __shared__ __attribute__((aligned(16))) float lds[RED];     // first WV x 1024 floats double as the dZ tiles
-    const int hs = blockIdx.x, k = blockIdx.y + k0;
+    int hs, ky;
+    xcd_grid_remap(hs, ky);                             // the hidden tiles of a sub-net on one XCD: its dZ and Dd blocks come from memory once
+    const int k = ky + k0;
     const int Hp = dm.Hp, Op = dm.Op;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
