@@ -1310,9 +1310,16 @@ static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, hipStream_t 
     });
 #undef W1_LAUNCH
 }
+// rows per workgroup of the fp32 forward: 64, or 16 where 64-row tiles would give at most half the CUs a workgroup (k_predict<.., MT = 1>)
+static int predict_tile_rows(dimn_handle h, int64_t n_rows) {
+    if (h->predict_bf16) return DIMN_TB;
+    const int64_t wg64 = ((n_rows + DIMN_TB - 1) / DIMN_TB) * h->K;
+    return 2 * wg64 <= (int64_t)h->ncu ? 16 : DIMN_TB;
+}
 template <int NT>
 static void launch_predict_impl(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out, float* loss_part) {
-    const unsigned tiles = (unsigned)((n_rows + DIMN_TB - 1) / DIMN_TB);
+    const int tile_rows = predict_tile_rows(h, n_rows);
+    const unsigned tiles = (unsigned)((n_rows + tile_rows - 1) / tile_rows);
     if (h->predict_bf16) {                         // bf16 matrix cores (precision bf16): fresh bf16 images of the weights, then the forward
         hipLaunchKernelGGL(k_prep_bf16, dim3(256, (unsigned)h->K), dim3(256), 0, h->stream, h->d_sn, (const float*)h->d_W1, (const float*)h->d_W2,
                            h->d_W1b, h->d_W2t, h->dm);
@@ -1344,9 +1351,15 @@ static void launch_predict_impl(dimn_handle h, const int32_t* rows, int64_t n_ro
     hipLaunchKernelGGL(k_prep_w2t, dim3(128, (unsigned)h->K), dim3(256), 0, h->stream, (const float*)h->d_W2, h->d_W2tf, h->dm);
     const size_t lds = ((size_t)DIMN_TB * h->dm.ldp + DIMN_PRED_XS) * sizeof(float);      // activations + the X staging ring
     WITH_XT(h, {
-        (void)hipFuncSetAttribute((const void*)k_predict<NT, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_predict<NT, XT>), dim3(tiles, (unsigned)h->K), dim3(256), lds, h->stream, h->d_sn, (const XT*)h->d_X, h->d_W1, h->d_b1,
-                           h->d_W2tf, h->d_b2, rows, n_rows, out, h->d_Y, h->n, loss_part, h->dm, h->cfg.loss_binary, h->act);
+        if (tile_rows == 16) {
+            (void)hipFuncSetAttribute((const void*)k_predict<NT, XT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_predict<NT, XT, 1>), dim3(tiles, (unsigned)h->K), dim3(256), lds, h->stream, h->d_sn, (const XT*)h->d_X, h->d_W1, h->d_b1,
+                               h->d_W2tf, h->d_b2, rows, n_rows, out, h->d_Y, h->n, loss_part, h->dm, h->cfg.loss_binary, h->act);
+        } else {
+            (void)hipFuncSetAttribute((const void*)k_predict<NT, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_predict<NT, XT>), dim3(tiles, (unsigned)h->K), dim3(256), lds, h->stream, h->d_sn, (const XT*)h->d_X, h->d_W1, h->d_b1,
+                               h->d_W2tf, h->d_b2, rows, n_rows, out, h->d_Y, h->n, loss_part, h->dm, h->cfg.loss_binary, h->act);
+        }
     });
 }
 template <int NT>
@@ -1845,7 +1858,8 @@ extern "C" int dimn_val_loss(dimn_handle h, double* val_loss) {
     for (int32_t r : h->val_rows) if (r < 0 || r >= h->n) return fail(DIMN_ERR_ARG, "dimn_val_loss: validation row %d outside the matrix", r);
     CHK(use_device(h));
     if (h->gen) return gen_val_loss(h, val_loss);
-    const int64_t tiles = (h->n_val + DIMN_TB - 1) / DIMN_TB;
+    const int64_t tile_rows = predict_tile_rows(h, h->n_val);
+    const int64_t tiles = (h->n_val + tile_rows - 1) / tile_rows;
     if (h->loss_part_cap < tiles * h->K) {
         HIPCHK(hipStreamSynchronize(h->stream));
         DEV_FREE(h->d_loss_part);

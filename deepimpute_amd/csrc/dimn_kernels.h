@@ -1760,17 +1760,20 @@ __device__ unsigned long long g_pred_tl[8];
 // and just the same with every load an L1 hit: bound by the vector-memory instruction rate of the CU, not by latency or bytes
 // (8 waves x 2 hidden tiles, at 64 or 128 rows: 12 loads per 64 MFMAs, 1.6x slower).  With the ring: 0.72; the same loop with
 // its loads removed 0.81, without its barrier 0.83 -- the rest is the second layer and the output epilogue (tools/predict_timeline.py).
-template <int NT, typename XT>
+// MT: 16-row tiles per workgroup -- 4 (64 rows), or 1 where 64-row tiles would leave most CUs without a workgroup (round 5: the validation pass of a small
+// problem -- configs[1]: 250 rows x 10 sub-nets = 40 workgroups, 0.31 ms each epoch, 8 % of the impute; with 16-row tiles 160 workgroups of a quarter of the
+// matrix work each; the four waves then stage the same 16 rows, identical values to identical places).
+template <int NT, typename XT, int MT = 4>
 __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ sn, const XT* __restrict__ X,
                                                  const float* __restrict__ W1, const float* __restrict__ b1,
                                                  const float* __restrict__ W2, const float* __restrict__ b2,
                                                  const int32_t* __restrict__ rows, int64_t n_rows,
                                                  float* __restrict__ out, const float* __restrict__ Y, int64_t n_cells,
                                                  float* __restrict__ loss_part, Dims dm, int loss_binary, int act) {
-    constexpr int MT = 4, NW = 4;
+    constexpr int NW = 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int k = blockIdx.y;
-    const int64_t r0 = (int64_t)blockIdx.x * DIMN_TB;
+    const int64_t r0 = (int64_t)blockIdx.x * (16 * MT);
     const SubnetDev s = sn[k];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lj = lane >> 4;
@@ -1785,7 +1788,7 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // this wave's rows of the X tile (rows past n_rows read row 0 and are dropped at the end: every load unconditional)
-    const int64_t irow = r0 + 16 * wave + li;
+    const int64_t irow = r0 + 16 * (wave % MT) + li;
     const int64_t xrow = irow < n_rows ? (rows ? (int64_t)rows[irow] : irow) : 0;
     const XT* xk = X + s.xoff + xrow * s.Dp + 4 * lj;
     const int64_t cstride = (int64_t)Hp * 16;
@@ -1803,7 +1806,7 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
         for (int nt = 0; nt < NT; ++nt) o.b[nt] = *(const f32x4*)(wbt[nt] + cc * cstride);
     };
     XRaw<XT> xr;                                             // the X piece in flight (chunk c + 1 at the top of iteration c)
-    float* xw = xs + (16 * wave + li) * 16 + 4 * lj;         // where this lane's piece goes in a stage
+    float* xw = xs + (16 * (wave % MT) + li) * 16 + 4 * lj;  // where this lane's piece goes in a stage
     const float* xrd = xs + li * 16 + 4 * lj;                // row tile mt of a stage: + 256 * mt
     // iteration c (stage st = c % 3):  X(c+1) -> stage st+1;  request X(c+2), W(c+2);  barrier;  MFMAs of chunk c from stage st, W(c)
     auto step = [&](WSet& wcur, WSet& wnew, int c, int st) {
