@@ -1310,11 +1310,12 @@ static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, hipStream_t 
     });
 #undef W1_LAUNCH
 }
-// rows per workgroup of the fp32 forward: 64, or 16 where 64-row tiles would give at most half the CUs a workgroup (k_predict<.., MT = 1>)
+// rows per workgroup of the fp32 forward: 64; 32 where 64-row tiles would not give every CU a workgroup, 16 where they would reach less than a quarter of the CUs
+// (k_predict<.., MT = 2 / 1>: more, smaller workgroups; every workgroup reads the sub-net's whole W1 from L2, so the tiles are no smaller than they must be)
 static int predict_tile_rows(dimn_handle h, int64_t n_rows) {
     if (h->predict_bf16) return DIMN_TB;
     const int64_t wg64 = ((n_rows + DIMN_TB - 1) / DIMN_TB) * h->K;
-    return 2 * wg64 <= (int64_t)h->ncu ? 16 : DIMN_TB;
+    return wg64 >= (int64_t)h->ncu ? DIMN_TB : (4 * wg64 >= (int64_t)h->ncu ? 32 : 16);
 }
 template <int NT>
 static void launch_predict_impl(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out, float* loss_part) {
@@ -1349,18 +1350,23 @@ static void launch_predict_impl(dimn_handle h, const int32_t* rows, int64_t n_ro
     }
     // the second-layer operand form of k_predict: a fresh W2T image (21 MB at 40 sub-nets: ~10 us per call)
     hipLaunchKernelGGL(k_prep_w2t, dim3(128, (unsigned)h->K), dim3(256), 0, h->stream, (const float*)h->d_W2, h->d_W2tf, h->dm);
-    const size_t lds = ((size_t)DIMN_TB * h->dm.ldp + DIMN_PRED_XS) * sizeof(float);      // activations + the X staging ring
+    const size_t lds = ((size_t)tile_rows * h->dm.ldp + 3 * (size_t)tile_rows * 16) * sizeof(float);      // activations + the X staging ring
+#define PRED_LAUNCH(MTV)                                                                                                                                     \
+            {                                                                                                                                                \
+                (void)hipFuncSetAttribute((const void*)k_predict<NT, XT, MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+                hipLaunchKernelGGL((k_predict<NT, XT, MTV>), dim3(tiles, (unsigned)h->K), dim3(256), lds, h->stream, h->d_sn, (const XT*)h->d_X, h->d_W1,     \
+                                   h->d_b1, h->d_W2tf, h->d_b2, rows, n_rows, out, h->d_Y, h->n, loss_part, h->dm, h->cfg.loss_binary, h->act);              \
+            }
     WITH_XT(h, {
-        if (tile_rows == 16) {
-            (void)hipFuncSetAttribute((const void*)k_predict<NT, XT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((k_predict<NT, XT, 1>), dim3(tiles, (unsigned)h->K), dim3(256), lds, h->stream, h->d_sn, (const XT*)h->d_X, h->d_W1, h->d_b1,
-                               h->d_W2tf, h->d_b2, rows, n_rows, out, h->d_Y, h->n, loss_part, h->dm, h->cfg.loss_binary, h->act);
-        } else {
+        if (tile_rows == 16) PRED_LAUNCH(1)
+        else if (tile_rows == 32) PRED_LAUNCH(2)
+        else {
             (void)hipFuncSetAttribute((const void*)k_predict<NT, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((k_predict<NT, XT>), dim3(tiles, (unsigned)h->K), dim3(256), lds, h->stream, h->d_sn, (const XT*)h->d_X, h->d_W1, h->d_b1,
                                h->d_W2tf, h->d_b2, rows, n_rows, out, h->d_Y, h->n, loss_part, h->dm, h->cfg.loss_binary, h->act);
         }
     });
+#undef PRED_LAUNCH
 }
 template <int NT>
 static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out, float* loss_part) {

@@ -1760,7 +1760,7 @@ __device__ unsigned long long g_pred_tl[8];
 // and just the same with every load an L1 hit: bound by the vector-memory instruction rate of the CU, not by latency or bytes
 // (8 waves x 2 hidden tiles, at 64 or 128 rows: 12 loads per 64 MFMAs, 1.6x slower).  With the ring: 0.72; the same loop with
 // its loads removed 0.81, without its barrier 0.83 -- the rest is the second layer and the output epilogue (tools/predict_timeline.py).
-// MT: 16-row tiles per workgroup -- 4 (64 rows), or 1 where 64-row tiles would leave most CUs without a workgroup (round 5: the validation pass of a small
+// MT: 16-row tiles per workgroup -- 4 (64 rows), or 2 / 1 where 64-row tiles would leave most CUs without a workgroup (round 5: the validation pass of a small
 // problem -- configs[1]: 250 rows x 10 sub-nets = 40 workgroups, 0.31 ms each epoch, 8 % of the impute; with 16-row tiles 160 workgroups of a quarter of the
 // matrix work each; the four waves then stage the same 16 rows, identical values to identical places).
 template <int NT, typename XT, int MT = 4>
@@ -1779,7 +1779,7 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
     const int li = lane & 15, lj = lane >> 4;
     const int nt0 = wave * NT;
     const int Hp = dm.Hp, ldp = dm.ldp;
-    float* xs = lds + DIMN_TB * ldp;                         // X staging ring [3][64 rows][16]
+    float* xs = lds + 16 * MT * ldp;                         // X staging ring [3][16 MT rows][16]
     PRED_TL_DECL
 
     f32x4 acc[MT][NT];
@@ -1810,14 +1810,14 @@ __global__ __launch_bounds__(256) void k_predict(const SubnetDev* __restrict__ s
     const float* xrd = xs + li * 16 + 4 * lj;                // row tile mt of a stage: + 256 * mt
     // iteration c (stage st = c % 3):  X(c+1) -> stage st+1;  request X(c+2), W(c+2);  barrier;  MFMAs of chunk c from stage st, W(c)
     auto step = [&](WSet& wcur, WSet& wnew, int c, int st) {
-        *(f32x4*)(xw + ((st + 1) % 3) * (DIMN_TB * 16)) = xr.get();
+        *(f32x4*)(xw + ((st + 1) % 3) * (16 * MT * 16)) = xr.get();
         xr.load(xk + 16 * clampc(c + 2));
         fetch_w(wnew, c + 2);
         __builtin_amdgcn_sched_barrier(0);                   // the requests leave before this chunk's MFMAs (hipcc sinks them otherwise)
         __syncthreads();
         f32x4 a4[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a4[mt] = *(const f32x4*)(xrd + st * (DIMN_TB * 16) + 256 * mt);
+        for (int mt = 0; mt < MT; ++mt) a4[mt] = *(const f32x4*)(xrd + st * (16 * MT * 16) + 256 * mt);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
