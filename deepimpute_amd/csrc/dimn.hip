@@ -1315,6 +1315,9 @@ static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, hipStream_t 
 static int predict_tile_rows(dimn_handle h, int64_t n_rows) {
     if (h->predict_bf16) return DIMN_TB;
     const int64_t wg64 = ((n_rows + DIMN_TB - 1) / DIMN_TB) * h->K;
+    // hidden widths whose 64-row activation image takes more than half of a CU's LDS (20 tiles on: ONE workgroup of four waves per CU): 32-row tiles, three
+    // workgroups per CU -- the forward over 50k cells 39.8 -> 34.0 ms at hidden 300, 45.4 -> 42.5 at 384 (same box, rocprofv3)
+    if (((size_t)DIMN_TB * h->dm.ldp + DIMN_PRED_XS) * sizeof(float) > 80 * 1024 && wg64 >= (int64_t)h->ncu) return 32;
     return wg64 >= (int64_t)h->ncu ? DIMN_TB : (4 * wg64 >= (int64_t)h->ncu ? 32 : 16);
 }
 template <int NT>
