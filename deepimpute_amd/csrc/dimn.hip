@@ -1314,17 +1314,20 @@ static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, hipStream_t 
 }
 // rows per workgroup of the fp32 forward: 64; 32 where 64-row tiles would not give every CU a workgroup, 16 where they would reach less than a quarter of the CUs
 // (k_predict<.., MT = 2 / 1>: more, smaller workgroups; every workgroup reads the sub-net's whole W1 from L2, so the tiles are no smaller than they must be)
-static int predict_tile_rows(dimn_handle h, int64_t n_rows) {
+static int predict_tile_rows(dimn_handle h, int64_t n_rows, bool validation) {
     if (h->predict_bf16) return DIMN_TB;
     const int64_t wg64 = ((n_rows + DIMN_TB - 1) / DIMN_TB) * h->K;
     // hidden widths whose 64-row activation image takes more than half of a CU's LDS (20 tiles on: ONE workgroup of four waves per CU): 32-row tiles, three
     // workgroups per CU -- the forward over 50k cells 39.8 -> 34.0 ms at hidden 300, 45.4 -> 42.5 at 384 (same box, rocprofv3)
     if (((size_t)DIMN_TB * h->dm.ldp + DIMN_PRED_XS) * sizeof(float) > 80 * 1024 && wg64 >= (int64_t)h->ncu) return 32;
+    // the validation pass (a few rounds of workgroups: 2 500 rows x 40 sub-nets = 3.1 rounds of 64-row tiles, the last one an eighth full): 32-row tiles halve
+    // what the partial round costs -- 1.72 -> 1.52 ms at 40 sub-nets, 0.97 -> 0.85 at 20 (rocprofv3); the forward over all cells (many rounds) keeps 64 rows
+    if (validation && wg64 >= 4 * (int64_t)h->ncu / 2 && wg64 < 8 * (int64_t)h->ncu) return 32;
     return wg64 >= (int64_t)h->ncu ? DIMN_TB : (4 * wg64 >= (int64_t)h->ncu ? 32 : 16);
 }
 template <int NT>
 static void launch_predict_impl(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out, float* loss_part) {
-    const int tile_rows = predict_tile_rows(h, n_rows);
+    const int tile_rows = predict_tile_rows(h, n_rows, loss_part != nullptr && out == nullptr);
     const unsigned tiles = (unsigned)((n_rows + tile_rows - 1) / tile_rows);
     if (h->predict_bf16) {                         // bf16 matrix cores (precision bf16): fresh bf16 images of the weights, then the forward
         hipLaunchKernelGGL(k_prep_bf16, dim3(256, (unsigned)h->K), dim3(256), 0, h->stream, h->d_sn, (const float*)h->d_W1, (const float*)h->d_W2,
@@ -1880,7 +1883,7 @@ extern "C" int dimn_val_loss(dimn_handle h, double* val_loss) {
     for (int32_t r : h->val_rows) if (r < 0 || r >= h->n) return fail(DIMN_ERR_ARG, "dimn_val_loss: validation row %d outside the matrix", r);
     CHK(use_device(h));
     if (h->gen) return gen_val_loss(h, val_loss);
-    const int64_t tile_rows = predict_tile_rows(h, h->n_val);
+    const int64_t tile_rows = predict_tile_rows(h, h->n_val, true);
     const int64_t tiles = (h->n_val + tile_rows - 1) / tile_rows;
     if (h->loss_part_cap < tiles * h->K) {
         HIPCHK(hipStreamSynchronize(h->stream));
