@@ -1929,10 +1929,15 @@ extern "C" int dimn_predict_device(dimn_handle h, const int32_t* rows, int64_t n
     if (!h->gathered) return fail(DIMN_ERR_STATE, "dimn_predict: call dimn_set_matrix, dimn_set_indices and dimn_gather first");
     if (!rows && n_rows > h->n) return fail(DIMN_ERR_ARG, "dimn_predict: n_rows exceeds the matrix");
     CHK(use_device(h));
+    // from here on the previous result is gone: no exit below may leave out_rows / pred_ev_rows describing it while d_out is a fresh,
+    // unwritten block (a following dimn_impute_finish* with the old n_rows would pass its state check and read it)
+    h->out_rows = 0;
+    h->pred_ev_rows.clear();
     const int64_t need = n_rows * h->K * h->O;
     if (h->out_cap < need) {
         HIPCHK(hipStreamSynchronize(h->stream));
         DEV_FREE(h->d_out);
+        h->out_cap = 0;
         CHK(dev_alloc(&h->d_out, (size_t)need));
         h->out_cap = need;
     }
@@ -1949,7 +1954,6 @@ extern "C" int dimn_predict_device(dimn_handle h, const int32_t* rows, int64_t n
         HIPCHK(hipStreamSynchronize(h->stream));
         drows = h->d_pred_rows;
     }
-    h->pred_ev_rows.clear();
     if (n_rows > 0 && h->gen) {
         CHK(gen_predict(h, drows, n_rows));
     } else if (n_rows > 0 && !rows && n_rows >= 8192 && !h->predict_bf16) {

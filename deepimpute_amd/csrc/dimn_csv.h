@@ -14,7 +14,10 @@
 // Host-only; no HIP call in this file.
 #pragma once
 #include <charconv>
+#include <errno.h>
 #include <fcntl.h>
+#include <pthread.h>
+#include <signal.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -204,10 +207,12 @@ static int csv_write(const char* path, const double* values, int64_t n_rows, int
     const char* c = col_labels;
     for (int64_t j = 0; j < n_cols; ++j) { head += ','; head += c; c += strlen(c) + 1; }
     head += '\n';
+    int werr = 0;
     auto write_all = [&](const char* p, size_t len) -> bool {
         while (len) {
             const ssize_t w = ::write(fd, p, len);
-            if (w <= 0) return false;
+            if (w < 0 && errno == EINTR) continue;            // a signal handler ran (CPython installs its own without SA_RESTART): not a failure
+            if (w <= 0) { werr = w < 0 ? errno : EIO; return false; }      // (errno is per thread: kept for the caller's message)
             p += w; len -= (size_t)w;
         }
         return true;
@@ -247,13 +252,20 @@ static int csv_write(const char* path, const double* values, int64_t n_rows, int
         });
         if (writer.joinable()) { writer.join(); ok = ok && wrote; }         // the other set is on disk: the next batch may be formatted into it
         writer = std::thread([&, set] {
+            sigset_t all;                                         // signals belong to the interpreter's main thread, not to this helper
+            sigfillset(&all);
+            pthread_sigmask(SIG_BLOCK, &all, nullptr);
             bool good = true;
             for (const std::string& s : buf[set]) good = good && (s.empty() || write_all(s.data(), s.size()));
             wrote = good;
         });
     }
     if (writer.joinable()) { writer.join(); ok = ok && wrote; }
-    if (::close(fd) != 0) ok = false;
-    if (!ok) { err = "write failed"; return -1; }
+    if (::close(fd) != 0) { ok = false; if (!werr) werr = errno; }
+    if (!ok) {
+        err = std::string("write failed (") + strerror(werr) + "); the partial file was removed";
+        ::unlink(path);                                           // never leave a truncated CSV behind under the final name
+        return -1;
+    }
     return 0;
 }

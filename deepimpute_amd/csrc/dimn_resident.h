@@ -62,6 +62,18 @@
 #define DIMN_RES_W2S 27104        // LDS float offset of the W2 state
 #define DIMN_RES_LDS_FLOATS (DIMN_RES_W2S + 3 * 16 * 256)
 #define DIMN_RES_SLOTS 2
+#ifndef DIMN_RES_WAVE_DD
+#define DIMN_RES_WAVE_DD 1        // round 6: role 2 takes its Dd tiles wave by wave into the operand registers (0: rounds 3-5, all sixteen through LDS)
+#endif
+#ifndef DIMN_RES_KEEP_EARLY
+#define DIMN_RES_KEEP_EARLY 1     // round 6: the manager's dropout keep word is requested at the top of the step, not behind the P gather
+#endif
+#ifndef DIMN_RES_POLL2
+#define DIMN_RES_POLL2 1          // round 6: two canary polls in flight (the next one leaves before the previous one is checked)
+#endif
+#ifndef DIMN_RES_SELF_DA
+#define DIMN_RES_SELF_DA 0        // round 6: the role-2 siblings of a hidden tile sum its dD partials themselves (0: rounds 3-5, the manager publishes dA)
+#endif
 // (round 3's experiment switches -- DIMN_RES_EVEN / _DIRECT / _XCD / _GDIRECT / _M2WIN / _ABL -- are gone from the source; what each
 //  measured is in DESIGN.md section 2b and profiles/r03_resident_*.txt)
 
@@ -137,6 +149,27 @@ __device__ __forceinline__ bool res_poll(__amdgpu_buffer_rsrc_t r, uint32_t base
     const int lane = threadIdx.x & 63;
     unsigned spins = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+#if DIMN_RES_POLL2
+    if (n <= 64) {
+        // two polls in flight: the next request leaves before the previous answer is looked at, so a piece that lands is seen after
+        // half a round trip on average instead of a whole one (a poll is one 16-byte request per producer tile)
+        const uint32_t off = base + (uint32_t)(lane < n ? lane : 0) * stride;
+        f32x4 x0 = res_ld(r, off);
+        for (;;) {
+            const f32x4 x1 = res_ld(r, off);
+            if (__builtin_amdgcn_ballot_w64(res_unwritten(x0)) == 0) return true;
+            x0 = x1;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63u) == 0u) {
+                if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > DIMN_RES_WAIT_TICKS) {
+                    __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return false;
+                }
+            }
+        }
+    }
+#endif
     for (;;) {
         bool missing = false;
         for (int i = lane; i < n; i += 64) missing |= res_unwritten(res_ld(r, base + (uint32_t)i * stride));
@@ -158,6 +191,7 @@ __device__ __forceinline__ void res_fix(f32x4& x, __amdgpu_buffer_rsrc_t r, uint
         asm volatile("" ::: "memory");                       // the reload is a new observation of memory
         x = res_ld(r, off);
         if (++spins > DIMN_RES_SPIN_LIMIT) { __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if ((spins & 255u) == 0u && __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // the launch is being abandoned
     }
 }
 // The dropout keep words of a whole epoch (they depend on no data): maskw[t][k][row b][word h/32], bit h%32 = keep(b, h);
@@ -244,6 +278,11 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
     const bool is_o = wi < dm.OT;                            // role 2: owns output tile wi
     const bool is_m = sp == S1 - 1;                          // manager of hidden tile ht
     const int ot = is_o ? wi : 0;
+    // Round 6: a sibling that is also a role-2 workgroup sums the dD partials of its hidden tile ITSELF (the same gather, in the same order, as
+    // the manager's: bit-identical dA), so the fourth hand-off of a step -- manager -> siblings, ~1.3 us + the receiving phase -- is gone for it;
+    // the manager publishes dA only when some sibling is NOT a role-2 workgroup (more than OT / 16 + 1 D-splits: never at 5 sub-nets per GPU).
+    const bool self_da = is_m || (DIMN_RES_SELF_DA && is_o);
+    const bool pub_da = (S1 - 1) * 16 > (DIMN_RES_SELF_DA ? dm.OT : 0);
     const SubnetDev s = p.sn[k];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
@@ -385,6 +424,11 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                     res_st(rP, slot_out + (uint32_t)(wi * 4096 + 16 * tid), a);
                 }
             }
+#if DIMN_RES_WAVE_DD
+            // role 2 of the next step writes LDS wave by wave with no barrier in front (its Dd tiles and Z partials alias `pred`): the
+            // waves that do not sum wait here for those that do -- behind the publishing store, off the step's critical path
+            if (is_o) __syncthreads();
+#endif
         }
         RES_STAMP(9)
     };
@@ -446,6 +490,13 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
         int32_t rn[4];
         xrows_raw(tid, (t + 1) * B, b_next, rn);
         const int32_t yrow_n = target_row(tid, t + 1);          // unconditional: a load under a divergent branch makes hipcc drain vmcnt at the join
+#if DIMN_RES_KEEP_EARLY
+        // the dropout keep word of this thread's four units (M1, manager): requested HERE, a whole P hand-off before its use -- rounds 2-5
+        // requested it behind the gather of the siblings' partials, a dependent round trip to HBM (the epoch's keep words are read once)
+        // in front of the Dd tile every role-2 workgroup of the sub-net waits for
+        unsigned keep_w = 0xffffffffu;
+        if (p.rate > 0.f) keep_w = __builtin_amdgcn_raw_buffer_load_b32(rM, moff(t) + (uint32_t)(32 * ((tid & 255) >> 2) + 4 * (ht >> 1)), 0, 0);
+#endif
         RES_STAMP(10)
 
         // =============================== M1 (manager): A = sum_s P_s + b1 -> the Dd tile ===============================
@@ -467,7 +518,11 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             }
             a += *(const f32x4*)(b1l + 4 * uq);
             unsigned keep = 0xfu;
+#if DIMN_RES_KEEP_EARLY
+            if (p.rate > 0.f) keep = keep_w >> (16 * (ht & 1) + 4 * uq);
+#else
             if (p.rate > 0.f) keep = __builtin_amdgcn_raw_buffer_load_b32(rM, moff(t) + (uint32_t)(32 * ub + 4 * (ht >> 1)), 0, 0) >> (16 * (ht & 1) + 4 * uq);
+#endif
             if (ub >= b_act) keep = 0u;
             f32x4 dd;
 #pragma unroll
@@ -484,13 +539,57 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             // P(t) of every sibling is in, so each of them has run the tile loop of step t-1, i.e. consumed dA(t-1): its slot is
             // free -- marked "not written" for dA(t+1) BEHIND the Dd tile; M2's drain (a role-2 phase later) acknowledges it before
             // dA(t) -- which is what lets a sibling get as far as polling that slot -- leaves
-            if (S1 > 1) res_st(rA, tnext + (uint32_t)(ht * 4096 + 16 * tid), sent4);
+            if (pub_da) res_st(rA, tnext + (uint32_t)(ht * 4096 + 16 * tid), sent4);
         }
         RES_STAMP(0)
 
         // =============================== phase A (role 2) ===============================
         if (is_o) {
             if (tid < 256) *(f32x4*)(yl + 4 * tid) = y_a;
+#if DIMN_RES_WAVE_DD
+            // Round 6: every wave takes ITS two Dd tiles (hidden tiles 2 wave, 2 wave + 1: the 32 hidden units of its Z partial) by itself,
+            // straight into the A-operand registers of the matrix instructions -- piece 64 m + 4 li + lj of a [64][16] tile IS
+            // Dd[b = 16 m + li][h = 4 lj ..]: no workgroup-wide poll, no staging of all sixteen tiles through LDS, no barrier in front of
+            // the first matrix instruction (rounds 3-5: one wave polled all sixteen managers, barrier, 64 KB -> LDS, barrier).  The tiles go
+            // to LDS afterwards, for the W2 gradient of the same wave (wave-private columns: no barrier either).
+            const uint32_t tb = tcur + (uint32_t)(2 * wave * 4096);
+            (void)res_poll(rT, tb, 2, 4096u, abort_w);              // (abort: the next workgroup-wide wait leaves)
+            f32x4 a4[2][4];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a4[h2][m] = res_ld(rT, tb + (uint32_t)(h2 * 4096 + 16 * (64 * m + 4 * li + lj)));
+            // Dd(t) of managers 2 wave, 2 wave + 1 is out, so both -- and their siblings, whose P(t) they summed first -- have finished
+            // gathering the dD partials of the step before: tiles (ot, 2 wave), (ot, 2 wave + 1) of that dD slot are free -- marked "not
+            // written" for the step after this one; acknowledged before this wave's dD stores of this step leave (vmcnt(0) there).
+#pragma unroll
+            for (int i = 0; i < 8; ++i) res_st(rD, dfree + (uint32_t)(ot * 65536 + 2 * wave * 4096 + (i * 64 + lane) * 16), sent4);
+            const float* ws = w2s + 2 * wave * 256;              // this wave's two W2 tiles [h][o]
+            RES_STAMP(1)
+            {   // Z partial over this wave's 32 hidden units
+                f32x4 acc[4] = {zero4, zero4, zero4, zero4};
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    f32x4 bq;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bq[r] = ws[h2 * 256 + (4 * lj + r) * 16 + li];   // W2[h = 4lj+r][o = li]
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        res_fix(a4[h2][m], rT, tb + (uint32_t)(h2 * 4096 + 16 * (64 * m + 4 * li + lj)), abort_w);
+                        acc[m] = res_mfma4<BF>(a4[h2][m], bq, acc[m]);
+                    }
+                }
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) *(f32x4*)(ddl + (16 * m + li) * ldd + 16 * (2 * wave + h2) + 4 * lj) = a4[h2][m];
+                RES_STAMP(2)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zred[wave * 1024 + (16 * m + 4 * lj + r) * 16 + li] = acc[m][r];
+            }
+#else
             if (wave == 4) { const bool ok = res_poll(rT, tcur, 16, 4096u, abort_w); if (lane == 0) flagl[0] = ok ? 1 : 0; }   // (wave 4: never busy with M1)
             __syncthreads();
             if (!flagl[0]) return;
@@ -531,6 +630,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
 #pragma unroll
                     for (int r = 0; r < 4; ++r) zred[wave * 1024 + (16 * m + 4 * lj + r) * 16 + li] = acc[m][r];
             }
+#endif
             __syncthreads();
             {   // epilogue of the forward: two elements per thread of the [64][16] tile
                 float lsum = 0.f, dzc = 0.f;
@@ -640,7 +740,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             }
             if (t + 1 < p.steps) y_a = targets(tid, yrow_n);     // every thread (unconditional load); role 2 uses the first 256
             RES_STAMP(5)
-            if (is_m) {
+            if (self_da) {
                 if (wave == 0) { const bool ok = res_poll(rD, dcur + (uint32_t)(ht * 4096), OT, 65536u, abort_w); if (lane == 0) flagl[1] = ok ? 1 : 0; }
                 __syncthreads();
                 if (!flagl[1]) return;
@@ -678,18 +778,28 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 __syncthreads();
                 if (half == 0) {
                     d += *(const f32x4*)(yl + 4 * tid);
+                    if (!is_m) {                                 // a role-2 sibling: the gate of its hidden tile from the Dd tiles it holds in LDS (Dd > 0 <=> kept and A > 0)
+                        const f32x4 ddv = *(const f32x4*)(ddl + ub * ldd + 16 * ht + 4 * uq);
+                        gate = (ddv[0] > 0.f ? 1u : 0u) | (ddv[1] > 0.f ? 2u : 0u) | (ddv[2] > 0.f ? 4u : 0u) | (ddv[3] > 0.f ? 8u : 0u);
+                    }
                     f32x4 da;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) da[r] = ((gate >> r) & 1u) ? d[r] * p.scale : 0.f;
                     *(f32x4*)(dzl + 4 * tid) = da;               // dA tile [64][16]
-                    if (S1 > 1) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the re-arm of this dA slot's sibling, issued behind the Dd tile in M1: long in place)
-                        res_st(rA, tcur + (uint32_t)(ht * 4096 + 16 * tid), da);
+                    if (is_m) {
+                        if (pub_da) {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the re-arm of this dA slot's sibling, issued behind the Dd tile in M1: long in place)
+                            res_st(rA, tcur + (uint32_t)(ht * 4096 + 16 * tid), da);
+                        }
+                        // every dD partial of this step was out, so every role-2 workgroup has read the Dd tiles of this step: that slot is
+                        // free -- marked "not written" for step t+2, BEHIND the dA tile; acknowledged by M1's drain of the next step, a tile
+                        // loop from here, before Dd(t+1) leaves
+                        res_st(rT, tcur + (uint32_t)(ht * 4096 + 16 * tid), sent4);
+                    } else {
+                        // dD(t) exists, so Dd(t) did, so the manager has summed P(t): this workgroup's P slot of step t is free -- marked "not
+                        // written" for P(t+2); acknowledged before P(t+1) leaves (vmcnt(0) in role1)
+                        res_st(rP, pcur + (uint32_t)(wi * 4096 + 16 * tid), sent4);
                     }
-                    // every dD partial of this step was out, so every role-2 workgroup has read the Dd tiles of this step: that slot is
-                    // free -- marked "not written" for step t+2, BEHIND the dA tile; acknowledged by M1's drain of the next step, a tile
-                    // loop from here, before Dd(t+1) leaves
-                    res_st(rT, tcur + (uint32_t)(ht * 4096 + 16 * tid), sent4);
                     col4(da);
                 }
             } else {

@@ -273,6 +273,10 @@ class GeneralEngine(Engine):
         return loss
 
 
+class FrameMismatch(Exception):
+    """impute_finish(raw=None, observed=frame): `frame` turned out not to be the count matrix the device holds."""
+
+
 class HipEngine(Engine):
     """Engine on libdimn.so (hand-written HIP kernels for gfx950).  Raises ImportError-like
     `DimnError` when the library is not built: the product never falls back to a CPU path."""
@@ -321,8 +325,12 @@ class HipEngine(Engine):
             if rc == 0:
                 self.last_observed_checksum = int(cs.value)
                 return out
-            if rc != -3:                          # DIMN_ERR_STATE: not the resident matrix -> the dense path below (the caller's checksum says the same)
-                self._check(rc)
+            if rc == -3:
+                # DIMN_ERR_STATE: `observed` is not the matrix the device holds.  The dense epilogue over the RESIDENT counts would finish a
+                # frame the caller did not pass (8 GB of device-to-host copy at 50k x 20k, thrown away): say so instead -- predict() uploads
+                # the frame it was given and runs the ordinary sequence once.
+                raise FrameMismatch("the frame is not the count matrix resident on the device")
+            self._check(rc)
         code = {None: 0, "restore": 1, "max": 2}.get(policy, 0)
         self._check(self._f["impute_finish"](self._h, p_f64(raw), shape[0], shape[1], p_i32(gene_off), p_i32(gene_slot),
                                              code, float(ceiling), int(bool(from_gathered)), p_f64(out)))

@@ -23,6 +23,7 @@ import glob
 import json
 import os
 import re
+import sys
 import tempfile
 import warnings
 
@@ -220,7 +221,23 @@ def _start_save(directory, work):
             box["error"] = exc
     thread = threading.Thread(target=run, name="dimn-save")      # not a daemon: the interpreter waits for the files at exit
     _pending_saves[key] = (thread, box)
+    if not _pending_saves_hooked:
+        import atexit
+        _pending_saves_hooked.append(True)
+        atexit.register(_report_unjoined_saves)
     thread.start()
+
+
+_pending_saves_hooked = []
+
+
+def _report_unjoined_saves():
+    """atexit: a write nobody joined (fit() joins its own: only a raise between save() and the join leaves one) must not fail silently."""
+    for key in list(_pending_saves):
+        try:
+            _join_saves(key)
+        except BaseException as exc:
+            sys.stderr.write("deepimpute_amd: writing the model files in %s failed: %r\n" % (key, exc))
 
 
 def _join_saves(directory=None):
@@ -396,17 +413,39 @@ class MultiNet:
             arrays = fetched[k]
             for i, arr in enumerate(arrays):
                 blobs["%s%d_%d" % ("Wb"[i % 2], i // 2 + 1, self._first_subnet + k)] = arr
-        if world == 1 and getattr(self, "_defer_save", False):
-            # fit() (round 5): the weights are on the host; writing them -- 119 MB of HDF5 at the 50k x 20k job, 0.03-0.05 s -- needs neither
-            # the GPU nor the caller, so it runs on a helper thread while fit() computes its held-out metrics and returns.  Whoever
-            # READS the directory in this process waits for it first (load(), a second save(), close(), interpreter exit): _join_saves.
-            _start_save(self.outputdir, lambda: self._write_weight_files(blobs, fmt, layers, dims, rank, world, comm, laps, t_write))
+        deferred = world == 1 and getattr(self, "_defer_save", False)
+        if deferred:
+            # fit(): the weights are on the host; writing them -- 119 MB of HDF5 at the 50k x 20k job, 0.03-0.05 s -- needs neither the GPU
+            # nor the caller, so it runs on a helper thread UNDER fit()'s held-out metrics only.  fit() joins it before it returns
+            # (_finish_deferred_save: the reference's save() is synchronous, multinet.py:105-115, :249 -- when fit() returns the files
+            # exist, a failed write raises out of fit(), and "Saved model to disk" is printed after the write).  The helper times itself
+            # into a private dict; the caller merges it into self.timings after the join.
+            self._deferred_laps = {}
+            _start_save(self.outputdir, lambda: self._write_weight_files(blobs, fmt, layers, dims, rank, world, comm, self._deferred_laps, t_write))
         else:
             self._write_weight_files(blobs, fmt, layers, dims, rank, world, comm, laps, t_write)
         written = {"h5": "model.json + model.h5 (Keras save_weights layout)", "npz": "model.json + model.npz (no HDF5 library found: set DIMN_LIBHDF5, "
                    "or DIMN_MODEL_FORMAT=h5 to insist)" if not os.environ.get("DIMN_MODEL_FORMAT") else "model.json + model.npz",
                    "both": "model.json + model.h5 + model.npz"}[fmt]
-        print("Saved model to disk in {}".format(self.outputdir) + " [%s%s]" % (written, "; shards model.rank0..%d.npz" % (world - 1) if world > 1 else ""))
+        message = "Saved model to disk in {}".format(self.outputdir) + " [%s%s]" % (written, "; shards model.rank0..%d.npz" % (world - 1) if world > 1 else "")
+        if deferred:
+            self._deferred_message = message
+        else:
+            print(message)
+
+    def _finish_deferred_save(self):
+        """fit()'s half of a deferred save(): wait for the weight files (a failed write raises HERE, out of fit()), merge the helper's
+        lap times, print the reference's message (multinet.py:115) now that it is true."""
+        try:
+            _join_saves(self.outputdir)
+        finally:
+            laps, extra = getattr(self, "timings", None), self.__dict__.pop("_deferred_laps", None)
+            if isinstance(laps, dict) and extra:
+                for name, seconds in extra.items():
+                    laps[name] = laps.get(name, 0.0) + seconds
+        message = self.__dict__.pop("_deferred_message", None)
+        if message:
+            print(message)
 
     def _write_weight_files(self, blobs, fmt, layers, dims, rank, world, comm, laps, t_write):
         """The file-system half of save(): stale files out, model.npz / model.h5 (and the shards of a sharded job) in."""
@@ -675,8 +714,12 @@ class MultiNet:
                 self.save(engine)
             finally:
                 self._defer_save = False
-        with tm.stage("fit.held_out_metrics"):
-            self.test_metrics = self._held_out_metrics(engine, norm_data, held_out, rows_val)
+        try:
+            with tm.stage("fit.held_out_metrics"):
+                self.test_metrics = self._held_out_metrics(engine, norm_data, held_out, rows_val)
+        finally:
+            with tm.stage("fit.save.join"):
+                self._finish_deferred_save()             # the files are on disk (or the write's error is raised) before fit() returns
         with tm.stage("fit.free"):
             del norm_data, var, mean, gene_metric
         return self
@@ -972,9 +1015,13 @@ class MultiNet:
 
         with tm.stage("predict.forward+finish"):
             engine.last_observed_checksum = None         # (set by the restore epilogue when it has read the whole frame)
-            values = self._finish_on_device(engine, observed, where[slot_gene], policy, ceiling, resident=resident is not None)
+            from .engine import FrameMismatch
             same = True
-            if resident is not None and held is not None and resident is held[0]:
+            try:
+                values = self._finish_on_device(engine, observed, where[slot_gene], policy, ceiling, resident=resident is not None)
+            except FrameMismatch:                        # the restore epilogue found the frame to differ from the resident counts: straight to the re-upload
+                values, same = None, False
+            if same and values is not None and resident is not None and held is not None and resident is held[0]:
                 same = verdict() if verdict is not None else getattr(engine, "last_observed_checksum", None) == resident.checksum
             if not same:
                 # the frame is not the one that was fitted: upload it and run the ordinary sequence
