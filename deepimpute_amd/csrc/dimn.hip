@@ -2591,6 +2591,14 @@ extern "C" int dimn_debug_res_timeline(unsigned long long* out, int n_words) {
 }
 #endif
 
+#ifdef DIMN_RES_TL2
+// diagnostic build only (tools/res_trace.py): absolute time stamps of four steps of the last resident epoch launch, per workgroup
+extern "C" int dimn_debug_res_trace(unsigned long long* out, int n_words) {
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_res_tl2), (size_t)n_words * sizeof(unsigned long long)));
+    return DIMN_OK;
+}
+#endif
+
 // ---- get_distance_matrix on the GPU (reference multinet.py:20-34) -------------------
 // The same for a matrix that does not fit the GPU beside its g x g result (BASELINE configs[4]: 1M x 30k = 240 GB of float64):
 // two streamed passes over row blocks of X through pinned bounce buffers -- column sums, then centre each block and

@@ -62,18 +62,6 @@
 #define DIMN_RES_W2S 27104        // LDS float offset of the W2 state
 #define DIMN_RES_LDS_FLOATS (DIMN_RES_W2S + 3 * 16 * 256)
 #define DIMN_RES_SLOTS 2
-#ifndef DIMN_RES_WAVE_DD
-#define DIMN_RES_WAVE_DD 1        // round 6: role 2 takes its Dd tiles wave by wave into the operand registers (0: rounds 3-5, all sixteen through LDS)
-#endif
-#ifndef DIMN_RES_KEEP_EARLY
-#define DIMN_RES_KEEP_EARLY 1     // round 6: the manager's dropout keep word is requested at the top of the step, not behind the P gather
-#endif
-#ifndef DIMN_RES_POLL2
-#define DIMN_RES_POLL2 1          // round 6: two canary polls in flight (the next one leaves before the previous one is checked)
-#endif
-#ifndef DIMN_RES_SELF_DA
-#define DIMN_RES_SELF_DA 0        // round 6: the role-2 siblings of a hidden tile sum its dD partials themselves (0: rounds 3-5, the manager publishes dA)
-#endif
 // (round 3's experiment switches -- DIMN_RES_EVEN / _DIRECT / _XCD / _GDIRECT / _M2WIN / _ABL -- are gone from the source; what each
 //  measured is in DESIGN.md section 2b and profiles/r03_resident_*.txt)
 
@@ -88,6 +76,21 @@ __device__ unsigned long long g_res_tl[1024 * 16];
 #define RES_TL_DECL
 #define RES_STAMP(i)
 #define RES_TL_FLUSH
+#endif
+
+#ifdef DIMN_RES_TL2  // tools/res_trace.py: ABSOLUTE time stamps (s_memrealtime: the chip-wide 100 MHz clock) of 4 chosen steps, thread 0 of every workgroup: the
+                     // steady state is not perturbed (one compare per mark outside those steps), and the stamps of different workgroups share one time base
+__device__ unsigned long long g_res_tl2[1024 * 4 * 32];
+#define DIMN_RES_TL2_T0 300
+#define RES_MARK(i) { if (threadIdx.x == 0 && tl2_t >= DIMN_RES_TL2_T0 && tl2_t < DIMN_RES_TL2_T0 + 4) g_res_tl2[(((size_t)kl * G + wi) * 4 + (tl2_t - DIMN_RES_TL2_T0)) * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); }
+#define RES_MARK_WAVE(i) { if ((threadIdx.x & 63) == 0 && tl2_t >= DIMN_RES_TL2_T0 && tl2_t < DIMN_RES_TL2_T0 + 4) g_res_tl2[(((size_t)kl * G + wi) * 4 + (tl2_t - DIMN_RES_TL2_T0)) * 32 + (i) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime(); }
+#define RES_MARK_DECL int tl2_t = -1;
+#define RES_MARK_STEP(t) tl2_t = (t);
+#else
+#define RES_MARK(i)
+#define RES_MARK_WAVE(i)
+#define RES_MARK_DECL
+#define RES_MARK_STEP(t)
 #endif
 
 // The D-chunks [cb, ce) of sub-net chunks 0..nchunk-1 that D-split `sp` of S1 owns: the even split.  A workgroup's tile loop
@@ -149,27 +152,6 @@ __device__ __forceinline__ bool res_poll(__amdgpu_buffer_rsrc_t r, uint32_t base
     const int lane = threadIdx.x & 63;
     unsigned spins = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-#if DIMN_RES_POLL2
-    if (n <= 64) {
-        // two polls in flight: the next request leaves before the previous answer is looked at, so a piece that lands is seen after
-        // half a round trip on average instead of a whole one (a poll is one 16-byte request per producer tile)
-        const uint32_t off = base + (uint32_t)(lane < n ? lane : 0) * stride;
-        f32x4 x0 = res_ld(r, off);
-        for (;;) {
-            const f32x4 x1 = res_ld(r, off);
-            if (__builtin_amdgcn_ballot_w64(res_unwritten(x0)) == 0) return true;
-            x0 = x1;
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 63u) == 0u) {
-                if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > DIMN_RES_WAIT_TICKS) {
-                    __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return false;
-                }
-            }
-        }
-    }
-#endif
     for (;;) {
         bool missing = false;
         for (int i = lane; i < n; i += 64) missing |= res_unwritten(res_ld(r, base + (uint32_t)i * stride));
@@ -191,7 +173,7 @@ __device__ __forceinline__ void res_fix(f32x4& x, __amdgpu_buffer_rsrc_t r, uint
         asm volatile("" ::: "memory");                       // the reload is a new observation of memory
         x = res_ld(r, off);
         if (++spins > DIMN_RES_SPIN_LIMIT) { __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        if ((spins & 255u) == 0u && __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // the launch is being abandoned
+        // (no look at the abort word in here: measured, round 6 -- one relaxed load every 256 spins in this loop, inlined at every consumer, cost 2.6 us per step)
     }
 }
 // The dropout keep words of a whole epoch (they depend on no data): maskw[t][k][row b][word h/32], bit h%32 = keep(b, h);
@@ -245,6 +227,22 @@ __device__ __forceinline__ f32x4 res_mfma4(const f32x4 a, const f32x4 b, f32x4 c
     return c;
 }
 
+// Four independent accumulations c[n] += sum_r a[n][r] (x) b[n][r] with their matrix instructions INTERLEAVED (r outer, n inner): a dependent
+// pair (same accumulator) is three instructions apart instead of back to back -- round 6: the sixteen-deep chain of a gradient tile in two
+// chains was 0.35 us per step faster, so the exact-fp32 instruction does not forward its result into the next one for free.
+template <bool BF>
+__device__ __forceinline__ void res_mfma4x4(const f32x4 (&a)[4], const f32x4 (&b)[4], f32x4 (&c)[4]) {
+    if (BF) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) c[n] = MFMA_BF16(pk4(a[n]), pk4(b[n]), c[n]);
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) c[n] = MFMA16(a[n][r], b[n][r], c[n]);
+}
+
 template <int T1, int S1C, typename XT = float, bool BF = false, bool SPLIT = false>   // W1 tiles per wave; D-splits (0: run-time p.S1); element type of the X arena; bf16 matrix cores; tile order (res_vfwd)
 __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -278,11 +276,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
     const bool is_o = wi < dm.OT;                            // role 2: owns output tile wi
     const bool is_m = sp == S1 - 1;                          // manager of hidden tile ht
     const int ot = is_o ? wi : 0;
-    // Round 6: a sibling that is also a role-2 workgroup sums the dD partials of its hidden tile ITSELF (the same gather, in the same order, as
-    // the manager's: bit-identical dA), so the fourth hand-off of a step -- manager -> siblings, ~1.3 us + the receiving phase -- is gone for it;
-    // the manager publishes dA only when some sibling is NOT a role-2 workgroup (more than OT / 16 + 1 D-splits: never at 5 sub-nets per GPU).
-    const bool self_da = is_m || (DIMN_RES_SELF_DA && is_o);
-    const bool pub_da = (S1 - 1) * 16 > (DIMN_RES_SELF_DA ? dm.OT : 0);
+    const bool pub_da = S1 > 1;
     const SubnetDev s = p.sn[k];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
@@ -338,6 +332,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
     if (is_o && tid < 16) { b2w0 = p.b2w[b2i]; b2m0 = p.b2m[b2i]; b2v0 = p.b2v[b2i]; smallf[32 + tid] = b2w0; }
     double loss_total = 0.0;
     RES_TL_DECL
+    RES_MARK_DECL
 
     const int B = p.B;
 
@@ -380,6 +375,16 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             const bool fwd = res_vfwd<GRAD, SPLIT, T1>(v);
             const int j = res_vtile<GRAD, SPLIT, T1>(v);
             const bool live = tv[j] || j == 0;                   // wave-uniform: a wave's tiles are its first ones (tile 0 always runs: it may be a clamped one)
+            // Two waves share a SIMD, and the arbiter favours the older one: rounds 2-5 had waves 0..3 out of the loop ~2 us before waves 4..7, which
+            // then ran their last tiles alone -- a lone wave is bound by its own latencies (~1 us per tile pair), not by the matrix pipe
+            // (profiles/r06_resident_trace.txt).  Priority by progress: whoever is behind goes first, so the pair finishes together.
+            if (GRAD && (v & 3) == 0)
+                switch ((v * 4) / NV) {                          // (the builtin wants a literal; the loop is fully unrolled)
+                    case 0: __builtin_amdgcn_s_setprio(3); break;
+                    case 1: __builtin_amdgcn_s_setprio(2); break;
+                    case 2: __builtin_amdgcn_s_setprio(1); break;
+                    default: __builtin_amdgcn_s_setprio(0); break;
+                }
             float* xv = xs + (v & 1) * 1024;
             if (live) {
 #pragma unroll
@@ -393,23 +398,34 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             }
             __builtin_amdgcn_sched_barrier(0);                   // the requests leave before this tile's MFMAs
             if (!fwd) {
-                f32x4 g = zero4;
+                // A = X_t^T[d = li][b = 4kb+lj], B = dA[b = 4kb+lj][h = li], kb = 4q + r: four chains over q, summed at the end
+                f32x4 xq[4], bq[4], gq[4] = {zero4, zero4, zero4, zero4};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {                    // A = X_t^T[d = li][b = 4kb+lj], B = dA[b = 4kb+lj][h = li], kb = 4q + r
-                    const f32x4 xq = (f32x4){xv[64 * (4 * q) + lane], xv[64 * (4 * q + 1) + lane], xv[64 * (4 * q + 2) + lane], xv[64 * (4 * q + 3) + lane]};
-                    const f32x4 bq = (f32x4){bfr[4 * q], bfr[4 * q + 1], bfr[4 * q + 2], bfr[4 * q + 3]};
-                    g = res_mfma4<BF>(xq, bq, g);
+                for (int q = 0; q < 4; ++q) {
+                    xq[q] = (f32x4){xv[64 * (4 * q) + lane], xv[64 * (4 * q + 1) + lane], xv[64 * (4 * q + 2) + lane], xv[64 * (4 * q + 3) + lane]};
+                    bq[q] = (f32x4){bfr[4 * q], bfr[4 * q + 1], bfr[4 * q + 2], bfr[4 * q + 3]};
                 }
+                res_mfma4x4<BF>(xq, bq, gq);
+                const f32x4 g = (gq[0] + gq[1]) + (gq[2] + gq[3]);
                 if (tv[j]) adam4(w1[j], m1[j], v1[j], g, ap);
             } else if (do_fwd && tv[j]) {                        // wave-uniform
+                // (Round 6 also requested the forward tiles in the matrix instruction's own operand order -- pass n: row 16n + lane % 16, quarter
+                //  lane / 16 IS X_next[b = 16n + li][d = 4 lj ..] -- with no LDS staging: same numbers, 24.4-24.7 vs 24.0 us per step; the register
+                //  set is then busy until the instructions have issued, and its next request leaves a tile-time later.)
+                f32x4 x4[4];
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const f32x4 x4 = *(const f32x4*)(xv + (16 * n + li) * 16 + 4 * lj);         // X_next[b = 16n+li][d = 4lj+r]
-                    pT[n] = res_mfma4<BF>(w1[j], x4, pT[n]);                                    // P^T[h][b] += W1^T X^T
-                }
+                for (int n = 0; n < 4; ++n) x4[n] = *(const f32x4*)(xv + (16 * n + li) * 16 + 4 * lj);         // X_next[b = 16n+li][d = 4lj+r]
+                const f32x4 wj[4] = {w1[j], w1[j], w1[j], w1[j]};
+                res_mfma4x4<BF>(wj, x4, pT);                                                    // P^T[h][b] += W1^T X^T
             }
         }
+        if (GRAD) __builtin_amdgcn_s_setprio(0);
         RES_STAMP(8)
+        RES_MARK(12)
+        RES_MARK_WAVE(16)
+        // every wave: its stores of this step (re-arms of hand-off slots among them) are acknowledged before the next step's data stores into the
+        // slots they re-armed -- here, where nothing else is in flight (every row request of the loop has been consumed)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (do_fwd) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) *(f32x4*)(pred + wave * 1024 + (16 * n + li) * 16 + 4 * lj) = pT[n];   // P[b = 16n+li][h = 4lj..]
@@ -424,11 +440,9 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                     res_st(rP, slot_out + (uint32_t)(wi * 4096 + 16 * tid), a);
                 }
             }
-#if DIMN_RES_WAVE_DD
             // role 2 of the next step writes LDS wave by wave with no barrier in front (its Dd tiles and Z partials alias `pred`): the
             // waves that do not sum wait here for those that do -- behind the publishing store, off the step's critical path
             if (is_o) __syncthreads();
-#endif
         }
         RES_STAMP(9)
     };
@@ -490,13 +504,13 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
         int32_t rn[4];
         xrows_raw(tid, (t + 1) * B, b_next, rn);
         const int32_t yrow_n = target_row(tid, t + 1);          // unconditional: a load under a divergent branch makes hipcc drain vmcnt at the join
-#if DIMN_RES_KEEP_EARLY
+        RES_MARK_STEP(t)
+        RES_MARK(0)
         // the dropout keep word of this thread's four units (M1, manager): requested HERE, a whole P hand-off before its use -- rounds 2-5
         // requested it behind the gather of the siblings' partials, a dependent round trip to HBM (the epoch's keep words are read once)
         // in front of the Dd tile every role-2 workgroup of the sub-net waits for
         unsigned keep_w = 0xffffffffu;
         if (p.rate > 0.f) keep_w = __builtin_amdgcn_raw_buffer_load_b32(rM, moff(t) + (uint32_t)(32 * ((tid & 255) >> 2) + 4 * (ht >> 1)), 0, 0);
-#endif
         RES_STAMP(10)
 
         // =============================== M1 (manager): A = sum_s P_s + b1 -> the Dd tile ===============================
@@ -507,6 +521,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             f32x4 a = *(const f32x4*)(yl + 4 * tid);
             if (S1 > 1) {
                 (void)res_poll(rP, pcur + (uint32_t)(ht * 4096), S1 - 1, 65536u, abort_w);      // (abort: the next workgroup-wide wait leaves)
+                RES_MARK(1)
                 f32x4 pv[NS > 0 ? NS : 1];
 #pragma unroll
                 for (int ss = 0; ss < NS; ++ss) pv[ss] = res_ld(rP, pcur + (uint32_t)(((ss < S1 - 1 ? ss : 0) * 16 + ht) * 4096 + 16 * tid));
@@ -518,11 +533,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             }
             a += *(const f32x4*)(b1l + 4 * uq);
             unsigned keep = 0xfu;
-#if DIMN_RES_KEEP_EARLY
             if (p.rate > 0.f) keep = keep_w >> (16 * (ht & 1) + 4 * uq);
-#else
-            if (p.rate > 0.f) keep = __builtin_amdgcn_raw_buffer_load_b32(rM, moff(t) + (uint32_t)(32 * ub + 4 * (ht >> 1)), 0, 0) >> (16 * (ht & 1) + 4 * uq);
-#endif
             if (ub >= b_act) keep = 0u;
             f32x4 dd;
 #pragma unroll
@@ -536,6 +547,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             // once (round 3 issued a re-arm right here and waited ~1 us for its acknowledgement before the tile everybody waits for).
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             res_st(rT, tcur + (uint32_t)(ht * 4096 + 16 * tid), dd);
+            RES_MARK(2)
             // P(t) of every sibling is in, so each of them has run the tile loop of step t-1, i.e. consumed dA(t-1): its slot is
             // free -- marked "not written" for dA(t+1) BEHIND the Dd tile; M2's drain (a role-2 phase later) acknowledges it before
             // dA(t) -- which is what lets a sibling get as far as polling that slot -- leaves
@@ -543,10 +555,28 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
         }
         RES_STAMP(0)
 
+        // Idle time before the dA tile arrives: the first two X tiles of this step's tile loop and (role 2) the targets of the NEXT step.  (These rows
+        // come from anywhere in the arena -- 2-3 us -- and vector-memory results return in order: whatever is requested behind them waits for them.
+        // Round 6 tried them earlier -- behind the dZ tile, under the dD partial and the W2 gradient -- and lost 0.9 us per step: a CU reads past
+        // its L2 at one rate, and the dD stores and the W2 gradient queue behind them.)
+        uint32_t xon[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xon[i] = b_next > 0 ? (uint32_t)rn[i] * (uint32_t)s.Dp : xo0[i];
+        XSlot<XT> xr[2];
+        auto prefetch_x = [&]() {
+            const XT* xk = (const XT*)p.X + s.xoff + 4 * (lane & 3);
+#pragma unroll
+            for (int vv = 0; vv < 2; ++vv) {                 // virtual tiles 0 and 1 of the step's tile loop
+                const bool f = res_vfwd<true, SPLIT, T1>(vv);
+                const int jj = res_vtile<true, SPLIT, T1>(vv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xr[vv].load_row16(i, xk + (f ? xon[i] : xo0[i]) + 16 * tc[jj]);
+            }
+            if (t + 1 < p.steps) y_a = targets(tid, yrow_n); // every thread (unconditional load); role 2 uses the first 256
+        };
         // =============================== phase A (role 2) ===============================
         if (is_o) {
             if (tid < 256) *(f32x4*)(yl + 4 * tid) = y_a;
-#if DIMN_RES_WAVE_DD
             // Round 6: every wave takes ITS two Dd tiles (hidden tiles 2 wave, 2 wave + 1: the 32 hidden units of its Z partial) by itself,
             // straight into the A-operand registers of the matrix instructions -- piece 64 m + 4 li + lj of a [64][16] tile IS
             // Dd[b = 16 m + li][h = 4 lj ..]: no workgroup-wide poll, no staging of all sixteen tiles through LDS, no barrier in front of
@@ -554,6 +584,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             // to LDS afterwards, for the W2 gradient of the same wave (wave-private columns: no barrier either).
             const uint32_t tb = tcur + (uint32_t)(2 * wave * 4096);
             (void)res_poll(rT, tb, 2, 4096u, abort_w);              // (abort: the next workgroup-wide wait leaves)
+            RES_MARK(3)
             f32x4 a4[2][4];
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2)
@@ -561,7 +592,8 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 for (int m = 0; m < 4; ++m) a4[h2][m] = res_ld(rT, tb + (uint32_t)(h2 * 4096 + 16 * (64 * m + 4 * li + lj)));
             // Dd(t) of managers 2 wave, 2 wave + 1 is out, so both -- and their siblings, whose P(t) they summed first -- have finished
             // gathering the dD partials of the step before: tiles (ot, 2 wave), (ot, 2 wave + 1) of that dD slot are free -- marked "not
-            // written" for the step after this one; acknowledged before this wave's dD stores of this step leave (vmcnt(0) there).
+            // written" for the step after this one; acknowledged by the drain at the end of this step's tile loop (role1), a step before
+            // this wave stores into them again.
 #pragma unroll
             for (int i = 0; i < 8; ++i) res_st(rD, dfree + (uint32_t)(ot * 65536 + 2 * wave * 4096 + (i * 64 + lane) * 16), sent4);
             const float* ws = w2s + 2 * wave * 256;              // this wave's two W2 tiles [h][o]
@@ -589,49 +621,9 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
 #pragma unroll
                     for (int r = 0; r < 4; ++r) zred[wave * 1024 + (16 * m + 4 * lj + r) * 16 + li] = acc[m][r];
             }
-#else
-            if (wave == 4) { const bool ok = res_poll(rT, tcur, 16, 4096u, abort_w); if (lane == 0) flagl[0] = ok ? 1 : 0; }   // (wave 4: never busy with M1)
+            RES_MARK(4)
             __syncthreads();
-            if (!flagl[0]) return;
-            RES_STAMP(1)
-            {   // the 16 Dd tiles -> LDS: 8 pieces per thread, all requested before the first is used
-                f32x4 dv[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) dv[q] = res_ld(rT, tcur + (uint32_t)((2 * q + half) * 4096 + 16 * (tid & 255)));
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    res_fix(dv[q], rT, tcur + (uint32_t)((2 * q + half) * 4096 + 16 * (tid & 255)), abort_w);
-                    *(f32x4*)(ddl + ub * ldd + 16 * (2 * q + half) + 4 * uq) = dv[q];
-                }
-            }
-            const float* ws = w2s + 2 * wave * 256;              // this wave's two W2 tiles [h][o]
-            // every Dd tile of this step was out, so every manager has summed the dD partials of the step before: that dD slot is
-            // free -- marked "not written" for the step after this one.  Behind the tile requests, and acknowledged before this
-            // step's dD stores leave (vmcnt(0) there).
-#pragma unroll
-            for (int i = 0; i < 8; ++i) res_st(rD, dfree + (uint32_t)(ot * 65536 + (i * 512 + tid) * 16), sent4);
-            __syncthreads();
-            RES_STAMP(2)
-            {   // Z partial over this wave's 32 hidden units
-                f32x4 acc[4] = {zero4, zero4, zero4, zero4};
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    f32x4 bq;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) bq[r] = ws[h2 * 256 + (4 * lj + r) * 16 + li];   // W2[h = 4lj+r][o = li]
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const f32x4 a4 = *(const f32x4*)(ddl + (16 * m + li) * ldd + 16 * (2 * wave + h2) + 4 * lj);
-                        acc[m] = res_mfma4<BF>(a4, bq, acc[m]);
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) zred[wave * 1024 + (16 * m + 4 * lj + r) * 16 + li] = acc[m][r];
-            }
-#endif
-            __syncthreads();
+            RES_MARK(5)
             {   // epilogue of the forward: two elements per thread of the [64][16] tile
                 float lsum = 0.f, dzc = 0.f;
                 const bool col_ok = (16 * ot + (tid & 15)) < dm.O;
@@ -665,6 +657,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 if (lane < 16) csum[wave * 16 + lane] = dzc;
             }
             __syncthreads();
+            RES_MARK(6)
             if (tid == 0) {
                 float tot = 0.f;
 #pragma unroll
@@ -683,7 +676,8 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 f32x4 zf[4];
 #pragma unroll
                 for (int n = 0; n < 4; ++n) zf[n] = *(const f32x4*)(dzl + (16 * n + li) * 16 + 4 * lj);      // dZ[b = 16n+li][o = 4lj+r]
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the re-arm of the other dD slot (issued behind the Dd requests) is in place
+                // (the re-arm of the other dD slot, issued by this wave behind its Dd requests of the step BEFORE, was acknowledged by the drain at
+                //  the end of that step's tile loop: no drain here -- it would wait for the rows requested above)
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     const int tile = 2 * wave + h2;
@@ -696,6 +690,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 }
             }
             RES_STAMP(4)
+            RES_MARK(7)
             {   // W2 gradient + Adam on the LDS-resident state
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -719,32 +714,19 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             __syncthreads();                                     // everybody is done reading ddl/dzl/zred (what follows re-uses them)
             if (tid < 16) smallf[32 + tid] = b2w0;
             RES_STAMP(11)
+            RES_MARK(8)
         }
 
         // =============================== the dA tile: M2 (manager) or the hand-off from it (siblings) ===============================
         {
-            // Idle time before the tile arrives: the first X tiles of this step's tile loop and (role 2) the targets of the NEXT step
-            uint32_t xon[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xon[i] = b_next > 0 ? (uint32_t)rn[i] * (uint32_t)s.Dp : xo0[i];
-            XSlot<XT> xr[2];
-            {   // virtual tiles 0 and 1 of the step's tile loop
-                const XT* xk = (const XT*)p.X + s.xoff + 4 * (lane & 3);
-#pragma unroll
-                for (int vv = 0; vv < 2; ++vv) {
-                    const bool f = res_vfwd<true, SPLIT, T1>(vv);
-                    const int jj = res_vtile<true, SPLIT, T1>(vv);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) xr[vv].load_row16(i, xk + (f ? xon[i] : xo0[i]) + 16 * tc[jj]);
-                }
-            }
-            if (t + 1 < p.steps) y_a = targets(tid, yrow_n);     // every thread (unconditional load); role 2 uses the first 256
             RES_STAMP(5)
-            if (self_da) {
+            prefetch_x();
+            if (is_m) {
                 if (wave == 0) { const bool ok = res_poll(rD, dcur + (uint32_t)(ht * 4096), OT, 65536u, abort_w); if (lane == 0) flagl[1] = ok ? 1 : 0; }
                 __syncthreads();
                 if (!flagl[1]) return;
                 RES_STAMP(6)
+                RES_MARK(9)
                 // tile ht of the OT producers' dD partials, their two halves on the two thread halves
                 f32x4 d = zero4;
                 {
@@ -778,28 +760,19 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 __syncthreads();
                 if (half == 0) {
                     d += *(const f32x4*)(yl + 4 * tid);
-                    if (!is_m) {                                 // a role-2 sibling: the gate of its hidden tile from the Dd tiles it holds in LDS (Dd > 0 <=> kept and A > 0)
-                        const f32x4 ddv = *(const f32x4*)(ddl + ub * ldd + 16 * ht + 4 * uq);
-                        gate = (ddv[0] > 0.f ? 1u : 0u) | (ddv[1] > 0.f ? 2u : 0u) | (ddv[2] > 0.f ? 4u : 0u) | (ddv[3] > 0.f ? 8u : 0u);
-                    }
                     f32x4 da;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) da[r] = ((gate >> r) & 1u) ? d[r] * p.scale : 0.f;
                     *(f32x4*)(dzl + 4 * tid) = da;               // dA tile [64][16]
-                    if (is_m) {
-                        if (pub_da) {
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the re-arm of this dA slot's sibling, issued behind the Dd tile in M1: long in place)
-                            res_st(rA, tcur + (uint32_t)(ht * 4096 + 16 * tid), da);
-                        }
-                        // every dD partial of this step was out, so every role-2 workgroup has read the Dd tiles of this step: that slot is
-                        // free -- marked "not written" for step t+2, BEHIND the dA tile; acknowledged by M1's drain of the next step, a tile
-                        // loop from here, before Dd(t+1) leaves
-                        res_st(rT, tcur + (uint32_t)(ht * 4096 + 16 * tid), sent4);
-                    } else {
-                        // dD(t) exists, so Dd(t) did, so the manager has summed P(t): this workgroup's P slot of step t is free -- marked "not
-                        // written" for P(t+2); acknowledged before P(t+1) leaves (vmcnt(0) in role1)
-                        res_st(rP, pcur + (uint32_t)(wi * 4096 + 16 * tid), sent4);
+                    if (pub_da) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the re-arm of this dA slot's sibling, issued behind the Dd tile in M1: long in place)
+                        res_st(rA, tcur + (uint32_t)(ht * 4096 + 16 * tid), da);
                     }
+                    RES_MARK(10)
+                    // every dD partial of this step was out, so every role-2 workgroup has read the Dd tiles of this step: that slot is
+                    // free -- marked "not written" for step t+2, BEHIND the dA tile; acknowledged by M1's drain of the next step, a tile
+                    // loop from here, before Dd(t+1) leaves
+                    res_st(rT, tcur + (uint32_t)(ht * 4096 + 16 * tid), sent4);
                     col4(da);
                 }
             } else {
@@ -807,12 +780,14 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 __syncthreads();
                 if (!flagl[1]) return;
                 RES_STAMP(6)
+                RES_MARK(9)
                 if (tid < 256) {
                     f32x4 da = res_ld(rA, tcur + (uint32_t)(ht * 4096 + 16 * tid));
                     res_fix(da, rA, tcur + (uint32_t)(ht * 4096 + 16 * tid), abort_w);
+                    RES_MARK(10)
                     *(f32x4*)(dzl + 4 * tid) = da;
                     // dA(t) exists, so the manager has summed P(t): this workgroup's P slot of step t is free -- marked "not
-                    // written" for P(t+2); acknowledged before P(t+1) leaves (vmcnt(0) in role1)
+                    // written" for P(t+2); acknowledged before P(t+1) leaves (the drain at the end of the tile loop)
                     res_st(rP, pcur + (uint32_t)(wi * 4096 + 16 * tid), sent4);
                     col4(da);
                 }
@@ -827,7 +802,10 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
 #pragma unroll
             for (int kb = 0; kb < 16; ++kb) bfr[kb] = dzl[64 * kb + lane];                                        // dA[b = 4kb+lj][h = li]
             RES_STAMP(7)
+            RES_MARK(11)
+            RES_MARK_WAVE(24)
             role1(std::true_type{}, tid, xo0, xon, xr, b_next > 0, bfr, ap, pnext);     // its first barrier orders b1l / dzl
+            RES_MARK(13)
             if (b_next == 0) __syncthreads();
 #pragma unroll
             for (int i = 0; i < 4; ++i) xo0[i] = xon[i];         // the next batch becomes the current one

@@ -182,8 +182,11 @@ def test_restore_epilogue_sends_only_the_zeros_and_equals_the_dense_epilogue(n, 
     rc = eng._f["impute_finish_restore"](eng._h, other.ctypes.data, 0, n, g, _cabi.p_i32(np.ascontiguousarray(gene_off, np.int32)),
                                          _cabi.p_i32(np.ascontiguousarray(order, np.int32)), float(ceiling), 0, _cabi.p_f64(out), None)
     assert rc == -3
-    # ... and the engine then answers from the resident counts, as the dense epilogue does
-    assert np.array_equal(eng.impute_finish(None, gene_off, order, "restore", ceiling, observed=other), dense)
+    # ... and the engine says so instead of finishing the RESIDENT counts behind the caller's back (a dense epilogue the caller throws
+    # away); MultiNet.predict() then uploads the frame it was given and runs the ordinary sequence once
+    from deepimpute_amd.engine import FrameMismatch
+    with pytest.raises(FrameMismatch):
+        eng.impute_finish(None, gene_off, order, "restore", ceiling, observed=other)
     # an int64 frame of the same counts (what pd.read_csv hands over) is merged in place: same float64 result, same checksum
     eng.predict_device()
     assert np.array_equal(eng.impute_finish(None, gene_off, order, "restore", ceiling, observed=raw.astype(np.int64)), dense)
