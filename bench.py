@@ -44,14 +44,14 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3
 
 
-def synth_counts(n, g, seed=0, threads=None):
+def synth_counts(n, g, seed=0, threads=None, out=None):
     """BASELINE.md generator: mu_j ~ LogNormal(0.5,1.2); lambda_ij ~ Gamma(2, mu_j/2);
     X_ij ~ Poisson(lambda_ij).  Row blocks are drawn by independent child streams in threads
     (numpy releases the GIL), so the matrix is a pure function of (n, g, seed)."""
     threads = threads or min(32, os.cpu_count() or 1)
     root = np.random.default_rng(seed)
     mu = root.lognormal(0.5, 1.2, size=g)
-    out = np.empty((n, g), np.float32)
+    out = np.empty((n, g), np.float32) if out is None else out       # (out: a caller's [n, g] float32 array, e.g. a shared segment)
     blk = 512
     starts = list(range(0, n, blk))
     seeds = np.random.SeedSequence(seed).spawn(len(starts))
@@ -185,6 +185,29 @@ def file_vote(rdzv, name, value, timeout=600.0):
     return total
 
 
+class VoteComm:
+    """barrier() for deepimpute_amd._shm before RCCL is up (the matrix is made before the engines exist): one file vote per barrier."""
+
+    def __init__(self, rdzv):
+        self.rdzv, self.rank, self.world, self._n = rdzv, rdzv.rank, rdzv.world, 0
+
+    def barrier(self):
+        self._n += 1
+        file_vote(self.rdzv, "shm%d" % self._n, 0.0)
+
+
+def shared_matrix(rdzv, n, g, seed=0):
+    """The synthetic log1p matrix ONCE per node (a streamed N-rank job: configs[4] is 120 GB -- eight private copies would be 1 TB of host
+    memory and eight times the generator's work): rank 0 generates it into a /dev/shm segment, every rank maps it."""
+    from deepimpute_amd import _shm
+    comm = VoteComm(rdzv)
+    seg = _shm.SharedArray(comm, (n, g), np.float32, "benchnorm")
+    if rdzv.rank == 0:
+        synth_counts(n, g, seed=seed, out=seg.array)             # the same function of (n, g, seed) as a private matrix
+    seg.publish()
+    return seg.array, seg
+
+
 def bring_up_rccl(eng, rdzv, rank, world):
     """(RcclBenchComm, None) when every rank holds a working RCCL communicator, else (None, error string) on EVERY rank.
     There is no other transport: without RCCL an N > 1 job has no gather and no global early-stopping quantity, so the
@@ -248,6 +271,8 @@ def make_engine(cls, cfg, targets, preds, norm, train, val, counts, offs, rank, 
         eng.set_indices(i, preds[k], targets[k])
     if stream:
         eng._bench_norm = norm                       # streamed hand-over: the matrix stays on the host, every impute re-streams it
+        if len(counts) > 1 and hasattr(eng, "set_stream_order"):
+            eng.set_stream_order(rank, len(counts))  # the ranks read one shared copy: each starts at another row block
     else:
         eng.set_matrix(norm)
     eng.n_cells = norm.shape[0]
@@ -583,7 +608,12 @@ def main():
         cfg["label"] += " [general path]"
     n, g = cfg["n"], cfg["g"]
     t_gen = time.time()
-    norm = synth_counts(n, g, seed=0)
+    rdzv = FileRendezvous(rank, world) if world > 1 else None
+    shared_seg = None
+    if world > 1 and args.stream:
+        norm, shared_seg = shared_matrix(rdzv, n, g, seed=0)     # one host copy for the node's ranks; each rank's hand-over starts elsewhere in it
+    else:
+        norm = synth_counts(n, g, seed=0)
     targets, preds = synth_indices(g, cfg["O"], seed=0)
     train, val = split_rows(n, seed=0)
     if args.limit_subnets:
@@ -605,7 +635,6 @@ def main():
                            **({"precision": "bf16"} if args.precision == "bf16" else {}))
     comm = None
     if world > 1:
-        rdzv = FileRendezvous(rank, world)
         eng, comm, rccl_error = bring_up_job(build_engine, rdzv, rank, world)
         if comm is None:
             sys.stderr.write("bench.py rank %d: the %d-rank job did not come up (%s): no measurement\n" % (rank, world, rccl_error))

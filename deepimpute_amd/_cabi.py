@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_BATCH = 64
 COMM_ID_BYTES = 128
 # hidden-layer activations the kernels implement (ids = DIMN_ACT_* of include/dimn.h; Keras names)
@@ -93,6 +93,7 @@ GPU_ONLY = {
     "cached_memory_info": [C.POINTER(C.c_int64)],
     "warm_up": [_i32],
     "set_matrix_streamed": [_H, _pf, _i64, _i64, _i32],
+    "set_stream_order": [_H, _i32, _i32],
     "predict_device": [_H, _pi, _i64, C.POINTER(C.c_void_p)],
     "synchronize": [_H],
     "get_timers": [_H, _pd, _i32],

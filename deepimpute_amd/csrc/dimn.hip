@@ -33,7 +33,7 @@
 #include "dimn_hoststats.h"
 #include "dimn_counts_dev.h"
 
-#define DIMN_ABI_VERSION 8
+#define DIMN_ABI_VERSION 9
 
 // DIMN_TRACE=1: stage times of the host-heavy entry points on stderr (diagnostic)
 struct Trace {
@@ -195,6 +195,7 @@ struct dimn_handle_s {
     int64_t w1_total = 0, x_total = 0, y_total = 0;
     int64_t n = 0, g = 0, n_tr = 0, n_val = 0;
     bool gathered = false, gathered_targets = false, have_idx = false, streamed = false;
+    int32_t stream_part = 0, stream_parts = 1;             // dimn_set_stream_order: where this handle's streamed hand-over starts (rank r of w ranks: block r NB / w)
     // device
     SubnetDev* d_sn = nullptr; Work* d_work = nullptr;
     float *d_norm = nullptr, *d_X = nullptr, *d_Y = nullptr;
@@ -1028,6 +1029,12 @@ extern "C" int dimn_gather(dimn_handle h, int32_t with_targets) {
 // BASELINE configs[4]: the log1p matrix streamed from host memory in row blocks (pinned bounce buffers, the copy of one
 // block overlapping the gather of the previous one); the device never holds the matrix itself, only the gathered X_k
 // (fp32 or bf16) and Y_k blocks.  Replaces dimn_set_matrix + dimn_gather; needs every dimn_set_indices first.
+extern "C" int dimn_set_stream_order(dimn_handle h, int32_t part, int32_t parts) {
+    if (!h || parts < 1 || part < 0 || part >= parts) return fail(DIMN_ERR_ARG, "dimn_set_stream_order: need 0 <= part < parts");
+    h->stream_part = part; h->stream_parts = parts;
+    return DIMN_OK;
+}
+
 extern "C" int dimn_set_matrix_streamed(dimn_handle h, const float* norm, int64_t n, int64_t g, int32_t with_targets) {
     if (h) h->counts = nullptr;
     if (!h || !norm || n < 1 || g < 1) return fail(DIMN_ERR_ARG, "dimn_set_matrix_streamed: bad argument");
@@ -1080,9 +1087,12 @@ extern "C" int dimn_set_matrix_streamed(dimn_handle h, const float* norm, int64_
         STR_TRY(dev_malloc_bytes((void**)&dev[b], (size_t)blk * gc * 4));
         STR_TRY(hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking));
     }
-    int64_t bi = 0;
-    for (int64_t r0 = 0; r0 < n && rc == DIMN_OK; r0 += blk, ++bi) {
+    // The ranks of one node read ONE host copy of the matrix (deepimpute_amd/_shm.py): rank r of w starts at block r NB / w and wraps around, so the
+    // w pack-and-copy pipelines walk different pages of it at any moment (the device gather of a block is independent of every other block)
+    const int64_t NB = (n + blk - 1) / blk, first = NB * (int64_t)h->stream_part / std::max(1, h->stream_parts);
+    for (int64_t bi = 0; bi < NB && rc == DIMN_OK; ++bi) {
         const int b = (int)(bi % NBUF);
+        const int64_t r0 = ((bi + first) % NB) * blk;
         const int64_t nr = std::min(blk, n - r0);
         STR_TRY(hipStreamSynchronize(st[b]));               // block bi-NBUF has left these buffers
         if (rc != DIMN_OK) break;

@@ -83,6 +83,11 @@ class Engine:
         else:
             self._check(self._f["set_matrix"](self._h, p_f32(norm), norm.shape[0], norm.shape[1]))
 
+    def set_stream_order(self, part, parts):
+        """Rank `part` of `parts` ranks reading one shared host copy of the matrix: its streamed hand-over starts that far into the row blocks."""
+        if "set_stream_order" in self._f:
+            self._check(self._f["set_stream_order"](self._h, int(part), int(parts)))
+
     def set_indices(self, k, pred_idx, targ_idx):
         pred_idx, targ_idx = i32(pred_idx), i32(targ_idx)
         if targ_idx.size != self.O:

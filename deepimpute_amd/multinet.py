@@ -652,15 +652,29 @@ class MultiNet:
                 self.setPredictors(correlations, ntop=ntop)
 
         print("Normalization")
+        # A sharded job whose frame is the node's ONE shared copy (_shm.share_frame; DIMN_SHARE_NORM=1 forces it for private frames too) makes
+        # the log1p matrix ONCE as well: each rank fills its slice of the rows of a /dev/shm segment -- that needs the communicator, which is
+        # bound to the engine, so it happens right after "Building network" (log1p draws no random numbers: the order is free)
+        from . import _shm
+        share_norm = (dev_counts is None and self._comm_spec is not None
+                      and (_shm.shared_of(raw.values) is not None or os.environ.get("DIMN_SHARE_NORM") == "1"))
         with tm.stage("fit.log1p"):
             # with the counts resident, log1p happens on the device (numpy's table); the frame below then only carries the labels
-            norm_data = _hostpar.log1p_float32(raw) if dev_counts is None else _ColumnsOnly(raw.columns, raw.index, raw.shape)
+            norm_data = None if share_norm else (_hostpar.log1p_float32(raw) if dev_counts is None else _ColumnsOnly(raw.columns, raw.index, raw.shape))
         np.random.seed(self.seed)                      # second seeding, multinet.py:219
 
         print("Building network")
         with tm.stage("fit.build"):
             self._release_engine()
             engine, comm, counts = self._build_shard([len(p) for p in self.predictors])
+        if norm_data is None:
+            with tm.stage("fit.log1p"):
+                if comm.world > 1:
+                    norm_data = pd.DataFrame(_shm.shared_log1p(raw, comm), index=raw.index, columns=raw.columns, copy=False)
+                else:
+                    norm_data = _hostpar.log1p_float32(raw)
+        if comm.world > 1 and hasattr(engine, "set_stream_order"):
+            engine.set_stream_order(comm.rank, comm.world)       # the ranks' streamed hand-overs walk different pages of the shared matrix
         t_split = tm.stage("fit.split")
         t_split.__enter__()
 
@@ -989,7 +1003,14 @@ class MultiNet:
         if resident is None:
             self._bind_columns(engine, raw.columns)
             with tm.stage("predict.log1p"):
-                norm = _hostpar.log1p_float32(raw).values                          # float32(log1p(raw)): what Keras is fed
+                from . import _shm
+                comm = self._comm
+                if comm is not None and comm.world > 1 and (_shm.shared_of(raw.values) is not None or os.environ.get("DIMN_SHARE_NORM") == "1"):
+                    norm = _shm.shared_log1p(raw, comm)                            # one copy for the node's ranks (as in fit())
+                    if hasattr(engine, "set_stream_order"):
+                        engine.set_stream_order(comm.rank, comm.world)
+                else:
+                    norm = _hostpar.log1p_float32(raw).values                      # float32(log1p(raw)): what Keras is fed
             with tm.stage("predict.hand_over"):
                 self._hand_over(engine, norm, False)
             with tm.stage("predict.free"):

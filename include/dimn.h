@@ -137,6 +137,10 @@ int dimn_set_matrix(dimn_handle h, const float* norm, int64_t n_cells, int64_t n
  * that do not fit beside their own gathered copy (BASELINE configs[4], 1M x 30k).  Replaces dimn_set_matrix +
  * dimn_gather; every dimn_set_indices must have been made. */
 int dimn_set_matrix_streamed(dimn_handle h, const float* norm, int64_t n_cells, int64_t n_genes, int32_t with_targets);
+/* Where the streamed hand-over of this handle starts: row block part * NB / parts of the NB blocks, wrapping around.  The ranks of a one-node
+ * job that read ONE host copy of the matrix (the reference materialises norm_data per process, multinet.py:217, and has one process; here
+ * rank r of w calls (r, w)) then walk different pages of it at any moment.  Default (0, 1): from the first row. */
+int dimn_set_stream_order(dimn_handle h, int32_t part, int32_t parts);
 /* Column lists of sub-net k: predictors (multinet.py:362) and targets (:338-342),
  * as column indices into the matrix. */
 int dimn_set_indices(dimn_handle h, int32_t k, const int32_t* pred_idx, int32_t D_k,

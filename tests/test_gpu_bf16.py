@@ -71,7 +71,9 @@ def test_streamed_matrix_equals_resident_matrix(precision):
     outs = []
     # resident; streamed with only the columns the sub-nets read packed into the bounce buffer (the default: 2 % of the genes here);
     # streamed as whole rows (DIMN_STREAM_PACK=0)
-    for streamed, pack in ((False, None), (True, None), (True, "0")):
+    # ... and, as rank 1 of 3 / rank 2 of 3 of a job whose ranks read ONE host copy, starting a third / two thirds into the row blocks
+    # (dimn_set_stream_order: the blocks are independent, their order is free)
+    for streamed, pack, order in ((False, None, None), (True, None, None), (True, "0", None), (True, None, (1, 3)), (True, "0", (2, 3))):
         if pack is None:
             os.environ.pop("DIMN_STREAM_PACK", None)
         else:
@@ -79,6 +81,8 @@ def test_streamed_matrix_equals_resident_matrix(precision):
         e = _hip()(Ds, 64, 64, batch_size=64, dropout_rate=0.2, learning_rate=1e-3, seed=5, precision=precision)
         for k in range(2):
             e.set_indices(k, pred[k], targ[k])
+        if order is not None:
+            e.set_stream_order(*order)
         e.set_matrix(norm, streamed=streamed)
         e.gather(True)
         e.set_split(train, val)
