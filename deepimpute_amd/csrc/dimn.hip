@@ -178,16 +178,13 @@ struct dimn_handle_s {
     Dims dm;
     int K, H, O, B, NT, NT2, OTW, HS;   // NT/NT2 hidden tiles per wave (4-/8-wave kernels); OTW out tiles per wave; HS = ceil(HT/2)
     int ncu = 256;
-    bool mid_fwd6 = true;                  // hidden 300: k_mid_fwd<20, 6> where 8 slices per sub-net would not fit one round of workgroups (DIMN_MID_FWD6=0: off)
     int w1_waves = 0;                      // B1F1 as k_w1_update_fwd_ring<w1_waves, 1, 4> (0: the width's older kernel): one hidden tile per wave, four-set register ring
     int w1_wpc = 1;                        // ... workgroups per CU (2 for 8 waves)
     int w1_split = 1;                      // B1F1: the hidden tiles of a D-slice over this many workgroups (grid.y); 2: 18 .. 24 hidden tiles on the ring (build_work)
     std::vector<SubnetDev> sn;
     std::vector<Work> work;
-    std::vector<MidWork> midwork;          // work table of the fused second-layer kernel (k_mid_fused)
+    std::vector<MidWork> midwork;          // work table of the fused second-layer kernel (k_mid_pipe)
     int mid_fused = 0, mid_slices = 0;     // 1: RED -> MFB -> RED2 -> B1F1; 0: RED -> MF -> MB -> B1F1
-    int mid_keep = 0;                      // 1: k_mid_fused<true> (the W2 column blocks stay in LDS between its phases)
-    int mid_pipe = 0;                      // 1: k_mid_pipe (dimn_mid_pipe.h: the slice's tiles as a software pipeline) instead of k_mid_fused
     int train_bf16 = 0;                    // 1: precision bf16 and the fused second layer runs its three GEMMs on the bf16 matrix cores
     MidWork* d_midwork = nullptr; int32_t* d_midk = nullptr; float* d_P2 = nullptr;
     std::vector<std::vector<int32_t>> pred, targ;
@@ -466,10 +463,10 @@ static void build_work(dimn_handle h) {
         // (8 waves x 1-3 tiles, one or two chunks in flight, 256 registers + spills at 3 tiles) ran at 0.47-0.49 of the HBM peak: profiles/r05_hidden_widths.txt
         h->w1_split = 1; h->w1_waves = 0; h->w1_wpc = 1;
         const int HT = h->dm.HT;
-        // From 2 chunks per CU on (same-box A/B at hidden 300, 5 / 10 / 20 / 30 sub-nets of D ~ 2 400 and configs[1]: the ring wins at every size, 3-9 % per step,
-        // thresholds 2 / 4 / 8 / 16 alike where they apply: profiles/r05_hidden_widths.txt).  DIMN_W1_SPLIT: 0 off; N >= 2: from N chunks per CU on.
-        const int w1_env = getenv("DIMN_W1_SPLIT") ? atoi(getenv("DIMN_W1_SPLIT")) : 1;
-        if (HT >= 8 && HT <= 24 && HT != 16 && w1_env != 0 && total_chunks >= (w1_env >= 2 ? w1_env : 2) * (int64_t)h->ncu) {
+        // (Same-box A/B at hidden 300, 5 / 10 / 20 / 30 sub-nets of D ~ 2 400 and configs[1]: the ring wins at every size, 3-9 % per step:
+        //  profiles/r05_hidden_widths.txt.  Round 6: at every chunk count -- the two-set shared-staging kernel k_w1_update_fwd_sh<10, 2>, which rounds 2-5 kept
+        //  for fewer than two chunks per CU, is retired.)
+        if (HT >= 8 && HT <= 24 && HT != 16) {
             h->w1_split = HT > 16 ? 2 : 1;
             h->w1_waves = HT / h->w1_split;
             h->w1_wpc = h->w1_waves == 8 ? 2 : 1;
@@ -522,14 +519,18 @@ static void build_mid(dimn_handle h) {
     h->mid_fused = 0;
     if (dm.HT != 16) return;
     int force = -1;
-    if (const char* e = getenv("DIMN_MID")) force = atoi(e) != 0;
+    int want_slices = 0;
+    if (const char* e = getenv("DIMN_MID")) {                       // "0": the two-kernel second layer; "1": the fused one whatever the size; "1:S": with S slices per sub-net (tests)
+        force = atoi(e) != 0;
+        if (const char* c = strchr(e, ':')) want_slices = atoi(c + 1);
+    }
     if (force == 0) return;
     // S <= 8: finer slices (down to one tile per workgroup) were measured for GPUs that own few sub-nets and
     // bring nothing (K=5: MFB 12.8 + RED2 8.5 us vs MF 11.3 + MB 10.6), so small K keeps the two-kernel path:
     // fused from ~0.6 workgroups per CU up (per step: K=5 62 vs 54 us, K=10 77 vs 68, K=20 106 vs 107, K=40 170 vs 186)
     int S = std::max(1, std::min(h->ncu / std::max(1, h->K), std::min(8, (int)dm.OT)));
     S = std::max(S, ceil_div(dm.OT, DIMN_MID_TMAX));
-    if (const char* e = getenv("DIMN_MID_SLICES")) S = std::max(ceil_div(dm.OT, DIMN_MID_TMAX), std::min(atoi(e), (int)dm.OT));   // tests
+    if (want_slices > 0) S = std::max(ceil_div(dm.OT, DIMN_MID_TMAX), std::min(want_slices, (int)dm.OT));
     if (S > dm.OT) return;
     // (precision bf16: the fused kernel has the bf16 matrix-core variant and wins from a quarter-filled GPU on -- configs[4]'s 8 sub-nets
     //  per rank: 62.0 vs 63.8 us per step)
@@ -545,18 +546,30 @@ static void build_mid(dimn_handle h) {
             h->midwork.push_back(m);
         }
     h->mid_fused = 1;
-    int tmax = 0;
-    for (auto& m : h->midwork) tmax = std::max(tmax, m.ot1 - m.ot0);
-    h->mid_keep = tmax <= 6;
-    h->mid_pipe = !(getenv("DIMN_MID_PIPE") && atoi(getenv("DIMN_MID_PIPE")) == 0);   // DIMN_MID_PIPE=0: the three-phase kernel (A/B, tests)
-    h->train_bf16 = (h->mid_keep || h->mid_pipe) && h->prec == DIMN_PREC_BF16 && !(getenv("DIMN_TRAIN_BF16") && atoi(getenv("DIMN_TRAIN_BF16")) == 0);   // (the pipeline has the bf16 form at any slice size)
+    h->train_bf16 = h->prec == DIMN_PREC_BF16 && !(getenv("DIMN_TRAIN_BF16") && atoi(getenv("DIMN_TRAIN_BF16")) == 0);   // (the pipeline has the bf16 form at any slice size)
 }
 
+// Test knobs of the register-resident path in ONE variable: DIMN_RES_TEST="s1=2,groups=2,split=1,erows=0,abort=3" (any subset; tests/test_gpu_*.py).
+//   s1      cap on the D-splits per hidden tile (other decompositions on small problems)     groups  minimum number of sub-net groups
+//   split   tile order of the kernel's loop (0 alternating, 1 all gradient tiles first)      erows   epoch-ordered row copies on / off
+//   abort   pretend the epoch launch number N (1-based) timed out
+static int res_test_knob(const char* key, int fallback) {
+    const char* e = getenv("DIMN_RES_TEST");
+    if (!e) return fallback;
+    const size_t kl = strlen(key);
+    for (const char* p = e; *p;) {
+        if (strncmp(p, key, kl) == 0 && p[kl] == '=') return atoi(p + kl + 1);
+        const char* c = strchr(p, ',');
+        if (!c) break;
+        p = c + 1;
+    }
+    return fallback;
+}
 static bool resident_plan(dimn_handle h, int Kg, int& S1o, int& T1o) {
     // the decomposition of one launch over Kg sub-nets: D-splits per hidden tile, W1 tiles per wave; false: not eligible
     const Dims& dm = h->dm;
     int S1 = std::min(8, h->ncu / std::max(1, Kg) / 16);
-    if (const char* e = getenv("DIMN_RES_S1")) S1 = std::min(S1, std::max(1, atoi(e)));      // tests: other decompositions
+    if (const int cap = res_test_knob("s1", 0)) S1 = std::min(S1, std::max(1, cap));         // tests: other decompositions
     if (S1 < 1 || dm.OT > 16 * S1) return false;
     int maxchunk = 0, minchunk = 1 << 30;
     for (auto& s : h->sn) { maxchunk = std::max(maxchunk, s.nchunk); minchunk = std::min(minchunk, s.nchunk); }
@@ -592,7 +605,7 @@ static void build_resident(dimn_handle h) {
     if (dm.HT != 16 || (dm.H & 3) != 0 || h->B > DIMN_TB) return;
     const int max_groups = 3;
     int min_groups = 1;
-    if (const char* e = getenv("DIMN_RES_MIN_GROUPS")) min_groups = std::max(1, atoi(e));      // tests: groups on small problems
+    min_groups = std::max(1, res_test_knob("groups", 1));                                      // tests: groups on small problems
     min_groups = std::min(min_groups, h->K);
     // (round 3: with the manager protocol a launch of five sub-nets costs 23.7 us per step, so FOUR groups of five -- the 2-GPU share of the
     //  50k x 20k job -- take 94 us against 104 us for the streaming kernels; four groups of four (K = 16) only draw: 86 vs 84-88 us)
@@ -678,7 +691,6 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
         w1 += (int64_t)s.Dp * dm.Hp;
     }
     h->w1_total = w1;
-    h->mid_fwd6 = !(getenv("DIMN_MID_FWD6") && atoi(getenv("DIMN_MID_FWD6")) == 0);
     build_work(h);
     if (!general) { build_mid(h); build_resident(h); }
     // One lane: every sub-net on the handle's stream.  (Two free-running lanes on two streams, a "W token" ring between them and a fixed
@@ -752,9 +764,6 @@ static int create_common(const dimn_config* cfg, const int32_t* D, bool general,
             dimn_destroy(h);
             return fail(DIMN_ERR_HIP, "dimn_create: descriptor upload failed");
         }
-        (void)hipFuncSetAttribute((const void*)k_mid_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_mid_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_mid_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)k_mid_pipe<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)k_mid_pipe<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
@@ -1311,9 +1320,7 @@ static void launch_w1(dimn_handle h, const dimn_handle_s::Lane& ln, hipStream_t 
                 case 14: W1_LAUNCH((k_w1_update_fwd_ring<14, 1, 4, 1, XT>), 896); break;
                 default: W1_LAUNCH((k_w1_update_fwd_ring<15, 1, 4, 1, XT>), 960); break;
             }
-        } else if (h->dm.HT == 20)                      // H = 300 (padded to 320): 10 waves x 2 hidden tiles, two-set shared-staging variant
-            W1_LAUNCH((k_w1_update_fwd_sh<10, 2, 1, XT>), 640);
-        else if (h->dm.HT == 16)                      // H = 256: 16 waves x 1 hidden tile, X tiles staged once per workgroup, 3-set register ring
+        } else if (h->dm.HT == 16)                      // H = 256: 16 waves x 1 hidden tile, X tiles staged once per workgroup, 3-set register ring
             W1_LAUNCH((k_w1_update_fwd_ring<16, 1, 3, 1, XT>), 1024);
         else if (h->dm.HT == 8 * NT2)
             W1_LAUNCH((k_w1_update_fwd<NT2, true, XT>), 512);
@@ -1388,25 +1395,6 @@ static void launch_predict_impl(dimn_handle h, const int32_t* rows, int64_t n_ro
 }
 template <int NT>
 static void launch_predict(dimn_handle h, const int32_t* rows, int64_t n_rows, float* out, float* loss_part) {
-#if DIMN_PB_TRACE                                  // diagnostic build only (dimn_kernels.h, PB_STAMP; tools/pb_trace.sh)
-    const char* tp = getenv("DIMN_PREDICT_TRACE");
-    if (tp && h->predict_bf16 && out && h->dm.Hp <= 256) {
-        const size_t nwg = (size_t)((n_rows + DIMN_PB_M - 1) / DIMN_PB_M) * h->K;
-        unsigned long long* d_tr = nullptr;
-        (void)hipMalloc(&d_tr, nwg * 64);
-        (void)hipMemset(d_tr, 0, nwg * 64);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pb_trace), &d_tr, sizeof(d_tr));
-        launch_predict_impl<NT>(h, rows, n_rows, out, loss_part);
-        (void)hipStreamSynchronize(h->stream);
-        std::vector<unsigned long long> host(nwg * 8);
-        (void)hipMemcpy(host.data(), d_tr, nwg * 64, hipMemcpyDeviceToHost);
-        if (FILE* f = fopen(tp, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
-        (void)hipFree(d_tr);
-        d_tr = nullptr;
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pb_trace), &d_tr, sizeof(d_tr));
-        return;
-    }
-#endif
     launch_predict_impl<NT>(h, rows, n_rows, out, loss_part);
 }
 #define DISPATCH_NT(fn, ...)                          \
@@ -1469,25 +1457,13 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
     hipLaunchKernelGGL(k_reduce_act, dim3((unsigned)ceil_div(DIMN_TB * dm.Hp, 1024), nk), dim3(256), 0, st, h->d_sn, h->d_P, h->d_b1, d_mask,
                        h->d_Dd, dm, b_act, rate, scale, h->cfg.seed, epoch_key, step_key, ln.k0, h->act, h->d_G);
     if (h->mid_fused) {
-        // RED -> MFB (whole second layer, W2 streamed once) -> RED2 (dD partials -> dA, Adam(b1))
-        const size_t lds = ((size_t)DIMN_TB * DIMN_MID_LDD + DIMN_MID_TMAX * 1024 + 8 * 1024 + 8 + 64) * sizeof(float);
-#define LAUNCH_MFB(KEEPV) hipLaunchKernelGGL(k_mid_fused<KEEPV>, dim3(nk * (unsigned)h->mid_slices), dim3(512), lds, st, h->d_midwork + (size_t)ln.k0 * h->mid_slices, \
-                                             h->d_W2, h->d_M2, h->d_V2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_P2,        \
-                                             h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary)
-        // keep: every slice <= 6 tiles, W2 read once (DIMN_MID_KEEP=0: off); with precision bf16 its GEMMs take bf16 operands
-        if (h->mid_pipe) {
+        // RED -> k_mid_pipe (whole second layer, W2 streamed once) -> RED2 (dD partials -> dA, Adam(b1)); with precision bf16 its GEMMs take bf16 operands
 #define LAUNCH_MFP(BFV) hipLaunchKernelGGL(k_mid_pipe<BFV>, dim3(nk * (unsigned)h->mid_slices), dim3(512), (size_t)DIMN_MIDP_LDS_FLOATS * sizeof(float), st, \
                                h->d_midwork + (size_t)ln.k0 * h->mid_slices,                                                                         \
                                h->d_W2, h->d_M2, h->d_V2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_P2,     \
                                h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary)
-            if (h->train_bf16) LAUNCH_MFP(true); else LAUNCH_MFP(false);
+        if (h->train_bf16) LAUNCH_MFP(true); else LAUNCH_MFP(false);
 #undef LAUNCH_MFP
-        } else if (h->mid_keep && h->train_bf16) {
-            hipLaunchKernelGGL((k_mid_fused<true, true>), dim3(nk * (unsigned)h->mid_slices), dim3(512), lds, st, h->d_midwork + (size_t)ln.k0 * h->mid_slices,
-                               h->d_W2, h->d_M2, h->d_V2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, h->n, d_rows, b_act, h->d_Dd, h->d_P2,
-                               h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary);
-        } else if (h->mid_keep) LAUNCH_MFB(true); else LAUNCH_MFB(false);
-#undef LAUNCH_MFB
         hipLaunchKernelGGL(k_reduce_dd, dim3((unsigned)ceil_div(dm.Hp, 64), nk), dim3(1024), 0, st, h->d_midk, h->d_P2, h->d_Dd,
                            h->d_b1, h->d_b1 + kh, h->d_b1 + 2 * kh, h->d_dA, dm, ap, scale, ln.k0, (const float*)h->d_G);
     } else {
@@ -1498,7 +1474,7 @@ static int step_launch(dimn_handle h, const dimn_handle_s::Lane& ln, bool timed,
         // other counts take the generic form (operands requested inside the loop).  From 13 tiles on the kernel holds > 128 VGPRs, from 20 on its Dd image > 80 KB
         // of LDS -- one workgroup per CU -- and 8 slices of four output tiles per sub-net would need two rounds of workgroups at 40 sub-nets: six output tiles per workgroup then (12 waves),
         // 40 x 6 = 240 workgroups in ONE round (hidden 300: 28.2 -> 20.5 us per launch; hidden 384 on the generic form: 43.3 us)
-        const bool six = dm.HT >= 13 && (int64_t)dm.OS * nk > (int64_t)h->ncu && h->mid_fwd6;      // (13 tiles on: > 128 VGPRs or > 80 KB of LDS, one workgroup per CU)
+        const bool six = dm.HT >= 13 && (int64_t)dm.OS * nk > (int64_t)h->ncu;      // (13 tiles on: > 128 VGPRs or > 80 KB of LDS, one workgroup per CU)
         const dim3 grid6((unsigned)ceil_div(dm.OT, 6), nk);
 #define LAUNCH_MF(HTC, NTW, GRID) hipLaunchKernelGGL((k_mid_fwd<HTC, NTW>), GRID, dim3(128 * NTW), lds, st, h->d_W2, h->d_b2, h->d_b2 + ko, h->d_b2 + 2 * ko, h->d_Y, \
                                                      h->n, d_rows, b_act, h->d_Dd, h->d_dZ, h->d_loss_step, d_loss_acc, dm, ap, inv_n, h->cfg.loss_binary, ln.k0)
@@ -1731,7 +1707,7 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
     bool erows = false;
     {
         erows = ((double)h->x_total * XBYTES(h) + (double)h->y_total * 4.0) > 16.0 * 1073741824.0;
-        if (const char* e = getenv("DIMN_RES_EPOCH_ROWS")) erows = atoi(e) != 0;
+        if (const int v = res_test_knob("erows", -1); v >= 0) erows = v != 0;
         if (erows && h->res_erows_off) erows = false;
         if (erows) {     // (no room for the copies: the kernel gathers its rows where they are, as for small arenas)
             if (!h->d_res_Xe && dev_malloc_bytes((void**)&h->d_res_Xe, std::max<size_t>(1, (size_t)h->x_total * XBYTES(h))) != hipSuccess) { h->d_res_Xe = nullptr; erows = false; }
@@ -1756,7 +1732,7 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
     // tile order of the kernel's loop: rows of a large arena are far away (TLB reach), so their requests get two tile-times of lead
     // (only when the rows stay where they are: with the epoch-ordered copies the alternating order is the better one again, 39.1 vs 39.8 us)
     bool split = !erows && (double)h->x_total * XBYTES(h) > 16.0 * 1073741824.0;
-    if (const char* e = getenv("DIMN_RES_SPLIT")) split = atoi(e) != 0;
+    if (const int v = res_test_knob("split", -1); v >= 0) split = v != 0;
     if (getenv("DIMN_TRACE") && atoi(getenv("DIMN_TRACE")) && epoch == 0) fprintf(stderr, "[dimn] resident epoch: arena %.1f GB, epoch-ordered rows %d, split tile order %d\n", ((double)h->x_total * XBYTES(h) + (double)h->y_total * 4.0) / 1073741824.0, (int)erows, (int)split);
     // one launch per group of res_Kg sub-nets (all of them when they fit at once), one after the other on the stream
     for (int k0 = 0; k0 < h->K && !not_resident; k0 += h->res_Kg) {
@@ -1783,7 +1759,7 @@ static int train_epoch_resident(dimn_handle h, int32_t epoch, double* train_loss
         if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && !not_resident && flags[(size_t)2 * h->K] == 0) { h->tm_res_ms += ms; h->tm_res_steps += steps; }
         h->ev_used = 0; h->ev_bytes.clear();
     }
-    if (getenv("DIMN_RES_TEST_ABORT") && atoi(getenv("DIMN_RES_TEST_ABORT")) == (int)epoch + 1) flags[(size_t)2 * h->K] = 1;   // tests: pretend epoch N-1 timed out
+    if (res_test_knob("abort", 0) == (int)epoch + 1) flags[(size_t)2 * h->K] = 1;   // tests: pretend epoch N-1 timed out
     if (not_resident || flags[(size_t)2 * h->K] != 0) {
         // not all workgroups of a launch could be resident together (or one was lost to another tenant of this GPU): the state
         // goes back to what it was before this epoch, the handle stops using the resident kernel, and the caller runs the epoch
@@ -2380,9 +2356,9 @@ extern "C" int dimn_path_info(dimn_handle h, int32_t* out8) {
     out8[2] = h->res_S1;                                        // resident: D-splits per hidden tile
     out8[3] = h->mid_fused;                                     // streaming: 1 fused second layer (RED -> MFB -> RED2), 0 two kernels (MF + MB)
     out8[4] = h->mid_fused ? h->mid_slices : 0;                 // ... output slices per sub-net
-    out8[5] = h->mid_fused && h->mid_pipe ? 2 : h->mid_keep;                                      // ... W2 column blocks kept in LDS between the phases
+    out8[5] = h->mid_fused ? 2 : 0;                             // ... its form: 2 = the tile pipeline k_mid_pipe (1 / 0 were the three-phase kernel of rounds 2-4, retired)
     out8[6] = h->res_G ? 2 * h->res_bf16 : h->train_bf16;      // training GEMMs on the bf16 matrix cores: 1 the second layer's (fused kernel), 2 all (resident kernel)
-    out8[7] = h->dm.HT == 16 ? 1 : (h->w1_waves ? 3 : (h->dm.HT == 20 ? 2 : 0));    // first layer: 1 ring B1F1 (H = 256), 2 shared-staging (H = 300), 3 four-set ring with one hidden tile per wave (8 .. 24 tiles other than 16, from 2 chunks per CU on), 0 generic
+    out8[7] = h->dm.HT == 16 ? 1 : (h->w1_waves ? 3 : 0);       // first layer: 1 ring B1F1 (H = 256), 3 four-set ring with one hidden tile per wave (8 .. 24 tiles other than 16), 0 generic (2 was the shared-staging kernel of hidden 300, retired)
     return DIMN_OK;
 }
 
@@ -2617,7 +2593,7 @@ static int corr_on_device_streamed(const double* X, int64_t n, int64_t g, hipStr
     const int64_t gp = (g + CORR_BT - 1) / CORR_BT * CORR_BT;
     const int nb = (int)(gp / CORR_BT);
     int64_t blk = std::max<int64_t>(CORR_KC, (int64_t)(2048ll << 20) / (gp * 8) / CORR_KC * CORR_KC);      // rows per block, a multiple of 16
-    if (const char* e = getenv("DIMN_CORR_BLOCK_ROWS")) blk = std::max<int64_t>(CORR_KC, atoll(e) / CORR_KC * CORR_KC);   // tests
+    if (const char* e = getenv("DIMN_CORR_BUDGET_GB")) if (const char* c = strchr(e, ':')) blk = std::max<int64_t>(CORR_KC, atoll(c + 1) / CORR_KC * CORR_KC);   // "B:rows" (tests)
     double *dZ[2] = {nullptr, nullptr}, *pin[2] = {nullptr, nullptr}, *dC = nullptr, *dOut = nullptr, *dMean = nullptr;
     int2* dPairs = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};

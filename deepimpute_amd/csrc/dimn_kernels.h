@@ -29,10 +29,10 @@
 //   k_reduce_act     RED      sum of split-K partials + bias + ReLU + Philox dropout -> Dd
 //   k_mid_fwd        MF       second layer, softplus, wMSE, dZ, Adam(b2)
 //   k_mid_bwd        MB       W2 gradient + Adam in registers, dD with the old W2, dA, Adam(b1)
-//   k_w1_update_fwd_ring      B1F1 for H = 256: W1 gradient + Adam in registers + next step's split-K
-//                             forward; 16 waves, LDS-staged X tiles, three-set register ring
-//   k_w1_update_fwd_sh        the same with a two-set ring (kept as DIMN_B1F1=2 for A/B measurements)
-//   k_w1_update_fwd           B1F1 for any H (8 independent waves, wave-private staging, no barrier)
+//   k_w1_update_fwd_ring      B1F1 for 8 .. 24 hidden tiles (H = 113 .. 384): W1 gradient + Adam in registers + next step's split-K
+//                             forward; one hidden tile per wave, LDS-staged X tiles, three- (H = 256) or four-set register ring
+//   k_w1_update_fwd           B1F1 for any other H (8 independent waves, wave-private staging, no barrier)
+//   k_mid_pipe (dimn_mid_pipe.h)  the whole second layer at H = 256 as a tile pipeline (RED -> k_mid_pipe -> RED2 -> B1F1)
 //   k_predict                 fused forward for model.predict and the validation loss
 #pragma once
 #include <hip/hip_runtime.h>
@@ -826,351 +826,12 @@ __global__ __launch_bounds__(WV * 64, WPS) void k_mid_bwd(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------
-// MFB: the whole second layer in ONE pass over W2 (H = 256 only: 8 waves x 2 hidden tiles).
-// Workgroup = (sub-net k, output tiles [ot0, ot1)), one workgroup per CU (<= ncu items, T = ot1-ot0 <= 8).
-// wMSE is element-wise, so dZ of an output slice needs only Z of that slice:
-//   phase 1  wave = one output tile: Z = Dd W2[:,tile] + b2 ; softplus ; wMSE ; dZ -> LDS ; gb2 -> Adam(b2)
-//   phase 2  per output tile: gW2^T = dZ^T Dd -> Adam on W2/m/v in registers ; dD[:, 32 h of this wave] += dZ W2old^T
-//   epilogue the slice's dD partial [64][Hp] -> P2[slot]  (summed over the slices by k_reduce_dd)
-// vs MF + MB: W2 is streamed once (24 B/param, no separate 4 B/param forward read), dZ never goes to
-// memory, one launch instead of two, and the work table gives every CU one workgroup.
+// The fused second layer (H = 256): workgroup = (sub-net k, output tiles [ot0, ot1)), T = ot1 - ot0 <= 8, one workgroup per CU; the kernel
+// is k_mid_pipe (dimn_mid_pipe.h).  (Rounds 2-4 ran it as three workgroup-wide phases -- k_mid_fused: load burst, forward over the slice,
+// backward over the slice; 39.9 us against the pipeline's 36.1 in the cfg3 step -- retired in round 6; profiles/HISTORY.md section 2.)
 // ---------------------------------------------------------------------------------------
 struct MidWork { int32_t k, ot0, ot1, slot, sidx; };   // slot: P2 partial; sidx: slice number inside the sub-net (loss slot)
 #define DIMN_MID_TMAX 8
-#define DIMN_MID_LDD 260   // LDS row stride of Dd in k_mid_fused: 16-byte aligned rows, 4 mod 32 words (conflict-free b128 row reads)
-#ifdef DIMN_MID_TL   // tools/k_probe_mid.hip: per-wave phase stamps (shader clock)
-__device__ unsigned long long g_mid_tl[512 * 8 * 8];
-#define MID_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_mid_tl[(blockIdx.x * 8 + wave) * 8 + (i)] = t_; }
-#else
-#define MID_STAMP(i)
-#endif
-
-// KEEP (every slice of the launch has T <= 6 tiles): the W2 column blocks that phase 1 loaded stay on the chip -- after phase 1
-// the units' owners copy them from registers into the LDS that Dd and the transpose buffers occupied (96 KB at T = 6), and
-// phase 2 takes the OLD W2 of a tile from there instead of reading it from memory a second time: 24 instead of 28 bytes per
-// W2 parameter.  And with w out of the phase-2 sets, m and v of ALL the slice's tiles fit in registers (96): they are requested
-// at the start of the kernel and travel under the load burst and phase 1, so phase 2 is compute + stores only (it runs at its
-// MFMA floor, tools/k_probe_mid.hip).  40.1 -> 36.4 us per launch at 40 sub-nets x 6 slices (tools/ab_mid_allmv.sh).
-// BF (with KEEP, handles of precision bf16): the three GEMMs of the layer take bf16 operands -- Dd, W2, dZ rounded to nearest even
-// in registers, one v_mfma_f32_16x16x16_bf16 where four fp32 MFMAs were (the k-slot register groups ARE its operands), fp32
-// accumulation, fp32 master weights and Adam state.  oracle/dimo.c restates the rounding (dimo_set_training_bf16).
-template <bool KEEP, bool BF = false>
-__global__ __launch_bounds__(512) void k_mid_fused(const MidWork* __restrict__ mwork,
-                                                   float* __restrict__ W2, float* __restrict__ M2, float* __restrict__ V2,
-                                                   float* __restrict__ b2w, float* __restrict__ b2m, float* __restrict__ b2v,
-                                                   const float* __restrict__ Y, int64_t n_cells,
-                                                   const int32_t* __restrict__ rows, int b_act,
-                                                   const float* __restrict__ Dd, float* __restrict__ P2,
-                                                   float* __restrict__ loss_step, double* __restrict__ loss_acc,
-                                                   Dims dm, AdamP ap, float inv_n, int loss_binary) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const MidWork mw = mwork[blockIdx.x];
-    const int k = mw.k, ot0 = mw.ot0, ot1 = mw.ot1, ot_last = mw.ot1 - 1;
-    const int Hp = dm.Hp, OT = dm.OT, Op = dm.Op;
-    constexpr int ldd = DIMN_MID_LDD;
-    float* dzl = lds;                                        // dZ tiles [T][64 b][16 o]
-    float* ddl = dzl + DIMN_MID_TMAX * 1024;                 // Dd [64][ldd]
-    float* wsl = ddl + DIMN_TB * ldd;                        // per-wave W2 transpose buffers [8][4 tiles]
-    float* w2l = ddl;                                        // KEEP: W2 column blocks [T <= 6][16 hidden tiles][256] over Dd + the transpose buffers (24 832 >= 24 576 floats)
-    float* lsl = wsl + 8 * 1024;                             // loss partials [8 waves]
-    float* gbl = lsl + 8;                                    // bias-gradient row parts of the shared units [8 waves][16]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lj = lane >> 4;
-    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    MID_STAMP(0)
-
-    // Loads are issued in the order they are needed (VMEM returns in order): batch rows, Dd, this wave's
-    // W2 column block and targets (phase 1), then the state of the first two output tiles (phase 2).
-    // All are 16-byte-per-lane, fully coalesced (47 requests per lane; dword-strided operand loads
-    // would be 119 and overflow the 6-bit vmcnt).
-    // phase 1: wave w -> output tile ot0 + w (all 64 batch rows), so every W2 column block is loaded once
-    // per workgroup; waves beyond the slice's tile count idle until phase 2.
-    // Unit u = output tile ot0 + u, shared by `ways` waves (64/ways batch rows each) so that all eight waves --
-    // and all four SIMDs' MFMA pipes -- carry phase 1:  T <= 2: 4 waves per unit;  T = 3, 4: 2 waves per unit;
-    // T = 5, 6: units 0..3 whole on waves 0..3 (one per SIMD), units 4, 5 halved over waves 4..7 (two whole
-    // units on one SIMD made phase 1 1.4x longer);  T = 7, 8: one unit per wave.
-    const int T = ot1 - ot0;
-    int ways, u, part;
-    if (T <= 2) { ways = 4; u = wave >> 2; part = wave & 3; }
-    else if (T <= 4) { ways = 2; u = wave >> 1; part = wave & 1; }
-    else if (T <= 6 && wave >= 4) { ways = 2; u = 4 + ((wave - 4) >> 1); part = (wave - 4) & 1; }
-    else { ways = 1; u = wave; part = 0; }
-    const bool split = ways > 1;
-    const int nm = 4 / ways;                                 // 16-row tiles of this wave
-    const int m0 = part * nm;                                // its first one
-    const bool p1 = u < T;
-    const int oc = p1 ? ot0 + u : ot_last;                   // clamped: loads stay in bounds
-    int rid[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                            // a split wave repeats its two tiles (same loads, same LDS words)
-        const int b = 16 * (m0 + i % nm) + (lane >> 2);
-        rid[i] = rows[b < b_act ? b : 0];
-    }
-    const float* ddk = Dd + (int64_t)k * DIMN_TB * Hp;
-    f32x4 ddv[8];                                            // 64 x 256 floats = 8 float4 per thread
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ddv[i] = *(const f32x4*)(ddk + tid * 4 + i * 2048);
-    f32x4 wt[16], yt[4];
-    const int64_t bi = (int64_t)k * Op + 16 * oc + li;
-    float bias = 0.f, b2m0 = 0.f, b2v0 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) yt[i] = zero4;
-    if (p1) {                                                // wave-uniform: idle waves request nothing
-        const float* w2 = W2 + (int64_t)k * Hp * Op + (int64_t)oc * 256 + lane * 4;
-#pragma unroll
-        for (int ht = 0; ht < 16; ++ht) wt[ht] = *(const f32x4*)(w2 + (int64_t)ht * OT * 256);   // tile (ht, oc), natural layout
-    }
-
-    // Dd[64][Hp] -> LDS
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int e = tid * 4 + i * 2048, b = e >> 8, h = e & 255;
-        *(f32x4*)(ddl + b * ldd + h) = ddv[i];
-    }
-    float* zb = dzl + (p1 ? u : wave) * 1024;                // the unit's [64 b][16 o] tile: targets first, dZ later
-    float* ws = wsl + wave * 1024;                           // this wave's W2 transpose buffer (4 tiles)
-    __syncthreads();                                         // only Dd and the W2 column block were requested so far: a
-    MID_STAMP(1)                                             // wave reaches this barrier as soon as ITS requests are issued
-
-    // requested after the barrier, consumed later: targets and bias state (end of phase 1), phase-2 state
-    if (p1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) yt[i] = *(const f32x4*)(Y + ((int64_t)k * n_cells + rid[i]) * Op + 16 * oc + 4 * (lane & 3));
-        bias = b2w[bi]; b2m0 = b2m[bi]; b2v0 = b2v[bi];
-    }
-    struct Set { f32x4 w[KEEP ? 1 : 2], m[2], v[2]; };       // (KEEP: w comes from LDS when the tile is processed)
-    const int64_t tbase = (int64_t)k * Hp * Op + li * 16 + 4 * lj;
-    auto tidx = [&](int ht, int ot) { return tbase + ((int64_t)(2 * wave + ht) * OT + ot) * 256; };
-    auto fetch = [&](Set& st, int ot) {
-        const int o2 = ot < ot_last ? ot : ot_last;
-#pragma unroll
-        for (int ht = 0; ht < 2; ++ht) {
-            const int64_t i = tidx(ht, o2);
-            if constexpr (!KEEP) st.w[ht] = *(const f32x4*)(W2 + i);
-            st.m[ht] = DIMN_LD_MV(M2 + i); st.v[ht] = DIMN_LD_MV(V2 + i);
-        }
-    };
-    Set A, B, C, D;                                          // !KEEP: four named sets, three tiles in flight
-    Set all[KEEP ? 6 : 1];                                   // KEEP: m and v of EVERY tile of the slice (<= 6) are requested here, 96 registers:
-    if constexpr (KEEP) {                                    // phase 2 then only computes and stores -- its reads travel under the load
-#pragma unroll                                               // burst and phase 1, when the memory system is not busy (the sixth tile's after phase 1, when
-        for (int i = 0; i < 5; ++i) fetch(all[i], ot0 + i);  // the registers of the W2 column block are free: all six up front spill 28 registers)
-    } else {
-        fetch(A, ot0);
-        fetch(B, ot0 + 1);
-        fetch(C, ot0 + 2);
-    }
-
-    float lsum = 0.f;
-    auto phase1 = [&](auto nmc) {
-        constexpr int NM = decltype(nmc)::value;
-        f32x4 acc[NM];
-#pragma unroll
-        for (int j = 0; j < NM; ++j) acc[j] = zero4;
-        // k-slot form: MFMA r of a hidden tile takes k = 4*lj + r, so one 16-byte LDS read of a Dd row feeds
-        // four MFMAs (A) and the W2 operand is the transposed tile read at row 4*lj + r (B)
-        const float* arow = ddl + (16 * m0 + li) * ldd + 4 * lj;
-#pragma unroll
-        for (int rd = 0; rd < 4; ++rd) {                     // four hidden tiles per round through the wave-private buffer
-#pragma unroll
-            for (int t = 0; t < 4; ++t) *(f32x4*)(ws + t * 256 + lane * 4) = wt[4 * rd + t];
-            float bq[4][4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) bq[t][r] = ws[t * 256 + (4 * lj + r) * 16 + li];     // W2[h = 16ht+4lj+r][o = li]
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                f32x4 a4[NM];
-#pragma unroll
-                for (int j = 0; j < NM; ++j) a4[j] = *(const f32x4*)(arow + 16 * j * ldd + 16 * (4 * rd + t));
-                if constexpr (BF) {
-                    const bf16x4 bp = pk4((f32x4){bq[t][0], bq[t][1], bq[t][2], bq[t][3]});
-#pragma unroll
-                    for (int j = 0; j < NM; ++j) acc[j] = MFMA_BF16(pk4(a4[j]), bp, acc[j]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int j = 0; j < NM; ++j) acc[j] = MFMA16(a4[j][r], bq[t][r], acc[j]);
-                }
-            }
-        }
-        // targets: row-major float4 pieces -> this wave's rows of the unit tile -> MFMA C layout (the rows are
-        // private to the wave, LDS is in order per wave: no barrier)
-#pragma unroll
-        for (int i = 0; i < NM; ++i) *(f32x4*)(zb + (16 * (m0 + i) + (lane >> 2)) * 16 + 4 * (lane & 3)) = yt[i];
-        float yv[NM][4];
-#pragma unroll
-        for (int j = 0; j < NM; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) yv[j][r] = zb[(16 * (m0 + j) + 4 * lj + r) * 16 + li];
-        const bool col_ok = (16 * oc + li) < dm.O;
-        float gb = 0.f;
-#pragma unroll
-        for (int j = 0; j < NM; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int b = 16 * (m0 + j) + 4 * lj + r;
-                // (computed for every lane and selected: under a branch per element the 16 softplus chains of a lane ran one after the other)
-                const bool ok = b < b_act && col_ok;
-                const float z = acc[j][r] + bias;
-                const float y = yv[j][r];
-                const float w = loss_binary ? (y > 0.f ? 1.f : 0.f) : y;       // multinet.py:37-40
-                float sp, sg;
-                softplus_sigmoid_fast(z, sp, sg);
-                const float e = y - sp;
-                lsum += ok ? w * e * e : 0.f;
-                const float dz = ok ? -2.f * w * e * inv_n * sg : 0.f;
-                zb[b * 16 + li] = dz;
-                gb += dz;
-            }
-        gb += __shfl_xor(gb, 16);                            // column sums over this wave's rows
-        gb += __shfl_xor(gb, 32);
-        if (lj == 0) {
-            if (NM == 4) {                                   // the wave holds all 64 rows: Adam(b2) here
-                adam1(bias, b2m0, b2v0, gb, ap);
-                b2w[bi] = bias; b2m[bi] = b2m0; b2v[bi] = b2v0;
-            } else {
-                gbl[wave * 16 + li] = gb;                    // part of the rows: finished after the barrier
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
-    };
-    if (p1) {
-        if (ways == 4) phase1(std::integral_constant<int, 1>{});
-        else if (ways == 2) phase1(std::integral_constant<int, 2>{});
-        else phase1(std::integral_constant<int, 4>{});
-    }
-    if (lane == 0) lsl[wave] = lsum;
-    MID_STAMP(2)
-    __syncthreads();                                         // dZ tiles and loss partials are in LDS
-    MID_STAMP(3)
-    if (tid == 0) {
-        float tot = 0.f;
-#pragma unroll
-        for (int wv = 0; wv < 8; ++wv) tot += lsl[wv];
-        loss_step[k * dm.LS + mw.sidx] = tot;
-        if (loss_acc) loss_acc[k * dm.LS + mw.sidx] += (double)tot;
-    }
-    if (split && p1 && part == 0 && lj == 0) {               // Adam(b2) of a shared unit: its waves' row parts, in order
-        float gb = gbl[wave * 16 + li];
-        for (int j = 1; j < ways; ++j) gb += gbl[(wave + j) * 16 + li];
-        adam1(bias, b2m0, b2v0, gb, ap);
-        b2w[bi] = bias; b2m[bi] = b2m0; b2v[bi] = b2v0;
-    }
-
-    // ---- phase 2: wave w owns hidden tiles 2w, 2w+1 for every output tile of the slice ----
-    float ddf[16][2];    // B operand of gW2^T: Dd[b = 4kb+lj][h = 16(2w+ht)+li]
-#pragma unroll
-    for (int kb = 0; kb < 16; ++kb)
-#pragma unroll
-        for (int ht = 0; ht < 2; ++ht) ddf[kb][ht] = ddl[(4 * kb + lj) * ldd + 16 * (2 * wave + ht) + li];
-    bf16x4 ddp[BF ? 4 : 1][2];                               // BF: the same operands, four batch rows per lane and instruction
-    if constexpr (BF) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int ht = 0; ht < 2; ++ht) ddp[q][ht] = pk4((f32x4){ddf[4 * q][ht], ddf[4 * q + 1][ht], ddf[4 * q + 2][ht], ddf[4 * q + 3][ht]});
-    }
-    f32x4 dacc[4][2];
-#pragma unroll
-    for (int m4 = 0; m4 < 4; ++m4)
-#pragma unroll
-        for (int ht = 0; ht < 2; ++ht) dacc[m4][ht] = zero4;
-    if constexpr (KEEP) {
-        __syncthreads();                                     // every wave holds its Dd operands: Dd and the transpose buffers are free
-        if (p1 && part == 0) {                               // the unit's column block, tiles in their natural [h][o] form
-#pragma unroll
-            for (int ht = 0; ht < 16; ++ht) *(f32x4*)(w2l + (u * 16 + ht) * 256 + lane * 4) = wt[ht];
-        }
-        fetch(all[5], ot0 + 5);
-        __syncthreads();
-    }
-
-    auto step = [&](Set& cur, Set& nx3, int ot) {
-        if constexpr (!KEEP) {
-            fetch(nx3, ot + 3);                              // into the set the previous tile has just released
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const float* zb = dzl + (ot - ot0) * 1024;
-        f32x4 g[2] = {zero4, zero4};
-        if constexpr (BF) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {                                    // batch rows 16q + 4i + lj in k-slot i of lane (.., lj)
-                const bf16x4 ap = pk4((f32x4){zb[64 * (4 * q) + lane], zb[64 * (4 * q + 1) + lane], zb[64 * (4 * q + 2) + lane], zb[64 * (4 * q + 3) + lane]});
-#pragma unroll
-                for (int ht = 0; ht < 2; ++ht) g[ht] = MFMA_BF16(ap, ddp[q][ht], g[ht]);
-            }
-        } else {
-#pragma unroll
-            for (int kb = 0; kb < 16; ++kb) {
-                const float az = zb[64 * kb + lane];                         // dZ^T[o = li][b = 4kb+lj]
-#pragma unroll
-                for (int ht = 0; ht < 2; ++ht) g[ht] = MFMA16(az, ddf[kb][ht], g[ht]);
-            }
-        }
-        f32x4 zf[4];
-#pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) zf[m4] = *(const f32x4*)(zb + (16 * m4 + li) * 16 + 4 * lj);   // dZ[b][o = 4lj+r]
-#pragma unroll
-        for (int ht = 0; ht < 2; ++ht) {
-            f32x4 wold;
-            if constexpr (KEEP) wold = *(const f32x4*)(w2l + ((ot - ot0) * 16 + 2 * wave + ht) * 256 + li * 16 + 4 * lj);
-            else wold = cur.w[ht];
-            if constexpr (BF) {
-                const bf16x4 wp = pk4(wold);
-#pragma unroll
-                for (int m4 = 0; m4 < 4; ++m4) dacc[m4][ht] = MFMA_BF16(pk4(zf[m4]), wp, dacc[m4][ht]);      // OLD W2
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int m4 = 0; m4 < 4; ++m4) dacc[m4][ht] = MFMA16(zf[m4][r], wold[r], dacc[m4][ht]);    // OLD W2
-            }
-            adam4(wold, cur.m[ht], cur.v[ht], g[ht], ap);
-            const int64_t i = tidx(ht, ot);
-            DIMN_ST_STATE(W2 + i, wold); DIMN_ST_STATE(M2 + i, cur.m[ht]); DIMN_ST_STATE(V2 + i, cur.v[ht]);
-        }
-    };
-    if constexpr (KEEP) {
-        MID_STAMP(4)
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-            if (i < T) step(all[i], all[i], ot0 + i);        // (wave-uniform; straight-line code: the compiler counts the exact vmcnt of every tile)
-    } else {
-#pragma unroll
-        for (int ht = 0; ht < 2; ++ht) {
-            asm volatile("" : "+v"(A.w[ht]), "+v"(B.w[ht]), "+v"(C.w[ht]));
-            asm volatile("" : "+v"(A.m[ht]), "+v"(A.v[ht]));
-            asm volatile("" : "+v"(B.m[ht]), "+v"(B.v[ht]));
-            asm volatile("" : "+v"(C.m[ht]), "+v"(C.v[ht]));
-        }
-        MID_STAMP(4)
-        int ot = ot0;
-        for (; ot + 4 <= ot1; ot += 4) {
-            step(A, D, ot);
-            step(B, A, ot + 1);
-            step(C, B, ot + 2);
-            step(D, C, ot + 3);
-        }
-        if (ot < ot1) {
-            step(A, D, ot);
-            if (ot + 1 < ot1) step(B, A, ot + 1);
-            if (ot + 2 < ot1) step(C, B, ot + 2);
-        }
-    }
-    MID_STAMP(5)
-    float* p2 = P2 + (int64_t)mw.slot * DIMN_TB * Hp;
-#pragma unroll
-    for (int m4 = 0; m4 < 4; ++m4)
-#pragma unroll
-        for (int ht = 0; ht < 2; ++ht)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) DIMN_ST_P2(&p2[(16 * m4 + 4 * lj + r) * Hp + 16 * (2 * wave + ht) + li], dacc[m4][ht][r]);
-    MID_STAMP(6)
-}
 
 // RED2: dA = (sum over the sub-net's slices of the dD partials) * scale * [Dd > 0] ; gb1 -> Adam(b1).
 // grid (ceil(Hp/64), K), 1024 threads: thread -> hidden unit h, 4 batch rows (a latency-bound kernel:
@@ -1395,147 +1056,10 @@ __global__ __launch_bounds__(512) void k_w1_update_fwd(const Work* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
-// B1F1 "shared staging" variant: WAVES waves (8 or 16) per workgroup, wave w owns NT2 =
-// HT/WAVES hidden tiles; the X_t / X_{t+1} chunk tiles are staged ONCE per workgroup through
-// LDS (one 16-byte load per staging thread) with one barrier per chunk.  With 16 waves of
-// <=128 VGPRs, four waves share each SIMD, so MFMA, Adam VALU work and memory waits of
-// different waves overlap inside every chunk.  With WAVES*NT2 < HT the hidden tiles are split over
-// grid.y (e.g. <8,1> x 2 for H = 256): two such workgroups fit on one CU, so the prologue/epilogue
-// of one overlaps the streaming of the other.
-// ---------------------------------------------------------------------------------------
-template <int WAVES, int NT2, int MINW = 1, typename XT = float>
-__global__ __launch_bounds__(WAVES * 64, MINW) void k_w1_update_fwd_sh(const Work* __restrict__ work, const SubnetDev* __restrict__ sn,
-                                                                const XT* __restrict__ X, float* __restrict__ W1,
-                                                                float* __restrict__ M1, float* __restrict__ V1,
-                                                                const int32_t* __restrict__ rows_t, int b_act,
-                                                                const int32_t* __restrict__ rows_n, int b_next,
-                                                                const float* __restrict__ dA, float* __restrict__ P, Dims dm, AdamP ap) {
-    constexpr int XTS = DIMN_TB * 16, XN = DIMN_TB * 20;
-    __shared__ __attribute__((aligned(16))) float sm[2 * (XTS + XN)];
-    const int nwg_ = gridDim.x, xq_ = nwg_ >> 3, xr_ = nwg_ & 7, xcd_ = blockIdx.x & 7;        // a sub-net's D-slices on one XCD (see the ring kernel)
-    const Work wk = work[xcd_ * xq_ + (xcd_ < xr_ ? xcd_ : xr_) + (blockIdx.x >> 3)];
-    const SubnetDev s = sn[wk.k];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lj = lane >> 4;
-    const int nt0 = (blockIdx.y * WAVES + wave) * NT2;     // grid.y splits the hidden tiles when WAVES*NT2 < HT
-    const int Hp = dm.Hp;
-    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    float bfr[16][NT2];
-    const float* dak = dA + (int64_t)wk.k * DIMN_TB * Hp;
-#pragma unroll
-    for (int kb = 0; kb < 16; ++kb)
-#pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) bfr[kb][nt] = dak[(4 * kb + lj) * Hp + 16 * (nt0 + nt) + li];
-
-    // staging roles: threads 0..255 move the X_t tile, 256..511 the X_{t+1} tile (others none)
-    const bool stager = tid < 512;
-    const bool stage_next = tid >= 256;
-    const bool have_next = b_next > 0;
-    const int sb = (tid & 255) >> 2, sq = tid & 3;
-    const bool svalid = stager && (stage_next ? (sb < b_next) : (sb < b_act));
-    const int32_t* srows = (stage_next && have_next) ? rows_n : rows_t;
-    const XT* xsrc = X + s.xoff + (int64_t)srows[svalid ? sb : 0] * s.Dp + 4 * sq;
-    const int sdst = stage_next ? (2 * XTS + sb * 20 + 4 * sq) : (sb * 16 + 4 * sq);
-    const int sbuf = stage_next ? XN : XTS;
-
-    const int64_t cstride = (int64_t)Hp * 16;
-    int64_t wb[NT2];
-#pragma unroll
-    for (int nt = 0; nt < NT2; ++nt) wb[nt] = s.w1off + (int64_t)(16 * (nt0 + nt) + li) * 16 + 4 * lj;
-
-    f32x4 pacc[4][NT2];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) pacc[mt][nt] = zero4;
-
-    const int clast = wk.c1 - 1;
-    f32x4 w[NT2], m[NT2], v[NT2];
-#pragma unroll
-    for (int nt = 0; nt < NT2; ++nt) {
-        const int64_t i0 = wb[nt] + wk.c0 * cstride;
-        w[nt] = *(const f32x4*)(W1 + i0); m[nt] = DIMN_LD_STATE_MV(M1 + i0); v[nt] = DIMN_LD_STATE_MV(V1 + i0);
-    }
-    XRaw<XT> xa;
-    xa.load(xsrc + 16 * (wk.c0 < clast ? wk.c0 + 1 : clast));
-    if (stager) {
-        XRaw<XT> x0;
-        x0.load(xsrc + 16 * wk.c0);
-        *(f32x4*)(sm + sdst) = svalid ? x0.get() : zero4;
-    }
-#pragma unroll
-    for (int kb = 0; kb < 16; ++kb)
-#pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) asm volatile("" : "+v"(bfr[kb][nt]));
-#pragma unroll
-    for (int nt = 0; nt < NT2; ++nt) asm volatile("" : "+v"(w[nt]), "+v"(m[nt]), "+v"(v[nt]));
-    asm volatile("" : "+v"(xa.v));
-    __syncthreads();
-
-    for (int c = wk.c0; c < wk.c1; ++c) {
-        const int cur = (c - wk.c0) & 1;
-        const int c1n = c < clast ? c + 1 : clast;
-        const int c2n = c + 2 < wk.c1 ? c + 2 : clast;
-        XRaw<XT> xb = xa;
-        if (stager) xb.load(xsrc + 16 * c2n);                       // X tile of chunk c+2
-        f32x4 w1[NT2], m1[NT2], v1[NT2];
-#pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) {
-            const int64_t idx = wb[nt] + c1n * cstride;                // state of chunk c+1
-            w1[nt] = *(const f32x4*)(W1 + idx); m1[nt] = DIMN_LD_STATE_MV(M1 + idx); v1[nt] = DIMN_LD_STATE_MV(V1 + idx);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-
-        const float* xt = sm + cur * XTS;
-        f32x4 g[NT2];
-#pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) g[nt] = zero4;
-#pragma unroll
-        for (int kb = 0; kb < 16; ++kb) {
-            const float a = xt[64 * kb + lane];
-#pragma unroll
-            for (int nt = 0; nt < NT2; ++nt) g[nt] = MFMA16(a, bfr[kb][nt], g[nt]);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) adam4(w[nt], m[nt], v[nt], g[nt], ap);
-        if (stager) *(f32x4*)(sm + sdst + (cur ^ 1) * sbuf) = svalid ? xa.get() : zero4;      // tile of chunk c+1
-#pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) {
-            const int64_t idx = wb[nt] + c * cstride;
-            DIMN_ST_STATE(W1 + idx, w[nt]); DIMN_ST_STATE(M1 + idx, m[nt]); DIMN_ST_STATE(V1 + idx, v[nt]);
-        }
-        if (have_next) {
-            const float* xn = sm + 2 * XTS + cur * XN;
-            f32x4 af[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) af[mt] = *(const f32x4*)(xn + (16 * mt + li) * 20 + 4 * lj);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT2; ++nt) pacc[mt][nt] = MFMA16(af[mt][r], w[nt][r], pacc[mt][nt]);
-        }
-        xa = xb;
-#pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) { w[nt] = w1[nt]; m[nt] = m1[nt]; v[nt] = v1[nt]; }
-        __syncthreads();
-    }
-    if (have_next) {
-        float* p = P + (int64_t)wk.slot * DIMN_TB * Hp;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) p[(16 * mt + 4 * lj + r) * Hp + 16 * (nt0 + nt) + li] = pacc[mt][nt][r];
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// B1F1 "shared staging, deep ring": as k_w1_update_fwd_sh, but the chunk loop is unrolled three
-// times over three NAMED register sets (A, B, C), so that rotating the prefetch ring costs no
+// B1F1 "shared staging, deep ring": WAVES waves per workgroup, wave w owns NT2 hidden tiles; the X_t / X_{t+1} chunk tiles are staged ONCE per
+// workgroup through LDS (one 16-byte load per staging thread) with one barrier per chunk; with 16 waves of <= 128 VGPRs four waves share each
+// SIMD, so MFMA, Adam VALU work and memory waits of different waves overlap inside every chunk.  The chunk loop is unrolled three (DEPTH = 4:
+// four) times over NAMED register sets (A, B, C), so that rotating the prefetch ring costs no
 // register copies -- a copy would force a wait on the load issued in the same iteration.  The
 // state of chunk c+2 and the X tile of chunk c+2 are requested while chunk c computes: two
 // chunks (~13 KB per wave) stay in flight.
@@ -2138,21 +1662,8 @@ typedef __bf16 bf16x8n __attribute__((ext_vector_type(8)));
 #ifndef DIMN_PB_WPS
 #define DIMN_PB_WPS 2
 #endif
-// Diagnostic build (-DDIMN_PB_TRACE=1, tools/pb_trace.sh): thread 0 of every workgroup stamps the 100 MHz clock at its phase boundaries
-// (0 start, 1 first layer done, 2 activations in LDS, 3 / 5 second-layer MFMAs of pass 0 / 1 done, 4 epilogue of pass 0 done, 6 end);
-// launch_predict writes the stamps to the file DIMN_PREDICT_TRACE names.  This is how the instruction-cache problem above was found.
-#ifndef DIMN_PB_TRACE
-#define DIMN_PB_TRACE 0
-#endif
-#ifndef DIMN_PB_ABL
-#define DIMN_PB_ABL 0      // diagnostic builds (tools/pb_trace.sh ablate-build / ablate-run; wrong results): 1 no output stores, 2 every workgroup reads the X rows of the first one (L2 hits)
-#endif
-#if DIMN_PB_TRACE
-__device__ unsigned long long* g_pb_trace = nullptr;
-#define PB_STAMP(j) do { if (g_pb_trace && threadIdx.x == 0) g_pb_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (j)] = wall_clock64(); } while (0)
-#else
-#define PB_STAMP(j) do { } while (0)
-#endif
+// (Rounds 4-5 had diagnostic builds of this kernel -- per-workgroup phase stamps, store / load ablations: that is how its instruction-cache
+//  problem was found; their results are profiles/r04_predict_bf16_phases.txt and r05_predict_bf16_ablation.txt.  Retired in round 6.)
 template <bool FAST, bool LOSS>
 __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetDev* __restrict__ sn, const bf16_t* __restrict__ X,
                                                          const bf16_t* __restrict__ W1b, const float* __restrict__ b1,
@@ -2174,8 +1685,6 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
     const int li = lane & 15, lj = lane >> 4;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-
-    PB_STAMP(0);
     // ---- first layer: A = X W1 over 64-deep steps ----
     // X goes from global memory straight into LDS (global_load_lds: no staging registers, no ds_write) in FRAGMENT ORDER: a stage of the
     // ring is [8 row tiles][2 k-halves] blocks of 1 KB, lane (li, lj) of block (rt, kh) holding row 16 rt + li, k's 64 step + 32 kh + 8 lj ..+7
@@ -2193,7 +1702,7 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int b = 4 * wave + u, rt = b >> 1, kh = b & 1;
-        const int64_t i = ((DIMN_PB_ABL & 2) ? 0 : r0) + 16 * rt + li;
+        const int64_t i = r0 + 16 * rt + li;
         const int64_t src = i < n_rows ? (rows ? (int64_t)rows[i] : i) : 0;            // rows past the end read row 0 and are dropped
         xsrc[u] = X + s.xoff + src * s.Dp + 32 * kh + 8 * lj;
     }
@@ -2300,7 +1809,6 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
                           "+v"(B1[1][0]), "+v"(B1[1][1]), "+v"(B1[1][2]), "+v"(B1[1][3]) :: "memory");
         __syncthreads();                                         // every wave is done with the ring (and every request has landed): the activations take its place
     }
-    PB_STAMP(1);
     // bias + activation, rounded to bf16 into LDS (four hidden units of a row at a time); columns [Hp, Hq) zero.
     // CODE SIZE matters here: this block is unrolled 32 x 4 times.  With the activation switch inlined at every element (tanhf, expm1f,
     // log1pf(expf)) the kernel was 250 KB of code against a 64 KB instruction cache, and a workgroup spent 36 us in this block --
@@ -2325,14 +1833,11 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
         }
     }
     __syncthreads();                                             // (the four waves cover 256 hidden columns: launch_predict sends Hp > 256 to the round-2 kernel)
-
-    PB_STAMP(2);
     // ---- second layer: Z = Dd W2, 16 output tiles per pass (4 per wave) ----
     float lsum0 = 0.f, lsum1 = 0.f;
     const bf16_t* w2k = W2t + (int64_t)k * Hp * dm.Op;
     const int nsteps2 = Hq >> 5;
     for (int ot0 = 0; ot0 < dm.OT; ot0 += 16) {
-        if (ot0) PB_STAMP(4);
 #pragma unroll
         for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
@@ -2402,7 +1907,6 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
         }
         // epilogue: bias, softplus, store / loss.  A lane holds outputs o0 .. o0+3 of batch row 16 rt + li; the four output tiles of a
         // wave are adjacent (64 outputs = 256 contiguous bytes of a row of `out`), written tile after tile for each row tile
-        PB_STAMP(ot0 ? 5 : 3);
         const bool vec_ok = FAST || (dm.O & 3) == 0;
         f32x4 b2v[4];
 #pragma unroll
@@ -2422,7 +1926,7 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
                 const f32x4 zz = acc[rt][ct] + b2v[ct];                                              // (b2 is padded to Op)
                 const f32x2 y01 = softplus_out2((f32x2){zz[0], zz[1]}), y23 = softplus_out2((f32x2){zz[2], zz[3]});
                 const f32x4 yh = (f32x4){y01.x, y01.y, y23.x, y23.y};
-                if (out && ok && (!(DIMN_PB_ABL & 1) || yh[0] == 123.456f)) {
+                if (out && ok) {
                     float* dst = out + (i * dm.K + k) * dm.O + o0;
                     if (vec_ok) DIMN_PB_STORE((f32x4*)dst, yh);
                     else
@@ -2444,7 +1948,6 @@ __global__ __launch_bounds__(256, DIMN_PB_WPS) void k_predict_bf16(const SubnetD
             }
         }
     }
-    PB_STAMP(6);
     if (LOSS) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { lsum0 += __shfl_xor(lsum0, off); lsum1 += __shfl_xor(lsum1, off); }

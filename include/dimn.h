@@ -281,10 +281,10 @@ int dimn_set_profiling(dimn_handle h, int32_t on);
 /* Which kernels the library chose for this handle (the automatic decision of dimn_create; DESIGN.md has the table): out8 =
  * [0] 0 streaming kernels / 1 register-resident epoch kernel / 2 general path, [1] resident: launches (sub-net groups) per epoch,
  * [2] resident: D-splits per hidden tile, [3] streaming: 1 fused second layer / 0 two kernels, [4] its slices per sub-net,
- * [5] the fused kernel's form ("mid_kernel"): 2 tile pipeline (k_mid_pipe, fp32 or bf16 operands; since ABI 7) / 1 three phases with W2 kept in
- * LDS between them / 0 three phases, W2 read twice, [6] training GEMMs on the bf16 matrix cores (1: the second layer's three, fused
- * kernel; 2: those of both layers, resident kernel; 0: none), [7] first-layer kernel
- * (1 ring, 2 shared staging, 3 four-set ring with one hidden tile per wave (8 .. 24 hidden tiles other than 16, many sub-nets), 0 generic).  A handle whose resident launch had to be undone reports 0 from then on.  ABI 5; [5] = 2 since ABI 7. */
+ * [5] the fused kernel's form ("mid_kernel"): 2 tile pipeline (k_mid_pipe, fp32 or bf16 operands; 1 / 0 were the three-phase kernel of ABI <= 8, retired),
+ * [6] training GEMMs on the bf16 matrix cores (1: the second layer's three, fused kernel; 2: those of both layers, resident kernel; 0: none),
+ * [7] first-layer kernel (1 ring, H = 256; 3 four-set ring with one hidden tile per wave, 8 .. 24 hidden tiles other than 16; 0 generic; 2 was the
+ * shared-staging kernel of hidden 300, retired in ABI 9).  A handle whose resident launch had to be undone reports 0 from then on.  ABI 5; [5] = 2 since ABI 7. */
 int dimn_path_info(dimn_handle h, int32_t* out8);
 
 /* ---- multi-GPU: sub-nets sharded over ranks, RCCL over xGMI (no reference analogue:

@@ -183,21 +183,19 @@ def test_bf16_matrix_core_inference_edge_shapes(H, O, B, Ds, n, act, monkeypatch
         e.close()
 
 
-@pytest.mark.parametrize("pipe", ["1", "0"])
-def test_bf16_matrix_core_training_of_the_second_layer(pipe, monkeypatch):
-    """precision="bf16" on either fused second-layer kernel (the tile pipeline k_mid_pipe<BF>, and with DIMN_MID_PIPE=0 k_mid_fused<KEEP, BF>): Z = Dd W2, gW2 = Dd^T dZ and dD = dZ W2^T take
+def test_bf16_matrix_core_training_of_the_second_layer(monkeypatch):
+    """precision="bf16" on the fused second-layer kernel (the tile pipeline k_mid_pipe<BF>): Z = Dd W2, gW2 = Dd^T dZ and dD = dZ W2^T take
     bf16 operands (rounded to nearest even in registers, fp32 accumulation, fp32 master weights and Adam state).  The oracle
     restates the rounding (train_bf16); what is left is the summation order and, rarely, an operand that rounds to the
     neighbouring bf16 value.  Stated tolerance: training / validation loss 1e-3 relative, imputed values 5e-3 relative +
     5e-4 absolute after two epochs; DIMN_TRAIN_BF16=0 keeps the fp32 matrix cores."""
     monkeypatch.setenv("DIMN_MID", "1")
-    monkeypatch.setenv("DIMN_MID_PIPE", pipe)
     monkeypatch.setenv("DIMN_RESIDENT", "0")
     prob = make_problem(n=330, g=700, Ds=[300, 150, 77], H=256, O=512, seed=11)
     kw = dict(batch_size=64, dropout_rate=0.2, learning_rate=1e-3, seed=4242)
     a = load_problem(_hip(), prob, precision="bf16", **kw)
     assert a.training_precision == "bf16"
-    assert (a.path_info()["mid_keep"] == 2) == (pipe == "1"), a.path_info()
+    assert a.path_info()["mid_keep"] == 2, a.path_info()
     b = load_problem(_oracle(), prob, precision="bf16", infer_bf16=True, train_bf16=True, **kw)
     c = load_problem(_oracle(), prob, precision="bf16", infer_bf16=True, **kw)           # fp32 training GEMMs
     for e in (a, b, c):
@@ -225,7 +223,7 @@ def test_bf16_matrix_core_training_on_the_resident_kernel(groups, monkeypatch):
     master weights and Adam state; also in two groups of sub-nets (one epoch launch each).  The oracle restates the rounding
     (train_bf16 = 2); tolerances as for the fused second layer: losses 1e-3, imputed values 5e-3 + 5e-4 after two epochs."""
     monkeypatch.setenv("DIMN_RESIDENT", "1")
-    monkeypatch.setenv("DIMN_RES_MIN_GROUPS", groups)
+    monkeypatch.setenv("DIMN_RES_TEST", "groups=" + groups)
     prob = make_problem(n=330, g=700, Ds=[300, 150, 77, 210], H=256, O=512, seed=11)
     kw = dict(batch_size=64, dropout_rate=0.2, learning_rate=1e-3, seed=4242)
     a = load_problem(_hip(), prob, precision="bf16", **kw)

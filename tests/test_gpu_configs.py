@@ -190,15 +190,12 @@ def test_cfg3_shapes_match_oracle(mid, monkeypatch):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("split,fwd6", [("1", "1"), ("0", "1"), ("1", "0")])
-def test_cfg3_shapes_hidden_300_match_oracle(split, fwd6, monkeypatch):
+def test_cfg3_shapes_hidden_300_match_oracle():
     """The CLI's default hidden width (parser.py:62-66; 300 = 19 hidden tiles, zero-padded to 20) at the shapes of the 50k x 20k
-    job, all K = 40 sub-nets, against the ORACLE: 3 full + 1 partial optimiser step, validation, predict.  split = 1 (what the
-    library picks at this size since round 5): the hidden tiles of a D-slice over two workgroups of 10 waves x 1 tile with a
-    four-set register ring (k_w1_update_fwd_ring<10, 1, 4>, grid.y = 2, 128 D-slices); 0: the 10 x 2 two-set kernel of rounds
-    2-4.  fwd6: the second layer's forward in 6 slices of six output tiles (12 waves, one round of workgroups) or 8 of four."""
-    monkeypatch.setenv("DIMN_W1_SPLIT", split)
-    monkeypatch.setenv("DIMN_MID_FWD6", fwd6)
+    job, all K = 40 sub-nets, against the ORACLE: 3 full + 1 partial optimiser step, validation, predict -- on what the library
+    picks: the hidden tiles of a D-slice over two workgroups of 10 waves x 1 tile with a four-set register ring
+    (k_w1_update_fwd_ring<10, 1, 4>, grid.y = 2, 128 D-slices), the second layer's forward in 6 slices of six output tiles (12 waves,
+    one round of workgroups).  (The 10 x 2 two-set kernel and the 8-slice forward of rounds 2-4 were retired in round 6.)"""
     cfg, norm, targets, preds = _cfg3_sample(2048)
     cfg = dict(cfg, H=300)
     K = targets.shape[0]
@@ -209,7 +206,7 @@ def test_cfg3_shapes_hidden_300_match_oracle(split, fwd6, monkeypatch):
     a = _load(_hip(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
     b = _load(_oracle(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
     info = a.path_info()
-    assert info["path"] == "streaming" and info["mid_fused"] == 0 and info["first_layer"] == (3 if split == "1" else 2), info
+    assert info["path"] == "streaming" and info["mid_fused"] == 0 and info["first_layer"] == 3, info
     _compare_with_oracle(a, b, norm, preds, targets, list(range(K)), train, val, 4, cfg, kw, rows)
     a.close(); b.close()
 
@@ -230,7 +227,7 @@ def test_cfg3_shapes_other_hidden_widths_match_oracle(H):
     a = _load(_hip(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
     b = _load(_oracle(), cfg, norm, preds, targets, list(range(K)), train, val, **kw)
     info = a.path_info()
-    assert info["path"] == "streaming" and info["mid_fused"] == 0 and info["first_layer"] == (0 if os.environ.get("DIMN_W1_SPLIT") == "0" else 3), info
+    assert info["path"] == "streaming" and info["mid_fused"] == 0 and info["first_layer"] == 3, info
     _compare_with_oracle(a, b, norm, preds, targets, list(range(K)), train, val, 4, cfg, kw, rows)
     a.close(); b.close()
 
@@ -256,14 +253,13 @@ def test_cfg3_shapes_hidden_300_bf16_arena_match_oracle():
 
 
 @pytest.mark.parametrize("split,erows", [("0", "0"), ("1", "0"), ("0", "1")])
-# split: tile order of the kernel's loop, alternating / all gradient tiles first (DIMN_RES_SPLIT); erows: the epoch's rows copied into
-# visiting order before the launch (DIMN_RES_EPOCH_ROWS; what the library does for large arenas)
+# split: tile order of the kernel's loop, alternating / all gradient tiles first; erows: the epoch's rows copied into visiting order before the
+# launch (what the library does for large arenas) -- both through DIMN_RES_TEST="split=..,erows=.."
 def test_cfg4_8gpu_share_resident_matches_oracle(split, erows, monkeypatch):
     """BASELINE configs[3], one rank's share of the 8-GPU job (sub-nets 10-14 of the 40, global Philox keys) on the path the
     library picks for it -- the register-resident epoch kernel -- against the ORACLE (not against the streaming kernels): 5 full
     + 1 partial optimiser step, validation, predict; two epochs' worth of hand-off slots (t % 3, t % 2) are cycled."""
-    monkeypatch.setenv("DIMN_RES_SPLIT", split)
-    monkeypatch.setenv("DIMN_RES_EPOCH_ROWS", erows)
+    monkeypatch.setenv("DIMN_RES_TEST", "split=%s,erows=%s" % (split, erows))
     cfg, norm, targets, preds = _cfg3_sample(2048)
     ks = list(range(10, 15))
     train = (np.arange(0, 5 * 64 + 33, dtype=np.int32) * 5) % 1800
@@ -285,8 +281,7 @@ def test_cfg5_share_shapes_match_oracle(split, erows, monkeypatch):
     (three ~128 MB row blocks), on the path the library picks; 3 full + 1 partial step, validation, predict against the oracle
     in the matching rounding modes at the tolerances DESIGN section 3b states for them."""
     import bench
-    monkeypatch.setenv("DIMN_RES_SPLIT", split)
-    monkeypatch.setenv("DIMN_RES_EPOCH_ROWS", erows)
+    monkeypatch.setenv("DIMN_RES_TEST", "split=%s,erows=%s" % (split, erows))
     cfg = dict(bench.CONFIGS["cfg5"])
     n = 3072
     norm = bench.synth_counts(n, cfg["g"], seed=0)                       # 369 MB -> 3 streamed blocks
@@ -429,12 +424,12 @@ def test_resident_groups_are_independent_launches(monkeypatch):
 
 
 def test_resident_launch_that_aborts_is_undone_and_rerun_on_the_streaming_kernels(monkeypatch, capfd):
-    """A resident epoch launch that times out (a GPU shared with another process: DIMN_RES_TEST_ABORT makes the host treat
+    """A resident epoch launch that times out (a GPU shared with another process: DIMN_RES_TEST="abort=2" makes the host treat
     the launch of epoch 1 as timed out) must not fail the fit: the pre-epoch state is restored, the epoch re-runs on the
     streaming kernels and the handle stays on them -- all three epochs still match the oracle."""
     from helpers import make_problem, load_problem
     monkeypatch.setenv("DIMN_RESIDENT", "1")
-    monkeypatch.setenv("DIMN_RES_TEST_ABORT", "2")
+    monkeypatch.setenv("DIMN_RES_TEST", "abort=2")
     prob = make_problem(n=500, g=900, Ds=[300, 280], H=256, O=512, seed=5, val_frac=0.1)
     kw = dict(batch_size=64, dropout_rate=0.2, learning_rate=1e-3, seed=99)
     a, b = load_problem(_hip(), prob, **kw), load_problem(_oracle(), prob, **kw)

@@ -91,7 +91,7 @@ def test_ring_first_layer_at_ragged_widths_matches_oracle(H, O, B, p):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("mid", ["1", "0", "1:6", "1:4", "1:10", "1:16", "1:32", "1F", "1F:6", "1F:4", "1F:10", "R", "R:1", "R:2", "RG"])     # fused (the tile pipeline k_mid_pipe; auto slices), two-kernel, fused with 6 / 4 / 10 / 16 / 32 slices (8 .. 1 tiles per workgroup); 1F: the three-phase fused kernel k_mid_fused (DIMN_MID_PIPE=0); R: register-resident epoch kernel (auto / 1 / 2 D-splits; RG: sub-nets in groups of two, one launch each)
+@pytest.mark.parametrize("mid", ["1", "0", "1:6", "1:4", "1:10", "1:16", "1:32", "R", "R:1", "R:2", "RG"])     # fused (the tile pipeline k_mid_pipe; auto slices), two-kernel, fused with 6 / 4 / 10 / 16 / 32 slices (8 .. 1 tiles per workgroup: DIMN_MID="1:S"); R: register-resident epoch kernel (auto / 1 / 2 D-splits; RG: sub-nets in groups of two, one launch each: DIMN_RES_TEST)
 @pytest.mark.parametrize("O,B,Ds,p", [
     (512, 64, [300, 150, 77], 0.2),     # the default architecture: H = 256, O = 512
     (500, 37, [97, 260], 0.3),          # ragged output width and partial batches
@@ -99,20 +99,16 @@ def test_ring_first_layer_at_ragged_widths_matches_oracle(H, O, B, p):
 ])
 def test_h256_both_second_layer_paths_match_oracle(O, B, Ds, p, mid, monkeypatch):
     """H = 256 takes the ring B1F1 kernel and, by default only when the GPU is well filled, the fused
-    second-layer kernel (k_mid_fused + k_reduce_dd); DIMN_MID forces either path (read at dimn_create)."""
+    second-layer kernel (k_mid_pipe + k_reduce_dd); DIMN_MID forces either path (read at dimn_create)."""
     if mid[0] == "R":                    # whole epochs in one persistent launch, state in registers (dimn_resident.h)
         monkeypatch.setenv("DIMN_RESIDENT", "1")
         if ":" in mid:
-            monkeypatch.setenv("DIMN_RES_S1", mid.split(":")[1])
+            monkeypatch.setenv("DIMN_RES_TEST", "s1=" + mid.split(":")[1])
         if mid == "RG":
-            monkeypatch.setenv("DIMN_RES_MIN_GROUPS", "2")
+            monkeypatch.setenv("DIMN_RES_TEST", "groups=2")
     else:
         monkeypatch.setenv("DIMN_RESIDENT", "0")
-        monkeypatch.setenv("DIMN_MID", mid.split(":")[0].rstrip("F"))
-        if "F" in mid:
-            monkeypatch.setenv("DIMN_MID_PIPE", "0")
-        if ":" in mid:                   # tiles per workgroup: 5-6 (units shared over SIMDs), 8, 3-4
-            monkeypatch.setenv("DIMN_MID_SLICES", mid.split(":")[1])
+        monkeypatch.setenv("DIMN_MID", mid)          # "1:S": S slices per sub-net -- 5-6 tiles per workgroup (units shared over SIMDs), 8, 3-4, ...
     prob = make_problem(n=330, g=700, Ds=Ds, H=256, O=O, seed=17)
     kw = dict(batch_size=B, dropout_rate=p, learning_rate=1e-3, seed=99)
     a = load_problem(_hip(), prob, **kw)
@@ -140,35 +136,6 @@ def test_h256_both_second_layer_paths_match_oracle(O, B, Ds, p, mid, monkeypatch
     rows = prob["train"][:B]
     mask = (np.random.default_rng(1).random((a.K, len(rows), 256)) > p).astype(np.uint8)
     np.testing.assert_allclose(a.train_step(rows, keep_mask=mask), b.train_step(rows, keep_mask=mask), rtol=1e-4)
-
-
-@pytest.mark.parametrize("O,B,slices", [(512, 64, "6"), (500, 37, "4"), (96, 64, "6")])
-def test_tile_pipeline_and_three_phase_kernel_agree(O, B, slices, monkeypatch):
-    """The two forms of the fused second layer -- the tile pipeline k_mid_pipe (what runs) and the three-phase k_mid_fused
-    (DIMN_MID_PIPE=0; the A/B form, fp32 and bf16 operands alike) -- are the same arithmetic in different summation orders: after two epochs from the same
-    seeds their weights and Adam moments agree far inside the tolerance either has against the oracle, and path_info says which ran."""
-    monkeypatch.setenv("DIMN_RESIDENT", "0")
-    monkeypatch.setenv("DIMN_MID", "1")
-    monkeypatch.setenv("DIMN_MID_SLICES", slices)
-    prob = make_problem(n=330, g=700, Ds=[300, 150, 77], H=256, O=O, seed=29)
-    kw = dict(batch_size=B, dropout_rate=0.2, learning_rate=1e-3, seed=5)
-    runs = []
-    for pipe in ("1", "0"):
-        monkeypatch.setenv("DIMN_MID_PIPE", pipe)
-        e = load_problem(_hip(), prob, **kw)
-        assert (e.path_info()["mid_keep"] == 2) == (pipe == "1"), e.path_info()      # 2: the pipeline; 1 / 0: k_mid_fused with / without W2 kept in LDS
-        e.init_weights()
-        losses = [e.train_epoch(epoch) for epoch in range(2)]
-        runs.append((losses, [e.get_weights(k) for k in range(e.K)], [e.get_adam_state(k, 0) for k in range(e.K)], e.predict()))
-        e.close()
-    (la, wa, ma, pa), (lb, wb, mb, pb) = runs
-    np.testing.assert_allclose(la, lb, rtol=2e-6)
-    for k in range(len(wa)):
-        for x, y, name in zip(wa[k], wb[k], ("W1", "b1", "W2", "b2")):
-            np.testing.assert_allclose(x, y, rtol=1e-4, atol=2e-6, err_msg="%s k=%d" % (name, k))
-        for x, y, name in zip(ma[k], mb[k], ("W1", "b1", "W2", "b2")):
-            np.testing.assert_allclose(x, y, rtol=1e-3, atol=1e-8, err_msg="adam m %s k=%d" % (name, k))
-    np.testing.assert_allclose(pa, pb, rtol=2e-5, atol=1e-6)
 
 
 def test_more_second_layer_workgroups_than_compute_units(monkeypatch):

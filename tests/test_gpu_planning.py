@@ -122,8 +122,7 @@ def test_streamed_correlation_matches_resident(monkeypatch):
     x = rng.poisson(rng.gamma(0.8, 3.0, size=700), size=(1111, 700)).astype(np.float64)
     x[:, 17] = 3.0                                                     # a constant gene: NaN -> 0
     resident = _abs_corrcoef(x, backend="hip")
-    monkeypatch.setenv("DIMN_CORR_BUDGET_GB", "0")                     # force the streamed form ...
-    monkeypatch.setenv("DIMN_CORR_BLOCK_ROWS", "208")                  # ... in six row blocks, the last one partial
+    monkeypatch.setenv("DIMN_CORR_BUDGET_GB", "0:208")                 # force the streamed form, in six row blocks of 208, the last one partial
     streamed = _abs_corrcoef(x, backend="hip")
     with np.errstate(invalid="ignore", divide="ignore"):
         ref = np.nan_to_num(np.abs(np.corrcoef(x.T)), nan=0.0)
