@@ -13,8 +13,9 @@ hand-overs reading eight different copies.  Here the ranks of a node share them 
     MultiNet.fit() calls it for a sharded job whose frame came from `share_frame` (or when DIMN_SHARE_NORM=1), so the
     streamed hand-over of every rank (dimn_set_matrix_streamed, rotated by dimn_set_stream_order) reads the same pages.
 
-Host memory of the 8-rank configs[4] job: 240 + 120 GB once instead of eight times.  The collectives needed are the ones
-sharded.Comm has: barrier() and allreduce_sum()."""
+Host memory of the 8-rank configs[4] job: 240 + 120 GB once instead of eight times.  The only collective needed is barrier():
+sharded's Comm objects have it, and `NodeComm` provides it before an engine exists (the product's RCCL communicator is bound to the
+engine inside fit())."""
 import mmap
 import os
 import pickle
@@ -33,6 +34,39 @@ def _segment_name(tag):
 
 def _shm_dir():
     return os.environ.get("DIMN_SHM_DIR", "/dev/shm")
+
+
+class NodeComm:
+    """rank / world / barrier() for the ranks of ONE node before any engine (hence any RCCL communicator) exists -- what share_frame needs
+    when the job's communicator is the product's (`MultiNet(comm="rccl")` binds RCCL to the engine inside fit()).  Rank and world size
+    come from the launcher's environment (RANK / WORLD_SIZE: torchrun); a barrier is one file per rank in a 0700 directory named after
+    the job.  Not a data path."""
+
+    def __init__(self, rank=None, world=None, timeout=600.0):
+        import time
+        from .sharded import _job_tag
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        self._dir = os.path.join("/tmp", "dimn_node_%d_%s" % (os.getuid(), _job_tag()))
+        os.makedirs(self._dir, mode=0o700, exist_ok=True)
+        self._n, self._timeout, self._time = 0, timeout, time
+
+    def barrier(self):
+        self._n += 1
+        open(os.path.join(self._dir, "b%d_%d" % (self._n, self.rank)), "w").close()
+        t0 = self._time.time()
+        for r in range(self.world):
+            q = os.path.join(self._dir, "b%d_%d" % (self._n, r))
+            while not os.path.exists(q):
+                if self._time.time() - t0 > self._timeout:
+                    raise TimeoutError("NodeComm.barrier: rank %d never arrived" % r)
+                self._time.sleep(0.001)
+
+    def close(self):
+        self.barrier()
+        if self.rank == 0:
+            import shutil
+            shutil.rmtree(self._dir, ignore_errors=True)
 
 
 class SharedArray:

@@ -29,7 +29,10 @@ def main(out_path):
         mu = rng.lognormal(0.5, 1.2, size=g)
         raw = pd.DataFrame(rng.poisson(rng.gamma(2.0, mu / 2.0, size=(n, g))).astype(np.float64),
                            index=["c%d" % i for i in range(n)], columns=["g%d" % j for j in range(g)])
-    shared = _shm.share_frame(raw, comm)
+    node = _shm.NodeComm()                                                   # (what a product job uses before its engine exists: RANK / WORLD_SIZE + file barrier)
+    assert (node.rank, node.world) == (comm.rank, comm.world)
+    shared = _shm.share_frame(raw, node)
+    node.close()
     seg = _shm.shared_of(shared.values)
     assert seg is not None and not os.path.exists(seg.path)                  # the name is gone as soon as every rank has mapped it
     if comm.rank == 0:

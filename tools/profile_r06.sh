@@ -1,8 +1,8 @@
 #!/bin/bash
-# End-of-round evidence of round 5 (one box): the driver's bench command, the same workload under rocprofv3 --kernel-trace --stats, one rank of
+# End-of-round evidence of round 6 (one box): the driver's bench command, the same workload under rocprofv3 --kernel-trace --stats, one rank of
 # the 8-GPU job (resident kernel), PMC passes (separate: traffic, MFMA), the shape families, configs[1], precision bf16.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-O=gpurun_out/r05p; mkdir -p $O
+O=gpurun_out/r06p; mkdir -p $O
 export TMPDIR=/tmp
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 B="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dropin --no-accuracy"
