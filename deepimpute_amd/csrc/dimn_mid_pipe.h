@@ -24,15 +24,6 @@
 #define DIMN_MIDP_LDW 36                                  // row stride of a wave's Dd slab [64 b][32 h]: 16-byte aligned rows, 4 mod 32 words
 #define DIMN_MIDP_LDS_FLOATS (8 * 64 * DIMN_MIDP_LDW + 2 * 8192 + 2 * 1024 + 9 * 128 + 8)     // 152 096 bytes
 
-#ifndef DIMN_MIDP_ABL
-#define DIMN_MIDP_ABL 0   // tools/k_probe_mid.hip ablations (wrong results): 1 no state stores, 2 no backward MFMAs, 4 no forward MFMAs, 8 no softplus arithmetic, 16 no Adam
-#endif
-#ifdef DIMN_MIDP_TL   // tools/k_probe_mid.hip: per-wave stamps
-__device__ unsigned long long g_midp_tl[512 * 8 * 12];
-#define MIDP_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_midp_tl[(blockIdx.x * 8 + wave) * 12 + (i)] = t_; }
-#else
-#define MIDP_STAMP(i)
-#endif
 
 // BF (handles of precision bf16): the three GEMMs take bf16 operands -- Dd, W2, dZ rounded to nearest even in registers, one v_mfma_f32_16x16x16_bf16 where
 // four fp32 MFMAs were (the k-slot register groups ARE its operands), fp32 accumulation, fp32 master weights and Adam state; as k_mid_fused<KEEP, BF>, which
@@ -62,7 +53,6 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lj = lane >> 4;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    MIDP_STAMP(0)
 
     // ---- requests, in the order they are needed: the wave's Dd slab and the first tile's w, then everything else ----
     const float* ddk = Dd + (int64_t)k * DIMN_TB * Hp + 32 * wave;
@@ -119,7 +109,6 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
     const int64_t b2i = (int64_t)k * Op + 16 * (ot0 + (b2_owner ? tid >> 4 : 0)) + (tid & 15);
     float b2w0 = 0.f, b2m0 = 0.f, b2v0 = 0.f;
     if (b2_owner) { b2w0 = b2w[b2i]; b2m0 = b2m[b2i]; b2v0 = b2v[b2i]; }
-    MIDP_STAMP(1)
     float ddf[16][2];    // B operand of gW2^T, kept for every tile: Dd[b = 4kb+lj][h = 16(2w+ht)+li]   (the slab is private to the wave: no barrier)
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb)
@@ -160,7 +149,7 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) { if (DIMN_MIDP_ABL & 4) acc[mt][r] += a4[mt][r] * bq[ht][r]; else acc[mt] = MFMA16(a4[mt][r], bq[ht][r], acc[mt]); }
+                    for (int mt = 0; mt < 4; ++mt) acc[mt] = MFMA16(a4[mt][r], bq[ht][r], acc[mt]);
             }
         }
 #pragma unroll
@@ -188,7 +177,6 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
             const float y = e ? g.y1 : g.y0;
             const float w = loss_binary ? (y > 0.f ? 1.f : 0.f) : y;       // multinet.py:37-40
             float sp, sg;
-            if (DIMN_MIDP_ABL & 8) { sp = z; sg = 1.f; } else
             softplus_sigmoid_fast(z, sp, sg);
             const float er = y - sp;
             const float le = w * er * er, de = -2.f * w * er * inv_n * sg;
@@ -218,7 +206,7 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
             for (int kb = 0; kb < 16; ++kb) {
                 const float az = zb[64 * kb + lane];                         // dZ^T[o = li][b = 4kb+lj]
 #pragma unroll
-                for (int ht = 0; ht < 2; ++ht) { if (DIMN_MIDP_ABL & 2) g[ht][kb & 3] += az * ddf[kb][ht]; else g[ht] = MFMA16(az, ddf[kb][ht], g[ht]); }
+                for (int ht = 0; ht < 2; ++ht) g[ht] = MFMA16(az, ddf[kb][ht], g[ht]);
             }
         }
         f32x4 zf[4];
@@ -234,19 +222,17 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int m4 = 0; m4 < 4; ++m4) { if (DIMN_MIDP_ABL & 2) dacc[m4][ht][r] += zf[m4][r] * cur.w[ht][r]; else dacc[m4][ht] = MFMA16(zf[m4][r], cur.w[ht][r], dacc[m4][ht]); }   // OLD W2
+                    for (int m4 = 0; m4 < 4; ++m4) dacc[m4][ht] = MFMA16(zf[m4][r], cur.w[ht][r], dacc[m4][ht]);   // OLD W2
             }
-            if (DIMN_MIDP_ABL & 16) { cur.w[ht] += g[ht]; } else
             adam4(cur.w[ht], cur.m[ht], cur.v[ht], g[ht], ap);
             const size_t tb = (size_t)(ot0 + t) * 1024;
-            if (!(DIMN_MIDP_ABL & 1) || cur.w[ht][0] == 123.456f) { DIMN_ST_STATE(const_cast<char*>(w2k) + tb + voff[ht], cur.w[ht]); DIMN_ST_STATE(const_cast<char*>(m2k) + tb + voff[ht], cur.m[ht]); DIMN_ST_STATE(const_cast<char*>(v2k) + tb + voff[ht], cur.v[ht]); }
+            { DIMN_ST_STATE(const_cast<char*>(w2k) + tb + voff[ht], cur.w[ht]); DIMN_ST_STATE(const_cast<char*>(m2k) + tb + voff[ht], cur.m[ht]); DIMN_ST_STATE(const_cast<char*>(v2k) + tb + voff[ht], cur.v[ht]); }
         }
     };
 
     forward(sA, 0);
     __syncthreads();
     softplus(gE, 0, true);
-    MIDP_STAMP(2)
     // Straight-line code, one block per tile, left at the slice's last tile (CUR / NXT / FRE: the sets of tiles I, I+1, I+2;
     // GN / GF: the targets of tiles I+1, I+2).  No path joins another with a different number of requests in flight, so every wait is
     // an exact vmcnt and none of them covers the stores of the tile before.
@@ -260,7 +246,6 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
         __syncthreads();                                                                \
         softplus(GN, (I) + 1, more);                                                    \
         backward(CUR, (I));                                                             \
-        MIDP_STAMP(5 + (I) % 7)                                                         \
         if (!more) break;                                                               \
     }
     do {
@@ -274,7 +259,6 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
         DIMN_MIDP_BLOCK(7, sB, sC, sA, gE, gO)
     } while (0);
 #undef DIMN_MIDP_BLOCK
-    MIDP_STAMP(3)
 
     float* p2 = P2 + (int64_t)mw.slot * DIMN_TB * Hp;
 #pragma unroll
@@ -302,5 +286,4 @@ __global__ __launch_bounds__(512) void k_mid_pipe(const MidWork* __restrict__ mw
         loss_step[k * dm.LS + mw.sidx] = tot;
         if (loss_acc) loss_acc[k * dm.LS + mw.sidx] += (double)tot;
     }
-    MIDP_STAMP(4)
 }
