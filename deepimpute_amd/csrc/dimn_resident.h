@@ -691,6 +691,10 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             }
             RES_STAMP(4)
             RES_MARK(7)
+            // the wave that will poll for the dA tile requests ITS rows now (they are back under the W2 gradient): vector-memory results return in
+            // order, and its poll was seen ~0.7 us after the tile had landed while it queued behind them (22.24 -> 21.83 us per step; all eight
+            // waves requesting here lose 0.7: the dD stores and the W2 gradient queue behind 64 KB of rows)
+            if (wave == 0 && !is_m) prefetch_x();
             {   // W2 gradient + Adam on the LDS-resident state
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -720,7 +724,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
         // =============================== the dA tile: M2 (manager) or the hand-off from it (siblings) ===============================
         {
             RES_STAMP(5)
-            prefetch_x();
+            if (!(is_o && !is_m && wave == 0)) prefetch_x();
             if (is_m) {
                 if (wave == 0) { const bool ok = res_poll(rD, dcur + (uint32_t)(ht * 4096), OT, 65536u, abort_w); if (lane == 0) flagl[1] = ok ? 1 : 0; }
                 __syncthreads();
@@ -789,11 +793,12 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                     // dA(t) exists, so the manager has summed P(t): this workgroup's P slot of step t is free -- marked "not
                     // written" for P(t+2); acknowledged before P(t+1) leaves (the drain at the end of the tile loop)
                     res_st(rP, pcur + (uint32_t)(wi * 4096 + 16 * tid), sent4);
-                    col4(da);
+                    // (no column sums here: a sibling keeps no b1 -- only the manager's M1 reads it, and the manager saves it)
                 }
             }
             __syncthreads();
-            if (tid < 16) {                                      // gb1 = column sums of dA -> Adam(b1); identical on the S1 siblings
+            if (is_m && tid < 16) {                              // gb1 = column sums of dA -> Adam(b1): the manager's copy is the one M1 reads and the epilogue saves
+                                                                 // (rounds 3-5: every sibling too, on the wave that the tile loop then waited for: 21.89 -> 21.56 us per step without)
                 const float gb = (csum[tid] + csum[16 + tid]) + (csum[32 + tid] + csum[48 + tid]);
                 adam1(b1w0, b1m0, b1v0, gb, ap);
                 b1l[tid] = b1w0;
@@ -820,7 +825,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             const int64_t idx = wbase + tc[j] * cstride;
             *(f32x4*)(p.W1 + idx) = w1[j]; *(f32x4*)(p.M1 + idx) = m1[j]; *(f32x4*)(p.V1 + idx) = v1[j];
         }
-    if (sp == 0 && tid < 16) { p.b1w[b1i] = b1w0; p.b1m[b1i] = b1m0; p.b1v[b1i] = b1v0; }
+    if (is_m && tid < 16) { p.b1w[b1i] = b1w0; p.b1m[b1i] = b1m0; p.b1v[b1i] = b1v0; }
     if (is_o) {
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
