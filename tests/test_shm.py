@@ -59,3 +59,27 @@ def test_two_ranks_share_one_copy_of_the_frame_and_of_the_log1p_matrix(tmp_path)
     assert int(got["epochs"]) == net.trained_epochs
     assert np.array_equal(got["val"], np.array(net.history["val_loss"]))
     assert np.array_equal(got["imputed"], ref.values)
+
+
+def test_bench_maps_one_synthetic_matrix_for_the_ranks_of_a_streamed_job(tmp_path):
+    """bench.py --gpus N --stream (configs[4]): rank 0 generates the matrix into /dev/shm, every rank maps it -- the same function of
+    (n, g, seed) as a private matrix, one inode."""
+    code = (
+        "import os, sys, json, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "r = int(os.environ['RANK'])\n"
+        "rd = bench.FileRendezvous(r, 2)\n"
+        "norm, seg = bench.shared_matrix(rd, 1300, 700, seed=0)\n"
+        "ok = bool(np.array_equal(norm, bench.synth_counts(1300, 700, seed=0)))\n"
+        "json.dump({'ok': ok, 'id': list(seg.identity), 'writable': bool(norm.flags.writeable)}, open(%r + str(r), 'w'))\n"
+        "bench.file_vote(rd, 'bye', 0.0); rd.cleanup()\n"
+    ) % (os.path.dirname(HERE), str(tmp_path / "out"))
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-2000:]
+    a, b = (json.load(open(str(tmp_path / "out") + str(r))) for r in range(2))
+    assert a["ok"] and b["ok"] and a["id"] == b["id"] and not b["writable"]
