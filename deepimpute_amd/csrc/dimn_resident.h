@@ -520,14 +520,14 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             constexpr int NS = S1C > 0 ? S1C - 1 : 7;            // siblings (run-time S1: up to 7, clamped requests)
             f32x4 a = *(const f32x4*)(yl + 4 * tid);
             if (S1 > 1) {
-                (void)res_poll(rP, pcur + (uint32_t)(ht * 4096), S1 - 1, 65536u, abort_w);      // (abort: the next workgroup-wide wait leaves)
+                const bool okp = res_poll(rP, pcur + (uint32_t)(ht * 4096), S1 - 1, 65536u, abort_w);      // (abort: no piece is waited for below; the next workgroup-wide wait leaves)
                 RES_MARK(1)
                 f32x4 pv[NS > 0 ? NS : 1];
 #pragma unroll
                 for (int ss = 0; ss < NS; ++ss) pv[ss] = res_ld(rP, pcur + (uint32_t)(((ss < S1 - 1 ? ss : 0) * 16 + ht) * 4096 + 16 * tid));
 #pragma unroll
                 for (int ss = 0; ss < NS; ++ss) {
-                    res_fix(pv[ss], rP, pcur + (uint32_t)(((ss < S1 - 1 ? ss : 0) * 16 + ht) * 4096 + 16 * tid), abort_w);
+                    if (okp) res_fix(pv[ss], rP, pcur + (uint32_t)(((ss < S1 - 1 ? ss : 0) * 16 + ht) * 4096 + 16 * tid), abort_w);
                     if (ss < S1 - 1) a += pv[ss];
                 }
             }
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
             // the first matrix instruction (rounds 3-5: one wave polled all sixteen managers, barrier, 64 KB -> LDS, barrier).  The tiles go
             // to LDS afterwards, for the W2 gradient of the same wave (wave-private columns: no barrier either).
             const uint32_t tb = tcur + (uint32_t)(2 * wave * 4096);
-            (void)res_poll(rT, tb, 2, 4096u, abort_w);              // (abort: the next workgroup-wide wait leaves)
+            const bool okd = res_poll(rT, tb, 2, 4096u, abort_w);   // (abort: no piece is waited for below -- an abandoned launch must not spin on pieces that never come; the next workgroup-wide wait leaves)
             RES_MARK(3)
             f32x4 a4[2][4];
 #pragma unroll
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                     for (int r = 0; r < 4; ++r) bq[r] = ws[h2 * 256 + (4 * lj + r) * 16 + li];   // W2[h = 4lj+r][o = li]
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
-                        res_fix(a4[h2][m], rT, tb + (uint32_t)(h2 * 4096 + 16 * (64 * m + 4 * li + lj)), abort_w);
+                        if (okd) res_fix(a4[h2][m], rT, tb + (uint32_t)(h2 * 4096 + 16 * (64 * m + 4 * li + lj)), abort_w);
                         acc[m] = res_mfma4<BF>(a4[h2][m], bq, acc[m]);
                     }
                 }
