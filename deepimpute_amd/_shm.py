@@ -153,10 +153,12 @@ def shared_of(values):
 
 
 def release(values):
-    """Forget (and, once the last numpy view of it is gone, unmap) the segment behind `values`."""
+    """Forget the segment behind `values`; it is unmapped once the last numpy view of it is gone (tmpfs pages live until EVERY rank has
+    unmapped them: a long-lived process should release what it no longer reads -- fit() / predict() do so for the log1p matrix)."""
     shared = shared_of(values)
     if shared is not None:
         _BY_ADDRESS.pop(shared.array.__array_interface__["data"][0], None)
+        shared.array = None
 
 
 def share_frame(raw, comm, dtype=None):
@@ -171,6 +173,8 @@ def share_frame(raw, comm, dtype=None):
     meta_path = os.path.join(_shm_dir(), _segment_name("labels"))
     if rank == 0:
         values = raw.values
+        if values.dtype.kind not in "fiu" or values.ndim != 2:
+            raise TypeError("share_frame: a numeric [cells, genes] frame is expected (got dtype %s)" % values.dtype)
         meta = {"shape": values.shape, "dtype": np.dtype(dtype or values.dtype).str, "index": raw.index, "columns": raw.columns}
         fd = os.open(meta_path, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
         with os.fdopen(fd, "wb") as f:

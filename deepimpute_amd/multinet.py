@@ -735,6 +735,8 @@ class MultiNet:
             with tm.stage("fit.save.join"):
                 self._finish_deferred_save()             # the files are on disk (or the write's error is raised) before fit() returns
         with tm.stage("fit.free"):
+            if share_norm and hasattr(norm_data, "values"):
+                _shm.release(norm_data.values)               # (the node's shared log1p segment: unmapped here, freed when the last rank has done so)
             del norm_data, var, mean, gene_metric
         return self
 
@@ -1014,6 +1016,8 @@ class MultiNet:
             with tm.stage("predict.hand_over"):
                 self._hand_over(engine, norm, False)
             with tm.stage("predict.free"):
+                from . import _shm as _shm_mod
+                _shm_mod.release(norm)                                             # (a shared segment: forget it; a private array: no-op)
                 del norm                                                           # (4 GB at 50k x 20k: unmapping it is not free)
         t_plan = tm.stage("predict.plan")
         t_plan.__enter__()

@@ -50,16 +50,20 @@ def main(out_path):
 
     def spy(frame, c):                                                        # fit() and predict() must take the shared log1p matrix, not a private one
         out = real(frame, c)
-        captured.setdefault("norm", []).append(_shm.shared_of(out))
+        seg_n = _shm.shared_of(out)
+        assert seg_n is not None
+        _ = float(out.sum())                                                  # touch every page
+        captured.setdefault("norm", []).append({"identity": list(seg_n.identity), "smaps": seg_n.smaps(),
+                                                "equal": bool(np.array_equal(out, np.log1p(frame.values).astype(np.float32))), "seg": seg_n})
         return out
     _shm.shared_log1p = spy
     net.fit(shared, NN_lim=192)
     imputed = net.predict(shared)
     assert len(captured["norm"]) == 2
-    norm_seg = captured["norm"][0]
-    report["norm_identity"] = list(norm_seg.identity)
-    report["norm_smaps"] = norm_seg.smaps()
-    report["norm_equal"] = bool(np.array_equal(norm_seg.array, np.log1p(shared.values).astype(np.float32)))
+    assert all(c["seg"].array is None for c in captured["norm"])             # fit() / predict() released their segment (tmpfs pages live until every rank unmaps)
+    report["norm_identity"] = captured["norm"][0]["identity"]
+    report["norm_smaps"] = captured["norm"][0]["smaps"]
+    report["norm_equal"] = captured["norm"][0]["equal"] and captured["norm"][1]["equal"]
     if comm.rank == 0:
         np.savez(out_path, imputed=imputed.values, epochs=net.trained_epochs, val=np.array(net.history["val_loss"]))
     else:
