@@ -50,6 +50,15 @@ class NodeComm:
         self._dir = os.path.join("/tmp", "dimn_node_%d_%s" % (os.getuid(), _job_tag()))
         os.makedirs(self._dir, mode=0o700, exist_ok=True)
         self._n, self._timeout, self._time = 0, timeout, time
+        self._closed = False
+        if self.rank == 0:                                       # (a job that never calls close(): the directory still goes when rank 0 exits)
+            import atexit
+            atexit.register(self._sweep)
+
+    def _sweep(self):
+        if not self._closed:
+            import shutil
+            shutil.rmtree(self._dir, ignore_errors=True)
 
     def barrier(self):
         self._n += 1
@@ -65,8 +74,8 @@ class NodeComm:
     def close(self):
         self.barrier()
         if self.rank == 0:
-            import shutil
-            shutil.rmtree(self._dir, ignore_errors=True)
+            self._sweep()
+        self._closed = True
 
 
 class SharedArray:
