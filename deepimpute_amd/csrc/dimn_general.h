@@ -3,7 +3,7 @@
 // :150-162: other losses; parser.py:50-66: any batch size, any hidden width).  Same arithmetic definitions (Keras-form
 // Adam, Philox dropout streams, softplus output, wMSE), plain structure: per layer one batched fp32-MFMA GEMM over the
 // sub-nets (64 x 64 output tile per workgroup, operands staged through LDS, transposes resolved while staging) with the
-// layer's epilogue fused, an element-wise loss kernel, and Keras-Adam fused behind the weight-gradient GEMM and the bias column sums.  Correct and
+// layer's epilogue fused, an element-wise loss kernel, and Keras-Adam fused behind the weight-gradient GEMM (bias gradient included).  Correct and
 // reasonably fast, not roofline-tuned: the default architecture (one hidden layer <= 384, batch <= 64) never comes here.
 #pragma once
 #include "dimn_kernels.h"
@@ -30,30 +30,41 @@ struct GEpi {
     AdamP ap;                              // mode 4
     const float* xbase; const SubnetDev* sn;   // agather descriptors: the X arena and the sub-nets' blocks in it (xoff, Dp), descriptor i <-> sub-net i
     const int32_t* arows; int64_t arow0;       //   batch row b = arows[b] (device row list) or arow0 + b
+    const float* Y; int64_t n_cells; int32_t Op, loss; float inv_n; double* loss_sum;   // k_gen_rowgemm EPI 4: the output layer's loss and dZ fused behind its forward (as k_gen_output, train)
     int32_t ksplit;                        // > 1: split-K -- grid.z = descriptors x ksplit, every workgroup multiplies one k-range and stores its raw
     float* part; int64_t part_stride;      //   partial tile into part[(desc * ksplit + s) * part_stride + row * N + col]; k_gen_splitk_fin applies `mode`
 };
+
+// Operand pointers come out of a descriptor in memory, so the compiler cannot tell they are global: it emits flat_load, whose results may
+// come back out of order with LDS traffic -- every wait becomes vmcnt(0) lgkmcnt(0) and nothing stays in flight across the matrix
+// instructions.  These say "global".
+typedef __attribute__((address_space(1))) const f32x4* gen_gp4;
+typedef __attribute__((address_space(1))) const float* gen_gp1;
+__device__ __forceinline__ f32x4 gen_gld4(const float* p) { return *(gen_gp4)p; }
+__device__ __forceinline__ float gen_gld1(const float* p) { return *(gen_gp1)p; }
+__device__ __forceinline__ void gen_gst4(float* p, f32x4 v) { *(__attribute__((address_space(1))) f32x4*)p = v; }
+__device__ __forceinline__ void gen_gst1(float* p, float v) { *(__attribute__((address_space(1))) float*)p = v; }
 
 // the per-element epilogue of modes 0 .. 3 (k_gen_gemm without split-K, k_gen_splitk_fin with it)
 __device__ __forceinline__ void gen_epilogue(const GEpi& ep, const GDesc& d, int row, int col, float v) {
     const int64_t o = (int64_t)row * d.ldc + col;
     if (ep.mode == 1) {
-        v += d.bias[col];
+        v += gen_gld1(d.bias + col);
         float f, df;
         hidden_act(ep.act, v, f, df);
         if (ep.train) {
             const bool keep = !(ep.rate > 0.f) || dimn_dropout_keep(ep.seed, (uint32_t)d.kg, ep.epoch, ep.step, (uint32_t)(row * d.N + col), ep.rate);
-            d.C[o] = keep ? f * ep.scale : 0.f;
-            d.G[o] = keep ? df * ep.scale : 0.f;
+            gen_gst1(d.C + o, keep ? f * ep.scale : 0.f);
+            gen_gst1(d.G + o, keep ? df * ep.scale : 0.f);
         } else {
-            d.C[o] = f;
+            gen_gst1(d.C + o, f);
         }
     } else if (ep.mode == 2) {
-        d.C[o] = v + d.bias[col];
+        gen_gst1(d.C + o, v + gen_gld1(d.bias + col));
     } else if (ep.mode == 3) {
-        d.C[o] = v * d.G[o];
+        gen_gst1(d.C + o, v * gen_gld1(d.G + o));
     } else {
-        d.C[o] = v;
+        gen_gst1(d.C + o, v);
     }
 }
 
@@ -120,9 +131,9 @@ __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ desc
         if (gmaj < lim_maj) {
             const int64_t r = rows ? (ep.arows ? (int64_t)ep.arows[gmaj] : ep.arow0 + gmaj) : (int64_t)gmaj;    // (the major index of A is the batch row in both forms)
             const float* p = base + r * ld + gmin;
-            if (vec && gmin + 3 < lim_min) v = *(const f32x4*)p;
+            if (vec && gmin + 3 < lim_min) v = gen_gld4(p);
             else
-                for (int r = 0; r < 4; ++r) if (gmin + r < lim_min) v[r] = p[r];
+                for (int r = 0; r < 4; ++r) if (gmin + r < lim_min) v[r] = gen_gld1(p + r);
         }
         return v;
     };
@@ -145,6 +156,8 @@ __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ desc
     };
     f32x4 ra[NA], rb[NB];
     load_a(kbeg, ra); load_b(kbeg, rb);
+    const bool colsum = TA && ep.mode == 4 && d.bias != nullptr && blockIdx.y == 0;
+    float cs = 0.f;
     for (int k0 = kbeg; k0 < d.K; k0 += BK) {
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
@@ -160,6 +173,12 @@ __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ desc
         }
         __syncthreads();
         if (k0 + BK < d.K) { load_a(k0 + BK, ra); load_b(k0 + BK, rb); }
+        if constexpr (TA && BN == 64) {
+            // Round 6: the bias gradient rides here (it was a launch of its own, k_gen_colsum_adam, 7 us per layer): the workgroups of the
+            // first row block see every dZ tile of their 64 columns pass through LDS.  Same order of additions as that kernel: batch rows
+            // b = rg, rg + 4, ... per row group (k0 is a multiple of 4), then (p0 + p1) + (p2 + p3).
+            if (colsum) for (int kk = tid >> 6; kk < BK; kk += 4) cs += Bs[kk][tid & 63];
+        }
         const int kend = d.K - k0 < BK ? ((d.K - k0 + 3) & ~3) : BK;      // (the tile beyond K is zero-filled: whole 4-deep instructions only)
         for (int kk = 0; kk < kend; kk += 4) {
             float a[2], b[NJ];
@@ -180,6 +199,8 @@ __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ desc
             // pass over the flat arrays read it back with w, m, v: 36 B per parameter and step, now 24).  The tile goes through LDS
             // so that every thread owns float4 pieces of a ROW: 256-byte runs per row and wave on each of the six streams, instead
             // of the accumulator layout's 64-byte ones.  Same gradient bits, same adam1 per element as the separate pass.
+            __shared__ float csp[4][64];
+            if (colsum) csp[tid >> 6][tid & 63] = cs;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -187,6 +208,13 @@ __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ desc
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Cs[wm + 16 * i + 4 * lj + r][wn + 16 * j + li] = acc[i][j][r];
             __syncthreads();
+            if (colsum && tid < 64 && n0 + tid < d.N) {
+                const float g = (csp[0][tid] + csp[1][tid]) + (csp[2][tid] + csp[3][tid]);
+                const int64_t o = (d.bias - ep.P) + n0 + tid;
+                float w = ep.P[o], m = ep.Mo[o], v = ep.Vo[o];
+                adam1(w, m, v, g, ep.ap);
+                ep.P[o] = w; ep.Mo[o] = m; ep.Vo[o] = v;
+            }
             const int64_t base = d.C - ep.P;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -252,7 +280,7 @@ __global__ __launch_bounds__(256) void k_gen_splitk_fin(const GDesc* __restrict_
     for (int s2 = 0; s2 < S; ++s2) v += *(const f32x4*)(p0 + (int64_t)s2 * ep.part_stride + e0);
     const int row = (int)(e0 / d.N), col = (int)(e0 - (int64_t)row * d.N);      // N % 4 == 0: the four elements share the row
     const int64_t o = (int64_t)row * d.ldc + col;
-    const f32x4 bias = *(const f32x4*)(d.bias + col);
+    const f32x4 bias = gen_gld4(d.bias + col);
     dimn_u32x4 rnd;
     const bool drop = ep.train && ep.rate > 0.f;
     if (drop) rnd = dimn_dropout_block(ep.seed, (uint32_t)d.kg, ep.epoch, ep.step, (uint32_t)(e0 >> 2));     // (row * N + col == e0)
@@ -267,8 +295,264 @@ __global__ __launch_bounds__(256) void k_gen_splitk_fin(const GDesc* __restrict_
             g[r] = keep ? df * ep.scale : 0.f;
         } else c[r] = f;
     }
-    *(f32x4*)(d.C + o) = c;
-    if (ep.train) *(f32x4*)(d.G + o) = g;
+    gen_gst4(d.C + o, c);
+    if (ep.train) gen_gst4(d.G + o, g);
+}
+
+#define GEN_OUT_CH 64         // loss slots per sub-net: one owner workgroup per slot and launch (k_gen_output, k_gen_rowgemm's output epilogue)
+// One element of build()'s `loss` (multinet.py:150-162): the term that is summed and dL/dyhat * N, from the target y, yhat = sp and er = y - sp.
+__device__ __forceinline__ void gen_loss_term(int loss, float y, float sp, float er, float& term, float& dy) {
+    if (loss == DIMN_LOSS_MAE) { term = fabsf(er); dy = er > 0.f ? -1.f : (er < 0.f ? 1.f : 0.f); }
+    else if (loss == DIMN_LOSS_MSLE) {                       // keras: first_log = log(max(yhat, eps) + 1), second_log = log(max(y, eps) + 1)
+        const float a = fmaxf(sp, 1e-7f), d = log1pf(fmaxf(y, 1e-7f)) - log1pf(a);
+        term = d * d; dy = sp > 1e-7f ? -2.f * d / (a + 1.f) : 0.f;
+    } else if (loss == DIMN_LOSS_LOGCOSH) {                  // x + softplus(-2x) - log 2, x = yhat - y; d/dx = tanh x
+        const float x = -er;
+        term = x + softplus_f(-2.f * x) - 0.69314718055994531f; dy = tanhf(x);
+    } else if (loss == DIMN_LOSS_HUBER) {                    // delta = 1
+        const float ae = fabsf(er);
+        term = ae <= 1.f ? 0.5f * er * er : ae - 0.5f; dy = ae <= 1.f ? -er : (er > 0.f ? -1.f : 1.f);
+    } else if (loss == DIMN_LOSS_POISSON) {
+        term = sp - y * logf(sp + 1e-7f); dy = 1.f - y / (sp + 1e-7f);
+    } else {
+        const float w = loss == DIMN_LOSS_WMSE ? y : (loss == DIMN_LOSS_WMSE_BINARY ? (y > 0.f ? 1.f : 0.f) : 1.f);
+        term = w * er * er; dy = -2.f * w * er;
+    }
+}
+
+// ---- round 6: the batch-row GEMMs (forward of every layer, hidden backward) with NO operand staged through LDS ----
+// C[M][N] = A[M][K] * B;  TB = false: B is [K][N] row-major (forward: the layer's kernel);  TB = true: B is given as [N][K] (hidden backward:
+// dZ W^T reads the kernel as stored).  k_gen_gemm moves both operands global -> registers -> LDS (the row-major A transposed by scalar
+// ds_writes, eight-way bank conflicts) -> registers, one barrier pair per 64-deep step.  Here the operands of the matrix instructions come
+// straight from global memory in the instructions' own lane layout:
+//   A: lane (li, lj) loads 16 bytes of row 16 m + li at k = 16 c + 4 lj .. + 3: element r feeds instruction r, whose four k's are then
+//      {16 c + 4 lj + r}: any assignment of k's to instructions gives the same sum as long as B follows it;
+//   B (TB = false): 16 bytes of row k = 16 c + 4 lj + r at columns n0 + 4 li .. + 3: element j feeds the instruction of column set j, so
+//      accumulator j holds columns n0 + 4 li + j -- a permutation of the block's columns that costs nothing and turns the epilogue into
+//      16-byte pieces of a row; every B instruction reads 4 rows x 256 contiguous bytes;
+//   B (TB = true): 16 bytes of row n0 + 16 nt + li at k = 16 c + 4 lj .. + 3, as A.
+// 4 + 4 requests of 16 bytes per 64 matrix instructions, three chunks of 16 k's in flight per wave, no barrier and no branch in
+// the steady-state loop.  Two lessons of the first versions, both measured with tools/probe/gemm_probe.hip:
+//   * operand pointers that come out of a descriptor in memory are "flat" to the compiler (see gen_gld4 above): every wait was vmcnt(0);
+//   * CODE SIZE is launch time.  With the guarded forms of every request (unaligned operands, ragged edges) and every epilogue of the path
+//     compiled into one kernel, a launch of 320 workgroups with ONE chunk each took 32 us against 2.7 us for an empty kernel of the same
+//     footprint and 9.7 us without the unused code: 256 CUs miss their instruction caches on the same lines at the same moment.  So
+//     this kernel is the ALIGNED form only (gen_rowgemm_ok on the host: 16-byte aligned operands and outputs, N % 4 == 0; everything
+//     else stays on k_gen_gemm), the epilogue is a template parameter, the ragged end of K is one masked chunk without a branch.
+// A workgroup owns 64 x 64 of C over one k-range; wave w takes every fourth chunk and accumulates the whole block, the four blocks are
+// added through LDS in the fixed order (w0 + w2) + (w1 + w3).  (Tried and dropped, same probe: waves along N with the workgroup walking B in
+// whole 1 KB rows -- no better at any number of k-ranges; blocks of 128 rows for batches > 64 -- 396 registers, one wave per SIMD, 217
+// against 178 us per 256-row validation block: the kernel of a layer read again per 64-row block comes from L2.)
+// EPI: 1 hidden forward (bias, activation, dropout -> C = H, G = gate), 2 bias, 3 C = acc * G, 9 the raw block into the split-K scratch
+//      (ep.ksplit k-ranges; k_gen_splitk_fin adds them and applies the layer's epilogue), 4 the output layer of a training step: bias,
+//      softplus, the loss term and dZ in place of Z (what k_gen_output does in a launch of its own: 13 us per step), the workgroup's loss
+//      sum into its slot of loss_sum[descriptor][GEN_OUT_CH] (the host launches this form only while a sub-net has <= GEN_OUT_CH blocks).
+// Workgroups of one descriptor share their A rows: with xcd_map they sit on one XCD (block b runs on XCD b % 8).
+template <bool TB, int EPI>
+__global__ __launch_bounds__(256) void k_gen_rowgemm(const GDesc* __restrict__ descs, int nd, int M, int nblk, int mblk, int xcd_map, GEpi ep) {
+    constexpr int MT = 4, ROWS = 16 * MT, KW = 4;                // 64 x 64 of C per workgroup; wave w takes every fourth chunk
+    static_assert(TB ? EPI == 3 : (EPI == 1 || EPI == 2 || EPI == 4 || EPI == 9), "epilogues of the forward / the hidden backward");
+    __shared__ __attribute__((aligned(16))) float red[2][64][68];
+    const int S = EPI == 9 ? ep.ksplit : 1;
+    const int per = nblk * mblk * S;
+    int zi, sub;
+    if (xcd_map) { const int q = (int)blockIdx.x >> 3; zi = (q / per) * 8 + ((int)blockIdx.x & 7); sub = q % per; }
+    else { zi = (int)blockIdx.x / per; sub = (int)blockIdx.x - zi * per; }
+    if (zi >= nd) return;
+    const GDesc d = descs[zi];
+    const int sp = sub % S, nb = (sub / S) % nblk, mb = sub / (S * nblk);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lj = lane >> 4;
+    const int m0 = mb * ROWS, n0 = nb * 64;
+    if (m0 >= M || n0 >= d.N) return;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int TC = (d.K + 15) >> 4, kc = (TC + S - 1) / S;       // 16-deep chunks: all of them, per range
+    const int cbeg = sp * kc, cend = TC < cbeg + kc ? TC : cbeg + kc;
+    const int kw = wave;                                         // this wave takes chunks cbeg + kw, + KW, ...
+    const float* Abase = d.A;
+    int64_t a_ld = d.lda;
+    if (d.agather) { const SubnetDev sd = ep.sn[zi]; Abase = ep.xbase + sd.xoff; a_ld = sd.Dp; }
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = zero4;
+    auto mma = [&](const f32x4 (&a)[MT], const f32x4 (&b)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[m][j] = MFMA16(a[m][r], TB ? b[j][r] : b[r][j], acc[m][j]);
+    };
+    // Every request is unconditional: rows past M and columns past N are clamped onto valid ones (their results are never stored).
+    const float* arc[MT];
+    const float* brc[4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        int row = m0 + 16 * m + li;
+        row = row < M ? row : M - 1;
+        const int64_t r = d.agather ? (ep.arows ? (int64_t)ep.arows[row] : ep.arow0 + row) : (int64_t)row;
+        arc[m] = Abase + r * a_ld + 4 * lj;
+    }
+    if constexpr (!TB) {
+        int col = n0 + 4 * li;
+        col = col + 4 <= d.N ? col : d.N - 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) brc[r] = d.B + (int64_t)(4 * lj + r) * d.ldb + col;
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            int n = n0 + 16 * nt + li;
+            n = n < d.N ? n : d.N - 1;
+            brc[nt] = d.B + (int64_t)n * d.ldb + 4 * lj;
+        }
+    }
+    const int64_t bstep = TB ? 16 : (int64_t)16 * d.ldb;
+    auto loadf = [&](int c, f32x4 (&a)[MT], f32x4 (&b)[4]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = gen_gld4(arc[m] + 16 * c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[r] = gen_gld4(brc[r] + bstep * c);
+    };
+    const int nfull = d.K >> 4;
+    const int cf = cend < nfull ? cend : nfull;                  // chunks [cbeg, cf): whole; chunk nfull (if this range holds it): masked
+    {
+        int c = cbeg + kw;
+        const int nw = c < cf ? (cf - c + KW - 1) / KW : 0;      // whole chunks of this wave: c, c + KW, ...
+        if (nw > 0) {
+            const int clast = c + KW * (nw - 1);
+            auto cl = [&](int x) { return x < clast ? x : clast; };   // (past the wave's last chunk: the last one again, an L1 hit nobody uses)
+            f32x4 a0[MT], b0[4], a1[MT], b1[4], a2[MT], b2[4];      // three chunks in flight per wave
+            loadf(c, a0, b0);
+            loadf(cl(c + KW), a1, b1);
+            const int n3 = nw / 3;
+            for (int i = 0; i < n3; ++i, c += 3 * KW) {
+                loadf(cl(c + 2 * KW), a2, b2);
+                mma(a0, b0);
+                loadf(cl(c + 3 * KW), a0, b0);
+                mma(a1, b1);
+                loadf(cl(c + 4 * KW), a1, b1);
+                mma(a2, b2);
+            }
+            const int rem = nw - 3 * n3;
+            if (rem >= 1) mma(a0, b0);
+            if (rem >= 2) mma(a1, b1);
+        }
+    }
+    if ((d.K & 15) != 0 && nfull >= cbeg && nfull < cend && ((nfull - cbeg) % KW) == kw) {
+        // the chunk that crosses K: requests at clamped k's (inside the row / the matrix), elements at k >= K replaced by zeros
+        const int kl = d.K - 1;
+        f32x4 a0[MT], b0[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 16 * nfull + 4 * lj + e, kq = (k < kl ? k : kl) - 4 * lj;     // (arc / brc already carry the lane's 4 lj)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { const float x = gen_gld1(arc[m] + kq); a0[m][e] = k < d.K ? x : 0.f; }
+            if constexpr (!TB) {
+                const f32x4 x = gen_gld4(brc[0] + (int64_t)kq * d.ldb);              // brc[0]: row 4 lj of the matrix
+                b0[e] = k < d.K ? x : zero4;
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) { const float x = gen_gld1(brc[nt] + kq); b0[nt][e] = k < d.K ? x : 0.f; }
+            }
+        }
+        mma(a0, b0);
+    }
+    // accumulator (m, j), element rr: row 16 m + 4 lj + rr;  TB = false: column 4 li + j;  TB = true: column 16 j + li
+    double ls = 0.0;                                             // EPI 4: this thread's loss terms
+    auto finish4 = [&](int row, int col, f32x4 v) __attribute__((always_inline)) {   // TB = false: four consecutive columns of one row
+        if (row >= M || col >= d.N) return;
+        const int64_t o = (int64_t)row * d.ldc + col;
+        if constexpr (EPI == 9) {
+            gen_gst4(ep.part + ((int64_t)zi * S + sp) * ep.part_stride + (int64_t)row * d.N + col, v);
+        } else if constexpr (EPI == 2) {
+            gen_gst4(d.C + o, v + gen_gld4(d.bias + col));
+        } else if constexpr (EPI == 4) {
+            const f32x4 z = v + gen_gld4(d.bias + col);
+            const int64_t arow = ep.arows ? (int64_t)ep.arows[row] : ep.arow0 + row;
+            const f32x4 y = gen_gld4(ep.Y + ((int64_t)zi * ep.n_cells + arow) * ep.Op + col);
+            f32x4 dz;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sp, sg, term, dy;
+                softplus_sigmoid_fast(z[r], sp, sg);
+                gen_loss_term(ep.loss, y[r], sp, y[r] - sp, term, dy);
+                ls += (double)term;
+                dz[r] = dy * ep.inv_n * sg;
+            }
+            gen_gst4(d.C + o, dz);
+        } else {                                                 // EPI 1: as k_gen_splitk_fin's fast path
+            const f32x4 bias = gen_gld4(d.bias + col);
+            const bool drop = ep.train && ep.rate > 0.f;
+            dimn_u32x4 rnd;
+            if (drop) rnd = dimn_dropout_block(ep.seed, (uint32_t)d.kg, ep.epoch, ep.step, (uint32_t)(row * d.N + col) >> 2);
+            f32x4 c, g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float f, df;
+                hidden_act(ep.act, v[r] + bias[r], f, df);
+                if (ep.train) {
+                    const bool keep = !drop || dimn_u01(rnd.v[r]) >= ep.rate;
+                    c[r] = keep ? f * ep.scale : 0.f;
+                    g[r] = keep ? df * ep.scale : 0.f;
+                } else c[r] = f;
+            }
+            gen_gst4(d.C + o, c);
+            if (ep.train) gen_gst4(d.G + o, g);
+        }
+    };
+    // the four waves' blocks: (w0 + w2) + (w1 + w3)
+    auto put = [&](int slot) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                if constexpr (!TB) *(f32x4*)&red[slot][16 * m + 4 * lj + rr][4 * li] = (f32x4){acc[m][0][rr], acc[m][1][rr], acc[m][2][rr], acc[m][3][rr]};
+                else {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) red[slot][16 * m + 4 * lj + rr][16 * nt + li] = acc[m][nt][rr];
+                }
+            }
+    };
+    if (wave >= 2) put(wave - 2);
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                if constexpr (!TB) {
+                    const f32x4 t = *(const f32x4*)&red[wave][16 * m + 4 * lj + rr][4 * li];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[m][j][rr] += t[j];
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[m][nt][rr] += red[wave][16 * m + 4 * lj + rr][16 * nt + li];
+                }
+            }
+    }
+    __syncthreads();
+    if (wave < 2) put(wave);
+    __syncthreads();
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {                        // (rolled: one copy of the epilogue's code)
+        const int p = tid + 256 * q, rr = p >> 4, c4 = (p & 15) * 4;
+        const f32x4 v = *(const f32x4*)&red[0][rr][c4] + *(const f32x4*)&red[1][rr][c4];
+        const int row = m0 + rr, col = n0 + c4;
+        if constexpr (!TB) finish4(row, col, v);
+        else if (row < M && col < d.N) {                 // (N need not be a multiple of 4 here: element by element)
+            const int64_t o = (int64_t)row * d.ldc + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (col + r < d.N) gen_gst1(d.C + o + r, v[r] * gen_gld1(d.G + o + r));
+        }
+    }    if constexpr (EPI == 4) {
+        __shared__ double lred[4];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ls += __shfl_xor(ls, off);
+        if (lane == 0) lred[wave] = ls;
+        __syncthreads();
+        if (tid == 0) ep.loss_sum[(int64_t)zi * GEN_OUT_CH + nb + nblk * mb] += (lred[0] + lred[1]) + (lred[2] + lred[3]);
+    }
 }
 
 // Xb[k][b][Dp_k] = X_k[rows[b]][:]  (the batch rows of every sub-net, dense, so that every GEMM operand is a plain matrix)
@@ -298,7 +582,6 @@ __global__ __launch_bounds__(256) void k_gen_gather_batch(const SubnetDev* __res
 // load -> softplus -> store rounds: 20 us; now 64).  out != NULL (predict):
 // out[(row0 + b)][k*O + o] = yhat, no loss.  loss_sum[k][c] += sum of the per-element loss terms of the workgroup's stripes (one
 // owner per slot: deterministic; the host adds the slots and divides by the element count); train != 0 writes dZ over Z.
-#define GEN_OUT_CH 64
 __global__ __launch_bounds__(256) void k_gen_output(float* __restrict__ Z, int ldz, int64_t z_stride, const float* __restrict__ Y, int64_t n_cells,
                                                     const int32_t* __restrict__ rows, int64_t row0, int b_cnt, Dims dm, int loss, int train,
                                                     float inv_n, double* __restrict__ loss_sum, float* __restrict__ out, int64_t out_row0, int k_off) {
@@ -319,22 +602,7 @@ __global__ __launch_bounds__(256) void k_gen_output(float* __restrict__ Z, int l
         if (train) softplus_sigmoid_fast(zz, sp, sg); else { sp = softplus_f(zz); sg = 0.f; }
         const float er = y - sp;
         float term, dy;                                          // loss term and dL/dyhat * N
-        if (loss == DIMN_LOSS_MAE) { term = fabsf(er); dy = er > 0.f ? -1.f : (er < 0.f ? 1.f : 0.f); }
-        else if (loss == DIMN_LOSS_MSLE) {                       // keras: first_log = log(max(yhat, eps) + 1), second_log = log(max(y, eps) + 1)
-            const float a = fmaxf(sp, 1e-7f), d = log1pf(fmaxf(y, 1e-7f)) - log1pf(a);
-            term = d * d; dy = sp > 1e-7f ? -2.f * d / (a + 1.f) : 0.f;
-        } else if (loss == DIMN_LOSS_LOGCOSH) {                  // x + softplus(-2x) - log 2, x = yhat - y; d/dx = tanh x
-            const float x = -er;
-            term = x + softplus_f(-2.f * x) - 0.69314718055994531f; dy = tanhf(x);
-        } else if (loss == DIMN_LOSS_HUBER) {                    // delta = 1
-            const float ae = fabsf(er);
-            term = ae <= 1.f ? 0.5f * er * er : ae - 0.5f; dy = ae <= 1.f ? -er : (er > 0.f ? -1.f : 1.f);
-        } else if (loss == DIMN_LOSS_POISSON) {
-            term = sp - y * logf(sp + 1e-7f); dy = 1.f - y / (sp + 1e-7f);
-        } else {
-            const float w = loss == DIMN_LOSS_WMSE ? y : (loss == DIMN_LOSS_WMSE_BINARY ? (y > 0.f ? 1.f : 0.f) : 1.f);
-            term = w * er * er; dy = -2.f * w * er;
-        }
+        gen_loss_term(loss, y, sp, er, term, dy);
         ls += (double)term;
         if (train) z[(int64_t)b * ldz + o] = dy * inv_n * sg;
     }
@@ -344,28 +612,6 @@ __global__ __launch_bounds__(256) void k_gen_output(float* __restrict__ Z, int l
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ls;
     __syncthreads();
     if (threadIdx.x == 0) loss_sum[(int64_t)k * GEN_OUT_CH + blockIdx.y] += red[0] + red[1] + red[2] + red[3];
-}
-
-// bias gradients: gb[n] = sum_b dZ[b][n] -> Keras-Adam on the bias.  grid (ceil(N / 64), entries of `descs` = sub-net x layer), 256
-// threads = 64 columns x 4 row groups (round 3: ONE workgroup per entry with a serial loop over the batch: 28 us per launch on 40 of
-// 256 CUs); the four partial sums of a column are added in row-group order.  A = dZ, N, lda; C addresses the bias inside the flat
-// parameter array, whose offsets the m / v arrays share (ep as in k_gen_gemm's mode 4).
-__global__ __launch_bounds__(256) void k_gen_colsum_adam(const GDesc* __restrict__ descs, int M, GEpi ep) {
-    __shared__ float part[4][64];
-    const GDesc d = descs[blockIdx.y];
-    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6, n = blockIdx.x * 64 + c;
-    float s = 0.f;
-    if (n < d.N)
-        for (int b = rg; b < M; b += 4) s += d.A[(int64_t)b * d.lda + n];
-    part[rg][c] = s;
-    __syncthreads();
-    if (rg == 0 && n < d.N) {
-        const float g = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
-        const int64_t o = (d.C - ep.P) + n;
-        float w = ep.P[o], m = ep.Mo[o], v = ep.Vo[o];
-        adam1(w, m, v, g, ep.ap);
-        ep.P[o] = w; ep.Mo[o] = m; ep.Vo[o] = v;
-    }
 }
 
 // Glorot-uniform kernels (Keras Dense default), Philox stream keyed (seed, global sub-net, layer, element) as k_init_weights

@@ -23,9 +23,9 @@ def test_general_kat_matches_autograd_golden(loss):
     check_general_kat(_hip(), loss, rtol=3e-4, atol=2e-6)
 
 
-def _pair(prob, layers, **kw):
+def _pair(prob, layers, classes=None, **kw):
     out = []
-    for cls in (_hip(), _oracle()):
+    for cls in (classes or (_hip(), _oracle())):
         e = cls(prob["Ds"], layers, prob["O"], **kw)
         e.set_matrix(prob["norm"])
         for k in range(len(prob["Ds"])):
@@ -43,6 +43,7 @@ def _pair(prob, layers, **kw):
     ([(300, "relu", 0.2)], 333, "mse"),                                   # odd batch, keras loss by name
     ([(40, "sigmoid", 0.0)], 16, "mae"),
     ([(0, "linear", 0.2), (96, "gelu", 0.3), (64, "selu", 0.0)], 100, "huber"),   # a Dropout layer before the first Dense layer; round-5 activations and loss
+    ([(50, "relu", 0.1), (30, "tanh", 0.0)], 64, "wmse"),                 # widths that are not multiples of 4: the batch-row GEMMs stay on the LDS-staged k_gen_gemm
 ])
 def test_general_two_epochs_match_oracle(layers, B, loss):
     prob = make_problem(n=700, g=600, Ds=[130, 77, 200], H=[l[0] for l in layers if l[0]][0], O=100, seed=21)
@@ -101,3 +102,26 @@ def test_general_path_at_configs2_widths_matches_general_oracle(layers, B):
     rows = prob["val"][:7]
     np.testing.assert_allclose(a.predict(rows), b.predict(rows), rtol=1e-4, atol=1e-6)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("knob", ["gemm=0", "gfuse=0", "gs=2", "gs=5"])
+def test_general_row_gemm_forms_agree(knob, monkeypatch):
+    """Round 6: the batch-row GEMMs of aligned shapes run on k_gen_rowgemm (operands straight from global memory, the output layer's
+    loss / dZ fused behind its forward, split-K by the grid's size).  Same problem with each choice forced the other way
+    (DIMN_RES_TEST, read per launch): the LDS-staged k_gen_gemm for all of them, the loss in k_gen_output's own launch, other numbers
+    of k-ranges -- same training to fp32 rounding of the sums' order."""
+    prob = make_problem(n=330, g=3000, Ds=[2400, 1210, 700, 64], H=256, O=512, seed=5)
+    kw = dict(batch_size=64, learning_rate=1e-3, seed=7, loss="wmse")
+    out = []
+    for env in (None, knob):
+        if env: monkeypatch.setenv("DIMN_RES_TEST", env)
+        else: monkeypatch.delenv("DIMN_RES_TEST", raising=False)
+        a, = _pair(prob, [(256, "relu", 0.2)], classes=(_hip(),), **kw)
+        losses = [a.train_epoch(ep) for ep in range(2)]
+        out.append((np.asarray(losses), np.asarray(a.val_loss()), a.predict(), [w for k in range(a.K) for w in a.get_weights(k)]))
+        a.close()
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=2e-6)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=2e-6)
+    np.testing.assert_allclose(out[0][2], out[1][2], rtol=2e-4, atol=2e-6)
+    for x, y in zip(out[0][3], out[1][3]):
+        np.testing.assert_allclose(x, y, rtol=1e-3, atol=2e-6)
