@@ -45,6 +45,26 @@ __device__ __forceinline__ float gen_gld1(const float* p) { return *(gen_gp1)p; 
 __device__ __forceinline__ void gen_gst4(float* p, f32x4 v) { *(__attribute__((address_space(1))) f32x4*)p = v; }
 __device__ __forceinline__ void gen_gst1(float* p, float v) { *(__attribute__((address_space(1))) float*)p = v; }
 
+// element r of a four-vector / one Philox block with r a run-time index (rolled loops over the four elements keep ONE copy of every activation
+// in the code: see the note on code size at k_gen_rowgemm)
+__device__ __forceinline__ float gen_sel4(const f32x4 v, int r) { return r == 0 ? v[0] : (r == 1 ? v[1] : (r == 2 ? v[2] : v[3])); }
+__device__ __forceinline__ void gen_put4(f32x4& v, int r, float x) { v[0] = r == 0 ? x : v[0]; v[1] = r == 1 ? x : v[1]; v[2] = r == 2 ? x : v[2]; v[3] = r == 3 ? x : v[3]; }
+// bias, activation and dropout of four consecutive units of one row (hidden forward): C = H, G = gate
+__device__ __forceinline__ void gen_hidden4(const GEpi& ep, const f32x4 x, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, bool drop, f32x4& c, f32x4& g) {
+    c = g = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        float f, df;
+        hidden_act(ep.act, gen_sel4(x, r), f, df);
+        if (ep.train) {
+            const uint32_t w = r == 0 ? r0 : (r == 1 ? r1 : (r == 2 ? r2 : r3));
+            const bool keep = !drop || dimn_u01(w) >= ep.rate;
+            gen_put4(c, r, keep ? f * ep.scale : 0.f);
+            gen_put4(g, r, keep ? df * ep.scale : 0.f);
+        } else gen_put4(c, r, f);
+    }
+}
+
 // the per-element epilogue of modes 0 .. 3 (k_gen_gemm without split-K, k_gen_splitk_fin with it)
 __device__ __forceinline__ void gen_epilogue(const GEpi& ep, const GDesc& d, int row, int col, float v) {
     const int64_t o = (int64_t)row * d.ldc + col;
@@ -239,20 +259,22 @@ __global__ __launch_bounds__(256) void k_gen_gemm(const GDesc* __restrict__ desc
             return;
         }
     }
+    if constexpr (!TA) {                                         // (the weight-gradient instance only ever runs mode 4: sixteen copies of every activation less to fetch)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int col = n0 + wn + 16 * j + li;
-            if (col >= d.N) continue;
+            for (int j = 0; j < NJ; ++j) {
+                const int col = n0 + wn + 16 * j + li;
+                if (col >= d.N) continue;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm + 16 * i + 4 * lj + r;
-                if (row >= M) continue;
-                if (S > 1) ep.part[((int64_t)zi * S + sp) * ep.part_stride + (int64_t)row * d.N + col] = acc[i][j][r];
-                else gen_epilogue(ep, d, row, col, acc[i][j][r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm + 16 * i + 4 * lj + r;
+                    if (row >= M) continue;
+                    if (S > 1) ep.part[((int64_t)zi * S + sp) * ep.part_stride + (int64_t)row * d.N + col] = acc[i][j][r];
+                    else gen_epilogue(ep, d, row, col, acc[i][j][r]);
+                }
             }
-        }
+    }
 }
 
 // second half of a split-K GEMM: element (row, col) = sum over the k-ranges of the partial tiles, in range order, then the epilogue.
@@ -281,20 +303,11 @@ __global__ __launch_bounds__(256) void k_gen_splitk_fin(const GDesc* __restrict_
     const int row = (int)(e0 / d.N), col = (int)(e0 - (int64_t)row * d.N);      // N % 4 == 0: the four elements share the row
     const int64_t o = (int64_t)row * d.ldc + col;
     const f32x4 bias = gen_gld4(d.bias + col);
-    dimn_u32x4 rnd;
+    dimn_u32x4 rnd = {{0u, 0u, 0u, 0u}};
     const bool drop = ep.train && ep.rate > 0.f;
     if (drop) rnd = dimn_dropout_block(ep.seed, (uint32_t)d.kg, ep.epoch, ep.step, (uint32_t)(e0 >> 2));     // (row * N + col == e0)
     f32x4 c, g;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float f, df;
-        hidden_act(ep.act, v[r] + bias[r], f, df);
-        if (ep.train) {
-            const bool keep = !drop || dimn_u01(rnd.v[r]) >= ep.rate;
-            c[r] = keep ? f * ep.scale : 0.f;
-            g[r] = keep ? df * ep.scale : 0.f;
-        } else c[r] = f;
-    }
+    gen_hidden4(ep, v + bias, rnd.v[0], rnd.v[1], rnd.v[2], rnd.v[3], drop, c, g);
     gen_gst4(d.C + o, c);
     if (ep.train) gen_gst4(d.G + o, g);
 }
@@ -484,19 +497,10 @@ __global__ __launch_bounds__(256) void k_gen_rowgemm(const GDesc* __restrict__ d
         } else {                                                 // EPI 1: as k_gen_splitk_fin's fast path
             const f32x4 bias = gen_gld4(d.bias + col);
             const bool drop = ep.train && ep.rate > 0.f;
-            dimn_u32x4 rnd;
+            dimn_u32x4 rnd = {{0u, 0u, 0u, 0u}};
             if (drop) rnd = dimn_dropout_block(ep.seed, (uint32_t)d.kg, ep.epoch, ep.step, (uint32_t)(row * d.N + col) >> 2);
             f32x4 c, g;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float f, df;
-                hidden_act(ep.act, v[r] + bias[r], f, df);
-                if (ep.train) {
-                    const bool keep = !drop || dimn_u01(rnd.v[r]) >= ep.rate;
-                    c[r] = keep ? f * ep.scale : 0.f;
-                    g[r] = keep ? df * ep.scale : 0.f;
-                } else c[r] = f;
-            }
+            gen_hidden4(ep, v + bias, rnd.v[0], rnd.v[1], rnd.v[2], rnd.v[3], drop, c, g);
             gen_gst4(d.C + o, c);
             if (ep.train) gen_gst4(d.G + o, g);
         }

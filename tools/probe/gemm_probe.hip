@@ -1,4 +1,6 @@
-// Probe of k_gen_rowgemm on synthetic dense operands: time per launch against the number of descriptors, k-ranges and the inner dimension.
+// Probe of k_gen_rowgemm on synthetic dense operands: time per launch against the number of descriptors (sub-nets), k-ranges S and the inner
+// dimension K -- args: nd K N S M.  K = 16 is one chunk per workgroup: the launch's fixed cost (round 6: 32 us with every guarded form and
+// epilogue compiled in, 6 us for the aligned, epilogue-templated kernel; an empty kernel of the same footprint: 2.7 us).
 // hipcc -O3 -std=c++17 --offload-arch=gfx950 -I deepimpute_amd/csrc -I include -o /tmp/gemm_probe tools/probe/gemm_probe.hip
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -11,7 +13,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("hip error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 int main(int argc, char** argv) {
     const int nd = argc > 1 ? atoi(argv[1]) : 40, K = argc > 2 ? atoi(argv[2]) : 2400, N = argc > 3 ? atoi(argv[3]) : 256, S = argc > 4 ? atoi(argv[4]) : 4;
-    const int M = argc > 5 ? atoi(argv[5]) : 64, NW = argc > 6 ? atoi(argv[6]) : 4, reps = 20;
+    const int M = argc > 5 ? atoi(argv[5]) : 64, reps = 20;
     float *A, *B, *C, *part;
     CK(hipMalloc(&A, (size_t)nd * M * K * 4)); CK(hipMalloc(&B, (size_t)nd * K * N * 4)); CK(hipMalloc(&C, (size_t)nd * M * N * 4)); CK(hipMalloc(&part, (size_t)nd * S * M * N * 4));
     CK(hipMemset(A, 0, (size_t)nd * M * K * 4)); CK(hipMemset(B, 0, (size_t)nd * K * N * 4));
@@ -31,7 +33,7 @@ int main(int argc, char** argv) {
         }
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        if (w) printf("NW %d nd %d K %d N %d S %d M %d grid %u: %.2f us per launch  (%.1f MB of B -> %.2f TB/s; %.2f TFLOP/s)\n", NW, nd, K, N, S, M, grid, ms * 1000 / reps, (double)nd * K * N * 4 / 1e6,
+        if (w) printf("nd %d K %d N %d S %d M %d grid %u: %.2f us per launch  (%.1f MB of B -> %.2f TB/s; %.2f TFLOP/s)\n", nd, K, N, S, M, grid, ms * 1000 / reps, (double)nd * K * N * 4 / 1e6,
                       (double)nd * K * N * 4 / (ms * 1e-3 / reps) / 1e12, 2.0 * nd * M * K * N / (ms * 1e-3 / reps) / 1e12);
     }
     return 0;
