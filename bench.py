@@ -127,10 +127,21 @@ class FileRendezvous:
         with open(path, "rb") as f:
             return f.read()
 
-    def cleanup(self):
-        if self.rank == 0:
-            import shutil
-            shutil.rmtree(self.dir, ignore_errors=True)
+    def cleanup(self, timeout=20.0):
+        """Every rank calls this when it no longer reads the directory; rank 0 removes it once the others have said so (or `timeout`
+        seconds later: a rank that died must not keep it forever).  Without the wait a rank still polling for a file of the last vote
+        could find the directory gone and spin until its own timeout."""
+        if self.rank != 0:
+            try:
+                open(os.path.join(self.dir, "left_%d" % self.rank), "w").close()
+            except OSError:
+                pass                                             # (already removed: rank 0 gave up waiting)
+            return
+        t0 = time.time()
+        while time.time() - t0 < timeout and not all(os.path.exists(os.path.join(self.dir, "left_%d" % r)) for r in range(1, self.world)):
+            time.sleep(0.002)
+        import shutil
+        shutil.rmtree(self.dir, ignore_errors=True)
 
 
 class RcclBenchComm:

@@ -71,9 +71,19 @@ class NodeComm:
                     raise TimeoutError("NodeComm.barrier: rank %d never arrived" % r)
                 self._time.sleep(0.001)
 
-    def close(self):
+    def close(self, timeout=20.0):
+        """Collective.  Rank 0 removes the directory only after every other rank has left the last barrier (a rank still polling for
+        a file of that barrier must not find the directory gone), or `timeout` seconds later."""
         self.barrier()
-        if self.rank == 0:
+        if self.rank != 0:
+            try:
+                open(os.path.join(self._dir, "left_%d" % self.rank), "w").close()
+            except OSError:
+                pass
+        else:
+            t0 = self._time.time()
+            while self._time.time() - t0 < timeout and not all(os.path.exists(os.path.join(self._dir, "left_%d" % r)) for r in range(1, self.world)):
+                self._time.sleep(0.002)
             self._sweep()
         self._closed = True
 
