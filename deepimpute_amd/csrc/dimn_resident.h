@@ -733,31 +733,6 @@ __global__ __launch_bounds__(DIMN_RES_THREADS, 2) void k_epoch_resident(ResParam
                 RES_MARK(9)
                 // tile ht of the OT producers' dD partials, their two halves on the two thread halves
                 f32x4 d = zero4;
-#ifndef DIMN_RES_NO_M2DMA
-                if (!is_o && OT <= 36) {
-                    // A manager that is not a role-2 workgroup has ~145 KB of LDS doing nothing here: the OT x 4 KB of partials come in by
-                    // LDS-DMA (global_load_lds: no destination registers), ALL of them in flight at once instead of a rolling window of
-                    // eight 16-byte requests per thread (64 of the 128 KB).  Tiles 0 .. 23 land in the tile-loop / phase-A region, the rest
-                    // in the (unused) W2 state region; a piece that arrives as "not written" is fetched again the usual way.
-                    const char* dsrc = (const char*)(p.Dpart + (size_t)k * DIMN_RES_SLOTS * OT * 16 * 1024) + dcur + (uint32_t)(ht * 4096) + (uint32_t)(lane * 16);
-                    for (int q = wave; q < 4 * OT; q += 8) {
-                        const int o = q >> 2, c = q & 3;
-                        float* dl = (o < 24 ? lds + o * 1024 : w2s + (o - 24) * 1024) + c * 256;
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dsrc + (size_t)o * 65536 + c * 1024),
-                                                         (__attribute__((address_space(3))) void*)dl, 16, 0, DIMN_RES_AUX);
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    const int o0 = half * (OT >> 1), o1 = half ? OT : (OT >> 1);
-                    const uint32_t base = dcur + (uint32_t)((ht * 1024 + 4 * (tid & 255)) * 4);
-#pragma unroll 4
-                    for (int o = o0; o < o1; ++o) {
-                        f32x4 t1 = *(const f32x4*)((o < 24 ? lds + o * 1024 : w2s + (o - 24) * 1024) + 4 * (tid & 255));
-                        if (res_unwritten(t1)) { t1 = res_ld(rD, base + (uint32_t)(o * 65536)); res_fix(t1, rD, base + (uint32_t)(o * 65536), abort_w); }
-                        d += t1;
-                    }
-                } else
-#endif
                 {
                     const int o0 = half * (OT >> 1), o1 = half ? OT : (OT >> 1);
                     const uint32_t base = dcur + (uint32_t)((ht * 1024 + 4 * (tid & 255)) * 4);
