@@ -2,9 +2,11 @@
 // dimn_kernels.h do not take (reference deepimpute/multinet.py:135-143: any sequence of Dense / Dropout layers;
 // :150-162: other losses; parser.py:50-66: any batch size, any hidden width).  Same arithmetic definitions (Keras-form
 // Adam, Philox dropout streams, softplus output, wMSE), plain structure: per layer one batched fp32-MFMA GEMM over the
-// sub-nets (64 x 64 output tile per workgroup, operands staged through LDS, transposes resolved while staging) with the
-// layer's epilogue fused, an element-wise loss kernel, and Keras-Adam fused behind the weight-gradient GEMM (bias gradient included).  Correct and
-// reasonably fast, not roofline-tuned: the default architecture (one hidden layer <= 384, batch <= 64) never comes here.
+// sub-nets with the layer's epilogue fused -- k_gen_rowgemm (round 6: operands straight from global memory in the matrix
+// instructions' lane layout, aligned shapes) for the forward and the hidden backward, k_gen_gemm (64 x 64 output tile, operands
+// staged through LDS, transposes resolved while staging) for the weight gradients with Keras-Adam and the bias gradient behind
+// them and for whatever k_gen_rowgemm does not take --, the output layer's loss in the last forward's epilogue (training) or
+// k_gen_output (validation, prediction).  The default architecture (one hidden layer <= 384, batch <= 64) never comes here.
 #pragma once
 #include "dimn_kernels.h"
 
