@@ -125,3 +125,16 @@ def test_general_row_gemm_forms_agree(knob, monkeypatch):
     np.testing.assert_allclose(out[0][2], out[1][2], rtol=2e-4, atol=2e-6)
     for x, y in zip(out[0][3], out[1][3]):
         np.testing.assert_allclose(x, y, rtol=1e-3, atol=2e-6)
+
+
+def test_general_random_shapes_agree_between_gemm_forms():
+    """tools/gen_shape_sweep.py: random widths (multiples of 4 and not), ragged predictor counts (the masked last chunk of K), batches 1 .. 200,
+    one to three hidden layers, every loss -- the default kernels against DIMN_RES_TEST=gemm=0, one epoch + validation + prediction."""
+    import os
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gen_shape_sweep.py")
+    env = {k: v for k, v in os.environ.items() if k != "DIMN_RES_TEST"}
+    r = subprocess.run([sys.executable, tool, "16", "11"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all 16 cases agree" in r.stdout
