@@ -391,6 +391,29 @@ __global__ __launch_bounds__(256) void k_gen_rowgemm(const GDesc* __restrict__ d
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[m][j] = zero4;
+    // EPI 4: the targets of this thread's four pieces of the block (piece q: row m0 + (tid + 256 q) / 16, columns n0 + ((tid + 256 q) % 16) * 4 ..)
+    // are requested HERE, before the k-loop: they are 64 gathered rows of a [cells][Op] arena -- requested inside the rolled epilogue loop
+    // they were four dependent round trips behind TLB misses (the fused launch ran 24.7 us against 16-19 for the plain forward)
+    f32x4 yq[4];
+    if constexpr (EPI == 3) {                                    // ... and so are the gates of the hidden backward (ldc = N, a multiple of 4: gen_rowgemm_ok)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = tid + 256 * q, row = m0 + (p >> 4), col = n0 + (p & 15) * 4;
+            yq[q] = zero4;
+            if (row < M && col < d.N) yq[q] = gen_gld4(d.G + (int64_t)row * d.ldc + col);
+        }
+    }
+    if constexpr (EPI == 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = tid + 256 * q, row = m0 + (p >> 4), col = n0 + (p & 15) * 4;
+            yq[q] = zero4;
+            if (row < M && col < d.N) {
+                const int64_t arow = ep.arows ? (int64_t)ep.arows[row] : ep.arow0 + row;
+                yq[q] = gen_gld4(ep.Y + ((int64_t)zi * ep.n_cells + arow) * ep.Op + col);
+            }
+        }
+    }
     auto mma = [&](const f32x4 (&a)[MT], const f32x4 (&b)[4]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -475,7 +498,7 @@ __global__ __launch_bounds__(256) void k_gen_rowgemm(const GDesc* __restrict__ d
     }
     // accumulator (m, j), element rr: row 16 m + 4 lj + rr;  TB = false: column 4 li + j;  TB = true: column 16 j + li
     double ls = 0.0;                                             // EPI 4: this thread's loss terms
-    auto finish4 = [&](int row, int col, f32x4 v) __attribute__((always_inline)) {   // TB = false: four consecutive columns of one row
+    auto finish4 = [&](int row, int col, f32x4 v, f32x4 y) __attribute__((always_inline)) {   // TB = false: four consecutive columns of one row (y: EPI 4's targets)
         if (row >= M || col >= d.N) return;
         const int64_t o = (int64_t)row * d.ldc + col;
         if constexpr (EPI == 9) {
@@ -484,8 +507,6 @@ __global__ __launch_bounds__(256) void k_gen_rowgemm(const GDesc* __restrict__ d
             gen_gst4(d.C + o, v + gen_gld4(d.bias + col));
         } else if constexpr (EPI == 4) {
             const f32x4 z = v + gen_gld4(d.bias + col);
-            const int64_t arow = ep.arows ? (int64_t)ep.arows[row] : ep.arow0 + row;
-            const f32x4 y = gen_gld4(ep.Y + ((int64_t)zi * ep.n_cells + arow) * ep.Op + col);
             f32x4 dz;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -545,12 +566,8 @@ __global__ __launch_bounds__(256) void k_gen_rowgemm(const GDesc* __restrict__ d
         const int p = tid + 256 * q, rr = p >> 4, c4 = (p & 15) * 4;
         const f32x4 v = *(const f32x4*)&red[0][rr][c4] + *(const f32x4*)&red[1][rr][c4];
         const int row = m0 + rr, col = n0 + c4;
-        if constexpr (!TB) finish4(row, col, v);
-        else if (row < M && col < d.N) {                 // (N need not be a multiple of 4 here: element by element)
-            const int64_t o = (int64_t)row * d.ldc + col;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (col + r < d.N) gen_gst1(d.C + o + r, v[r] * gen_gld1(d.G + o + r));
-        }
+        if constexpr (!TB) finish4(row, col, v, EPI == 4 ? (q == 0 ? yq[0] : (q == 1 ? yq[1] : (q == 2 ? yq[2] : yq[3]))) : v);
+        else if (row < M && col < d.N) gen_gst4(d.C + (int64_t)row * d.ldc + col, v * (q == 0 ? yq[0] : (q == 1 ? yq[1] : (q == 2 ? yq[2] : yq[3]))));
     }    if constexpr (EPI == 4) {
         __shared__ double lred[4];
 #pragma unroll
