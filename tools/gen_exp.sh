@@ -1,4 +1,6 @@
 #!/bin/bash
+# A general-path epoch under rocprofv3 --kernel-trace --stats once per DIMN_RES_TEST value given (e.g. `tools/gen_exp.sh x=1 gemm=0 gs=2 gfuse=0`):
+# the step time and the per-kernel table of each -- how the round-6 variants of the batch-row GEMMs were compared kernel by kernel.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/genexp; mkdir -p $O
 export TMPDIR=/tmp
