@@ -394,6 +394,9 @@ __global__ __launch_bounds__(256) void k_gen_rowgemm(const GDesc* __restrict__ d
     // EPI 4: the targets of this thread's four pieces of the block (piece q: row m0 + (tid + 256 q) / 16, columns n0 + ((tid + 256 q) % 16) * 4 ..)
     // are requested HERE, before the k-loop: they are 64 gathered rows of a [cells][Op] arena -- requested inside the rolled epilogue loop
     // they were four dependent round trips behind TLB misses (the fused launch ran 24.7 us against 16-19 for the plain forward)
+    // the bias of this thread's four pieces is ONE 16-byte piece (their column is n0 + (tid % 16) * 4 in every piece): requested here, once
+    f32x4 biasv = zero4;
+    if constexpr (EPI == 1 || EPI == 2 || EPI == 4) { if (n0 + (tid & 15) * 4 < d.N) biasv = gen_gld4(d.bias + n0 + (tid & 15) * 4); }
     f32x4 yq[4];
     if constexpr (EPI == 3) {                                    // ... and so are the gates of the hidden backward (ldc = N, a multiple of 4: gen_rowgemm_ok)
 #pragma unroll
@@ -504,9 +507,9 @@ __global__ __launch_bounds__(256) void k_gen_rowgemm(const GDesc* __restrict__ d
         if constexpr (EPI == 9) {
             gen_gst4(ep.part + ((int64_t)zi * S + sp) * ep.part_stride + (int64_t)row * d.N + col, v);
         } else if constexpr (EPI == 2) {
-            gen_gst4(d.C + o, v + gen_gld4(d.bias + col));
+            gen_gst4(d.C + o, v + biasv);
         } else if constexpr (EPI == 4) {
-            const f32x4 z = v + gen_gld4(d.bias + col);
+            const f32x4 z = v + biasv;
             f32x4 dz;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -518,12 +521,11 @@ __global__ __launch_bounds__(256) void k_gen_rowgemm(const GDesc* __restrict__ d
             }
             gen_gst4(d.C + o, dz);
         } else {                                                 // EPI 1: as k_gen_splitk_fin's fast path
-            const f32x4 bias = gen_gld4(d.bias + col);
             const bool drop = ep.train && ep.rate > 0.f;
             dimn_u32x4 rnd = {{0u, 0u, 0u, 0u}};
             if (drop) rnd = dimn_dropout_block(ep.seed, (uint32_t)d.kg, ep.epoch, ep.step, (uint32_t)(row * d.N + col) >> 2);
             f32x4 c, g;
-            gen_hidden4(ep, v + bias, rnd.v[0], rnd.v[1], rnd.v[2], rnd.v[3], drop, c, g);
+            gen_hidden4(ep, v + biasv, rnd.v[0], rnd.v[1], rnd.v[2], rnd.v[3], drop, c, g);
             gen_gst4(d.C + o, c);
             if (ep.train) gen_gst4(d.G + o, g);
         }
@@ -574,7 +576,9 @@ __global__ __launch_bounds__(256) void k_gen_rowgemm(const GDesc* __restrict__ d
         for (int off = 32; off > 0; off >>= 1) ls += __shfl_xor(ls, off);
         if (lane == 0) lred[wave] = ls;
         __syncthreads();
-        if (tid == 0) ep.loss_sum[(int64_t)zi * GEN_OUT_CH + nb + nblk * mb] += (lred[0] + lred[1]) + (lred[2] + lred[3]);
+        // one owner per slot and launch, so the sum is still deterministic; the atomic form returns nothing -- a load + add + store here kept the
+        // workgroup alive for a memory round trip
+        if (tid == 0) unsafeAtomicAdd(ep.loss_sum + (int64_t)zi * GEN_OUT_CH + nb + nblk * mb, (lred[0] + lred[1]) + (lred[2] + lred[3]));
     }
 }
 
