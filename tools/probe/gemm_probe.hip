@@ -14,6 +14,7 @@
 int main(int argc, char** argv) {
     const int nd = argc > 1 ? atoi(argv[1]) : 40, K = argc > 2 ? atoi(argv[2]) : 2400, N = argc > 3 ? atoi(argv[3]) : 256, S = argc > 4 ? atoi(argv[4]) : 4;
     const int M = argc > 5 ? atoi(argv[5]) : 64, reps = 20;
+    const unsigned dyn = argc > 6 ? (unsigned)atoi(argv[6]) : 0u;        // unused dynamic LDS bytes per workgroup: caps the workgroups a CU takes
     float *A, *B, *C, *part;
     CK(hipMalloc(&A, (size_t)nd * M * K * 4)); CK(hipMalloc(&B, (size_t)nd * K * N * 4)); CK(hipMalloc(&C, (size_t)nd * M * N * 4)); CK(hipMalloc(&part, (size_t)nd * S * M * N * 4));
     CK(hipMemset(A, 0, (size_t)nd * M * K * 4)); CK(hipMemset(B, 0, (size_t)nd * K * N * 4));
@@ -28,12 +29,12 @@ int main(int argc, char** argv) {
     for (int w = 0; w < 2; ++w) {
         CK(hipEventRecord(e0, 0));
         for (int r = 0; r < reps; ++r) {
-#define LAUNCH(EV) hipLaunchKernelGGL((k_gen_rowgemm<false, EV>), dim3(grid), dim3(256), 0, 0, dd, nd, M, nblk, mblk, nd % 8 == 0 ? 1 : 0, ep)
+#define LAUNCH(EV) hipLaunchKernelGGL((k_gen_rowgemm<false, EV>), dim3(grid), dim3(256), dyn, 0, dd, nd, M, nblk, mblk, nd % 8 == 0 ? 1 : 0, ep)
             if (S > 1) LAUNCH(9); else LAUNCH(2);
         }
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        if (w) printf("nd %d K %d N %d S %d M %d grid %u: %.2f us per launch  (%.1f MB of B -> %.2f TB/s; %.2f TFLOP/s)\n", nd, K, N, S, M, grid, ms * 1000 / reps, (double)nd * K * N * 4 / 1e6,
+        if (w) printf("dynLDS %u nd %d K %d N %d S %d M %d grid %u: %.2f us per launch  (%.1f MB of B -> %.2f TB/s; %.2f TFLOP/s)\n", dyn, nd, K, N, S, M, grid, ms * 1000 / reps, (double)nd * K * N * 4 / 1e6,
                       (double)nd * K * N * 4 / (ms * 1e-3 / reps) / 1e12, 2.0 * nd * M * K * N / (ms * 1e-3 / reps) / 1e12);
     }
     return 0;
